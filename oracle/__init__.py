@@ -1,0 +1,208 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+
+ctypes bindings for the two CPU checkers (see oracle/oracle_abi.h):
+
+* ``load_oracle()``  -> oracle/libbvh_oracle.so, functions ``orc_*``: restatement of the reference's
+  algorithm (oracle/bvh_oracle.cpp, cites the reference file:line it follows).
+* ``load_ref()``     -> oracle/_ref/libbvh_ref.so, functions ``ref_*``: the unmodified reference
+  compiled where it lies under /root/reference (oracle/ref_harness.cpp); ``None`` when absent.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package; the product (bvh_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+BUILDER_DEFAULT_SERIAL, BUILDER_DEFAULT_PARALLEL, BUILDER_BINNED, BUILDER_SWEEP = 0, 1, 2, 3
+QUALITY_LOW, QUALITY_MEDIUM, QUALITY_HIGH = 0, 1, 2
+INVALID = 0xFFFFFFFF
+
+HITF = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+HITD = np.dtype([("prim", "<u4"), ("pad", "<u4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8")])
+NODEF = np.dtype([("bounds", "<f4", (6,)), ("index", "<u4")])
+NODED = np.dtype([("bounds", "<f8", (6,)), ("index", "<u8")])
+assert HITF.itemsize == 16 and HITD.itemsize == 32 and NODEF.itemsize == 28 and NODED.itemsize == 56
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class CpuBvh:
+    """A BVH held by one of the CPU checkers."""
+
+    def __init__(self, lib: "CpuLib", handle, suffix: str):
+        self.lib, self.h, self.s = lib, handle, suffix
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib._fn("destroy", self.s)(self.h)
+            self.h = None
+
+    @property
+    def node_count(self) -> int:
+        return self.lib._fn("node_count", self.s)(self.h)
+
+    @property
+    def prim_count(self) -> int:
+        return self.lib._fn("prim_count", self.s)(self.h)
+
+    def nodes(self) -> np.ndarray:
+        out = np.empty(self.node_count, dtype=NODEF if self.s == "3f" else NODED)
+        self.lib._fn("get_nodes", self.s)(self.h, _ptr(out))
+        return out
+
+    def prim_ids(self) -> np.ndarray:
+        out = np.empty(self.prim_count, dtype=np.uint64)
+        self.lib._fn("get_prim_ids", self.s)(self.h, _ptr(out))
+        return out
+
+    def serialize(self) -> bytes:
+        n = self.lib._fn("serialize", self.s)(self.h, None, 0)
+        buf = np.empty(n, dtype=np.uint8)
+        self.lib._fn("serialize", self.s)(self.h, _ptr(buf), n)
+        return buf.tobytes()
+
+    def optimize(self, threads: int = -1):
+        """ReinsertionOptimizer::optimize; threads < 0 = SequentialExecutor overload."""
+        self.lib._fn("optimize", self.s)(self.h, threads)
+
+    def refit(self):
+        self.lib._fn("refit", self.s)(self.h)
+
+    def intersect_tri(self, tris12, rays8, any_hit=False, robust=True, threads=1, counters=False):
+        return self._intersect("intersect_tri", tris12, rays8, any_hit, robust, threads, counters)
+
+    def intersect_sphere(self, sph4, rays8, any_hit=False, robust=True, threads=1, counters=False):
+        return self._intersect("intersect_sphere", sph4, rays8, any_hit, robust, threads, counters)
+
+    def _intersect(self, name, prims, rays8, any_hit, robust, threads, counters):
+        dt = np.float32 if self.s == "3f" else np.float64
+        prims = np.ascontiguousarray(prims, dtype=dt)
+        rays8 = np.ascontiguousarray(rays8, dtype=dt).reshape(-1, 8)
+        out = np.empty(len(rays8), dtype=HITF if self.s == "3f" else HITD)
+        cnt = np.zeros(3, dtype=np.uint64)
+        self.lib._fn(name, self.s)(self.h, _ptr(prims), _ptr(rays8), len(rays8), int(any_hit), int(robust),
+                                   int(threads), _ptr(out), _ptr(cnt))
+        return (out, cnt) if counters else out
+
+
+class CpuLib:
+    def __init__(self, path: str, prefix: str):
+        self.path, self.prefix = path, prefix
+        self.dll = C.CDLL(path)
+        self._cache = {}
+
+    _SIG = {
+        "build": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                               C.c_size_t, C.c_int]),
+        "destroy": (None, [C.c_void_p]),
+        "node_count": (C.c_size_t, [C.c_void_p]),
+        "prim_count": (C.c_size_t, [C.c_void_p]),
+        "get_nodes": (None, [C.c_void_p, C.c_void_p]),
+        "get_prim_ids": (None, [C.c_void_p, C.c_void_p]),
+        "from_arrays": (C.c_void_p, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+        "serialize": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
+        "optimize": (None, [C.c_void_p, C.c_int]),
+        "refit": (None, [C.c_void_p]),
+        "prep_tris": (None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+        "precompute_tris": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+        "sphere_bboxes": (None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+        "intersect_tri": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p]),
+        "intersect_sphere": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
+    }
+
+    def _fn(self, name, suffix):
+        key = f"{self.prefix}_{name}{suffix}"
+        f = self._cache.get(key)
+        if f is None:
+            f = getattr(self.dll, key)
+            f.restype, f.argtypes = self._SIG[name]
+            self._cache[key] = f
+        return f
+
+    @staticmethod
+    def _sfx(dtype):
+        return "3f" if np.dtype(dtype) == np.float32 else "3d"
+
+    def hardware_threads(self) -> int:
+        return int(getattr(self.dll, f"{self.prefix}_hardware_threads")())
+
+    def build(self, bboxes, centers, builder=BUILDER_DEFAULT_SERIAL, quality=QUALITY_HIGH, min_leaf=1,
+              max_leaf=8, parallel_threshold=1024, threads=0) -> CpuBvh:
+        dt = bboxes.dtype
+        s = self._sfx(dt)
+        bboxes = np.ascontiguousarray(bboxes, dtype=dt).reshape(-1, 6)
+        centers = np.ascontiguousarray(centers, dtype=dt).reshape(-1, 3)
+        assert len(bboxes) == len(centers) and len(bboxes) > 0
+        h = self._fn("build", s)(_ptr(bboxes), _ptr(centers), len(bboxes), builder, quality, min_leaf, max_leaf,
+                                 parallel_threshold, threads)
+        if not h:
+            raise RuntimeError("oracle build failed")
+        return CpuBvh(self, h, s)
+
+    def from_arrays(self, nodes: np.ndarray, prim_ids: np.ndarray) -> CpuBvh:
+        s = "3f" if nodes.dtype.itemsize == 28 else "3d"
+        nodes = np.ascontiguousarray(nodes)
+        ids = np.ascontiguousarray(prim_ids, dtype=np.uint64)
+        h = self._fn("from_arrays", s)(_ptr(nodes), len(nodes), _ptr(ids), len(ids))
+        return CpuBvh(self, h, s)
+
+    def prep_tris(self, tris9):
+        dt = tris9.dtype
+        t = np.ascontiguousarray(tris9, dtype=dt).reshape(-1, 9)
+        bb = np.empty((len(t), 6), dtype=dt)
+        cc = np.empty((len(t), 3), dtype=dt)
+        self._fn("prep_tris", self._sfx(dt))(_ptr(t), len(t), _ptr(bb), _ptr(cc))
+        return bb, cc
+
+    def precompute_tris(self, tris9, perm=None):
+        dt = tris9.dtype
+        t = np.ascontiguousarray(tris9, dtype=dt).reshape(-1, 9)
+        n = len(t) if perm is None else len(perm)
+        p = None if perm is None else np.ascontiguousarray(perm, dtype=np.uint64)
+        out = np.empty((n, 12), dtype=dt)
+        self._fn("precompute_tris", self._sfx(dt))(_ptr(t), _ptr(p), n, _ptr(out))
+        return out
+
+    def sphere_bboxes(self, sph4):
+        dt = sph4.dtype
+        s4 = np.ascontiguousarray(sph4, dtype=dt).reshape(-1, 4)
+        bb = np.empty((len(s4), 6), dtype=dt)
+        cc = np.empty((len(s4), 3), dtype=dt)
+        self._fn("sphere_bboxes", self._sfx(dt))(_ptr(s4), len(s4), _ptr(bb), _ptr(cc))
+        return bb, cc
+
+
+ORACLE_SO = os.path.join(_HERE, "libbvh_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libbvh_ref.so")
+
+
+def build_checkers(quiet: bool = True) -> None:
+    """Compiles the restatement, and the reference harness when /root/reference is present."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def load_oracle() -> CpuLib:
+    if not os.path.exists(ORACLE_SO):
+        build_checkers()
+    return CpuLib(ORACLE_SO, "orc")
+
+
+def load_ref():
+    if not os.path.exists(REF_SO):
+        if os.path.isdir("/root/reference/src/bvh/v2"):
+            build_checkers()
+        else:
+            return None
+    return CpuLib(REF_SO, "ref")

@@ -1,0 +1,309 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+//
+// C-ABI harness around the *unmodified* reference library (madmann91/bvh v2), which is header-only
+// C++20. This translation unit contains no reference code: it only `#include`s the headers where they
+// lie under /root/reference/src (never copied into this repository) and forwards to them. It is built
+// by oracle/Makefile into oracle/_ref/libbvh_ref.so (git-ignored, shipped to the GPU box by gpurun)
+// and is used
+//   * to validate the restatement in oracle/bvh_oracle.cpp (tests/test_oracle_vs_ref.py),
+//   * to generate the committed golden fixtures (tests/golden/make_golden.py),
+//   * as bench.py's `cpu_baseline` leg of kind "reference".
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+//
+// Pinned build flags (they are part of the observable behaviour):
+//   g++ 11 -std=c++20 -O3 -mavx2 -mfma -ffp-contract=off -DNDEBUG
+// -mfma makes <cmath> define FP_FAST_FMAF so that fast_mul_add (utils.h:74-81) is a real fma, and
+// -ffp-contract=off forbids any other fusion, i.e. "one rounding per operation, fma exactly at the
+// fast_mul_add call sites". (-mavx2 -mfma instead of -march=native so that the .so also runs on the
+// GPU box's host CPU; vectorisation cannot change IEEE results without -ffast-math.)
+
+#include <bvh/v2/bvh.h>
+#include <bvh/v2/vec.h>
+#include <bvh/v2/ray.h>
+#include <bvh/v2/node.h>
+#include <bvh/v2/default_builder.h>
+#include <bvh/v2/binned_sah_builder.h>
+#include <bvh/v2/sweep_sah_builder.h>
+#include <bvh/v2/mini_tree_builder.h>
+#include <bvh/v2/reinsertion_optimizer.h>
+#include <bvh/v2/thread_pool.h>
+#include <bvh/v2/executor.h>
+#include <bvh/v2/stack.h>
+#include <bvh/v2/tri.h>
+#include <bvh/v2/sphere.h>
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "oracle_abi.h"
+
+namespace {
+
+using namespace bvh::v2;
+
+template <typename T> using Node3 = Node<T, 3>;
+template <typename T> using Bvh3 = Bvh<Node3<T>>;
+
+template <typename T>
+Bvh3<T>* build(const T* bboxes, const T* centers, size_t n, int builder, int quality,
+               size_t min_leaf, size_t max_leaf, size_t par_threshold, int threads)
+{
+    using N = Node3<T>;
+    std::vector<BBox<T, 3>> bb(n);
+    std::vector<Vec<T, 3>> cc(n);
+    for (size_t i = 0; i < n; ++i) {
+        bb[i] = BBox<T, 3>(Vec<T, 3>(bboxes[6 * i + 0], bboxes[6 * i + 1], bboxes[6 * i + 2]),
+                           Vec<T, 3>(bboxes[6 * i + 3], bboxes[6 * i + 4], bboxes[6 * i + 5]));
+        cc[i] = Vec<T, 3>(centers[3 * i + 0], centers[3 * i + 1], centers[3 * i + 2]);
+    }
+    typename DefaultBuilder<N>::Config cfg;
+    cfg.quality = static_cast<typename DefaultBuilder<N>::Quality>(quality);
+    cfg.min_leaf_size = min_leaf;
+    cfg.max_leaf_size = max_leaf;
+    cfg.parallel_threshold = par_threshold;
+    auto out = std::make_unique<Bvh3<T>>();
+    switch (builder) {
+    case ORC_BUILDER_DEFAULT_SERIAL:
+        *out = DefaultBuilder<N>::build(bb, cc, cfg);
+        break;
+    case ORC_BUILDER_DEFAULT_PARALLEL: {
+        ThreadPool pool(static_cast<size_t>(threads));
+        *out = DefaultBuilder<N>::build(pool, bb, cc, cfg);
+        break;
+    }
+    case ORC_BUILDER_BINNED:
+        *out = BinnedSahBuilder<N>::build(bb, cc, cfg);
+        break;
+    case ORC_BUILDER_SWEEP:
+        *out = SweepSahBuilder<N>::build(bb, cc, cfg);
+        break;
+    default:
+        return nullptr;
+    }
+    return out.release();
+}
+
+template <typename T>
+void get_nodes(const Bvh3<T>* b, void* out) {
+    static_assert(sizeof(Node3<float>) == 28 && sizeof(Node3<double>) == 56);
+    std::memcpy(out, b->nodes.data(), b->nodes.size() * sizeof(Node3<T>));
+}
+
+template <typename T>
+Bvh3<T>* from_arrays(const void* nodes, size_t nn, const uint64_t* prim_ids, size_t np) {
+    auto b = std::make_unique<Bvh3<T>>();
+    b->nodes.resize(nn);
+    std::memcpy(b->nodes.data(), nodes, nn * sizeof(Node3<T>));
+    b->prim_ids.assign(prim_ids, prim_ids + np);
+    return b.release();
+}
+
+struct VecStream : OutputStream {
+    std::vector<uint8_t> bytes;
+    bool write_raw(const void* p, size_t n) override {
+        auto q = static_cast<const uint8_t*>(p);
+        bytes.insert(bytes.end(), q, q + n);
+        return true;
+    }
+};
+
+template <typename T>
+size_t serialize(const Bvh3<T>* b, uint8_t* out, size_t cap) {
+    VecStream s;
+    b->serialize(s);
+    if (out && cap >= s.bytes.size())
+        std::memcpy(out, s.bytes.data(), s.bytes.size());
+    return s.bytes.size();
+}
+
+template <typename T>
+void optimize(Bvh3<T>* b, int threads) {
+    if (threads < 0) {
+        ReinsertionOptimizer<Node3<T>>::optimize(*b);
+    } else {
+        ThreadPool pool(static_cast<size_t>(threads));
+        ReinsertionOptimizer<Node3<T>>::optimize(pool, *b);
+    }
+}
+
+template <typename T>
+void prep_tris(const T* t9, size_t n, T* bboxes, T* centers) {
+    for (size_t i = 0; i < n; ++i) {
+        Tri<T, 3> tri(Vec<T, 3>(t9[9 * i + 0], t9[9 * i + 1], t9[9 * i + 2]),
+                      Vec<T, 3>(t9[9 * i + 3], t9[9 * i + 4], t9[9 * i + 5]),
+                      Vec<T, 3>(t9[9 * i + 6], t9[9 * i + 7], t9[9 * i + 8]));
+        auto bb = tri.get_bbox();
+        auto c = tri.get_center();
+        for (int k = 0; k < 3; ++k) {
+            bboxes[6 * i + k] = bb.min[k];
+            bboxes[6 * i + 3 + k] = bb.max[k];
+            centers[3 * i + k] = c[k];
+        }
+    }
+}
+
+template <typename T>
+void precompute_tris(const T* t9, const uint64_t* perm, size_t n, T* out12) {
+    static_assert(sizeof(PrecomputedTri<T>) == 12 * sizeof(T));
+    for (size_t i = 0; i < n; ++i) {
+        size_t j = perm ? perm[i] : i;
+        PrecomputedTri<T> p(Vec<T, 3>(t9[9 * j + 0], t9[9 * j + 1], t9[9 * j + 2]),
+                            Vec<T, 3>(t9[9 * j + 3], t9[9 * j + 4], t9[9 * j + 5]),
+                            Vec<T, 3>(t9[9 * j + 6], t9[9 * j + 7], t9[9 * j + 8]));
+        std::memcpy(out12 + 12 * i, &p, sizeof(p));
+    }
+}
+
+template <typename T>
+void sphere_bboxes(const T* s4, size_t n, T* bboxes, T* centers) {
+    for (size_t i = 0; i < n; ++i) {
+        Sphere<T, 3> s(Vec<T, 3>(s4[4 * i + 0], s4[4 * i + 1], s4[4 * i + 2]), s4[4 * i + 3]);
+        auto bb = s.get_bbox();
+        auto c = s.get_center();
+        for (int k = 0; k < 3; ++k) {
+            bboxes[6 * i + k] = bb.min[k];
+            bboxes[6 * i + 3 + k] = bb.max[k];
+            centers[3 * i + k] = c[k];
+        }
+    }
+}
+
+template <typename T> struct HitOf;
+template <> struct HitOf<float>  { using Type = orc_hitf; };
+template <> struct HitOf<double> { using Type = orc_hitd; };
+
+// Runs `fn(begin, end, thread_slot)` over [0, n) on `threads` std::threads (threads <= 1: inline).
+template <typename F>
+void parallel_chunks(size_t n, int threads, F&& fn) {
+    if (threads <= 1 || n < 1024) { fn(size_t{0}, n, 0); return; }
+    std::vector<std::thread> pool;
+    size_t chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        size_t b = std::min(n, chunk * t), e = std::min(n, b + chunk);
+        pool.emplace_back([=, &fn] { fn(b, e, t); });
+    }
+    for (auto& t : pool) t.join();
+}
+
+// The leaf lambda below is the closest-hit / any-hit pattern of test/benchmark.cpp:277-298 and
+// test/simple_example.cpp:81-92 (permuted primitives: the BVH-order index i addresses prims[i]).
+template <typename T, bool Any, bool Robust, typename Prim, typename LeafTest>
+void intersect_all(const Bvh3<T>* b, const Prim* prims, const T* rays8, size_t nrays, int threads,
+                   typename HitOf<T>::Type* out, uint64_t* counters, LeafTest&& leaf_test)
+{
+    std::vector<uint64_t> cnt(3 * std::max(threads, 1), 0);
+    parallel_chunks(nrays, threads, [&](size_t rb, size_t re, int slot) {
+        uint64_t pairs = 0, tests = 0, leaves = 0;
+        for (size_t r = rb; r < re; ++r) {
+            const T* q = rays8 + 8 * r;
+            Ray<T, 3> ray(Vec<T, 3>(q[0], q[1], q[2]), Vec<T, 3>(q[3], q[4], q[5]), q[6], q[7]);
+            typename HitOf<T>::Type h{};
+            h.prim = ORC_INVALID; h.t = q[7]; h.u = 0; h.v = 0;
+            SmallStack<typename Bvh3<T>::Index, 64> stack;
+            b->template intersect<Any, Robust>(ray, b->get_root().index, stack,
+                [&](size_t begin, size_t end) {
+                    ++leaves;
+                    for (size_t i = begin; i < end; ++i) {
+                        ++tests;
+                        leaf_test(prims[i], ray, i, h);
+                    }
+                    return h.prim != ORC_INVALID;
+                },
+                [&](const Node3<T>&, const Node3<T>&) { ++pairs; });
+            out[r] = h;
+        }
+        cnt[3 * slot + 0] += pairs; cnt[3 * slot + 1] += tests; cnt[3 * slot + 2] += leaves;
+    });
+    if (counters) {
+        counters[0] = counters[1] = counters[2] = 0;
+        for (size_t i = 0; i < cnt.size(); i += 3) {
+            counters[0] += cnt[i]; counters[1] += cnt[i + 1]; counters[2] += cnt[i + 2];
+        }
+    }
+}
+
+template <typename T, bool Any, bool Robust>
+void intersect_tri(const Bvh3<T>* b, const T* tris12, const T* rays8, size_t nrays, int threads,
+                   typename HitOf<T>::Type* out, uint64_t* counters)
+{
+    auto prims = reinterpret_cast<const PrecomputedTri<T>*>(tris12);
+    intersect_all<T, Any, Robust>(b, prims, rays8, nrays, threads, out, counters,
+        [](const PrecomputedTri<T>& tri, Ray<T, 3>& ray, size_t i, typename HitOf<T>::Type& h) {
+            if (auto hit = tri.intersect(ray)) {
+                std::tie(ray.tmax, h.u, h.v) = *hit;
+                h.t = ray.tmax;
+                h.prim = static_cast<decltype(h.prim)>(i);
+            }
+        });
+}
+
+template <typename T, bool Any, bool Robust>
+void intersect_sphere(const Bvh3<T>* b, const T* sph4, const T* rays8, size_t nrays, int threads,
+                      typename HitOf<T>::Type* out, uint64_t* counters)
+{
+    auto prims = reinterpret_cast<const Sphere<T, 3>*>(sph4);
+    static_assert(sizeof(Sphere<T, 3>) == 4 * sizeof(T));
+    intersect_all<T, Any, Robust>(b, prims, rays8, nrays, threads, out, counters,
+        [](const Sphere<T, 3>& s, Ray<T, 3>& ray, size_t i, typename HitOf<T>::Type& h) {
+            if (auto hit = s.intersect(ray)) {
+                ray.tmax = hit->first;
+                h.t = hit->first;
+                h.u = hit->second;
+                h.v = 0;
+                h.prim = static_cast<decltype(h.prim)>(i);
+            }
+        });
+}
+
+template <typename T, template <typename, bool, bool> class Fn>
+struct Dispatch;
+
+#define DISPATCH4(fn, T, any, robust, ...)                                  \
+    do {                                                                    \
+        if (any) { if (robust) fn<T, true, true>(__VA_ARGS__); else fn<T, true, false>(__VA_ARGS__); } \
+        else     { if (robust) fn<T, false, true>(__VA_ARGS__); else fn<T, false, false>(__VA_ARGS__); } \
+    } while (0)
+
+} // namespace
+
+extern "C" {
+
+#define REF_IMPL(T, S)                                                                                  \
+    ORC_EXPORT void* ref_build##S(const T* bboxes, const T* centers, size_t n, int builder,            \
+        int quality, size_t min_leaf, size_t max_leaf, size_t par_threshold, int threads) {            \
+        return build<T>(bboxes, centers, n, builder, quality, min_leaf, max_leaf, par_threshold, threads); } \
+    ORC_EXPORT void ref_destroy##S(void* h) { delete static_cast<Bvh3<T>*>(h); }                        \
+    ORC_EXPORT size_t ref_node_count##S(const void* h) { return static_cast<const Bvh3<T>*>(h)->nodes.size(); } \
+    ORC_EXPORT size_t ref_prim_count##S(const void* h) { return static_cast<const Bvh3<T>*>(h)->prim_ids.size(); } \
+    ORC_EXPORT void ref_get_nodes##S(const void* h, void* out) { get_nodes<T>(static_cast<const Bvh3<T>*>(h), out); } \
+    ORC_EXPORT void ref_get_prim_ids##S(const void* h, uint64_t* out) {                                \
+        auto b = static_cast<const Bvh3<T>*>(h);                                                        \
+        for (size_t i = 0; i < b->prim_ids.size(); ++i) out[i] = b->prim_ids[i]; }                      \
+    ORC_EXPORT void* ref_from_arrays##S(const void* nodes, size_t nn, const uint64_t* ids, size_t np) { \
+        return from_arrays<T>(nodes, nn, ids, np); }                                                    \
+    ORC_EXPORT size_t ref_serialize##S(const void* h, uint8_t* out, size_t cap) {                       \
+        return serialize<T>(static_cast<const Bvh3<T>*>(h), out, cap); }                                \
+    ORC_EXPORT void ref_optimize##S(void* h, int threads) { optimize<T>(static_cast<Bvh3<T>*>(h), threads); } \
+    ORC_EXPORT void ref_refit##S(void* h) { static_cast<Bvh3<T>*>(h)->refit(); }                        \
+    ORC_EXPORT void ref_prep_tris##S(const T* t9, size_t n, T* bb, T* cc) { prep_tris<T>(t9, n, bb, cc); } \
+    ORC_EXPORT void ref_precompute_tris##S(const T* t9, const uint64_t* perm, size_t n, T* out12) {     \
+        precompute_tris<T>(t9, perm, n, out12); }                                                       \
+    ORC_EXPORT void ref_sphere_bboxes##S(const T* s4, size_t n, T* bb, T* cc) { sphere_bboxes<T>(s4, n, bb, cc); } \
+    ORC_EXPORT void ref_intersect_tri##S(const void* h, const T* tris12, const T* rays8, size_t nrays,  \
+        int any, int robust, int threads, HitOf<T>::Type* out, uint64_t* counters) {                    \
+        DISPATCH4(intersect_tri, T, any, robust, static_cast<const Bvh3<T>*>(h), tris12, rays8, nrays,  \
+                  threads, out, counters); }                                                            \
+    ORC_EXPORT void ref_intersect_sphere##S(const void* h, const T* sph4, const T* rays8, size_t nrays, \
+        int any, int robust, int threads, HitOf<T>::Type* out, uint64_t* counters) {                    \
+        DISPATCH4(intersect_sphere, T, any, robust, static_cast<const Bvh3<T>*>(h), sph4, rays8, nrays, \
+                  threads, out, counters); }
+
+REF_IMPL(float, 3f)
+REF_IMPL(double, 3d)
+
+ORC_EXPORT int ref_hardware_threads(void) { return static_cast<int>(std::thread::hardware_concurrency()); }
+
+} // extern "C"

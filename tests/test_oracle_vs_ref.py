@@ -1,0 +1,75 @@
+"""Restatement vs the compiled, unmodified reference on seeded inputs (authoring container only:
+needs oracle/_ref/libbvh_ref.so, which can only be built where /root/reference exists)."""
+import numpy as np
+import pytest
+
+import oracle
+from bvh_amd import synth
+from conftest import MODES
+
+
+def _scene(name):
+    if name == "soup":
+        return synth.soup(20000, seed=5, jitter=0.02)
+    if name == "terrain":
+        return synth.terrain(20000)
+    if name == "sponza":
+        return synth.sponza_proxy(30000)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("scene", ["soup", "terrain", "sponza"])
+def test_builders_and_traversal_match_reference(orc, ref, scene):
+    tris = _scene(scene)
+    bb, cc = ref.prep_tris(tris)
+    bb2, cc2 = orc.prep_tris(tris)
+    assert bb.tobytes() == bb2.tobytes() and cc.tobytes() == cc2.tobytes()
+    lo, hi = synth.scene_bounds(tris)
+    rays = synth.rays_closest(5000, lo, hi)
+    srays = synth.rays_shadow(5000, lo, hi)
+    for mode, builder, quality in MODES:
+        a = ref.build(bb, cc, builder=builder, quality=quality, threads=3)
+        b = orc.build(bb, cc, builder=builder, quality=quality)
+        assert a.serialize() == b.serialize(), mode
+    pa, pb = ref.precompute_tris(tris, a.prim_ids()), orc.precompute_tris(tris, b.prim_ids())
+    assert pa.tobytes() == pb.tobytes()
+    for any_hit in (0, 1):
+        for robust in (0, 1):
+            rr = srays if any_hit else rays
+            ha, ca = a.intersect_tri(pa, rr, any_hit, robust, counters=True)
+            hb, cb = b.intersect_tri(pb, rr, any_hit, robust, counters=True)
+            assert ha.tobytes() == hb.tobytes() and (ca == cb).all()
+
+
+def test_double_spheres_match_reference(orc, ref):
+    sph = synth.spheres(8000, rmin=0.005, rmax=0.02)
+    bb, cc = ref.sphere_bboxes(sph)
+    bb2, cc2 = orc.sphere_bboxes(sph)
+    assert bb.tobytes() == bb2.tobytes() and cc.tobytes() == cc2.tobytes()
+    a = ref.build(bb, cc, builder=1, quality=2, threads=3)
+    b = orc.build(bb, cc, builder=1, quality=2)
+    assert a.serialize() == b.serialize()
+    perm = a.prim_ids().astype(np.int64)
+    lo, hi = synth.scene_bounds(sph)
+    rays = synth.rays_closest(5000, lo, hi, dtype=np.float64)
+    for any_hit in (0, 1):
+        for robust in (0, 1):
+            ha, ca = a.intersect_sphere(sph[perm], rays, any_hit, robust, counters=True)
+            hb, cb = b.intersect_sphere(sph[perm], rays, any_hit, robust, counters=True)
+            assert ha.tobytes() == hb.tobytes() and (ca == cb).all()
+
+
+def test_optimize_and_refit_match_reference(orc, ref):
+    tris = synth.soup(6000, seed=9, jitter=0.03)
+    bb, cc = ref.prep_tris(tris)
+    a = ref.build(bb, cc, builder=oracle.BUILDER_SWEEP)
+    b = orc.build(bb, cc, builder=oracle.BUILDER_SWEEP)
+    a.optimize(-1)
+    b.optimize(-1)
+    assert a.serialize() == b.serialize()
+    a.optimize(3)
+    b.optimize(3)
+    assert a.serialize() == b.serialize()
+    a.refit()
+    b.refit()
+    assert a.serialize() == b.serialize()
