@@ -1,0 +1,113 @@
+"""ctypes binding of libbvh_amd.so (include/bvh_amd.h). Fails loudly when the library is missing:
+there is no Python/CPU fallback for any entry point."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libbvh_amd.so")
+
+_lib = None
+
+
+class BvhAmdError(RuntimeError):
+    pass
+
+
+class BuildConfig(C.Structure):
+    _fields_ = [("quality", C.c_int), ("min_leaf_size", C.c_size_t), ("max_leaf_size", C.c_size_t),
+                ("parallel_threshold", C.c_size_t)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("node_pairs", C.c_ulonglong), ("prim_tests", C.c_ulonglong), ("leaves", C.c_ulonglong)]
+
+
+class BBox3f(C.Structure):
+    _fields_ = [("v", C.c_float * 6)]
+
+
+class BBox3d(C.Structure):
+    _fields_ = [("v", C.c_double * 6)]
+
+
+# name -> (restype, argtypes); `{S}` expands to 3f / 3d
+_P, _Z, _I, _U = C.c_void_p, C.c_size_t, C.c_int, C.c_uint
+_SIGS = {
+    "bvh_amd_last_error": (C.c_char_p, []),
+    "bvh_amd_version": (C.c_char_p, []),
+    "bvh_amd_last_kernel_name": (C.c_char_p, []),
+    "bvh_amd_device_count": (_I, []),
+    "bvh_amd_device_name": (_I, [_I, C.c_char_p, _Z]),
+    "bvh_thread_pool_create": (_P, [_Z]),
+    "bvh_thread_pool_destroy": (None, [_P]),
+    "bvh_amd_gather": (_I, [_P, _P, _Z, _Z, _P, _P]),
+}
+_SIGS_T = {
+    "bvh{S}_build": (_P, [_P, _P, _P, _Z, _P]),
+    "bvh{S}_build_device": (_P, [_P, _P, _Z, _P, _I, _P]),
+    "bvh{S}_from_nodes": (_P, [_P, _Z, _P, _Z]),
+    "bvh{S}_destroy": (None, [_P]),
+    "bvh{S}_save": (None, [_P, _P]),
+    "bvh{S}_load": (_P, [_P]),
+    "bvh{S}_serialize": (_Z, [_P, _P, _Z]),
+    "bvh{S}_deserialize": (_P, [_P, _Z]),
+    "bvh{S}_get_node": (_P, [_P, _Z]),
+    "bvh{S}_get_prim_id": (_Z, [_P, _Z]),
+    "bvh{S}_get_prim_count": (_Z, [_P]),
+    "bvh{S}_get_node_count": (_Z, [_P]),
+    "bvh_node{S}_is_leaf": (C.c_bool, [_P]),
+    "bvh_node{S}_get_prim_count": (_Z, [_P]),
+    "bvh_node{S}_get_first_id": (_Z, [_P]),
+    "bvh{S}_copy_nodes": (None, [_P, _P]),
+    "bvh{S}_copy_prim_ids": (None, [_P, _P]),
+    "bvh{S}_device_prim_ids": (_P, [_P]),
+    "bvh_amd_tri_bounds{S}": (_I, [_P, _Z, _P, _P, _P]),
+    "bvh_amd_precompute_tris{S}": (_I, [_P, _P, _Z, _P, _P]),
+    "bvh_amd_sphere_bounds{S}": (_I, [_P, _Z, _P, _P, _P]),
+    "bvh{S}_intersect_rays_tri": (_I, [_P, _P, _P, _Z, _U, _P, _P, _P]),
+    "bvh{S}_intersect_rays_sphere": (_I, [_P, _P, _P, _Z, _U, _P, _P, _P]),
+}
+
+
+def exported_symbols():
+    """Every symbol include/bvh_amd.h declares."""
+    names = list(_SIGS)
+    for s in ("3f", "3d"):
+        names += [k.format(S=s) for k in _SIGS_T]
+        names += [f"bvh_node{s}_get_bbox"]
+    return names
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own HIP runtime (same SONAME as /opt/rocm's). It must be the first one mapped, or the
+    # process ends up with two runtimes and the second cannot open the device ("no ROCm-capable device").
+    import torch  # noqa: F401  (device memory + streams plumbing)
+    if not os.path.exists(LIB_PATH):
+        raise BvhAmdError(f"{LIB_PATH} is missing: build it with `python -m bvh_amd.build` "
+                          "(no fallback path exists)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    for s in ("3f", "3d"):
+        for name, (res, args) in _SIGS_T.items():
+            f = getattr(lib, name.format(S=s))
+            f.restype, f.argtypes = res, args
+    lib.bvh_node3f_get_bbox.restype, lib.bvh_node3f_get_bbox.argtypes = BBox3f, [_P]
+    lib.bvh_node3d_get_bbox.restype, lib.bvh_node3d_get_bbox.argtypes = BBox3d, [_P]
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().bvh_amd_last_error().decode()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise BvhAmdError(f"{what} failed ({rc}): {last_error()}")

@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference interface (bvh::v2) over the C-ABI. torch = device memory + streams."""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+INVALID = 0xFFFFFFFF
+HITF = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+HITD = np.dtype([("prim", "<u4"), ("pad", "<u4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8")])
+NODEF = np.dtype([("bounds", "<f4", (6,)), ("index", "<u4")])     # reference node.h:31-37
+NODED = np.dtype([("bounds", "<f8", (6,)), ("index", "<u8")])
+
+
+class Quality(enum.IntEnum):          # default_builder.h:21
+    Low = 0
+    Medium = 1
+    High = 2
+
+
+class RayFlags(enum.IntFlag):
+    ANY_HIT = 1
+    ROBUST = 2
+    SORTED = 4
+
+
+class _Builder(enum.IntEnum):
+    DEFAULT_SERIAL = 0
+    DEFAULT_PARALLEL = 1
+    BINNED = 2
+    SWEEP = 3
+
+
+@dataclass
+class Config:                         # default_builder.h:23-30 + top_down_sah_builder.h:27-40
+    quality: Quality = Quality.High
+    min_leaf_size: int = 1
+    max_leaf_size: int = 8
+    parallel_threshold: int = 1024
+
+    def _c(self):
+        return _lib.BuildConfig(int(self.quality), self.min_leaf_size, self.max_leaf_size, self.parallel_threshold)
+
+
+class ThreadPool:
+    """bvh::v2::ThreadPool stand-in (thread_pool.h:13-46). The GPU grid replaces the pool; passing one
+    selects the reference's parallel (mini-tree) builder semantics exactly like the reference API."""
+
+    def __init__(self, thread_count: int = 0):
+        self.thread_count = thread_count
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _lib.BvhAmdError("no HIP device visible to torch: bvh_amd has no CPU path")
+    return torch
+
+
+def _suffix(dtype) -> str:
+    import torch
+    if dtype in (torch.float32, np.float32, np.dtype(np.float32)):
+        return "3f"
+    if dtype in (torch.float64, np.float64, np.dtype(np.float64)):
+        return "3d"
+    raise TypeError(f"unsupported scalar type {dtype}")
+
+
+def _dev(x, cols=None):
+    """numpy / torch (any device) -> contiguous torch tensor on the current HIP device."""
+    torch = _torch()
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not x.is_cuda:
+        x = x.cuda()
+    x = x.contiguous()
+    if cols is not None:
+        x = x.reshape(-1, cols)
+    return x
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+class Bvh:
+    """bvh::v2::Bvh<Node<T,3>> (bvh.h:17-89): host mirror in the reference layout + device-resident copy."""
+
+    def __init__(self, handle, suffix: str):
+        if not handle:
+            raise _lib.BvhAmdError(_lib.last_error())
+        self._h, self._s = handle, suffix
+        self._lib = _lib.load()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            getattr(self._lib, f"bvh{self._s}_destroy")(self._h)
+            self._h = None
+
+    def _f(self, name):
+        return getattr(self._lib, name.format(S=self._s))
+
+    @property
+    def dtype(self):
+        return np.float32 if self._s == "3f" else np.float64
+
+    @property
+    def node_count(self) -> int:
+        return self._f("bvh{S}_get_node_count")(self._h)
+
+    @property
+    def prim_count(self) -> int:
+        return self._f("bvh{S}_get_prim_count")(self._h)
+
+    @property
+    def nodes(self) -> np.ndarray:
+        out = np.empty(self.node_count, dtype=NODEF if self._s == "3f" else NODED)
+        self._f("bvh{S}_copy_nodes")(self._h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    @property
+    def prim_ids(self) -> np.ndarray:
+        out = np.empty(self.prim_count, dtype=np.uint64)
+        self._f("bvh{S}_copy_prim_ids")(self._h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def device_prim_ids(self):
+        """uint32 prim ids resident in HBM, as a torch tensor view (no copy)."""
+        torch = _torch()
+        ptr = self._f("bvh{S}_device_prim_ids")(self._h)
+        n = self.prim_count
+
+        class _Holder:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        t = torch.as_tensor(_Holder(), device="cuda")
+        t._bvh_keepalive = self
+        return t
+
+    def get_root(self):
+        return self.nodes[0]
+
+    def serialize(self) -> bytes:                     # bvh.h:221-229
+        n = self._f("bvh{S}_serialize")(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._f("bvh{S}_serialize")(self._h, buf, n)
+        return buf.raw
+
+    @staticmethod
+    def deserialize(data: bytes, dtype=np.float32) -> "Bvh":   # bvh.h:231-243
+        s = _suffix(np.dtype(dtype))
+        lib = _lib.load()
+        _torch()
+        return Bvh(getattr(lib, f"bvh{s}_deserialize")(data, len(data)), s)
+
+    @staticmethod
+    def from_nodes(nodes: np.ndarray, prim_ids: np.ndarray) -> "Bvh":
+        s = "3f" if nodes.dtype.itemsize == 28 else "3d"
+        lib = _lib.load()
+        _torch()
+        nodes = np.ascontiguousarray(nodes)
+        ids = np.ascontiguousarray(prim_ids, dtype=np.uint64)
+        return Bvh(getattr(lib, f"bvh{s}_from_nodes")(nodes.ctypes.data_as(C.c_void_p), len(nodes),
+                                                      ids.ctypes.data_as(C.c_void_p), len(ids)), s)
+
+
+def _build(bboxes, centers, config: Config, builder: _Builder) -> Bvh:
+    lib = _lib.load()
+    bb = _dev(bboxes, 6)
+    cc = _dev(centers, 3)
+    if bb.dtype != cc.dtype or bb.shape[0] != cc.shape[0]:
+        raise ValueError("bboxes (n,6) and centers (n,3) must agree in dtype and length")
+    s = _suffix(bb.dtype)
+    cfg = config._c()
+    h = getattr(lib, f"bvh{s}_build_device")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), int(builder), _stream())
+    return Bvh(h, s)
+
+
+class DefaultBuilder:
+    """bvh::v2::DefaultBuilder<Node>::build (default_builder.h:33-62)."""
+
+    Config = Config
+    Quality = Quality
+
+    @staticmethod
+    def build(bboxes, centers, config: Config | None = None, thread_pool: ThreadPool | None = None) -> Bvh:
+        return _build(bboxes, centers, config or Config(),
+                      _Builder.DEFAULT_PARALLEL if thread_pool is not None else _Builder.DEFAULT_SERIAL)
+
+
+class BinnedSahBuilder:
+    """bvh::v2::BinnedSahBuilder<Node>::build (binned_sah_builder.h:32-38)."""
+
+    @staticmethod
+    def build(bboxes, centers, config: Config | None = None) -> Bvh:
+        return _build(bboxes, centers, config or Config(), _Builder.BINNED)
+
+
+class SweepSahBuilder:
+    """bvh::v2::SweepSahBuilder<Node>::build (sweep_sah_builder.h:30-36)."""
+
+    @staticmethod
+    def build(bboxes, centers, config: Config | None = None) -> Bvh:
+        return _build(bboxes, centers, config or Config(), _Builder.SWEEP)
+
+
+def tri_bounds(tris9):
+    """Tri::get_bbox / Tri::get_center (tri.h:24-25) for n triangles -> (bboxes (n,6), centers (n,3)) in HBM."""
+    torch = _torch()
+    t = _dev(tris9, 9)
+    s = _suffix(t.dtype)
+    bb = torch.empty((t.shape[0], 6), dtype=t.dtype, device=t.device)
+    cc = torch.empty((t.shape[0], 3), dtype=t.dtype, device=t.device)
+    _lib.check(getattr(_lib.load(), f"bvh_amd_tri_bounds{s}")(t.data_ptr(), t.shape[0], bb.data_ptr(), cc.data_ptr(), _stream()),
+               "tri_bounds")
+    return bb, cc
+
+
+def precompute_tris(tris9, perm=None):
+    """PrecomputedTri (tri.h:35-37) of tris[perm[i]] -> (n,12) {p0,e1,e2,n} in HBM."""
+    torch = _torch()
+    t = _dev(tris9, 9)
+    s = _suffix(t.dtype)
+    if perm is not None:
+        perm = _dev(perm) if not isinstance(perm, np.ndarray) else _dev(perm.astype(np.int32))
+        perm = perm.to(torch.int32)
+        n = perm.shape[0]
+    else:
+        n = t.shape[0]
+    out = torch.empty((n, 12), dtype=t.dtype, device=t.device)
+    _lib.check(getattr(_lib.load(), f"bvh_amd_precompute_tris{s}")(t.data_ptr(), perm.data_ptr() if perm is not None else None,
+                                                                    n, out.data_ptr(), _stream()), "precompute_tris")
+    return out
+
+
+def sphere_bounds(sph4):
+    torch = _torch()
+    t = _dev(sph4, 4)
+    s = _suffix(t.dtype)
+    bb = torch.empty((t.shape[0], 6), dtype=t.dtype, device=t.device)
+    cc = torch.empty((t.shape[0], 3), dtype=t.dtype, device=t.device)
+    _lib.check(getattr(_lib.load(), f"bvh_amd_sphere_bounds{s}")(t.data_ptr(), t.shape[0], bb.data_ptr(), cc.data_ptr(), _stream()),
+               "sphere_bounds")
+    return bb, cc
+
+
+def gather(records, perm):
+    """out[i] = records[perm[i]] on the device (prim permutation, test/benchmark.cpp:221-225)."""
+    torch = _torch()
+    r = _dev(records)
+    p = _dev(perm).to(torch.int32)
+    out = torch.empty((p.shape[0],) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device)
+    stride = r.element_size() * int(np.prod(r.shape[1:]))
+    _lib.check(_lib.load().bvh_amd_gather(r.data_ptr(), p.data_ptr(), p.shape[0], stride, out.data_ptr(), _stream()), "gather")
+    return out
+
+
+def intersect(bvh: Bvh, prims, rays, any_hit: bool = False, robust: bool = False, leaf: str = "tri",
+              counters: bool = False, out=None, sort_rays: bool = False):
+    """Batched Bvh::intersect<IsAnyHit, IsRobust> (bvh.h:160-182) with the closest/any-hit leaf loop of
+    test/benchmark.cpp:281-291. prims are in BVH order. Returns a torch tensor of hit records
+    ((n,4) of the BVH scalar type; view with hits_to_numpy) and, optionally, (pairs, tests, leaves)."""
+    torch = _torch()
+    lib = _lib.load()
+    s = bvh._s
+    dt = torch.float32 if s == "3f" else torch.float64
+    r = _dev(rays, 8)
+    p = _dev(prims)
+    if r.dtype != dt or p.dtype != dt:
+        raise TypeError("prims/rays dtype must match the BVH scalar type")
+    n = r.shape[0]
+    if out is None:
+        out = torch.empty((n, 4), dtype=dt, device=r.device)
+    cnt = torch.zeros(3, dtype=torch.int64, device=r.device) if counters else None
+    flags = (RayFlags.ANY_HIT if any_hit else 0) | (RayFlags.ROBUST if robust else 0) | (RayFlags.SORTED if sort_rays else 0)
+    fn = getattr(lib, f"bvh{s}_intersect_rays_{'tri' if leaf == 'tri' else 'sphere'}")
+    _lib.check(fn(bvh._h, p.data_ptr(), r.data_ptr(), n, int(flags), out.data_ptr(),
+                  cnt.data_ptr() if counters else None, _stream()), "intersect_rays")
+    if counters:
+        return out, cnt
+    return out
+
+
+def hits_to_numpy(hits) -> np.ndarray:
+    a = hits.detach().cpu().numpy()
+    return a.view(HITF if a.dtype == np.float32 else HITD).reshape(-1)

@@ -1,0 +1,237 @@
+// The C-ABI of libbvh_amd.so (include/bvh_amd.h). Thin: argument checks, handle ownership, host mirror
+// bookkeeping; all compute is in the HIP kernels (traverse.hip, prep.hip, build_*.hip). No CPU fallback.
+#include "common.h"
+
+#include <cstring>
+#include <memory>
+
+namespace bvh_amd {
+
+namespace {
+thread_local std::string g_error;
+}
+
+void set_error(const std::string& msg) { g_error = msg; }
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+namespace {
+
+struct ThreadPoolTag { size_t thread_count; };   // opaque `bvh_thread_pool`: only its presence matters
+
+template <typename T> struct CTypes;
+template <> struct CTypes<float>  { using Bvh = bvh3f; using Node = bvh_node3f; using BBox = bvh_bbox3f; using Vec = bvh_vec3f; using Ray = bvh_ray3f; };
+template <> struct CTypes<double> { using Bvh = bvh3d; using Node = bvh_node3d; using BBox = bvh_bbox3d; using Vec = bvh_vec3d; using Ray = bvh_ray3d; };
+
+template <typename T> BvhImpl<T>* impl(typename CTypes<T>::Bvh* b) { return reinterpret_cast<BvhImpl<T>*>(b); }
+template <typename T> const BvhImpl<T>* impl(const typename CTypes<T>::Bvh* b) { return reinterpret_cast<const BvhImpl<T>*>(b); }
+template <typename T> typename CTypes<T>::Bvh* handle(BvhImpl<T>* b) { return reinterpret_cast<typename CTypes<T>::Bvh*>(b); }
+
+bvh_build_config default_config() {               // default_builder.h:23-30, top_down_sah_builder.h:27-40
+    bvh_build_config c;
+    c.quality = BVH_BUILD_QUALITY_HIGH;
+    c.min_leaf_size = 1;
+    c.max_leaf_size = 8;
+    c.parallel_threshold = 1024;
+    return c;
+}
+
+template <typename T>
+typename CTypes<T>::Bvh* build_device(const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config* config,
+                                      bvh_amd_builder builder, void* stream)
+{
+    if (!d_bboxes || !d_centers || n == 0) { set_error("build: empty input (the reference's behaviour is undefined for 0 primitives)"); return nullptr; }
+    bvh_build_config cfg = config ? *config : default_config();
+    if (cfg.min_leaf_size < 1 || cfg.min_leaf_size > cfg.max_leaf_size || cfg.max_leaf_size > 15) {
+        set_error("build: need 1 <= min_leaf_size <= max_leaf_size <= 15 (4-bit primitive count, index.h:38)");
+        return nullptr;
+    }
+    auto b = std::make_unique<BvhImpl<T>>();
+    if (build_on_device<T>(*b, d_bboxes, d_centers, n, cfg, builder, static_cast<hipStream_t>(stream)) != BVH_AMD_OK)
+        return nullptr;
+    return handle<T>(b.release());
+}
+
+template <typename T>
+typename CTypes<T>::Bvh* build_host(bvh_thread_pool* pool, const typename CTypes<T>::BBox* bboxes,
+                                    const typename CTypes<T>::Vec* centers, size_t n, const bvh_build_config* config)
+{
+    if (!bboxes || !centers || n == 0) { set_error("build: empty input"); return nullptr; }
+    static_assert(sizeof(typename CTypes<T>::BBox) == 6 * sizeof(T) && sizeof(typename CTypes<T>::Vec) == 3 * sizeof(T));
+    T *d_bb = nullptr, *d_cc = nullptr;
+    BVH_HIP_TRY_PTR(hipMalloc(&d_bb, n * 6 * sizeof(T)));
+    hipError_t e = hipMalloc(&d_cc, n * 3 * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpy(d_bb, bboxes, n * 6 * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cc, centers, n * 3 * sizeof(T), hipMemcpyHostToDevice);
+    typename CTypes<T>::Bvh* out = nullptr;
+    if (e == hipSuccess)
+        out = build_device<T>(d_bb, d_cc, n, config, pool ? BVH_AMD_BUILDER_DEFAULT_PARALLEL : BVH_AMD_BUILDER_DEFAULT_SERIAL, nullptr);
+    else
+        set_error(std::string("build: ") + hipGetErrorString(e));
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d_bb);
+    if (d_cc) (void)hipFree(d_cc);
+    return out;
+}
+
+template <typename T>
+typename CTypes<T>::Bvh* from_nodes(const void* nodes, size_t nn, const size_t* prim_ids, size_t np) {
+    if (!nodes || nn == 0 || (!prim_ids && np)) { set_error("from_nodes: null/empty input"); return nullptr; }
+    auto b = std::make_unique<BvhImpl<T>>();
+    b->nodes.resize(nn);
+    std::memcpy(b->nodes.data(), nodes, nn * sizeof(HostNode<T>));
+    b->prim_ids.assign(prim_ids, prim_ids + np);
+    if (upload_bvh<T>(*b, nullptr) != BVH_AMD_OK) return nullptr;
+    return handle<T>(b.release());
+}
+
+// Byte stream of Bvh::serialize (bvh.h:221-229): [node_count][prim_count] in Index::Type, nodes, prim ids.
+template <typename T>
+size_t stream_size(const BvhImpl<T>& b) {
+    using I = typename IndexOf<T>::Type;
+    return 2 * sizeof(I) + b.nodes.size() * sizeof(HostNode<T>) + b.prim_ids.size() * sizeof(I);
+}
+
+template <typename T>
+size_t serialize(const BvhImpl<T>& b, void* out, size_t cap) {
+    using I = typename IndexOf<T>::Type;
+    size_t need = stream_size(b);
+    if (!out || cap < need) return need;
+    auto p = static_cast<uint8_t*>(out);
+    I hdr[2] = { static_cast<I>(b.nodes.size()), static_cast<I>(b.prim_ids.size()) };
+    std::memcpy(p, hdr, sizeof(hdr)); p += sizeof(hdr);
+    std::memcpy(p, b.nodes.data(), b.nodes.size() * sizeof(HostNode<T>)); p += b.nodes.size() * sizeof(HostNode<T>);
+    for (size_t id : b.prim_ids) { I v = static_cast<I>(id); std::memcpy(p, &v, sizeof(v)); p += sizeof(v); }
+    return need;
+}
+
+template <typename T>
+typename CTypes<T>::Bvh* deserialize(const void* bytes, size_t size) {
+    using I = typename IndexOf<T>::Type;
+    if (!bytes || size < 2 * sizeof(I)) { set_error("deserialize: truncated stream"); return nullptr; }
+    auto p = static_cast<const uint8_t*>(bytes);
+    I hdr[2];
+    std::memcpy(hdr, p, sizeof(hdr)); p += sizeof(hdr);
+    size_t nn = hdr[0], np = hdr[1];
+    if (size < 2 * sizeof(I) + nn * sizeof(HostNode<T>) + np * sizeof(I)) { set_error("deserialize: truncated stream"); return nullptr; }
+    auto b = std::make_unique<BvhImpl<T>>();
+    b->nodes.resize(nn);
+    std::memcpy(b->nodes.data(), p, nn * sizeof(HostNode<T>)); p += nn * sizeof(HostNode<T>);
+    b->prim_ids.resize(np);
+    for (size_t i = 0; i < np; ++i) { I v; std::memcpy(&v, p, sizeof(v)); p += sizeof(v); b->prim_ids[i] = static_cast<size_t>(v); }
+    if (upload_bvh<T>(*b, nullptr) != BVH_AMD_OK) return nullptr;
+    return handle<T>(b.release());
+}
+
+template <typename T>
+void save(const BvhImpl<T>& b, FILE* f) {
+    std::vector<uint8_t> buf(stream_size(b));
+    serialize(b, buf.data(), buf.size());
+    fwrite(buf.data(), 1, buf.size(), f);
+}
+
+template <typename T>
+typename CTypes<T>::Bvh* load(FILE* f) {
+    using I = typename IndexOf<T>::Type;
+    I hdr[2] = {0, 0};
+    if (fread(hdr, sizeof(I), 2, f) != 2) { set_error("load: truncated stream"); return nullptr; }
+    std::vector<uint8_t> buf(2 * sizeof(I) + size_t(hdr[0]) * sizeof(HostNode<T>) + size_t(hdr[1]) * sizeof(I));
+    std::memcpy(buf.data(), hdr, sizeof(hdr));
+    size_t rest = buf.size() - sizeof(hdr);
+    if (fread(buf.data() + sizeof(hdr), 1, rest, f) != rest) { set_error("load: truncated stream"); return nullptr; }
+    return deserialize<T>(buf.data(), buf.size());
+}
+
+template <typename T>
+int intersect(const typename CTypes<T>::Bvh* bvh, int leaf, const T* d_prims, const typename CTypes<T>::Ray* d_rays, size_t n,
+              unsigned flags, typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, void* stream)
+{
+    if (!bvh) return fail(BVH_AMD_ERR_ARG, "intersect_rays: null bvh");
+    static_assert(sizeof(typename CTypes<T>::Ray) == 8 * sizeof(T));
+    const BvhImpl<T>& b = *impl<T>(bvh);
+    int cur = -1;
+    BVH_HIP_TRY(hipGetDevice(&cur), BVH_AMD_ERR_HIP);
+    if (cur != b.device) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH lives on another device than the current one");
+    return launch_traverse<T>(b, leaf, d_prims, reinterpret_cast<const T*>(d_rays), n, flags, d_hits, d_counters,
+                              static_cast<hipStream_t>(stream));
+}
+
+} // namespace
+} // namespace bvh_amd
+
+using namespace bvh_amd;
+
+extern "C" {
+
+const char* bvh_amd_last_error(void) { return g_error.c_str(); }
+const char* bvh_amd_version(void) { return "bvh_amd 0.1 (gfx950)"; }
+const char* bvh_amd_last_kernel_name(void) { return last_kernel_name(); }
+
+int bvh_amd_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
+    return n;
+}
+
+int bvh_amd_device_name(int device, char* out, size_t cap) {
+    hipDeviceProp_t p;
+    BVH_HIP_TRY(hipGetDeviceProperties(&p, device), BVH_AMD_ERR_HIP);
+    snprintf(out, cap, "%s (%s)", p.name, p.gcnArchName);
+    return BVH_AMD_OK;
+}
+
+bvh_thread_pool* bvh_thread_pool_create(size_t thread_count) {
+    return reinterpret_cast<bvh_thread_pool*>(new ThreadPoolTag{thread_count});
+}
+void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<ThreadPoolTag*>(p); }
+
+#define BVH_AMD_IMPL(T, S)                                                                                          \
+    bvh##S* bvh##S##_build(bvh_thread_pool* pool, const bvh_bbox##S* bb, const bvh_vec##S* cc, size_t n,            \
+                           const bvh_build_config* cfg) { return build_host<T>(pool, bb, cc, n, cfg); }             \
+    bvh##S* bvh##S##_build_device(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,              \
+                                  enum bvh_amd_builder builder, void* stream) {                                     \
+        return build_device<T>(d_bb, d_cc, n, cfg, builder, stream); }                                              \
+    bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
+        return from_nodes<T>(nodes, nn, ids, np); }                                                                 \
+    void bvh##S##_destroy(bvh##S* b) { delete impl<T>(b); }                                                         \
+    void bvh##S##_save(const bvh##S* b, FILE* f) { if (b && f) save<T>(*impl<T>(b), f); }                           \
+    bvh##S* bvh##S##_load(FILE* f) { return f ? load<T>(f) : nullptr; }                                             \
+    size_t bvh##S##_serialize(const bvh##S* b, void* out, size_t cap) { return b ? serialize<T>(*impl<T>(b), out, cap) : 0; } \
+    bvh##S* bvh##S##_deserialize(const void* bytes, size_t size) { return deserialize<T>(bytes, size); }            \
+    bvh_node##S* bvh##S##_get_node(bvh##S* b, size_t i) { return reinterpret_cast<bvh_node##S*>(&impl<T>(b)->nodes[i]); } \
+    size_t bvh##S##_get_prim_id(const bvh##S* b, size_t i) { return impl<T>(b)->prim_ids[i]; }                      \
+    size_t bvh##S##_get_prim_count(const bvh##S* b) { return impl<T>(b)->prim_ids.size(); }                         \
+    size_t bvh##S##_get_node_count(const bvh##S* b) { return impl<T>(b)->nodes.size(); }                            \
+    bool bvh_node##S##_is_leaf(const bvh_node##S* n) { return (reinterpret_cast<const HostNode<T>*>(n)->index & kCountMask) != 0; } \
+    size_t bvh_node##S##_get_prim_count(const bvh_node##S* n) { return reinterpret_cast<const HostNode<T>*>(n)->index & kCountMask; } \
+    size_t bvh_node##S##_get_first_id(const bvh_node##S* n) { return reinterpret_cast<const HostNode<T>*>(n)->index >> kCountBits; } \
+    bvh_bbox##S bvh_node##S##_get_bbox(const bvh_node##S* n) {                                                      \
+        auto h = reinterpret_cast<const HostNode<T>*>(n);                                                           \
+        bvh_bbox##S r; r.min.x = h->bounds[0]; r.max.x = h->bounds[1]; r.min.y = h->bounds[2]; r.max.y = h->bounds[3]; \
+        r.min.z = h->bounds[4]; r.max.z = h->bounds[5]; return r; }                                                 \
+    void bvh##S##_copy_nodes(const bvh##S* b, void* out) {                                                          \
+        std::memcpy(out, impl<T>(b)->nodes.data(), impl<T>(b)->nodes.size() * sizeof(HostNode<T>)); }               \
+    void bvh##S##_copy_prim_ids(const bvh##S* b, size_t* out) {                                                     \
+        std::memcpy(out, impl<T>(b)->prim_ids.data(), impl<T>(b)->prim_ids.size() * sizeof(size_t)); }              \
+    const uint32_t* bvh##S##_device_prim_ids(const bvh##S* b) { return impl<T>(b)->d_prim_ids; }                    \
+    int bvh_amd_tri_bounds##S(const T* t, size_t n, T* bb, T* cc, void* s) {                                        \
+        return launch_tri_bounds<T>(t, n, bb, cc, static_cast<hipStream_t>(s)); }                                   \
+    int bvh_amd_precompute_tris##S(const T* t, const uint32_t* perm, size_t n, T* out, void* s) {                   \
+        return launch_precompute_tris<T>(t, perm, n, out, static_cast<hipStream_t>(s)); }                           \
+    int bvh_amd_sphere_bounds##S(const T* sp, size_t n, T* bb, T* cc, void* s) {                                    \
+        return launch_sphere_bounds<T>(sp, n, bb, cc, static_cast<hipStream_t>(s)); }                               \
+    int bvh##S##_intersect_rays_tri(const bvh##S* b, const T* prims, const bvh_ray##S* rays, size_t n, unsigned flags, \
+                                    bvh_hit##S* hits, bvh_amd_counters* cnt, void* s) {                             \
+        return intersect<T>(b, LEAF_TRIANGLE, prims, rays, n, flags, hits, cnt, s); }                               \
+    int bvh##S##_intersect_rays_sphere(const bvh##S* b, const T* prims, const bvh_ray##S* rays, size_t n, unsigned flags, \
+                                       bvh_hit##S* hits, bvh_amd_counters* cnt, void* s) {                          \
+        return intersect<T>(b, LEAF_SPHERE, prims, rays, n, flags, hits, cnt, s); }
+
+BVH_AMD_IMPL(float, 3f)
+BVH_AMD_IMPL(double, 3d)
+
+int bvh_amd_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t stride, void* d_out, void* stream) {
+    return launch_gather(d_in, d_perm, n, stride, d_out, static_cast<hipStream_t>(stream));
+}
+
+} // extern "C"

@@ -1,0 +1,115 @@
+// Internal definitions shared by the host layer and the HIP kernels of libbvh_amd.so.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts are assumed throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/bvh_amd.h"
+
+namespace bvh_amd {
+
+constexpr unsigned kCountBits = 4;            // reference node.h:22 (PrimCountBits)
+constexpr uint32_t kCountMask = 15u;
+constexpr int kWave = 64;
+
+// ---- host-visible node in the reference's layout (node.h:31-37, index.h:74-81) ----------------
+template <typename T> struct IndexOf;
+template <> struct IndexOf<float>  { using Type = uint32_t; };
+template <> struct IndexOf<double> { using Type = uint64_t; };
+
+template <typename T>
+struct HostNode {
+    T bounds[6];                               // {minx,maxx,miny,maxy,minz,maxz}
+    typename IndexOf<T>::Type index;           // first_id << 4 | prim_count
+};
+static_assert(sizeof(HostNode<float>) == 28 && sizeof(HostNode<double>) == 56);
+
+// ---- device traversal record: both children of one inner node in one aligned line ------------
+// The reference fetches nodes[first_id] and nodes[first_id + 1] (bvh.h:133-134), 2 x 28 B that start at
+// byte 28 * odd and straddle cache lines. On the device the sibling pair p = (first_id - 1) / 2 is one
+// 64-byte (float) / 128-byte (double) record; child indices are narrowed to 32 bits (checked on upload).
+template <typename T> struct PairNode;
+template <> struct alignas(64) PairNode<float> {
+    float lb[6], rb[6];
+    uint32_t li, ri;
+    uint32_t pad[2];
+};
+template <> struct alignas(128) PairNode<double> {
+    double lb[6], rb[6];
+    uint32_t li, ri;
+    uint32_t pad[6];
+};
+static_assert(sizeof(PairNode<float>) == 64 && sizeof(PairNode<double>) == 128);
+
+template <typename T> struct HitOf;
+template <> struct HitOf<float>  { using Type = bvh_hit3f; };
+template <> struct HitOf<double> { using Type = bvh_hit3d; };
+
+// ---- error plumbing --------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define BVH_HIP_TRY(expr, code)                                                                     \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return ::bvh_amd::fail((code), std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+#define BVH_HIP_TRY_PTR(expr)                                                                       \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            ::bvh_amd::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                \
+            return nullptr;                                                                         \
+        }                                                                                           \
+    } while (0)
+
+enum : int { BVH_AMD_OK = 0, BVH_AMD_ERR_HIP = -1, BVH_AMD_ERR_ARG = -2, BVH_AMD_ERR_UNSUPPORTED = -3,
+             BVH_AMD_ERR_OVERFLOW = -4 };
+
+// ---- the object behind `struct bvh3f` / `struct bvh3d` ---------------------------------------------
+template <typename T>
+struct BvhImpl {
+    // host mirror, reference layout (authoritative for the accessor API)
+    std::vector<HostNode<T>> nodes;
+    std::vector<size_t> prim_ids;
+    // device copy
+    int device = -1;
+    PairNode<T>* d_pairs = nullptr;            // (node_count - 1) / 2 records
+    size_t pair_count = 0;
+    uint32_t* d_prim_ids = nullptr;            // prim_count
+    uint32_t root_index = 0;                   // nodes[0].index narrowed to 32 bits
+    // per-object scratch for batch launches
+    unsigned long long* d_work = nullptr;      // [0] ray counter, [1] status word
+    ~BvhImpl();
+};
+
+// upload.hip
+template <typename T> int upload_bvh(BvhImpl<T>& b, hipStream_t stream);
+
+// traverse.hip
+template <typename T>
+int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
+                    typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream);
+const char* last_kernel_name();
+
+// prep.hip
+template <typename T> int launch_tri_bounds(const T* d_tris9, size_t n, T* d_bb, T* d_cc, hipStream_t s);
+template <typename T> int launch_precompute_tris(const T* d_tris9, const uint32_t* d_perm, size_t n, T* d_out, hipStream_t s);
+template <typename T> int launch_sphere_bounds(const T* d_sph4, size_t n, T* d_bb, T* d_cc, hipStream_t s);
+int launch_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t stride, void* d_out, hipStream_t s);
+
+// build_*.hip
+template <typename T>
+int build_on_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
+                    bvh_amd_builder builder, hipStream_t stream);
+
+enum { LEAF_TRIANGLE = 0, LEAF_SPHERE = 1 };
+
+} // namespace bvh_amd

@@ -1,0 +1,378 @@
+// K11 — batched single-ray traversal for gfx950.
+//
+// Reproduces, per ray, Bvh<Node>::intersect<IsAnyHit, IsRobust> (reference bvh.h:160-182) driving
+// traverse_top_down (bvh.h:125-157) with the leaf lambda of test/benchmark.cpp:281-291 over permuted
+// primitives: identical visit order, identical arithmetic (one rounding per operation, fma only where the
+// reference says fast_mul_add: node.h:85-86), hence identical hits.
+//
+// MI355X mapping:
+//   * one ray per lane, persistent wavefronts: a wave keeps 64 ray slots busy and refills finished slots
+//     from a global ticket counter with one wave-aggregated atomic (ballot + popcount), so incoherent rays of
+//     very different trip counts do not idle the SIMD until the slowest lane finishes;
+//   * while-while loop: all lanes descend inner nodes until every active lane holds a leaf, then leaves;
+//   * the traversal stack (bvh.h:128-131, SmallStack<Index,64>) lives in LDS, laid out [depth][lane] so a
+//     push/pop is conflict-free (lane -> bank), with the rarely used entries 24..63 in per-lane scratch;
+//   * both children of a node come from ONE 64-byte (128-byte for double) aligned record (common.h).
+//
+// Compiled with -ffp-contract=off; division and sqrt are the correctly rounded forms.
+
+#include "common.h"
+
+namespace bvh_amd {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLdsDepth = 24;
+constexpr int kSpillDepth = 40;               // 24 + 40 = 64 = the reference's SmallStack capacity
+constexpr int kRefillThreshold = 16;          // refill when at least this many lanes of the wave are idle
+
+thread_local const char* g_last_kernel = "";
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+    static constexpr float kMax = 3.402823466e+38f, kEps = 1.1920928955078125e-07f;
+    __device__ static bool finite(float x) { return (__float_as_uint(x) & 0x7F800000u) != 0x7F800000u; }
+    __device__ static float bump2(float x) { return __uint_as_float(__float_as_uint(x) + 2u); }
+    __device__ static bool sign(float x) { return (__float_as_uint(x) >> 31) != 0; }
+    __device__ static float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    __device__ static float sqrt_(float x) { return __builtin_sqrtf(x); }
+    __device__ static float abs_(float x) { return __builtin_fabsf(x); }
+    __device__ static float copysign_(float a, float b) { return __builtin_copysignf(a, b); }
+};
+template <> struct Num<double> {
+    static constexpr double kMax = 1.7976931348623157e+308, kEps = 2.220446049250313e-16;
+    __device__ static bool finite(double x) {
+        return (static_cast<uint32_t>(__double_as_longlong(x) >> 32) & 0x7FF00000u) != 0x7FF00000u;
+    }
+    __device__ static double bump2(double x) { return __longlong_as_double(__double_as_longlong(x) + 2ll); }
+    __device__ static bool sign(double x) { return (__double_as_longlong(x) >> 63) != 0; }
+    __device__ static double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    __device__ static double sqrt_(double x) { return __builtin_sqrt(x); }
+    __device__ static double abs_(double x) { return __builtin_fabs(x); }
+    __device__ static double copysign_(double a, double b) { return __builtin_copysign(a, b); }
+};
+
+// utils.h:41-43 — must stay compare+select: the second operand wins on NaN and on equality.
+template <typename T> __device__ inline T pick_min(T a, T b) { return a < b ? a : b; }
+template <typename T> __device__ inline T pick_max(T a, T b) { return a > b ? a : b; }
+
+template <typename T> __device__ inline T dot3(T a0, T a1, T a2, T b0, T b1, T b2) {   // vec.h:98-100
+    return ((T(0) + a0 * b0) + a1 * b1) + a2 * b2;
+}
+
+template <typename T>
+struct TraceArgs {
+    const PairNode<T>* pairs;
+    const T* prims;
+    const T* rays;
+    typename HitOf<T>::Type* hits;
+    unsigned long long n;
+    unsigned long long* work;                  // [0] next ray ticket, [1] status (stack overflow)
+    bvh_amd_counters* counters;
+    uint32_t root_index;
+};
+
+__device__ inline void load_pair(const PairNode<float>* p, float (&lb)[6], float (&rb)[6], uint32_t& li, uint32_t& ri) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float4 a = q[0], b = q[1], c = q[2];
+    uint2 d = reinterpret_cast<const uint2*>(p)[6];
+    lb[0] = a.x; lb[1] = a.y; lb[2] = a.z; lb[3] = a.w; lb[4] = b.x; lb[5] = b.y;
+    rb[0] = b.z; rb[1] = b.w; rb[2] = c.x; rb[3] = c.y; rb[4] = c.z; rb[5] = c.w;
+    li = d.x; ri = d.y;
+}
+__device__ inline void load_pair(const PairNode<double>* p, double (&lb)[6], double (&rb)[6], uint32_t& li, uint32_t& ri) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { double2 v = q[i]; lb[2 * i] = v.x; lb[2 * i + 1] = v.y; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { double2 v = q[3 + i]; rb[2 * i] = v.x; rb[2 * i + 1] = v.y; }
+    uint2 d = reinterpret_cast<const uint2*>(p)[12];
+    li = d.x; ri = d.y;
+}
+
+__device__ inline void load_prim12(const float* p, float (&v)[12]) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float4 a = q[0], b = q[1], c = q[2];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+}
+__device__ inline void load_prim12(const double* p, double (&v)[12]) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+}
+__device__ inline void load_prim4(const float* p, float (&v)[4]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ inline void load_prim4(const double* p, double (&v)[4]) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+    double2 a = q[0], b = q[1];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+__device__ inline void load_ray(const float* p, float (&v)[8]) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float4 a = q[0], b = q[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ inline void load_ray(const double* p, double (&v)[8]) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+}
+__device__ inline void store_hit(bvh_hit3f* out, uint32_t prim, float t, float u, float v) {
+    *reinterpret_cast<float4*>(out) = make_float4(__uint_as_float(prim), t, u, v);
+}
+__device__ inline void store_hit(bvh_hit3d* out, uint32_t prim, double t, double u, double v) {
+    double2* q = reinterpret_cast<double2*>(out);
+    q[0] = make_double2(__longlong_as_double(static_cast<long long>(prim)), t);
+    q[1] = make_double2(u, v);
+}
+
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
+__global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
+    __shared__ uint32_t lds_stack[kLdsDepth * kBlock];
+    uint32_t spill[kSpillDepth];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const uint64_t lanes_below = (uint64_t{1} << lane) - 1;
+
+    // per-slot ray state
+    bool have = false, done = false, drained = false, overflow = false;
+    unsigned long long ray_id = 0;
+    T org[3], dir[3], inv[3], aux[3];            // aux = inv_dir_pad (robust) or inv_org (fast)
+    T tmin = 0, tmax = 0;
+    uint32_t oct[3] = {0, 0, 0};
+    uint32_t top = 0, sp = 0;
+    uint32_t hit_prim = BVH_AMD_INVALID;
+    T hit_t = 0, hit_u = 0, hit_v = 0;
+    unsigned long long n_pairs = 0, n_tests = 0, n_leaves = 0;
+
+    auto push = [&](uint32_t v) {
+        if (sp < kLdsDepth) lds_stack[sp * kBlock + tid] = v;
+        else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = v;
+        else overflow = true;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        if (sp < kLdsDepth) return lds_stack[sp * kBlock + tid];
+        if (sp < kLdsDepth + kSpillDepth) return spill[sp - kLdsDepth];
+        return 0u;
+    };
+
+    for (;;) {
+        // ---- refill idle slots with new rays (one atomic per wave) --------------------------------
+        const uint64_t idle = __ballot(!have);
+        const int n_idle = __popcll(idle);
+        if (!drained && (n_idle >= kRefillThreshold || n_idle == kWave)) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(a.work, static_cast<unsigned long long>(n_idle));
+            base = __shfl(base, 0);
+            if (base + n_idle >= a.n) drained = true;
+            if (!have) {
+                const unsigned long long my = base + __popcll(idle & lanes_below);
+                if (my < a.n) {
+                    T r[8];
+                    load_ray(a.rays + 8 * my, r);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {                       // bvh.h:162-165, ray.h:29-48
+                        org[k] = r[k]; dir[k] = r[3 + k];
+                        T d = dir[k];
+                        T iv = Robust ? T(1) / d
+                                      : (Num<T>::abs_(d) <= Num<T>::kEps ? Num<T>::copysign_(Num<T>::kMax, d) : T(1) / d);
+                        inv[k] = iv;
+                        aux[k] = Robust ? (Num<T>::finite(iv) ? Num<T>::bump2(iv) : iv) : (-iv) * org[k];
+                        oct[k] = Num<T>::sign(d) ? 1u : 0u;
+                    }
+                    tmin = r[6]; tmax = r[7];
+                    ray_id = my;
+                    have = true; done = false;
+                    sp = 0;
+                    top = a.root_index;                                 // bvh.h:128-131: push(start); pop()
+                    hit_prim = BVH_AMD_INVALID; hit_t = tmax; hit_u = 0; hit_v = 0;
+                }
+            }
+        }
+        if (__ballot(have) == 0) break;
+
+        // ---- inner nodes (bvh.h:132-150) ------------------------------------------------------------
+        while (have && !done && (top & kCountMask) == 0) {
+            T lb[6], rb[6];
+            uint32_t li, ri;
+            load_pair(a.pairs + (top >> (kCountBits + 1)), lb, rb, li, ri);
+            if (Stats) ++n_pairs;
+            T l0 = tmin, l1 = tmax, r0 = tmin, r1 = tmax;               // node.h:105-117
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T ln = oct[k] ? lb[2 * k + 1] : lb[2 * k], lf = oct[k] ? lb[2 * k] : lb[2 * k + 1];
+                const T rn = oct[k] ? rb[2 * k + 1] : rb[2 * k], rf = oct[k] ? rb[2 * k] : rb[2 * k + 1];
+                T la, lz, ra, rz;
+                if (Robust) {                                           // node.h:74-75
+                    la = (ln - org[k]) * inv[k]; lz = (lf - org[k]) * aux[k];
+                    ra = (rn - org[k]) * inv[k]; rz = (rf - org[k]) * aux[k];
+                } else {                                                // node.h:85-86
+                    la = Num<T>::fma_(ln, inv[k], aux[k]); lz = Num<T>::fma_(lf, inv[k], aux[k]);
+                    ra = Num<T>::fma_(rn, inv[k], aux[k]); rz = Num<T>::fma_(rf, inv[k], aux[k]);
+                }
+                l0 = pick_max(la, l0); l1 = pick_min(lz, l1);
+                r0 = pick_max(ra, r0); r1 = pick_min(rz, r1);
+            }
+            const bool hl = l0 <= l1, hr = r0 <= r1;                    // bvh.h:177-180
+            if (hl) {
+                uint32_t near_i = li;
+                if (hr) {
+                    uint32_t far_i = ri;
+                    if (!Any && l0 > r0) { near_i = ri; far_i = li; }
+                    push(far_i);
+                }
+                top = near_i;
+            } else if (hr) {
+                top = ri;
+            } else if (sp == 0) {
+                done = true;
+            } else {
+                top = pop();
+            }
+        }
+
+        // ---- leaf (bvh.h:152-155 + test/benchmark.cpp:281-291) ------------------------------------------
+        if (have && !done) {
+            const uint32_t first = top >> kCountBits, count = top & kCountMask;
+            if (Stats) ++n_leaves;
+            for (uint32_t i = first; i < first + count; ++i) {
+                if (Stats) ++n_tests;
+                if (Leaf == LEAF_TRIANGLE) {                            // tri.h:56-74
+                    T p[12];
+                    load_prim12(a.prims + 12ull * i, p);
+                    const T c0 = p[0] - org[0], c1 = p[1] - org[1], c2 = p[2] - org[2];
+                    const T rx = dir[1] * c2 - dir[2] * c1, ry = dir[2] * c0 - dir[0] * c2, rz = dir[0] * c1 - dir[1] * c0;
+                    const T inv_det = T(1) / dot3(p[9], p[10], p[11], dir[0], dir[1], dir[2]);
+                    const T u = dot3(rx, ry, rz, p[6], p[7], p[8]) * inv_det;
+                    const T v = dot3(rx, ry, rz, p[3], p[4], p[5]) * inv_det;
+                    const T w = T(1) - u - v;
+                    const T tol = -Num<T>::kEps;
+                    if (u >= tol && v >= tol && w >= tol) {
+                        const T t = dot3(p[9], p[10], p[11], c0, c1, c2) * inv_det;
+                        if (t >= tmin && t <= tmax) { tmax = t; hit_t = t; hit_u = u; hit_v = v; hit_prim = i; }
+                    }
+                } else {                                                // sphere.h:32-49
+                    T s[4];
+                    load_prim4(a.prims + 4ull * i, s);
+                    const T o0 = org[0] - s[0], o1 = org[1] - s[1], o2 = org[2] - s[2];
+                    const T qa = dot3(dir[0], dir[1], dir[2], dir[0], dir[1], dir[2]);
+                    const T qb = T(2) * dot3(dir[0], dir[1], dir[2], o0, o1, o2);
+                    const T qc = dot3(o0, o1, o2, o0, o1, o2) - s[3] * s[3];
+                    const T delta = qb * qb - T(4) * qa * qc;
+                    if (delta >= 0) {
+                        const T iv = -T(0.5) / qa;
+                        const T root = Num<T>::sqrt_(delta);
+                        const T t0 = pick_max((qb + root) * iv, tmin);
+                        const T t1 = pick_min((qb - root) * iv, tmax);
+                        if (t0 <= t1) { tmax = t0; hit_t = t0; hit_u = t1; hit_v = 0; hit_prim = i; }
+                    }
+                }
+            }
+            if (Any && hit_prim != BVH_AMD_INVALID) done = true;
+            else if (sp == 0) done = true;
+            else top = pop();
+        }
+
+        // ---- retire finished rays --------------------------------------------------------------------
+        if (have && done) {
+            store_hit(a.hits + ray_id, hit_prim, hit_t, hit_u, hit_v);
+            have = false;
+        }
+    }
+
+    if (overflow) atomicOr(a.work + 1, 1ull);
+    if (Stats) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            n_pairs += __shfl_down(n_pairs, off);
+            n_tests += __shfl_down(n_tests, off);
+            n_leaves += __shfl_down(n_leaves, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.counters->node_pairs, n_pairs);
+            atomicAdd(&a.counters->prim_tests, n_tests);
+            atomicAdd(&a.counters->leaves, n_leaves);
+        }
+    }
+}
+
+struct Grid { int blocks = 0; };
+
+template <typename K>
+int persistent_grid(K kernel, int device, Grid& g) {
+    int per_cu = 0, cus = 0;
+    BVH_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device), BVH_AMD_ERR_HIP);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    g.blocks = per_cu * cus;
+    return BVH_AMD_OK;
+}
+
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
+int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
+    static thread_local int cached_blocks[16] = {0};
+    auto kernel = trace_kernel<T, Any, Robust, Leaf, Stats>;
+    int& blocks = cached_blocks[b.device & 15];
+    if (blocks == 0) {
+        Grid g;
+        int rc = persistent_grid(kernel, b.device, g);
+        if (rc) return rc;
+        blocks = g.blocks;
+    }
+    unsigned long long need = (args.n + kBlock - 1) / kBlock;
+    int grid = static_cast<int>(need < static_cast<unsigned long long>(blocks) ? need : blocks);
+    if (grid < 1) grid = 1;
+    g_last_kernel = name;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args);
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
+}
+
+#define BVH_VARIANT(T, ANY, ROB, LEAF, STATS) \
+    launch_variant<T, ANY, ROB, LEAF, STATS>(b, args, stream, "trace_kernel<" #T "," #ANY "," #ROB "," #LEAF "," #STATS ">")
+
+template <typename T, int Leaf>
+int dispatch(const BvhImpl<T>& b, const TraceArgs<T>& args, unsigned flags, bool stats, hipStream_t stream) {
+    const bool any = flags & BVH_AMD_RAY_ANY_HIT, rob = flags & BVH_AMD_RAY_ROBUST;
+    if (stats) {
+        if (any) return rob ? BVH_VARIANT(T, true, true, Leaf, true) : BVH_VARIANT(T, true, false, Leaf, true);
+        return rob ? BVH_VARIANT(T, false, true, Leaf, true) : BVH_VARIANT(T, false, false, Leaf, true);
+    }
+    if (any) return rob ? BVH_VARIANT(T, true, true, Leaf, false) : BVH_VARIANT(T, true, false, Leaf, false);
+    return rob ? BVH_VARIANT(T, false, true, Leaf, false) : BVH_VARIANT(T, false, false, Leaf, false);
+}
+
+} // namespace
+
+const char* last_kernel_name() { return g_last_kernel; }
+
+template <typename T>
+int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
+                    typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream)
+{
+    if (n == 0) return BVH_AMD_OK;
+    if (!d_prims || !d_rays || !d_hits) return fail(BVH_AMD_ERR_ARG, "intersect_rays: null device pointer");
+    if (b.nodes.empty() || !b.d_work) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device copy");
+    if (b.pair_count && !b.d_pairs) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device nodes");
+    BVH_HIP_TRY(hipMemsetAsync(b.d_work, 0, 2 * sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
+    if (d_counters) BVH_HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream), BVH_AMD_ERR_HIP);
+    TraceArgs<T> args;
+    args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
+    args.n = n; args.work = b.d_work; args.counters = d_counters; args.root_index = b.root_index;
+    if (leaf_kind == LEAF_TRIANGLE) return dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream);
+    return dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream);
+}
+
+template int launch_traverse<float>(const BvhImpl<float>&, int, const float*, const float*, size_t, unsigned,
+                                    bvh_hit3f*, bvh_amd_counters*, hipStream_t);
+template int launch_traverse<double>(const BvhImpl<double>&, int, const double*, const double*, size_t, unsigned,
+                                     bvh_hit3d*, bvh_amd_counters*, hipStream_t);
+
+} // namespace bvh_amd

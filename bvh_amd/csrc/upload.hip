@@ -1,0 +1,91 @@
+// Device copy of a reference-layout BVH: sibling pairs re-laid out as aligned PairNode records.
+#include "common.h"
+
+namespace bvh_amd {
+
+namespace {
+
+// nodes: reference layout (28/56 B per node, node.h:31-37). Pair p holds nodes[2p+1], nodes[2p+2]
+// (children are always allocated as adjacent pairs after the root, top_down_sah_builder.h:91-94, and the
+// reinsertion optimizer keeps siblings adjacent, reinsertion_optimizer.h:190-213).
+template <typename T>
+__global__ void __launch_bounds__(256) relayout_pairs(const HostNode<T>* nodes, size_t pair_count, PairNode<T>* out) {
+    size_t p = blockIdx.x * size_t{256} + threadIdx.x;
+    if (p >= pair_count) return;
+    const HostNode<T>& l = nodes[2 * p + 1];
+    const HostNode<T>& r = nodes[2 * p + 2];
+    PairNode<T> rec;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { rec.lb[k] = l.bounds[k]; rec.rb[k] = r.bounds[k]; }
+    rec.li = static_cast<uint32_t>(l.index);
+    rec.ri = static_cast<uint32_t>(r.index);
+#pragma unroll
+    for (size_t k = 0; k < sizeof(rec.pad) / 4; ++k) rec.pad[k] = 0;
+    out[p] = rec;
+}
+
+} // namespace
+
+template <typename T>
+BvhImpl<T>::~BvhImpl() {
+    if (device >= 0) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        if (d_pairs) (void)hipFree(d_pairs);
+        if (d_prim_ids) (void)hipFree(d_prim_ids);
+        if (d_work) (void)hipFree(d_work);
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    }
+}
+
+template <typename T>
+int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream) {
+    b.pair_count = (b.nodes.size() - 1) / 2;
+    if (b.d_pairs) { (void)hipFree(b.d_pairs); b.d_pairs = nullptr; }
+    if (b.pair_count) {
+        BVH_HIP_TRY(hipMalloc(&b.d_pairs, b.pair_count * sizeof(PairNode<T>)), BVH_AMD_ERR_HIP);
+        unsigned grid = static_cast<unsigned>((b.pair_count + 255) / 256);
+        hipLaunchKernelGGL(relayout_pairs<T>, dim3(grid), dim3(256), 0, stream, d_nodes, b.pair_count, b.d_pairs);
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    }
+    return BVH_AMD_OK;
+}
+
+// Uploads the host mirror (b.nodes, b.prim_ids) to the current device.
+template <typename T>
+int upload_bvh(BvhImpl<T>& b, hipStream_t stream) {
+    if (b.nodes.empty()) return fail(BVH_AMD_ERR_ARG, "upload: empty BVH");
+    if (b.nodes.size() % 2 == 0) return fail(BVH_AMD_ERR_ARG, "upload: node count must be odd (root + sibling pairs)");
+    if (b.nodes.size() >= (size_t{1} << 28) || b.prim_ids.size() >= (size_t{1} << 28))
+        return fail(BVH_AMD_ERR_UNSUPPORTED, "upload: more than 2^28 nodes/primitives (32-bit device indices)");
+    BVH_HIP_TRY(hipGetDevice(&b.device), BVH_AMD_ERR_HIP);
+    if (!b.d_work) BVH_HIP_TRY(hipMalloc(&b.d_work, 2 * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
+    b.root_index = static_cast<uint32_t>(b.nodes[0].index);
+
+    HostNode<T>* d_nodes = nullptr;
+    BVH_HIP_TRY(hipMalloc(&d_nodes, b.nodes.size() * sizeof(HostNode<T>)), BVH_AMD_ERR_HIP);
+    hipError_t e = hipMemcpyAsync(d_nodes, b.nodes.data(), b.nodes.size() * sizeof(HostNode<T>), hipMemcpyHostToDevice, stream);
+    int rc = e == hipSuccess ? relayout_on_device(b, d_nodes, stream) : fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
+    if (rc == BVH_AMD_OK) {
+        std::vector<uint32_t> ids(b.prim_ids.size());
+        for (size_t i = 0; i < ids.size(); ++i) ids[i] = static_cast<uint32_t>(b.prim_ids[i]);
+        if (b.d_prim_ids) { (void)hipFree(b.d_prim_ids); b.d_prim_ids = nullptr; }
+        e = hipMalloc(&b.d_prim_ids, std::max<size_t>(ids.size(), 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(b.d_prim_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // `ids` and the staging copy die here
+        if (e != hipSuccess) rc = fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(d_nodes);
+    return rc;
+}
+
+template struct BvhImpl<float>;
+template struct BvhImpl<double>;
+template int upload_bvh<float>(BvhImpl<float>&, hipStream_t);
+template int upload_bvh<double>(BvhImpl<double>&, hipStream_t);
+template int relayout_on_device<float>(BvhImpl<float>&, const HostNode<float>*, hipStream_t);
+template int relayout_on_device<double>(BvhImpl<double>&, const HostNode<double>*, hipStream_t);
+
+} // namespace bvh_amd

@@ -1,0 +1,192 @@
+/* bvh_amd — MI355X-native BVH construction and traversal behind madmann91/bvh's C bindings.
+ *
+ * This header is the C-ABI boundary of libbvh_amd.so. It has two parts:
+ *
+ *  (1) the reference's own C API (reference src/bvh/v2/c_api/bvh.h), re-declared here with the same
+ *      names, argument meaning and ownership rules so that code written against libbvh_c.so links
+ *      against libbvh_amd.so unchanged. Each declaration cites the reference line it replaces.
+ *      `struct bvh3f` etc. stay opaque; ours additionally owns the device-resident copy.
+ *
+ *  (2) additive, callback-free batch entry points (`*_device`, `*_rays_*`). The reference's
+ *      per-ray `bvhXX_intersect_ray(bvh, ray, callback)` (c_api/bvh.h:277-295) takes a host function
+ *      pointer per leaf and therefore cannot run on a GPU; the batch family is what a maintainer binds
+ *      for the hot path (INTEGRATION.md shows the binding). Buffers named d_* are DEVICE pointers
+ *      (HBM of the current HIP device); all others are host pointers. `stream` is a hipStream_t
+ *      passed as void* (NULL = the default stream); batch calls are asynchronous on it.
+ *
+ * Error behaviour: the reference reports no errors at all. Functions here that
+ * return int return 0 on success and a negative code on failure; pointer-returning functions return
+ * NULL on failure; `bvh_amd_last_error()` gives the thread's last message. There is NO CPU fallback:
+ * if no MI355X/HIP device is usable the calls fail.
+ */
+#ifndef BVH_AMD_H
+#define BVH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVH_AMD_API __attribute__((visibility("default")))
+
+#define BVH_ROOT_INDEX 0                     /* c_api/bvh.h:32 */
+#define BVH_INVALID_PRIM_ID SIZE_MAX         /* c_api/bvh.h:33 */
+
+/* ---- types shared with the reference (c_api/bvh.h:35-83) ---------------------------------- */
+struct bvh3f;
+struct bvh3d;
+struct bvh_node3f;
+struct bvh_node3d;
+struct bvh_thread_pool;
+
+enum bvh_build_quality { BVH_BUILD_QUALITY_LOW, BVH_BUILD_QUALITY_MEDIUM, BVH_BUILD_QUALITY_HIGH };
+
+struct bvh_build_config {                    /* c_api/bvh.h:53-58 */
+    enum bvh_build_quality quality;
+    size_t min_leaf_size;
+    size_t max_leaf_size;
+    size_t parallel_threshold;
+};
+
+struct bvh_vec3f { float x, y, z; };
+struct bvh_vec3d { double x, y, z; };
+struct bvh_bbox3f { struct bvh_vec3f min, max; };
+struct bvh_bbox3d { struct bvh_vec3d min, max; };
+struct bvh_ray3f { struct bvh_vec3f org, dir; float tmin, tmax; };
+struct bvh_ray3d { struct bvh_vec3d org, dir; double tmin, tmax; };
+
+/* ---- additive types --------------------------------------------------------------------------- */
+
+/* One record per ray. prim = BVH-order primitive index (the `i` the reference's leaf callback
+ * receives, bvh.h:152; original id = bvhXX_get_prim_id(bvh, prim)), or BVH_AMD_INVALID on a miss, in
+ * which case t = the ray's input tmax. Triangles: (t,u,v) of PrecomputedTri::intersect (tri.h:56-74).
+ * Spheres: t = t0, u = t1 of Sphere::intersect (sphere.h:32-49), v = 0. */
+#define BVH_AMD_INVALID 0xFFFFFFFFu
+struct bvh_hit3f { uint32_t prim; float t, u, v; };
+struct bvh_hit3d { uint32_t prim; uint32_t pad; double t, u, v; };
+
+/* Traversal statistics (the reference's optional InnerFn/leaf counters, test/benchmark.cpp:258-296).
+ * Sums over the batch: inner-node pair visits, primitive tests, leaf visits. */
+struct bvh_amd_counters { unsigned long long node_pairs, prim_tests, leaves; };
+
+enum bvh_amd_ray_flags {
+    BVH_AMD_RAY_ANY_HIT = 1u,  /* Bvh::intersect<IsAnyHit = true>: no near/far reordering, stop at first hit */
+    BVH_AMD_RAY_ROBUST  = 2u,  /* Bvh::intersect<IsRobust = true>: Ize's robust slab test (node.h:68-77)      */
+    BVH_AMD_RAY_SORTED  = 4u   /* internal ray reordering for coherence; per-ray results are unchanged           */
+};
+
+/* Which reference builder a device build reproduces (bit-exact node/prim order). */
+enum bvh_amd_builder {
+    BVH_AMD_BUILDER_DEFAULT_SERIAL   = 0, /* DefaultBuilder::build(bboxes, centers, cfg), default_builder.h:49  */
+    BVH_AMD_BUILDER_DEFAULT_PARALLEL = 1, /* DefaultBuilder::build(pool, ...), default_builder.h:33             */
+    BVH_AMD_BUILDER_BINNED           = 2, /* BinnedSahBuilder::build, binned_sah_builder.h:32                   */
+    BVH_AMD_BUILDER_SWEEP            = 3  /* SweepSahBuilder::build, sweep_sah_builder.h:30                     */
+};
+
+/* ---- library / device ------------------------------------------------------------------------- */
+BVH_AMD_API const char* bvh_amd_last_error(void);
+BVH_AMD_API const char* bvh_amd_version(void);
+BVH_AMD_API int bvh_amd_device_count(void);            /* < 0 on HIP failure */
+BVH_AMD_API int bvh_amd_device_name(int device, char* out, size_t cap);
+
+/* ---- thread pool (c_api/bvh.h:90-91). Kept for signature compatibility; the GPU grid replaces it.
+ * A non-NULL pool selects the reference's *parallel* builder semantics (mini-trees). ------------- */
+BVH_AMD_API struct bvh_thread_pool* bvh_thread_pool_create(size_t thread_count);
+BVH_AMD_API void bvh_thread_pool_destroy(struct bvh_thread_pool*);
+
+/* ---- construction ------------------------------------------------------------------------------ */
+/* c_api/bvh.h:106-118. Host arrays in; the build runs on the current HIP device; the returned object
+ * holds the reference-layout host mirror (for the accessors below) and the device-resident copy. */
+BVH_AMD_API struct bvh3f* bvh3f_build(struct bvh_thread_pool*, const struct bvh_bbox3f* bboxes,
+    const struct bvh_vec3f* centers, size_t prim_count, const struct bvh_build_config* config);
+BVH_AMD_API struct bvh3d* bvh3d_build(struct bvh_thread_pool*, const struct bvh_bbox3d* bboxes,
+    const struct bvh_vec3d* centers, size_t prim_count, const struct bvh_build_config* config);
+
+/* Additive: inputs already resident in HBM (n x {min,max} and n x center, tightly packed). */
+BVH_AMD_API struct bvh3f* bvh3f_build_device(const float* d_bboxes, const float* d_centers, size_t prim_count,
+    const struct bvh_build_config* config, enum bvh_amd_builder builder, void* stream);
+BVH_AMD_API struct bvh3d* bvh3d_build_device(const double* d_bboxes, const double* d_centers, size_t prim_count,
+    const struct bvh_build_config* config, enum bvh_amd_builder builder, void* stream);
+
+/* Additive: wrap an existing reference-layout BVH (28/56-byte nodes, node.h:31-37) and upload it. */
+BVH_AMD_API struct bvh3f* bvh3f_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
+BVH_AMD_API struct bvh3d* bvh3d_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
+
+BVH_AMD_API void bvh3f_destroy(struct bvh3f*);                                   /* c_api/bvh.h:130 */
+BVH_AMD_API void bvh3d_destroy(struct bvh3d*);                                   /* c_api/bvh.h:132 */
+
+/* ---- serialization (c_api/bvh.h:136-144; byte format of Bvh::serialize, bvh.h:221-229) -------- */
+BVH_AMD_API void bvh3f_save(const struct bvh3f*, FILE*);
+BVH_AMD_API void bvh3d_save(const struct bvh3d*, FILE*);
+BVH_AMD_API struct bvh3f* bvh3f_load(FILE*);
+BVH_AMD_API struct bvh3d* bvh3d_load(FILE*);
+/* Additive: the same byte stream to/from memory (it is the RCCL broadcast payload). Returns the
+ * stream size; writes only if cap is large enough. */
+BVH_AMD_API size_t bvh3f_serialize(const struct bvh3f*, void* out, size_t cap);
+BVH_AMD_API size_t bvh3d_serialize(const struct bvh3d*, void* out, size_t cap);
+BVH_AMD_API struct bvh3f* bvh3f_deserialize(const void* bytes, size_t size);
+BVH_AMD_API struct bvh3d* bvh3d_deserialize(const void* bytes, size_t size);
+
+/* ---- accessors (c_api/bvh.h:148-203), on the host mirror -------------------------------------- */
+BVH_AMD_API struct bvh_node3f* bvh3f_get_node(struct bvh3f*, size_t);
+BVH_AMD_API struct bvh_node3d* bvh3d_get_node(struct bvh3d*, size_t);
+BVH_AMD_API size_t bvh3f_get_prim_id(const struct bvh3f*, size_t);
+BVH_AMD_API size_t bvh3d_get_prim_id(const struct bvh3d*, size_t);
+BVH_AMD_API size_t bvh3f_get_prim_count(const struct bvh3f*);
+BVH_AMD_API size_t bvh3d_get_prim_count(const struct bvh3d*);
+BVH_AMD_API size_t bvh3f_get_node_count(const struct bvh3f*);
+BVH_AMD_API size_t bvh3d_get_node_count(const struct bvh3d*);
+BVH_AMD_API bool bvh_node3f_is_leaf(const struct bvh_node3f*);
+BVH_AMD_API bool bvh_node3d_is_leaf(const struct bvh_node3d*);
+BVH_AMD_API size_t bvh_node3f_get_prim_count(const struct bvh_node3f*);
+BVH_AMD_API size_t bvh_node3d_get_prim_count(const struct bvh_node3d*);
+BVH_AMD_API size_t bvh_node3f_get_first_id(const struct bvh_node3f*);
+BVH_AMD_API size_t bvh_node3d_get_first_id(const struct bvh_node3d*);
+BVH_AMD_API struct bvh_bbox3f bvh_node3f_get_bbox(const struct bvh_node3f*);
+BVH_AMD_API struct bvh_bbox3d bvh_node3d_get_bbox(const struct bvh_node3d*);
+/* Additive bulk accessors: copy all nodes (reference layout) / prim ids out of the host mirror. */
+BVH_AMD_API void bvh3f_copy_nodes(const struct bvh3f*, void* out_nodes28);
+BVH_AMD_API void bvh3d_copy_nodes(const struct bvh3d*, void* out_nodes56);
+BVH_AMD_API void bvh3f_copy_prim_ids(const struct bvh3f*, size_t* out);
+BVH_AMD_API void bvh3d_copy_prim_ids(const struct bvh3d*, size_t* out);
+/* Device-resident prim ids (uint32, BVH order) for device-side permutation of primitives. */
+BVH_AMD_API const uint32_t* bvh3f_device_prim_ids(const struct bvh3f*);
+BVH_AMD_API const uint32_t* bvh3d_device_prim_ids(const struct bvh3d*);
+
+/* ---- primitive preparation on the device (caller-side loops of test/benchmark.cpp:205-225) ---- */
+/* tris9: n x {p0,p1,p2}. Writes Tri::get_bbox / Tri::get_center (tri.h:24-25). */
+BVH_AMD_API int bvh_amd_tri_bounds3f(const float* d_tris9, size_t n, float* d_bboxes, float* d_centers, void* stream);
+BVH_AMD_API int bvh_amd_tri_bounds3d(const double* d_tris9, size_t n, double* d_bboxes, double* d_centers, void* stream);
+/* out[i] = PrecomputedTri(tris[perm ? perm[i] : i]) (tri.h:35-37): n x {p0,e1,e2,n}. */
+BVH_AMD_API int bvh_amd_precompute_tris3f(const float* d_tris9, const uint32_t* d_perm, size_t n, float* d_tris12, void* stream);
+BVH_AMD_API int bvh_amd_precompute_tris3d(const double* d_tris9, const uint32_t* d_perm, size_t n, double* d_tris12, void* stream);
+/* spheres4: n x {center, radius}. Sphere::get_bbox / get_center (sphere.h:24-27). */
+BVH_AMD_API int bvh_amd_sphere_bounds3f(const float* d_sph4, size_t n, float* d_bboxes, float* d_centers, void* stream);
+BVH_AMD_API int bvh_amd_sphere_bounds3d(const double* d_sph4, size_t n, double* d_bboxes, double* d_centers, void* stream);
+/* out[i] = in[perm[i]] for records of `stride` bytes (multiple of 4). */
+BVH_AMD_API int bvh_amd_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t stride, void* d_out, void* stream);
+
+/* ---- batched traversal: Bvh::intersect<IsAnyHit, IsRobust> (bvh.h:160-182) for n rays ---------- */
+/* d_prims are in BVH order (prims[i] belongs to prim_ids[i]), like the reference's permuted
+ * primitives (test/simple_example.cpp:57-65). d_counters may be NULL. */
+BVH_AMD_API int bvh3f_intersect_rays_tri(const struct bvh3f*, const float* d_tris12, const struct bvh_ray3f* d_rays,
+    size_t n, unsigned flags, struct bvh_hit3f* d_hits, struct bvh_amd_counters* d_counters, void* stream);
+BVH_AMD_API int bvh3d_intersect_rays_tri(const struct bvh3d*, const double* d_tris12, const struct bvh_ray3d* d_rays,
+    size_t n, unsigned flags, struct bvh_hit3d* d_hits, struct bvh_amd_counters* d_counters, void* stream);
+BVH_AMD_API int bvh3f_intersect_rays_sphere(const struct bvh3f*, const float* d_sph4, const struct bvh_ray3f* d_rays,
+    size_t n, unsigned flags, struct bvh_hit3f* d_hits, struct bvh_amd_counters* d_counters, void* stream);
+BVH_AMD_API int bvh3d_intersect_rays_sphere(const struct bvh3d*, const double* d_sph4, const struct bvh_ray3d* d_rays,
+    size_t n, unsigned flags, struct bvh_hit3d* d_hits, struct bvh_amd_counters* d_counters, void* stream);
+
+/* Name and average duration source for profiling: the kernel symbol the last intersect call used. */
+BVH_AMD_API const char* bvh_amd_last_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,147 @@
+"""-m gpu: the HIP traversal path (through the C-ABI) against the oracle and the golden vectors.
+Bar: bit-exact hit records (prim, t, u, v) — stricter than north_star's 1e-5 relative on t, because the
+kernel replicates the reference's visit order and arithmetic."""
+import numpy as np
+import pytest
+
+import oracle
+from bvh_amd import synth
+from conftest import load_golden, parse_stream
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5   # north_star's tolerance for float traversal; asserted in addition to bit equality
+
+
+def _check_hits(gpu_hits, ref_hits):
+    assert (gpu_hits["prim"] == ref_hits["prim"]).all()
+    hit = ref_hits["prim"] != oracle.INVALID
+    assert np.all(np.abs(gpu_hits["t"][hit] - ref_hits["t"][hit]) <= REL_TOL * np.abs(ref_hits["t"][hit]))
+    assert gpu_hits.tobytes() == ref_hits.tobytes()
+
+
+@pytest.mark.parametrize("scene", ["cornell", "soup2k", "terrain2k", "soup2k_f64", "spheres2k_f64"])
+@pytest.mark.parametrize("mode", ["serial_low", "parallel_high"])
+@pytest.mark.parametrize("any_hit", [False, True])
+@pytest.mark.parametrize("robust", [False, True])
+def test_golden_hits(scene, mode, any_hit, robust):
+    import bvh_amd
+    g = load_golden(scene)
+    double = g["prims"].dtype == np.float64
+    nodes, ids = parse_stream(g[f"bvh_{mode}"].tobytes(), double)
+    bvh = bvh_amd.Bvh.from_nodes(nodes, ids)
+    assert bvh.serialize() == g[f"bvh_{mode}"].tobytes()
+    rays = g["rays_shadow"] if any_hit else g["rays_closest"]
+    key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
+    if "spheres" in scene:
+        prims = bvh_amd.gather(g["prims"], ids.astype(np.int32))
+        hits, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit, robust, leaf="sphere", counters=True)
+    else:
+        prims = bvh_amd.precompute_tris(g["prims"], ids.astype(np.int32))
+        hits, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit, robust, counters=True)
+    _check_hits(bvh_amd.hits_to_numpy(hits), g[f"hits_{key}"])
+    assert (cnt.cpu().numpy().astype(np.uint64) == g[f"counters_{key}"]).all()
+    hits2 = bvh_amd.intersect(bvh, prims, rays, any_hit, robust, leaf="sphere" if "spheres" in scene else "tri")
+    assert bvh_amd.hits_to_numpy(hits2).tobytes() == g[f"hits_{key}"].tobytes()
+
+
+def test_prep_kernels_match_oracle(orc):
+    import bvh_amd
+    for dt in (np.float32, np.float64):
+        tris = synth.soup(5000, seed=2, jitter=0.02, dtype=dt)
+        bb, cc = bvh_amd.tri_bounds(tris)
+        obb, occ = orc.prep_tris(tris)
+        assert bb.cpu().numpy().tobytes() == obb.tobytes() and cc.cpu().numpy().tobytes() == occ.tobytes()
+        perm = np.random.default_rng(0).permutation(5000).astype(np.uint64)
+        pt = bvh_amd.precompute_tris(tris, perm.astype(np.int32))
+        assert pt.cpu().numpy().tobytes() == orc.precompute_tris(tris, perm).tobytes()
+        sph = synth.spheres(3000, dtype=dt)
+        sb, sc = bvh_amd.sphere_bounds(sph)
+        osb, osc = orc.sphere_bboxes(sph)
+        assert sb.cpu().numpy().tobytes() == osb.tobytes() and sc.cpu().numpy().tobytes() == osc.tobytes()
+
+
+def test_reference_known_answers_on_gpu(orc):
+    """simple_example: primitive 1, t = 1, (u, v) = (-0, 0.5); cornell render: 1,027,152 hits."""
+    import bvh_amd
+    ka = load_golden("known_answers")
+    tris = ka["simple_tris"]
+    bb, cc = orc.prep_tris(tris)
+    ob = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_HIGH)
+    bvh = bvh_amd.Bvh.from_nodes(ob.nodes(), ob.prim_ids())
+    hit = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, bvh_amd.precompute_tris(tris, ob.prim_ids().astype(np.int32)),
+                                                  ka["simple_ray"]))
+    assert hit.tobytes() == ka["simple_hit"].tobytes()
+
+    g = load_golden("cornell")
+    nodes, ids = parse_stream(g["bvh_parallel_high"].tobytes())
+    bvh = bvh_amd.Bvh.from_nodes(nodes, ids)
+    assert bvh.node_count == 37
+    rays = synth.rays_pinhole(1024, 1024, (0, 1, 2), (0, 0, -1), (0, 1, 0))
+    prims = bvh_amd.precompute_tris(g["prims"], ids.astype(np.int32))
+    hits, cnt = bvh_amd.intersect(bvh, prims, rays, counters=True)
+    h = bvh_amd.hits_to_numpy(hits)
+    assert int((h["prim"] != oracle.INVALID).sum()) == 1027152
+    cnt = cnt.cpu().numpy()
+    assert cnt[0] == 7632318 and cnt[2] == 1445436
+    assert (cnt.astype(np.uint64) == ka["cornell_render_counters_high"]).all()
+
+
+@pytest.mark.parametrize("scene,n", [("soup", 200_000), ("terrain", 200_000), ("sponza", 262_144)])
+def test_seeded_scene_matches_oracle(orc, scene, n):
+    import bvh_amd
+    tris = {"soup": lambda: synth.soup(n, jitter=0.01), "terrain": lambda: synth.terrain(n),
+            "sponza": lambda: synth.sponza_proxy(n)}[scene]()
+    bb, cc = orc.prep_tris(tris)
+    ob = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_HIGH)
+    ids = ob.prim_ids()
+    bvh = bvh_amd.Bvh.from_nodes(ob.nodes(), ids)
+    prims = bvh_amd.precompute_tris(tris, ids.astype(np.int32))
+    oprims = orc.precompute_tris(tris, ids)
+    lo, hi = synth.scene_bounds(tris)
+    nr = 200_000
+    for any_hit, rays in ((False, synth.rays_closest(nr, lo, hi)), (True, synth.rays_shadow(nr, lo, hi))):
+        for robust in (False, True):
+            hits, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit, robust, counters=True)
+            oh, oc = ob.intersect_tri(oprims, rays, any_hit, robust, threads=8, counters=True)
+            _check_hits(bvh_amd.hits_to_numpy(hits), oh)
+            assert (cnt.cpu().numpy().astype(np.uint64) == oc).all()
+
+
+def test_edge_cases(orc):
+    import bvh_amd
+    import torch
+    # single-primitive BVH: the root is a leaf and its box is never tested (bvh.h:128-131)
+    tri = np.array([[0, 0, 1, 1, 0, 1, 0, 1, 1]], dtype=np.float32)
+    bb, cc = orc.prep_tris(tri)
+    ob = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    assert ob.node_count == 1
+    bvh = bvh_amd.Bvh.from_nodes(ob.nodes(), ob.prim_ids())
+    rays = np.array([[0.2, 0.2, 0, 0, 0, 1, 0, 10], [5, 5, 0, 0, 0, 1, 0, 10], [0.2, 0.2, 0, 0, 0, 1, 0, 0.5]], dtype=np.float32)
+    pt = bvh_amd.precompute_tris(tri)
+    h = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, pt, rays))
+    oh = ob.intersect_tri(orc.precompute_tris(tri), rays, 0, 0)
+    assert h.tobytes() == oh.tobytes() and h["prim"][0] == 0 and h["prim"][1] == oracle.INVALID
+    # empty batch
+    out = bvh_amd.intersect(bvh, pt, np.zeros((0, 8), np.float32))
+    assert out.shape[0] == 0
+    # ragged batch sizes around the wave/block granularity, axis-parallel and degenerate directions
+    tris = synth.soup(3000, seed=4, jitter=0.05)
+    bb, cc = orc.prep_tris(tris)
+    ob = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_HIGH)
+    ids = ob.prim_ids()
+    bvh = bvh_amd.Bvh.from_nodes(ob.nodes(), ids)
+    prims = bvh_amd.precompute_tris(tris, ids.astype(np.int32))
+    oprims = orc.precompute_tris(tris, ids)
+    lo, hi = synth.scene_bounds(tris)
+    base = synth.rays_closest(5000, lo, hi, seed=99)
+    base[::7, 3] = 0.0            # zero direction components: inf/NaN slabs (Ize's robust case)
+    base[::11, 4] = -0.0
+    base[::13, 3:6] = [0, 0, 1]
+    base[::17, 3:6] = 0.0         # fully degenerate direction
+    for n in (1, 63, 64, 65, 255, 257, 4097):
+        for robust in (False, True):
+            h = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, prims, base[:n], False, robust))
+            oh = ob.intersect_tri(oprims, base[:n], 0, robust)
+            assert h.tobytes() == oh.tobytes(), (n, robust)
+    torch.cuda.synchronize()
