@@ -1,0 +1,1007 @@
+// K5/K6 — binned-SAH top-down construction on gfx950, bit-exact with the reference's
+// BinnedSahBuilder (binned_sah_builder.h:82-156) driven by TopDownSahBuilder::build
+// (top_down_sah_builder.h:74-139): same nodes, same node numbering, same prim_ids order.
+//
+// The reference is a serial explicit-stack DFS; its output is reproduced by three phases:
+//
+//  Phase A  (level-synchronous, segments > 64 primitives): per level, for all such segments at once,
+//           bin (LDS-staged bins, one block per 2048-primitive chunk, order-preserving-integer atomics),
+//           decide (21 SAH candidates per segment), partition (the exact permutation libstdc++'s Hoare
+//           std::partition produces, SURVEY A.3: ballot/prefix ranks, violator tables, pairwise swap),
+//           child bounds (LDS-staged min/max), and child creation with SATO order.
+//  Phase B  (segments <= 64 primitives): ONE WAVEFRONT finishes the whole subtree, one primitive per
+//           lane in registers, replaying the reference's DFS (same stack discipline) with ballot/popcount
+//           partitions and LDS bins; nodes are staged in the subtree's own DFS numbering.
+//  Phase C  numbering: an inner node's children live at 1 + 2 * (its pre-order rank among inner
+//           nodes, in the order the reference's stack pops them: fewer primitives first, ties -> second
+//           child); ranks come from bottom-up inner counts + a top-down pass, then nodes are scattered.
+//
+// Arithmetic is the reference's (-ffp-contract=off; fma only at fast_mul_add sites: bin position,
+// binned_sah_builder.h:92, and split plane, :145-148). min/max accumulations are order-independent for
+// non-NaN inputs, which is what makes the parallel binning exact; the one order-dependent case, the sign of
+// a zero bound when +0 and -0 both occur (the reference keeps the LAST one), is reproduced by tracking the
+// last zero-valued position per bound. Known divergence: NaN coordinates.
+
+#include "common.h"
+
+#include <algorithm>
+#include <cfloat>
+
+namespace bvh_amd {
+
+template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
+
+namespace {
+
+constexpr int kSmall = 64;              // Phase B threshold: one primitive per lane
+constexpr int kChunk = 2048;            // primitives per block in Phase A passes
+constexpr int kBins = 8;                // binned_sah_builder.h:19
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+enum : uint32_t { KIND_BIG = 0, KIND_INNER = 1, KIND_SMALL = 2 };
+enum : uint32_t { MODE_PARTITION = 0, MODE_FALLBACK = 1 };
+
+// ---- order-preserving integer image of a float (for atomic min/max) ---------------------------------
+template <typename T> struct Ord;
+template <> struct Ord<float> {
+    using U = uint32_t;
+    static constexpr float kMax = FLT_MAX;
+    __device__ static U enc(float f) { U u = __float_as_uint(f); return u ^ (static_cast<U>(static_cast<int32_t>(u) >> 31) | 0x80000000u); }
+    __device__ static float dec(U k) { U u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k; return __uint_as_float(u); }
+    __device__ static float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    __device__ static uint32_t sign(float f) { return __float_as_uint(f) >> 31; }
+    __device__ static float zero(uint32_t negative) { return __uint_as_float(negative << 31); }
+};
+template <> struct Ord<double> {
+    using U = unsigned long long;
+    static constexpr double kMax = DBL_MAX;
+    __device__ static U enc(double f) {
+        U u = static_cast<U>(__double_as_longlong(f));
+        return u ^ (static_cast<U>(static_cast<long long>(u) >> 63) | 0x8000000000000000ull);
+    }
+    __device__ static double dec(U k) {
+        U u = (k & 0x8000000000000000ull) ? (k ^ 0x8000000000000000ull) : ~k;
+        return __longlong_as_double(static_cast<long long>(u));
+    }
+    __device__ static double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    __device__ static uint32_t sign(double f) { return static_cast<uint32_t>(static_cast<U>(__double_as_longlong(f)) >> 63); }
+    __device__ static double zero(uint32_t negative) { return __longlong_as_double(static_cast<long long>(static_cast<U>(negative) << 63)); }
+};
+
+template <typename T> __device__ inline T pick_min(T a, T b) { return a < b ? a : b; }    // utils.h:41-43
+template <typename T> __device__ inline T pick_max(T a, T b) { return a > b ? a : b; }
+
+template <typename T> __device__ inline T half_area(const T* lo, const T* hi) {            // bbox.h:32-38
+    T d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+    return (d0 + d1) * d2 + d0 * d1;
+}
+template <typename T> __device__ inline int widest_axis(const T* lo, const T* hi) {        // vec.h:23-33
+    T d[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] };
+    int axis = 0;
+    if (d[1] > d[axis]) axis = 1;
+    if (d[2] > d[axis]) axis = 2;
+    return axis;
+}
+// min(BinCount - 1, size_t(max(pos, 0)))  (binned_sah_builder.h:94-95); NaN -> 0, +inf saturates to 7.
+template <typename T> __device__ inline uint32_t bin_of(T pos) {
+    T v = pick_max(pos, T(0));
+    return v >= T(kBins - 1) ? uint32_t(kBins - 1) : static_cast<uint32_t>(v);
+}
+
+// ---- data structures ---------------------------------------------------------------------------------
+template <typename T>
+struct ANode {                           // Phase A tree node (BFS allocation order)
+    T lo[3], hi[3];
+    uint32_t begin, end;
+    uint32_t child;                      // A id of the first child (KIND_INNER)
+    uint32_t parent;                     // parent A id | which << 31; root: kNone
+    uint32_t kind;
+    uint32_t ic;                         // inner nodes in this subtree (incl. itself)
+    uint32_t rank;                       // pre-order rank among inner nodes, in the reference's processing order
+    uint32_t pad;
+};
+
+template <typename T>
+struct SlotBins {                        // 3 axes x 8 bins of {box, count}
+    typename Ord<T>::U lo[3][kBins][3];
+    typename Ord<T>::U hi[3][kBins][3];
+    uint32_t cnt[3][kBins];
+};
+
+template <typename T>
+struct SlotState {
+    T split_pos;
+    typename Ord<T>::U clo[2][3], chi[2][3];   // child boxes: [0] = positions < split, [1] = the rest
+    // robust_min/max return their SECOND argument on equality (utils.h:41-43), so when a bound is zero its
+    // sign is that of the LAST zero in position order. (position << 1 | sign) of the last zero-valued
+    // contribution per component; consulted only when the decoded bound compares equal to zero.
+    uint32_t zlo[2][3], zhi[2][3];
+    uint32_t axis, wide, mode;
+    uint32_t m;                          // #primitives satisfying the partition predicate
+    uint32_t nviol;                      // #misplaced pairs (Hoare swaps)
+    uint32_t split;                      // absolute split index
+    uint32_t node, task0, ntasks;
+};
+
+struct Task { uint32_t slot, begin, end; };
+
+struct Counters {
+    uint32_t n_nodes, n_active_next, n_tasks_next, n_small, error, pad[3];
+};
+
+template <typename T>
+struct BuildCtx {
+    const T* bboxes;                     // n x {min xyz, max xyz}
+    const T* centers;                    // n x 3
+    uint32_t* ids;
+    uint32_t n;
+    uint32_t min_leaf, max_leaf;
+    ANode<T>* nodes;
+    uint32_t node_cap;
+    SlotBins<T>* bins;
+    SlotState<T>* state;
+    SlotState<T>* state_next;
+    uint32_t slot_cap;
+    Task* tasks;
+    Task* tasks_next;
+    uint32_t task_cap;
+    uint32_t* chunk_true;
+    uint32_t* ltab;
+    uint32_t* rtab;
+    uint32_t* small_list;
+    HostNode<T>* stage;                  // 2n staged nodes of the Phase B subtrees
+    Counters* counters;
+};
+
+// ---- libstdc++ std::partial_sort, replayed by one lane (stl_heap.h / stl_algo.h:1912-1919)
+// Operates on `ids[0..)` with keys key(id); comp(a, b) = key(a) < key(b).
+template <typename KeyFn>
+__device__ void heap_push(uint32_t* a, long hole, long top, uint32_t value, KeyFn key) {
+    long parent = (hole - 1) / 2;
+    while (hole > top && key(a[parent]) < key(value)) {
+        a[hole] = a[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[hole] = value;
+}
+template <typename KeyFn>
+__device__ void heap_adjust(uint32_t* a, long hole, long len, uint32_t value, KeyFn key) {
+    const long top = hole;
+    long second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (key(a[second]) < key(a[second - 1])) second--;
+        a[hole] = a[second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        a[hole] = a[second - 1];
+        hole = second - 1;
+    }
+    heap_push(a, hole, top, value, key);
+}
+template <typename KeyFn>
+__device__ void partial_sort_replay(uint32_t* a, long middle, long last, KeyFn key) {
+    if (middle >= 2) {                                       // __make_heap(first, middle)
+        long parent = (middle - 2) / 2;
+        for (;;) {
+            uint32_t v = a[parent];
+            heap_adjust(a, parent, middle, v, key);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (long i = middle; i < last; ++i) {                   // __heap_select
+        if (key(a[i]) < key(a[0])) {                         // __pop_heap(first, middle, i)
+            uint32_t v = a[i];
+            a[i] = a[0];
+            heap_adjust(a, 0, middle, v, key);
+        }
+    }
+    for (long end = middle; end > 1;) {                      // __sort_heap(first, middle)
+        --end;
+        uint32_t v = a[end];
+        a[end] = a[0];
+        heap_adjust(a, 0, end, v, key);
+    }
+}
+
+// ---- SAH candidate sweep over one axis (binned_sah_builder.h:101-116) -----------------------------------
+// Starts from (FLT_MAX, -) and reports the first strict minimum; combining axes 0,1,2 with strict `<`
+// afterwards equals the reference's carried `best_split`.
+template <typename T, typename LoadBin>
+__device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin) {
+    T right_cost[kBins];
+    {
+        T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = kBins - 1; i > 0; --i) {
+            T blo[3], bhi[3]; uint32_t bc;
+            load(i, blo, bhi, bc);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = pick_min(lo[k], blo[k]); hi[k] = pick_max(hi[k], bhi[k]); }
+            cnt += bc;
+            right_cost[i] = half_area(lo, hi) * static_cast<T>(cnt);
+        }
+    }
+    best_cost = Ord<T>::kMax;
+    best_bin = kBins / 2;
+    T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < kBins - 1; ++i) {
+        T blo[3], bhi[3]; uint32_t bc;
+        load(i, blo, bhi, bc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] = pick_min(lo[k], blo[k]); hi[k] = pick_max(hi[k], bhi[k]); }
+        cnt += bc;
+        T cost = half_area(lo, hi) * static_cast<T>(cnt) + right_cost[i + 1];
+        if (cost < best_cost) { best_cost = cost; best_bin = i + 1; }
+    }
+}
+
+// =====================================================================================================
+// Phase A kernels
+// =====================================================================================================
+
+template <typename T>
+__device__ inline T decode_bound(typename Ord<T>::U key, uint32_t ztrack) {
+    T v = Ord<T>::dec(key);
+    if (v == T(0)) v = Ord<T>::zero(ztrack & 1u);
+    return v;
+}
+template <typename T>
+__device__ inline void track_zero(uint32_t* slot, T value, uint32_t pos) {
+    if (value == T(0)) atomicMax(slot, (pos << 1) | Ord<T>::sign(value));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_init_root(BuildCtx<T> c) {
+    // ids = iota (binned_sah_builder.h:77); root box = union of all boxes (top_down_sah_builder.h:80)
+    __shared__ typename Ord<T>::U slo[3], shi[3];
+    if (threadIdx.x < 3) { slo[threadIdx.x] = Ord<T>::enc(Ord<T>::kMax); shi[threadIdx.x] = Ord<T>::enc(-Ord<T>::kMax); }
+    __syncthreads();
+    T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+    for (size_t i = blockIdx.x * size_t{256} + threadIdx.x; i < c.n; i += size_t{gridDim.x} * 256) {
+        c.ids[i] = static_cast<uint32_t>(i);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T a = c.bboxes[6 * i + k], b = c.bboxes[6 * i + 3 + k];
+            lo[k] = pick_min(lo[k], a);
+            hi[k] = pick_max(hi[k], b);
+            track_zero(&c.state[0].zlo[0][k], a, static_cast<uint32_t>(i));
+            track_zero(&c.state[0].zhi[0][k], b, static_cast<uint32_t>(i));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { atomicMin(&slo[k], Ord<T>::enc(lo[k])); atomicMax(&shi[k], Ord<T>::enc(hi[k])); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        // the root's key box lives in state[0].clo[0]/chi[0] until k_make_root decodes it
+        atomicMin(&c.state[0].clo[0][threadIdx.x], slo[threadIdx.x]);
+        atomicMax(&c.state[0].chi[0][threadIdx.x], shi[threadIdx.x]);
+    }
+}
+
+template <typename T>
+__global__ void k_prepare_root(BuildCtx<T> c) {
+    for (int k = 0; k < 3; ++k) {
+        c.state[0].clo[0][k] = Ord<T>::enc(Ord<T>::kMax); c.state[0].chi[0][k] = Ord<T>::enc(-Ord<T>::kMax);
+        c.state[0].zlo[0][k] = 0; c.state[0].zhi[0][k] = 0;
+    }
+    Counters z = {};
+    *c.counters = z;
+}
+
+template <typename T>
+__device__ void emit_child(const BuildCtx<T>& c, uint32_t id) {
+    // registers a freshly created node either as a big segment of the next level or as a Phase B root
+    ANode<T>& nd = c.nodes[id];
+    const uint32_t size = nd.end - nd.begin;
+    if (size > kSmall) {
+        nd.kind = KIND_BIG;
+        const uint32_t slot = atomicAdd(&c.counters->n_active_next, 1u);
+        const uint32_t nt = (size + kChunk - 1) / kChunk;
+        const uint32_t t0 = atomicAdd(&c.counters->n_tasks_next, nt);
+        if (slot >= c.slot_cap || t0 + nt > c.task_cap) { atomicOr(&c.counters->error, 1u); return; }
+        SlotState<T>& st = c.state_next[slot];
+        st.node = id; st.task0 = t0; st.ntasks = nt;
+        for (uint32_t t = 0; t < nt; ++t) {
+            Task tk;
+            tk.slot = slot;
+            tk.begin = nd.begin + t * kChunk;
+            tk.end = min(nd.end, tk.begin + kChunk);
+            c.tasks_next[t0 + t] = tk;
+        }
+    } else {
+        nd.kind = KIND_SMALL;
+        const uint32_t s = atomicAdd(&c.counters->n_small, 1u);
+        c.small_list[s] = id;
+    }
+}
+
+template <typename T>
+__global__ void k_make_root(BuildCtx<T> c) {
+    ANode<T>& r = c.nodes[0];
+    for (int k = 0; k < 3; ++k) {
+        r.lo[k] = decode_bound<T>(c.state[0].clo[0][k], c.state[0].zlo[0][k]);
+        r.hi[k] = decode_bound<T>(c.state[0].chi[0][k], c.state[0].zhi[0][k]);
+    }
+    r.begin = 0; r.end = c.n; r.child = kNone; r.parent = kNone; r.ic = 0; r.rank = 0;
+    c.counters->n_nodes = 1;
+    emit_child(c, 0);
+}
+
+// One block per active slot: reset its accumulators.
+template <typename T>
+__global__ void __launch_bounds__(64) k_init_slots(BuildCtx<T> c) {
+    const uint32_t slot = blockIdx.x;
+    SlotBins<T>& b = c.bins[slot];
+    const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
+    for (int w = threadIdx.x; w < 3 * kBins * 3; w += 64) { (&b.lo[0][0][0])[w] = lo0; (&b.hi[0][0][0])[w] = hi0; }
+    for (int w = threadIdx.x; w < 3 * kBins; w += 64) (&b.cnt[0][0])[w] = 0;
+    SlotState<T>& st = c.state[slot];
+    if (threadIdx.x < 6) {
+        st.clo[threadIdx.x / 3][threadIdx.x % 3] = lo0; st.chi[threadIdx.x / 3][threadIdx.x % 3] = hi0;
+        st.zlo[threadIdx.x / 3][threadIdx.x % 3] = 0;   st.zhi[threadIdx.x / 3][threadIdx.x % 3] = 0;
+    }
+    if (threadIdx.x == 0) { st.m = 0; st.nviol = 0; st.mode = MODE_PARTITION; st.split = 0; }
+}
+
+// fill_bins (binned_sah_builder.h:82-99) for one chunk of one segment.
+template <typename T>
+__global__ void __launch_bounds__(256) k_bin(BuildCtx<T> c) {
+    __shared__ SlotBins<T> sb;
+    const Task tk = c.tasks[blockIdx.x];
+    const ANode<T>& nd = c.nodes[c.state[tk.slot].node];
+    const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
+    for (int w = threadIdx.x; w < 3 * kBins * 3; w += 256) { (&sb.lo[0][0][0])[w] = lo0; (&sb.hi[0][0][0])[w] = hi0; }
+    for (int w = threadIdx.x; w < 3 * kBins; w += 256) (&sb.cnt[0][0])[w] = 0;
+    T scale[3], shift[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                            // :88-89
+        scale[k] = T(kBins) / (nd.hi[k] - nd.lo[k]);
+        shift[k] = (-nd.lo[k]) * scale[k];
+    }
+    __syncthreads();
+    for (uint32_t pos = tk.begin + threadIdx.x; pos < tk.end; pos += 256) {
+        const uint32_t id = c.ids[pos];
+        T ctr[3], blo[3], bhi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ctr[k] = c.centers[3ull * id + k]; blo[k] = c.bboxes[6ull * id + k]; bhi[k] = c.bboxes[6ull * id + 3 + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t s = bin_of(Ord<T>::fma_(ctr[k], scale[k], shift[k]));   // :92-95
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { atomicMin(&sb.lo[k][s][j], Ord<T>::enc(blo[j])); atomicMax(&sb.hi[k][s][j], Ord<T>::enc(bhi[j])); }
+            atomicAdd(&sb.cnt[k][s], 1u);
+        }
+    }
+    __syncthreads();
+    SlotBins<T>& gb = c.bins[tk.slot];
+    for (int w = threadIdx.x; w < 3 * kBins; w += 256) {
+        const uint32_t n = (&sb.cnt[0][0])[w];
+        if (!n) continue;
+        atomicAdd(&(&gb.cnt[0][0])[w], n);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            atomicMin(&(&gb.lo[0][0][0])[3 * w + j], (&sb.lo[0][0][0])[3 * w + j]);
+            atomicMax(&(&gb.hi[0][0][0])[3 * w + j], (&sb.hi[0][0][0])[3 * w + j]);
+        }
+    }
+}
+
+// try_split's decision (binned_sah_builder.h:128-148), one thread per segment.
+template <typename T>
+__global__ void __launch_bounds__(64) k_decide(BuildCtx<T> c, uint32_t n_active) {
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n_active) return;
+    SlotState<T>& st = c.state[slot];
+    const ANode<T>& nd = c.nodes[st.node];
+    const SlotBins<T>& b = c.bins[slot];
+    const int wide = widest_axis(nd.lo, nd.hi);
+    uint32_t best_bin = kBins / 2; T best_cost = Ord<T>::kMax; int best_axis = wide;     // :132-133
+    for (int k = 0; k < 3; ++k) {
+        T cost; uint32_t bin;
+        sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
+            for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(b.lo[k][i][j]); hi[j] = Ord<T>::dec(b.hi[k][i][j]); }
+            n = b.cnt[k][i];
+        }, cost, bin);
+        if (cost < best_cost) { best_cost = cost; best_bin = bin; best_axis = k; }
+    }
+    const uint32_t size = nd.end - nd.begin;
+    const T stay = half_area(nd.lo, nd.hi) * (static_cast<T>(size) - T(1));              // split_heuristic.h:36-38
+    st.wide = wide;
+    st.axis = best_axis;
+    if (best_cost >= stay) {
+        st.mode = MODE_FALLBACK;                             // size > 64 > max_leaf_size: never a leaf here (:140-142)
+    } else {
+        st.mode = MODE_PARTITION;
+        st.split_pos = Ord<T>::fma_((nd.hi[best_axis] - nd.lo[best_axis]) / T(kBins), static_cast<T>(best_bin), nd.lo[best_axis]);   // :145-148
+    }
+}
+
+// #primitives of the chunk with center[axis] < split_pos (the std::partition predicate, :151).
+template <typename T>
+__global__ void __launch_bounds__(256) k_count(BuildCtx<T> c) {
+    __shared__ uint32_t total;
+    const Task tk = c.tasks[blockIdx.x];
+    SlotState<T>& st = c.state[tk.slot];
+    if (st.mode != MODE_PARTITION) return;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t pos = tk.begin + threadIdx.x; pos < tk.end; pos += 256)
+        mine += c.centers[3ull * c.ids[pos] + st.axis] < st.split_pos ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) { c.chunk_true[blockIdx.x] = total; atomicAdd(&st.m, total); }
+}
+
+// Hoare-partition characterisation: with m = #true, the misplaced elements left of begin+m
+// (ascending) are swapped pairwise with the misplaced elements right of it (descending).
+template <typename T>
+__global__ void __launch_bounds__(256) k_scatter(BuildCtx<T> c) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t base_sh, viol_sh;
+    const Task tk = c.tasks[blockIdx.x];
+    SlotState<T>& st = c.state[tk.slot];
+    if (st.mode != MODE_PARTITION) return;
+    const ANode<T>& nd = c.nodes[st.node];
+    const uint32_t size = nd.end - nd.begin, m = st.m;
+    if (m == 0 || m == size) return;                         // :152-153 -> fallback
+    if (threadIdx.x == 0) { base_sh = 0; viol_sh = 0; }
+    __syncthreads();
+    uint32_t before = 0;                                     // #true in earlier chunks of this segment
+    for (uint32_t t = st.task0 + threadIdx.x; t < blockIdx.x; t += 256) before += c.chunk_true[t];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if ((threadIdx.x & 63) == 0 && before) atomicAdd(&base_sh, before);
+    __syncthreads();
+    uint32_t running = base_sh, viol = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t boundary = nd.begin + m;
+    for (uint32_t tile = tk.begin; tile < tk.end; tile += 256) {
+        const uint32_t pos = tile + threadIdx.x;
+        const bool in = pos < tk.end;
+        const bool pred = in && (c.centers[3ull * c.ids[in ? pos : tk.begin] + st.axis] < st.split_pos);
+        const uint64_t bal = __ballot(pred);
+        if (lane == 0) wave_sum[wave] = __popcll(bal);
+        __syncthreads();
+        uint32_t excl = __popcll(bal & ((uint64_t{1} << lane) - 1));
+        uint32_t tile_total = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) excl += wave_sum[w]; tile_total += wave_sum[w]; }
+        const uint32_t t_before = running + excl;            // #true in [begin, pos)
+        if (in) {
+            if (pos < boundary) {
+                if (!pred) { c.ltab[nd.begin + (pos - nd.begin) - t_before] = pos; ++viol; }
+            } else if (pred) {
+                c.rtab[nd.begin + (m - t_before - 1)] = pos;
+            }
+        }
+        running += tile_total;
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) viol += __shfl_down(viol, off);
+    if (lane == 0 && viol) atomicAdd(&viol_sh, viol);
+    __syncthreads();
+    if (threadIdx.x == 0 && viol_sh) atomicAdd(&st.nviol, viol_sh);
+}
+
+// fallback_split (:118-126): std::partial_sort replayed by one lane; also settles the split index.
+template <typename T>
+__global__ void __launch_bounds__(64) k_fallback(BuildCtx<T> c, uint32_t n_active) {
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n_active) return;
+    SlotState<T>& st = c.state[slot];
+    const ANode<T>& nd = c.nodes[st.node];
+    const uint32_t size = nd.end - nd.begin;
+    if (st.mode == MODE_PARTITION && st.m != 0 && st.m != size) { st.split = nd.begin + st.m; return; }
+    st.mode = MODE_FALLBACK;
+    const uint32_t mid = (nd.begin + nd.end + 1) / 2;        // absolute indices, :119
+    const int axis = st.wide;
+    const T* ctr = c.centers;
+    partial_sort_replay(c.ids + nd.begin, long(mid - nd.begin), long(size), [=](uint32_t id) { return ctr[3ull * id + axis]; });
+    st.split = mid;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_swap(BuildCtx<T> c) {
+    const Task tk = c.tasks[blockIdx.x];
+    const SlotState<T>& st = c.state[tk.slot];
+    if (st.mode != MODE_PARTITION) return;
+    const ANode<T>& nd = c.nodes[st.node];
+    const uint32_t chunk = blockIdx.x - st.task0;
+    const uint32_t kend = min(st.nviol, (chunk + 1) * kChunk);
+    for (uint32_t k = chunk * kChunk + threadIdx.x; k < kend; k += 256) {
+        const uint32_t p = c.ltab[nd.begin + k], q = c.rtab[nd.begin + k];
+        const uint32_t a = c.ids[p], b = c.ids[q];
+        c.ids[p] = b;
+        c.ids[q] = a;
+    }
+}
+
+// compute_bbox of both children (top_down_sah_builder.h:96-97, :133-139).
+template <typename T>
+__global__ void __launch_bounds__(256) k_child_bounds(BuildCtx<T> c) {
+    __shared__ typename Ord<T>::U slo[2][3], shi[2][3];
+    const Task tk = c.tasks[blockIdx.x];
+    SlotState<T>& st = c.state[tk.slot];
+    if (threadIdx.x < 6) { slo[threadIdx.x / 3][threadIdx.x % 3] = Ord<T>::enc(Ord<T>::kMax); shi[threadIdx.x / 3][threadIdx.x % 3] = Ord<T>::enc(-Ord<T>::kMax); }
+    __syncthreads();
+    const uint32_t split = st.split;
+    // the chunk lies on one side unless it straddles the split: reduce in registers per side first
+    T lo[2][3], hi[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[s][k] = Ord<T>::kMax; hi[s][k] = -Ord<T>::kMax; }
+    for (uint32_t pos = tk.begin + threadIdx.x; pos < tk.end; pos += 256) {
+        const uint32_t id = c.ids[pos];
+        const bool right = pos >= split;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T a = c.bboxes[6ull * id + k], b = c.bboxes[6ull * id + 3 + k];
+            track_zero(&st.zlo[right ? 1 : 0][k], a, pos);
+            track_zero(&st.zhi[right ? 1 : 0][k], b, pos);
+            if (right) { lo[1][k] = pick_min(lo[1][k], a); hi[1][k] = pick_max(hi[1][k], b); }
+            else       { lo[0][k] = pick_min(lo[0][k], a); hi[0][k] = pick_max(hi[0][k], b); }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            T a = lo[s][k], b = hi[s][k];
+            for (int off = 32; off > 0; off >>= 1) { a = pick_min(a, __shfl_xor(a, off)); b = pick_max(b, __shfl_xor(b, off)); }
+            if ((threadIdx.x & 63) == 0) { atomicMin(&slo[s][k], Ord<T>::enc(a)); atomicMax(&shi[s][k], Ord<T>::enc(b)); }
+        }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int s = threadIdx.x / 3, k = threadIdx.x % 3;
+        atomicMin(&st.clo[s][k], slo[s][k]);
+        atomicMax(&st.chi[s][k], shi[s][k]);
+    }
+}
+
+// Child creation with SATO order (top_down_sah_builder.h:91-113).
+template <typename T>
+__global__ void __launch_bounds__(64) k_finalize(BuildCtx<T> c, uint32_t n_active) {
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n_active) return;
+    const SlotState<T>& st = c.state[slot];
+    ANode<T>& nd = c.nodes[st.node];
+    T lo[2][3], hi[2][3];
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < 3; ++k) { lo[s][k] = decode_bound<T>(st.clo[s][k], st.zlo[s][k]); hi[s][k] = decode_bound<T>(st.chi[s][k], st.zhi[s][k]); }
+    uint32_t rb[2] = { nd.begin, st.split }, re[2] = { st.split, nd.end };
+    int first = 0;
+    if (half_area(lo[0], hi[0]) < half_area(lo[1], hi[1])) first = 1;                      // :105-108
+    const uint32_t child = atomicAdd(&c.counters->n_nodes, 2u);
+    if (child + 2 > c.node_cap) { atomicOr(&c.counters->error, 2u); return; }
+    nd.child = child;
+    nd.kind = KIND_INNER;
+    for (int w = 0; w < 2; ++w) {
+        const int s = w == 0 ? first : 1 - first;
+        ANode<T>& ch = c.nodes[child + w];
+        for (int k = 0; k < 3; ++k) { ch.lo[k] = lo[s][k]; ch.hi[k] = hi[s][k]; }
+        ch.begin = rb[s]; ch.end = re[s];
+        ch.child = kNone; ch.parent = st.node | (uint32_t(w) << 31); ch.ic = 0; ch.rank = 0;
+        emit_child(c, child + w);
+    }
+}
+
+// =====================================================================================================
+// Phase B: one wavefront builds a whole subtree of <= 64 primitives
+// =====================================================================================================
+
+template <typename T>
+struct WaveLds {
+    typename Ord<T>::U lo[3][kBins][3], hi[3][kBins][3];
+    uint32_t cnt[3][kBins];
+    T nbox[2 * kSmall][6];               // local node boxes {lo xyz, hi xyz}
+    uint32_t stack[kSmall + 4];
+    uint32_t ltab[kSmall], rtab[kSmall];
+    uint32_t perm[kSmall];
+    T keys[kSmall];
+    T axis_cost[3];
+    uint32_t axis_bin[3];
+};
+
+__device__ inline uint32_t pack_item(uint32_t node, uint32_t b, uint32_t e) { return node | (b << 8) | (e << 16); }
+
+// Lanes of one wavefront communicate through LDS without a workgroup barrier (waves of a block run
+// independent subtrees). LDS operations of a wave execute in order; this only stops the compiler from
+// moving memory operations across the hand-off.
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) {
+    __shared__ WaveLds<T> lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_small) return;
+    WaveLds<T>& L = lds_all[threadIdx.x >> 6];
+    const uint32_t node_id = c.small_list[w];
+    ANode<T>& A = c.nodes[node_id];
+    const uint32_t B = A.begin, s = A.end - A.begin;
+    HostNode<T>* stage = c.stage + 2ull * B;
+
+    // one primitive per lane
+    uint32_t id = 0;
+    T ctr[3] = {0, 0, 0}, blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0};
+    if (lane < int(s)) {
+        id = c.ids[B + lane];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ctr[k] = c.centers[3ull * id + k]; blo[k] = c.bboxes[6ull * id + k]; bhi[k] = c.bboxes[6ull * id + 3 + k]; }
+    }
+    if (lane < 3) { L.nbox[0][lane] = A.lo[lane]; L.nbox[0][3 + lane] = A.hi[lane]; }
+    if (lane == 0) L.stack[0] = pack_item(0, 0, s);
+    uint32_t sp = 1, ncount = 1;
+    const uint64_t lanes_below = (uint64_t{1} << lane) - 1;
+
+    while (sp > 0) {
+        wave_sync();
+        const uint32_t item = L.stack[--sp];
+        const uint32_t ln = item & 0xFF, lb = (item >> 8) & 0xFF, le = (item >> 16) & 0xFF;
+        const uint32_t cnt = le - lb;
+        T nlo[3], nhi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { nlo[k] = L.nbox[ln][k]; nhi[k] = L.nbox[ln][3 + k]; }
+        const bool in = uint32_t(lane) >= lb && uint32_t(lane) < le;
+        bool split = false;
+        uint32_t cut = 0;                                     // local split index
+
+        if (cnt > c.min_leaf) {                               // top_down_sah_builder.h:89
+            // ---- fill_bins
+            const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
+            for (int q = lane; q < 3 * kBins * 3; q += 64) { (&L.lo[0][0][0])[q] = lo0; (&L.hi[0][0][0])[q] = hi0; }
+            if (lane < 3 * kBins) (&L.cnt[0][0])[lane] = 0;
+            wave_sync();
+            if (in) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T scale = T(kBins) / (nhi[k] - nlo[k]);
+                    const T shift = (-nlo[k]) * scale;
+                    const uint32_t b = bin_of(Ord<T>::fma_(ctr[k], scale, shift));
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { atomicMin(&L.lo[k][b][j], Ord<T>::enc(blo[j])); atomicMax(&L.hi[k][b][j], Ord<T>::enc(bhi[j])); }
+                    atomicAdd(&L.cnt[k][b], 1u);
+                }
+            }
+            // ---- find_best_split: lane k sweeps axis k
+            wave_sync();
+            if (lane < 3) {
+                T cost; uint32_t bin;
+                const int k = lane;
+                sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
+                    for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(L.lo[k][i][j]); hi[j] = Ord<T>::dec(L.hi[k][i][j]); }
+                    n = L.cnt[k][i];
+                }, cost, bin);
+                L.axis_cost[k] = cost;
+                L.axis_bin[k] = bin;
+            }
+            wave_sync();
+            const int wide = widest_axis(nlo, nhi);
+            uint32_t best_bin = kBins / 2; T best_cost = Ord<T>::kMax; int best_axis = wide;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T cst = L.axis_cost[k];
+                if (cst < best_cost) { best_cost = cst; best_bin = L.axis_bin[k]; best_axis = k; }
+            }
+            const T stay = half_area(nlo, nhi) * (static_cast<T>(cnt) - T(1));
+            bool fallback = false;
+            if (best_cost >= stay) {
+                if (cnt > c.max_leaf) fallback = true;        // else: leaf
+            } else {
+                const T plane = Ord<T>::fma_((nhi[best_axis] - nlo[best_axis]) / T(kBins), static_cast<T>(best_bin), nlo[best_axis]);
+                const T key = best_axis == 0 ? ctr[0] : (best_axis == 1 ? ctr[1] : ctr[2]);
+                const bool pred = in && key < plane;
+                const uint64_t tmask = __ballot(pred);
+                const uint32_t m = __popcll(tmask);
+                if (m == 0 || m == cnt) fallback = true;
+                else {
+                    // Hoare permutation inside the wave
+                    const uint32_t boundary = lb + m;
+                    const bool lv = in && uint32_t(lane) < boundary && !pred;
+                    const bool rv = in && uint32_t(lane) >= boundary && pred;
+                    const uint64_t lmask = __ballot(lv), rmask = __ballot(rv);
+                    const uint32_t lrank = __popcll(lmask & lanes_below);
+                    const uint32_t rrank = __popcll(rmask & ~(lanes_below | (uint64_t{1} << lane)));   // descending rank
+                    if (lv) L.ltab[lrank] = lane;
+                    if (rv) L.rtab[rrank] = lane;
+                    wave_sync();
+                    int src = lane;
+                    if (lv) src = L.rtab[lrank];
+                    if (rv) src = L.ltab[rrank];
+                    id = __shfl(id, src);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { ctr[k] = __shfl(ctr[k], src); blo[k] = __shfl(blo[k], src); bhi[k] = __shfl(bhi[k], src); }
+                    split = true;
+                    cut = boundary;
+                }
+            }
+            if (fallback) {                                   // fallback_split on the widest axis
+                const uint32_t mid_abs = (B + lb + B + le + 1) / 2;
+                const uint32_t mid = mid_abs - B;
+                const T key = wide == 0 ? ctr[0] : (wide == 1 ? ctr[1] : ctr[2]);
+                L.keys[lane] = key;
+                L.perm[lane] = lane;
+                wave_sync();
+                if (lane == 0) {
+                    const T* keys = L.keys;
+                    partial_sort_replay(L.perm + lb, long(mid - lb), long(cnt), [=](uint32_t q) { return keys[q]; });
+                }
+                wave_sync();
+                const int src = L.perm[lane];
+                id = __shfl(id, src);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { ctr[k] = __shfl(ctr[k], src); blo[k] = __shfl(blo[k], src); bhi[k] = __shfl(bhi[k], src); }
+                split = true;
+                cut = mid;
+            }
+        }
+
+        HostNode<T> rec;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rec.bounds[2 * k] = nlo[k]; rec.bounds[2 * k + 1] = nhi[k]; }
+        if (split) {
+            // child boxes by butterfly reductions over the two lane ranges
+            T lo[2][3], hi[2][3];
+            const bool left = in && uint32_t(lane) < cut, right = in && uint32_t(lane) >= cut;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[0][k] = left ? blo[k] : Ord<T>::kMax;  hi[0][k] = left ? bhi[k] : -Ord<T>::kMax;
+                lo[1][k] = right ? blo[k] : Ord<T>::kMax; hi[1][k] = right ? bhi[k] : -Ord<T>::kMax;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        lo[q][k] = pick_min(lo[q][k], __shfl_xor(lo[q][k], off));
+                        hi[q][k] = pick_max(hi[q][k], __shfl_xor(hi[q][k], off));
+                    }
+            // a zero bound takes the sign of the last zero in position (= lane) order, see SlotState::zlo
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const bool side = q == 0 ? left : right;
+                    if (lo[q][k] == T(0)) {
+                        const uint64_t zm = __ballot(side && blo[k] == T(0));
+                        lo[q][k] = Ord<T>::zero(__shfl(Ord<T>::sign(blo[k]), 63 - __clzll(zm)));
+                    }
+                    if (hi[q][k] == T(0)) {
+                        const uint64_t zm = __ballot(side && bhi[k] == T(0));
+                        hi[q][k] = Ord<T>::zero(__shfl(Ord<T>::sign(bhi[k]), 63 - __clzll(zm)));
+                    }
+                }
+            const int first = half_area(lo[0], hi[0]) < half_area(lo[1], hi[1]) ? 1 : 0;   // SATO
+            const uint32_t child = ncount;
+            ncount += 2;
+            const uint32_t rb[2] = { lb, cut }, re[2] = { cut, le };
+            if (lane < 3) {
+                L.nbox[child][lane] = lo[first][lane];         L.nbox[child][3 + lane] = hi[first][lane];
+                L.nbox[child + 1][lane] = lo[1 - first][lane]; L.nbox[child + 1][3 + lane] = hi[1 - first][lane];
+            }
+            uint32_t ia = pack_item(child, rb[first], re[first]), ib = pack_item(child + 1, rb[1 - first], re[1 - first]);
+            if (re[first] - rb[first] < re[1 - first] - rb[1 - first]) { const uint32_t t = ia; ia = ib; ib = t; }   // :116-120
+            if (lane == 0) { L.stack[sp] = ia; L.stack[sp + 1] = ib; }
+            sp += 2;
+            rec.index = static_cast<typename IndexOf<T>::Type>(child) << kCountBits;
+        } else {
+            rec.index = (static_cast<typename IndexOf<T>::Type>(B + lb) << kCountBits) | cnt;
+        }
+        if (lane == 0) stage[ln] = rec;
+    }
+    if (lane < int(s)) c.ids[B + lane] = id;
+    if (lane == 0) A.ic = (ncount - 1) / 2;
+}
+
+// =====================================================================================================
+// Phase C: numbering and emission
+// =====================================================================================================
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_count_inner(BuildCtx<T> c, uint32_t first, uint32_t last) {
+    const uint32_t v = first + blockIdx.x * 256 + threadIdx.x;
+    if (v >= last) return;
+    ANode<T>& nd = c.nodes[v];
+    if (nd.kind == KIND_INNER) nd.ic = 1 + c.nodes[nd.child].ic + c.nodes[nd.child + 1].ic;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_assign_ranks(BuildCtx<T> c, uint32_t first, uint32_t last) {
+    const uint32_t v = first + blockIdx.x * 256 + threadIdx.x;
+    if (v >= last) return;
+    const ANode<T>& nd = c.nodes[v];
+    if (nd.kind != KIND_INNER) return;
+    ANode<T>& c0 = c.nodes[nd.child];
+    ANode<T>& c1 = c.nodes[nd.child + 1];
+    // the item with fewer primitives is popped first; on a tie the second child (top_down_sah_builder.h:116-121)
+    const bool c0_first = (c0.end - c0.begin) < (c1.end - c1.begin);
+    if (c0_first) { c0.rank = nd.rank + 1; c1.rank = nd.rank + 1 + c0.ic; }
+    else          { c1.rank = nd.rank + 1; c0.rank = nd.rank + 1 + c1.ic; }
+}
+
+template <typename T>
+__device__ inline uint32_t final_id(const BuildCtx<T>& c, const ANode<T>& nd) {
+    if (nd.parent == kNone) return 0;
+    return 1 + 2 * c.nodes[nd.parent & 0x7FFFFFFFu].rank + (nd.parent >> 31);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_emit_tree(BuildCtx<T> c, uint32_t n_nodes, HostNode<T>* out) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_nodes) return;
+    const ANode<T>& nd = c.nodes[v];
+    using I = typename IndexOf<T>::Type;
+    HostNode<T> rec;
+    for (int k = 0; k < 3; ++k) { rec.bounds[2 * k] = nd.lo[k]; rec.bounds[2 * k + 1] = nd.hi[k]; }
+    if (nd.kind == KIND_INNER) {
+        rec.index = static_cast<I>(1 + 2 * nd.rank) << kCountBits;
+    } else {                                                  // KIND_SMALL: the staged subtree root
+        const HostNode<T>& sr = c.stage[2ull * nd.begin];
+        rec.index = (sr.index & kCountMask) ? sr.index : ((sr.index >> kCountBits) + 2 * I(nd.rank)) << kCountBits;
+    }
+    out[final_id(c, nd)] = rec;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_emit_small(BuildCtx<T> c, uint32_t n_small, HostNode<T>* out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_small) return;
+    const ANode<T>& nd = c.nodes[c.small_list[w]];
+    using I = typename IndexOf<T>::Type;
+    const uint32_t count = 2 * nd.ic;                         // staged nodes besides the root
+    const HostNode<T>* stage = c.stage + 2ull * nd.begin;
+    for (uint32_t j = 1 + lane; j <= count; j += 64) {
+        HostNode<T> rec = stage[j];
+        if ((rec.index & kCountMask) == 0) rec.index = ((rec.index >> kCountBits) + 2 * I(nd.rank)) << kCountBits;
+        out[2ull * nd.rank + j] = rec;
+    }
+}
+
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)); }
+};
+
+} // namespace
+
+// BinnedSahBuilder::build on the device. On success `out` holds the host mirror and the device copy.
+template <typename T>
+int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
+                        hipStream_t stream)
+{
+    if (n >= (size_t{1} << 28)) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: more than 2^28 primitives");
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // capacities: typical first, worst case (degenerate chains of big nodes) on retry
+        const uint32_t node_cap = attempt == 0 ? n32 / 8 + 1024 : 2 * n32 + 2;
+        const uint32_t slot_cap = n32 / (kSmall + 1) + 2;
+        const uint32_t task_cap = n32 / kChunk + slot_cap + 2;
+        DevBuf<uint32_t> ids, chunk_true, ltab, rtab, small_list;
+        DevBuf<ANode<T>> nodes;
+        DevBuf<SlotBins<T>> bins;
+        DevBuf<SlotState<T>> st_a, st_b;
+        DevBuf<Task> tk_a, tk_b;
+        DevBuf<HostNode<T>> stage, final_nodes;
+        DevBuf<Counters> counters;
+        hipError_t e = hipSuccess;
+        auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+        A(ids.alloc(n)); A(chunk_true.alloc(task_cap)); A(ltab.alloc(n)); A(rtab.alloc(n)); A(small_list.alloc(node_cap));
+        A(nodes.alloc(node_cap)); A(bins.alloc(slot_cap)); A(st_a.alloc(slot_cap)); A(st_b.alloc(slot_cap));
+        A(tk_a.alloc(task_cap)); A(tk_b.alloc(task_cap)); A(stage.alloc(2 * n)); A(counters.alloc(1));
+        if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+
+        BuildCtx<T> c;
+        c.bboxes = d_bboxes; c.centers = d_centers; c.ids = ids.p; c.n = n32;
+        c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
+        c.nodes = nodes.p; c.node_cap = node_cap; c.bins = bins.p; c.state = st_a.p; c.state_next = st_b.p; c.slot_cap = slot_cap;
+        c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = chunk_true.p;
+        c.ltab = ltab.p; c.rtab = rtab.p; c.small_list = small_list.p; c.stage = stage.p; c.counters = counters.p;
+
+        // ---- root
+        hipLaunchKernelGGL(k_prepare_root<T>, dim3(1), dim3(1), 0, stream, c);
+        const unsigned root_grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 2048));
+        hipLaunchKernelGGL(k_init_root<T>, dim3(root_grid), dim3(256), 0, stream, c);
+        {   // the root's children go to state_next/tasks_next; swap so they become the current level
+            BuildCtx<T> r = c;
+            hipLaunchKernelGGL(k_make_root<T>, dim3(1), dim3(1), 0, stream, r);
+        }
+        Counters h;
+        BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+
+        std::vector<uint32_t> level_start{0, 1};              // A-node id ranges per level
+        uint32_t n_active = h.n_active_next, n_tasks = h.n_tasks_next;
+        bool overflow = h.error != 0;
+        // ---- Phase A
+        while (n_active > 0 && !overflow) {
+            std::swap(c.state, c.state_next);
+            std::swap(c.tasks, c.tasks_next);
+            BVH_HIP_TRY(hipMemsetAsync(&counters.p->n_active_next, 0, 2 * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
+            const unsigned slot_grid = (n_active + 63) / 64;
+            hipLaunchKernelGGL(k_init_slots<T>, dim3(n_active), dim3(64), 0, stream, c);
+            hipLaunchKernelGGL(k_bin<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+            hipLaunchKernelGGL(k_decide<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
+            hipLaunchKernelGGL(k_count<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+            hipLaunchKernelGGL(k_scatter<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+            hipLaunchKernelGGL(k_fallback<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
+            hipLaunchKernelGGL(k_swap<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+            hipLaunchKernelGGL(k_child_bounds<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+            hipLaunchKernelGGL(k_finalize<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
+            BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+            BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+            BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+            overflow = h.error != 0;
+            level_start.push_back(h.n_nodes);
+            n_active = h.n_active_next;
+            n_tasks = h.n_tasks_next;
+        }
+        if (overflow) {
+            if (attempt == 0) continue;
+            return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
+        }
+        const uint32_t n_nodes_a = h.n_nodes, n_small = h.n_small;
+
+        // ---- Phase B
+        if (n_small) hipLaunchKernelGGL(k_small<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, c, n_small);
+        // ---- Phase C
+        const size_t levels = level_start.size() - 1;
+        for (size_t l = levels; l-- > 0;) {
+            const uint32_t a = level_start[l], b = level_start[l + 1];
+            if (b > a) hipLaunchKernelGGL(k_count_inner<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
+        }
+        for (size_t l = 0; l < levels; ++l) {
+            const uint32_t a = level_start[l], b = level_start[l + 1];
+            if (b > a) hipLaunchKernelGGL(k_assign_ranks<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
+        }
+        ANode<T> root;
+        BVH_HIP_TRY(hipMemcpyAsync(&root, nodes.p, sizeof(root), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        const size_t total_nodes = 2 * size_t{root.ic} + 1;
+        A(final_nodes.alloc(total_nodes));
+        if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+        hipLaunchKernelGGL(k_emit_tree<T>, dim3((n_nodes_a + 255) / 256), dim3(256), 0, stream, c, n_nodes_a, final_nodes.p);
+        if (n_small) hipLaunchKernelGGL(k_emit_small<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, c, n_small, final_nodes.p);
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+
+        // ---- results: device copy (pairs + prim ids) and host mirror
+        out.nodes.resize(total_nodes);
+        out.prim_ids.resize(n);
+        std::vector<uint32_t> ids_h(n);
+        BVH_HIP_TRY(hipMemcpyAsync(out.nodes.data(), final_nodes.p, total_nodes * sizeof(HostNode<T>), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMemcpyAsync(ids_h.data(), ids.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        int rc = relayout_on_device(out, final_nodes.p, stream);
+        if (rc) return rc;
+        if (!out.d_work) BVH_HIP_TRY(hipMalloc(&out.d_work, 2 * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
+        if (out.d_prim_ids) { (void)hipFree(out.d_prim_ids); out.d_prim_ids = nullptr; }
+        out.d_prim_ids = ids.p;                               // hand the buffer over
+        ids.p = nullptr;
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        for (size_t i = 0; i < n; ++i) out.prim_ids[i] = ids_h[i];
+        out.root_index = static_cast<uint32_t>(out.nodes[0].index);
+        return BVH_AMD_OK;
+    }
+    return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
+}
+
+template int build_binned_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
+template int build_binned_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
+
+} // namespace bvh_amd

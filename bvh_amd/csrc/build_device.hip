@@ -1,11 +1,22 @@
-// Device builders (placeholder dispatch until build_binned.hip lands).
+// Dispatch of DefaultBuilder's modes (reference default_builder.h:33-62) onto the device builders.
 #include "common.h"
 
 namespace bvh_amd {
 
 template <typename T>
-int build_on_device(BvhImpl<T>&, const T*, const T*, size_t, const bvh_build_config&, bvh_amd_builder, hipStream_t) {
-    return fail(BVH_AMD_ERR_UNSUPPORTED, "build: this builder mode is not implemented on the device yet");
+int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
+                        hipStream_t stream);
+
+template <typename T>
+int build_on_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
+                    bvh_amd_builder builder, hipStream_t stream)
+{
+    // default_builder.h:39-40: the parallel overload falls back to the serial one below the threshold
+    if (builder == BVH_AMD_BUILDER_DEFAULT_PARALLEL && n < cfg.parallel_threshold) builder = BVH_AMD_BUILDER_DEFAULT_SERIAL;
+    if (builder == BVH_AMD_BUILDER_BINNED || (builder == BVH_AMD_BUILDER_DEFAULT_SERIAL && cfg.quality == BVH_BUILD_QUALITY_LOW))
+        return build_binned_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
+    return fail(BVH_AMD_ERR_UNSUPPORTED, "build: this builder/quality combination is not implemented on the device yet "
+                                         "(available: BinnedSahBuilder, DefaultBuilder serial Low)");
 }
 
 template int build_on_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, bvh_amd_builder, hipStream_t);

@@ -1,0 +1,110 @@
+"""-m gpu: device builders against the oracle / golden streams. Bar: memcmp-equal Bvh::serialize streams
+(bit-exact node bounds, packed indices, node numbering and prim_ids order)."""
+import numpy as np
+import pytest
+
+import oracle
+from bvh_amd import synth
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_binned(bb, cc, **kw):
+    import bvh_amd
+    cfg = bvh_amd.Config(quality=bvh_amd.Quality.Low, **kw)
+    return bvh_amd.BinnedSahBuilder.build(bb, cc, cfg)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "soup2k", "terrain2k", "soup2k_f64", "spheres2k_f64"])
+def test_binned_matches_golden_stream(scene):
+    import bvh_amd
+    g = load_golden(scene)
+    bvh = _gpu_binned(g["bboxes"], g["centers"])
+    assert bvh.serialize() == g["bvh_binned"].tobytes()
+    # DefaultBuilder serial overload at Quality::Low is the same builder (default_builder.h:54-55)
+    bvh2 = bvh_amd.DefaultBuilder.build(g["bboxes"], g["centers"], bvh_amd.Config(quality=bvh_amd.Quality.Low))
+    assert bvh2.serialize() == g["bvh_serial_low"].tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 63, 64, 65, 66, 127, 129, 1000, 2047, 2048, 2049, 4097, 30000])
+def test_binned_sizes(orc, n):
+    tris = synth.soup(n, seed=n, jitter=0.05)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    assert _gpu_binned(bb, cc).serialize() == ref.serialize()
+
+
+@pytest.mark.parametrize("scene,n", [("soup", 300_000), ("terrain", 300_000), ("sponza", 262_144), ("soup", 1_000_000)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_binned_scenes(orc, scene, n, dtype):
+    if dtype == np.float64 and n > 300_000:
+        pytest.skip("covered by the float case")
+    tris = {"soup": lambda: synth.soup(n, dtype=dtype), "terrain": lambda: synth.terrain(n, dtype=dtype),
+            "sponza": lambda: synth.sponza_proxy(n, dtype=dtype)}[scene]()
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    gpu = _gpu_binned(bb, cc)
+    assert gpu.node_count == ref.node_count
+    assert gpu.serialize() == ref.serialize()
+
+
+@pytest.mark.parametrize("min_leaf,max_leaf", [(1, 1), (1, 4), (2, 8), (4, 4), (1, 15), (8, 15)])
+def test_binned_leaf_limits(orc, min_leaf, max_leaf):
+    tris = synth.soup(20000, seed=11, jitter=0.02)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_BINNED, min_leaf=min_leaf, max_leaf=max_leaf)
+    gpu = _gpu_binned(bb, cc, min_leaf_size=min_leaf, max_leaf_size=max_leaf)
+    assert gpu.serialize() == ref.serialize()
+
+
+def test_binned_degenerate_inputs(orc):
+    """Coincident centroids and flat boxes force fallback_split (std::partial_sort order) in both phases."""
+    rng = np.random.default_rng(5)
+    cases = []
+    # many exact duplicates: SAH cannot separate them
+    base = synth.soup(40, seed=1, jitter=0.05)
+    cases.append(np.repeat(base, 50, axis=0))                      # 2000 prims, 50 copies each
+    cases.append(np.repeat(base[:3], 400, axis=0))                 # 1200 prims on 3 sites (big fallback segments)
+    # all primitives identical
+    cases.append(np.repeat(base[:1], 300, axis=0))
+    # flat: everything in the plane z = 0.5, centroids on a coarse lattice (heavy ties)
+    t = synth.soup(5000, seed=2, jitter=0.03)
+    t[:, 2::3] = 0.5
+    t = np.round(t * 8) / 8
+    cases.append(t.astype(np.float32))
+    # a line of points with equal x
+    t = synth.soup(3000, seed=3, jitter=0.0)
+    t[:, 0::3] = 0.25
+    cases.append(t)
+    for tris in cases:
+        tris = tris[rng.permutation(len(tris))]
+        bb, cc = orc.prep_tris(np.ascontiguousarray(tris))
+        ref = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+        gpu = _gpu_binned(bb, cc)
+        assert gpu.serialize() == ref.serialize()
+
+
+def test_build_then_trace_matches_oracle(orc):
+    """End to end on the device: bounds -> build -> permute/precompute -> trace, vs the CPU oracle."""
+    import bvh_amd
+    tris = synth.sponza_proxy(100_000)
+    bb, cc = bvh_amd.tri_bounds(tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Low))
+    prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    rays = synth.rays_closest(100_000, lo, hi)
+    hits = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, prims, rays, robust=True))
+    obb, occ = orc.prep_tris(tris)
+    ob = orc.build(obb, occ, builder=oracle.BUILDER_DEFAULT_SERIAL, quality=oracle.QUALITY_LOW)
+    assert bvh.serialize() == ob.serialize()
+    oh = ob.intersect_tri(orc.precompute_tris(tris, ob.prim_ids()), rays, 0, 1, threads=8)
+    assert hits.tobytes() == oh.tobytes()
+
+
+def test_unsupported_modes_fail_loudly():
+    import bvh_amd
+    tris = synth.soup(5000)
+    bb, cc = bvh_amd.tri_bounds(tris)
+    with pytest.raises(bvh_amd.BvhAmdError):
+        bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High))
