@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s closest-hit on a ~1M-triangle scene, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload soup_1m|sponza_262k|terrain_1m]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic rays: `rays_per_gpu` uniform-random
+closest-hit rays (origin uniform in the 1.1x scene box, direction uniform on the sphere, seed 1234 + rank)
+traced through the device-resident BVH by ONE launch of the traversal kernel; rays and hit records are
+resident in HBM before/after the timed region. The BVH is built on the GPU by the product builder (rank 0),
+serialized in the reference's byte format and broadcast to the other ranks over RCCL; nothing else is
+exchanged (weak scaling: every rank traces its own `rays_per_gpu`).
+
+Rank 0 prints ONE JSON line (metric/value/unit/... + "roofline" + "cpu_baseline").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (generator, n_tris, description)
+    "soup_1m": ("soup", 1_000_000, "1,000,000-triangle random soup (M3), worst-case incoherent"),
+    "terrain_1m": ("terrain", 1_000_000, "~1M-triangle height field (M2), tie-heavy"),
+    "sponza_262k": ("sponza_proxy", 262_144, "262,144-triangle Sponza proxy (M1) — BASELINE configs[1]"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="soup_1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--rays", type=int, default=1 << 24, help="rays per GPU per step")
+    ap.add_argument("--fast", action="store_true", help="intersect_fast instead of the robust slab test")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rays of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample):
+    """The reference's CPU path (oracle/_ref when present, else the restatement) on a bounded sample of the same
+    workload, all host threads; also a parity spot-check of the GPU result. Test infrastructure only."""
+    import oracle
+    lib = oracle.load_ref()
+    kind = "reference"
+    if lib is None:
+        lib = oracle.load_oracle()
+        kind = "port"
+    threads = lib.hardware_threads()
+    cb = lib.from_arrays(bvh.nodes, bvh.prim_ids)
+    prims = lib.precompute_tris(tris, bvh.prim_ids)
+    cb.intersect_tri(prims, rays_sample[:65536], 0, robust, threads=threads)          # warm-up
+    t0 = time.perf_counter()
+    hits, cnt = cb.intersect_tri(prims, rays_sample, 0, robust, threads=threads, counters=True)
+    dt = time.perf_counter() - t0
+    parity = bool(hits.tobytes() == gpu_hits_sample.tobytes())
+    # CPU build of the same tree (single-threaded builder in the reference: BinnedSahBuilder)
+    bb, cc = lib.prep_tris(tris)
+    t0 = time.perf_counter()
+    cb2 = lib.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    bt = time.perf_counter() - t0
+    same_tree = bool(cb2.serialize() == bvh.serialize())
+    return {
+        "value": round(len(rays_sample) / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": kind,
+        "sample": f"first {len(rays_sample)} rays of rank 0's batch, same BVH, {threads} host threads "
+                  f"(std::thread ray chunks around Bvh::intersect)",
+        "build_mtris_s": round(len(tris) / bt / 1e6, 3), "build_threads": 1,
+        "gpu_matches_cpu_hits": parity, "gpu_tree_equals_cpu_tree": same_tree,
+        "P": round(float(cnt[0]) / len(rays_sample), 3), "T": round(float(cnt[1]) / len(rays_sample), 3),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: bvh_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import bvh_amd
+    from bvh_amd import synth
+    from bvh_amd.parallel import broadcast_scene
+
+    gen, n_tris, desc = WORKLOADS[args.workload]
+    robust = not args.fast
+
+    # ---- scene + build on rank 0, broadcast of the serialized BVH + BVH-ordered PrecomputedTri ------------
+    tris = None
+    build_ms = None
+    if rank == 0:
+        tris = getattr(synth, gen)(n_tris)
+        d_tris = torch.from_numpy(tris).cuda()
+        cfg = bvh_amd.Config(quality=bvh_amd.Quality.Low)
+        bb, cc = bvh_amd.tri_bounds(d_tris)
+        bvh = bvh_amd.DefaultBuilder.build(bb, cc, cfg)                      # warm-up build (allocations, code load)
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bb, cc = bvh_amd.tri_bounds(d_tris)
+            bvh = bvh_amd.DefaultBuilder.build(bb, cc, cfg)                  # includes D2H of the host mirror
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        build_ms = sorted(times)[1] * 1e3
+        prims = bvh_amd.precompute_tris(d_tris, bvh.device_prim_ids())
+    else:
+        bvh, prims = None, None
+    if distributed:
+        bvh, prims = broadcast_scene(bvh, prims, src=0)
+    lo, hi = synth.scene_bounds(tris) if rank == 0 else (None, None)
+    if distributed:
+        box = torch.tensor(np.stack([lo, hi]) if rank == 0 else np.zeros((2, 3)), dtype=torch.float64, device="cuda")
+        dist.broadcast(box, 0)
+        lo, hi = box[0].cpu().numpy(), box[1].cpu().numpy()
+
+    # ---- this rank's ray shard, resident in HBM ---------------------------------------------------------------
+    rays_h = synth.rays_closest(args.rays, lo, hi, seed=1234 + rank)
+    rays = torch.from_numpy(rays_h).cuda()
+    hits = torch.empty((args.rays, 4), dtype=torch.float32, device="cuda")
+
+    def step():
+        bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, out=hits)
+
+    # traversal statistics of this batch (stats variant of the kernel; equal to the oracle's counters, tests/)
+    _, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, counters=True)
+    cnt = cnt.cpu().numpy()
+    P, T = cnt[0] / args.rays, cnt[1] / args.rays
+    b_ray = 32.0 + 56.0 * P + 48.0 * T + 16.0            # ray + node pairs + triangles + hit record
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))   # HIP events, launch stream
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_rays = args.rays * world * args.steps
+        value = total_rays / elapsed / 1e6
+        achieved = b_ray * args.rays / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s closest-hit (1M-tri scene)", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}; {'robust' if robust else 'fast'} traversal, "
+                                   f"DefaultBuilder serial Low (binned SAH) built on the GPU",
+                       "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(args.rays),
+                       "parallelism": f"rays sharded x{world}, BVH broadcast over RCCL" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": bvh_amd._lib.load().bvh_amd_last_kernel_name().decode(),
+                         "kernel_ms": round(kernel_ms, 4), "bytes_per_ray": round(b_ray, 1),
+                         "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)},
+            "build": {"mtris_s": round(n_tris / (build_ms * 1e-3) / 1e6, 2), "ms": round(build_ms, 3),
+                      "what": "tri bounds + DefaultBuilder Low on device + D2H host mirror, median of 3"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ns = min(args.cpu_sample, args.rays)
+            out["cpu_baseline"] = cpu_baseline(tris, bvh, rays_h[:ns], int(robust), bvh_amd.hits_to_numpy(hits[:ns]))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
