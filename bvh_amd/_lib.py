@@ -43,6 +43,9 @@ _SIGS = {
     "bvh_thread_pool_create": (_P, [_Z]),
     "bvh_thread_pool_destroy": (None, [_P]),
     "bvh_amd_gather": (_I, [_P, _P, _Z, _Z, _P, _P]),
+    "bvh_amd_std_sort_ids3f": (_I, [_P, _Z, _P, _P]),
+    "bvh_amd_std_sort_ids3d": (_I, [_P, _Z, _P, _P]),
+    "bvh_amd_radix_sort_pairs_u32": (_I, [_P, _P, _Z, _I, _P]),
 }
 _SIGS_T = {
     "bvh{S}_build": (_P, [_P, _P, _P, _Z, _P]),

@@ -287,3 +287,22 @@ def intersect(bvh: Bvh, prims, rays, any_hit: bool = False, robust: bool = False
 def hits_to_numpy(hits) -> np.ndarray:
     a = hits.detach().cpu().numpy()
     return a.view(HITF if a.dtype == np.float32 else HITD).reshape(-1)
+
+
+def std_sort_ids(keys):
+    """ids sorted exactly like libstdc++'s std::sort(iota, by keys[i] < keys[j]) incl. tie arrangement (int32 tensor)."""
+    torch = _torch()
+    k = _dev(keys).reshape(-1)
+    s = _suffix(k.dtype)
+    out = torch.empty(k.shape[0], dtype=torch.int32, device=k.device)
+    _lib.check(getattr(_lib.load(), f"bvh_amd_std_sort_ids{s}")(k.data_ptr(), k.shape[0], out.data_ptr(), _stream()), "std_sort_ids")
+    return out
+
+
+def radix_sort_pairs(keys_u32, vals_u32, bits=32):
+    """Stable LSD radix sort by the low `bits` bits; returns (keys, vals) as new int32 tensors."""
+    torch = _torch()
+    k = _dev(keys_u32).to(torch.int32).clone()
+    v = _dev(vals_u32).to(torch.int32).clone()
+    _lib.check(_lib.load().bvh_amd_radix_sort_pairs_u32(k.data_ptr(), v.data_ptr(), k.shape[0], bits, _stream()), "radix_sort_pairs")
+    return k, v

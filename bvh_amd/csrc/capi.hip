@@ -230,6 +230,23 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
 BVH_AMD_IMPL(float, 3f)
 BVH_AMD_IMPL(double, 3d)
 
+int bvh_amd_std_sort_ids3f(const float* d_keys, size_t n, uint32_t* d_ids_out, void* stream) {
+    return std_sort_ids<float>(d_ids_out, d_keys, static_cast<uint32_t>(n), 1, 0, 1, static_cast<hipStream_t>(stream));
+}
+int bvh_amd_std_sort_ids3d(const double* d_keys, size_t n, uint32_t* d_ids_out, void* stream) {
+    return std_sort_ids<double>(d_ids_out, d_keys, static_cast<uint32_t>(n), 1, 0, 1, static_cast<hipStream_t>(stream));
+}
+int bvh_amd_radix_sort_pairs_u32(uint32_t* d_keys, uint32_t* d_vals, size_t n, int bits, void* stream) {
+    uint32_t *kt = nullptr, *vt = nullptr;
+    BVH_HIP_TRY(hipMalloc(&kt, std::max<size_t>(n, 1) * 4), BVH_AMD_ERR_HIP);
+    hipError_t e = hipMalloc(&vt, std::max<size_t>(n, 1) * 4);
+    int rc = e == hipSuccess ? radix_sort_pairs<uint32_t>(d_keys, d_vals, kt, vt, static_cast<uint32_t>(n), 1, bits, static_cast<hipStream_t>(stream))
+                             : fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
+    (void)hipFree(kt);
+    if (vt) (void)hipFree(vt);
+    return rc;
+}
+
 int bvh_amd_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t stride, void* d_out, void* stream) {
     return launch_gather(d_in, d_perm, n, stride, d_out, static_cast<hipStream_t>(stream));
 }

@@ -1,0 +1,298 @@
+// Device sorts whose ORDER is part of the reference's observable output.
+//
+//  * radix_sort_pairs: stable LSD radix sort (8 bits per pass) of (key, value) pairs. Reproduces any
+//    stable sort by an integer key, e.g. "ids ascending within a grid bin" (mini_tree_builder.h:124).
+//  * std_sort_ids: libstdc++ 11 `std::sort(ids, ids + n, [&](i, j) { return key[i] < key[j]; })`,
+//    including the arrangement of EQUAL keys, which is what SweepSahBuilder (sweep_sah_builder.h:57-63) and
+//    ReinsertionOptimizer (reinsertion_optimizer.h:256) leak into their results:
+//      introsort = repeat { median-of-3 to front (stl_algo.h:79-103); __unguarded_partition (:1878-1895) }
+//      on every segment longer than 16 with a depth budget of 2*floor(log2 n), then one insertion sort,
+//      which is a STABLE sort of whatever arrangement the partition phase left.
+//    Segments are disjoint, so the partition phase runs level-synchronously, one block per segment, using
+//    the exact characterisation of the Hoare-style loop: with L = ascending positions whose key is >= pivot and
+//    R = descending positions whose key is <= pivot, the loop swaps L_j <-> R_j for j < k = #{j : L_j < R_j} and
+//    returns cut = (k == 0) ? L_0 : (L_k exists and L_k < R_{k-1} ? L_k : R_{k-1}).
+//    The stable finish is a radix sort on the order-preserving integer image of the key.
+//    The depth-exhausted heap-sort branch (stl_algo.h:1933) is replayed by one lane (never observed).
+
+#include "build_common.h"
+
+namespace bvh_amd {
+
+using namespace bld;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// stable LSD radix sort
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRadixTile = 4096;        // elements per block
+constexpr int kRadixThreads = 256;
+
+template <typename K>
+__global__ void __launch_bounds__(kRadixThreads) k_radix_hist(const K* keys, uint32_t n, uint32_t blocks_per_array, int shift,
+                                                              uint32_t* hist) {
+    __shared__ uint32_t h[256];
+    const uint32_t arr = blockIdx.x / blocks_per_array, blk = blockIdx.x % blocks_per_array;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = size_t{arr} * n;
+    const uint32_t b = blk * kRadixTile, e = min(n, b + kRadixTile);
+    for (uint32_t i = b + threadIdx.x; i < e; i += uint32_t(kRadixThreads))
+        atomicAdd(&h[(keys[base + i] >> shift) & 0xFF], 1u);
+    __syncthreads();
+    hist[(size_t{arr} * 256 + threadIdx.x) * blocks_per_array + blk] = h[threadIdx.x];    // digit-major, block-minor
+}
+
+// exclusive scan of one array's histogram (256 * blocks entries), one block per array
+__global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* hist, uint32_t entries) {
+    __shared__ uint32_t part[1024];
+    uint32_t* h = hist + size_t{blockIdx.x} * entries;
+    const uint32_t per = (entries + 1023) / 1024;
+    const uint32_t b = min(entries, threadIdx.x * per), e = min(entries, b + per);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += h[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t i = b; i < e; ++i) { uint32_t v = h[i]; h[i] = run; run += v; }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kRadixThreads) k_radix_scatter(const K* keys, const uint32_t* vals, K* keys_out, uint32_t* vals_out,
+                                                                 uint32_t n, uint32_t blocks_per_array, int shift, const uint32_t* hist) {
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wave_cnt[4][256];
+    const uint32_t arr = blockIdx.x / blocks_per_array, blk = blockIdx.x % blocks_per_array;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    running[threadIdx.x] = hist[(size_t{arr} * 256 + threadIdx.x) * blocks_per_array + blk];
+    const size_t base = size_t{arr} * n;
+    const uint32_t b = blk * kRadixTile, e = min(n, b + kRadixTile);
+    for (uint32_t tile = b; tile < e; tile += kRadixThreads) {
+        for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t i = tile + threadIdx.x;
+        const bool in = i < e;
+        K key = 0; uint32_t val = 0, d = 0;
+        if (in) { key = keys[base + i]; val = vals[base + i]; d = (key >> shift) & 0xFF; }
+        uint64_t same = __ballot(in);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const uint64_t bal = __ballot((d >> bit) & 1);
+            same &= ((d >> bit) & 1) ? bal : ~bal;
+        }
+        const uint32_t rank_in_wave = __popcll(same & ((uint64_t{1} << lane) - 1));
+        if (in && rank_in_wave == 0) wave_cnt[wave][d] = __popcll(same);
+        __syncthreads();
+        if (in) {
+            uint32_t before = running[d] + rank_in_wave;
+            for (int w = 0; w < wave; ++w) before += wave_cnt[w][d];
+            keys_out[base + before] = key;
+            vals_out[base + before] = val;
+        }
+        __syncthreads();
+        running[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// std::sort partition phase
+// ---------------------------------------------------------------------------------------------------
+struct SortSeg { uint32_t first, last, depth; };      // indices into the batched id array
+struct SortCounters { uint32_t next, pad[3]; };
+
+template <typename T>
+struct SortCtx {
+    uint32_t* ids;              // batch * n
+    const T* keys;              // key(a, id) = keys[a * astride + id * istride]
+    uint32_t n, astride, istride;
+    SortSeg* segs; SortSeg* segs_next;
+    uint32_t* ltab; uint32_t* rtab;                     // batch * n scratch
+    SortCounters* counters;
+    uint32_t seg_cap;
+};
+
+constexpr int kSortThreads = 512;
+
+template <typename T>
+__global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c) {
+    __shared__ uint32_t wsum_l[8], wsum_r[8];
+    __shared__ uint32_t sh_k;
+    const SortSeg sg = c.segs[blockIdx.x];
+    const uint32_t arr = sg.first / c.n;
+    const T* kb = c.keys + size_t{arr} * c.astride;
+    const uint32_t istride = c.istride;
+    auto key = [=](uint32_t id) { return kb[size_t{id} * istride]; };
+    uint32_t* ids = c.ids;
+    const uint32_t first = sg.first, last = sg.last, len = last - first;
+    if (sg.depth == 0) {                                 // __partial_sort(first, last, last): heap sort
+        if (threadIdx.x == 0) partial_sort_replay(ids + first, long(len), long(len), key);
+        return;
+    }
+    if (threadIdx.x == 0) {                              // __move_median_to_first(first, first + 1, mid, last - 1)
+        const uint32_t a = first + 1, b = first + len / 2, cc = last - 1;
+        const T ka = key(ids[a]), kbv = key(ids[b]), kc = key(ids[cc]);
+        uint32_t pick;
+        if (ka < kbv) { if (kbv < kc) pick = b; else if (ka < kc) pick = cc; else pick = a; }
+        else if (ka < kc) pick = a;
+        else if (kbv < kc) pick = cc;
+        else pick = b;
+        const uint32_t t = ids[first]; ids[first] = ids[pick]; ids[pick] = t;
+        sh_k = 0;
+    }
+    __syncthreads();
+    const T pivot = key(ids[first]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pass 1: L (key >= pivot) and R (key <= pivot) position tables over [first + 1, last), both ascending
+    uint32_t run_l = 0, run_r = 0;
+    for (uint32_t tile = first + 1; tile < last; tile += kSortThreads) {
+        const uint32_t pos = tile + threadIdx.x;
+        const bool in = pos < last;
+        const T kv = in ? key(ids[pos]) : pivot;
+        const bool fl = in && !(kv < pivot), fr = in && !(pivot < kv);
+        const uint64_t bl = __ballot(fl), br = __ballot(fr);
+        if (lane == 0) { wsum_l[wave] = __popcll(bl); wsum_r[wave] = __popcll(br); }
+        __syncthreads();
+        uint32_t el = __popcll(bl & ((uint64_t{1} << lane) - 1)), er = __popcll(br & ((uint64_t{1} << lane) - 1));
+        uint32_t tl = 0, tr = 0;
+        for (int w = 0; w < kSortThreads / 64; ++w) { if (w < wave) { el += wsum_l[w]; er += wsum_r[w]; } tl += wsum_l[w]; tr += wsum_r[w]; }
+        if (fl) c.ltab[first + run_l + el] = pos;
+        if (fr) c.rtab[first + run_r + er] = pos;
+        run_l += tl; run_r += tr;
+        __syncthreads();
+    }
+    const uint32_t nl = run_l, nr = run_r;               // both >= 1 (median-of-3 sentinels)
+    __threadfence_block();
+    __syncthreads();
+    // pass 2: k = #{j : L_j < R_j}, R_j (descending) = rtab[nr - 1 - j]
+    const uint32_t lim = min(nl, nr);
+    uint32_t mine = 0;
+    for (uint32_t j = threadIdx.x; j < lim; j += kSortThreads)
+        mine += c.ltab[first + j] < c.rtab[first + nr - 1 - j] ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if (lane == 0 && mine) atomicAdd(&sh_k, mine);
+    __syncthreads();
+    const uint32_t k = sh_k;
+    // pass 3: the swaps
+    for (uint32_t j = threadIdx.x; j < k; j += kSortThreads) {
+        const uint32_t p = c.ltab[first + j], q = c.rtab[first + nr - 1 - j];
+        const uint32_t a = ids[p], b = ids[q];
+        ids[p] = b; ids[q] = a;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t cut;
+        if (k == 0) cut = c.ltab[first];
+        else {
+            const uint32_t rk1 = c.rtab[first + nr - k];                 // R_{k-1}
+            cut = (k < nl && c.ltab[first + k] < rk1) ? c.ltab[first + k] : rk1;
+        }
+        const uint32_t cb[2] = { first, cut }, ce[2] = { cut, last };
+        for (int s = 0; s < 2; ++s) {
+            if (ce[s] - cb[s] > 16) {                                    // _S_threshold
+                const uint32_t slot = atomicAdd(&c.counters->next, 1u);
+                if (slot < c.seg_cap) c.segs_next[slot] = SortSeg{ cb[s], ce[s], sg.depth - 1 };
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_make_sort_keys(const uint32_t* ids, const T* keys, uint32_t n, uint32_t total, uint32_t astride,
+                                                        uint32_t istride, typename Ord<T>::U* out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t arr = i / n;
+    T v = keys[size_t{arr} * astride + size_t{ids[i]} * istride];
+    if (v == T(0)) v = T(0);                              // -0 and +0 are EQUAL keys for operator<: one integer image
+    out[i] = Ord<T>::enc(v);
+}
+
+__global__ void __launch_bounds__(256) k_iota(uint32_t* ids, uint32_t n, uint32_t total) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total) ids[i] = i % n;
+}
+
+} // namespace
+
+// Stable sort of `batch` independent arrays of n (key, value) pairs by the low `bits` bits of the key.
+// keys/vals are overwritten with the result; tmp buffers have the same sizes.
+template <typename K>
+int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream) {
+    if (n == 0 || batch == 0) return BVH_AMD_OK;
+    const uint32_t bpa = (n + kRadixTile - 1) / kRadixTile;
+    DevBuf<uint32_t> hist;
+    BVH_HIP_TRY(hist.alloc(size_t{batch} * 256 * bpa), BVH_AMD_ERR_HIP);
+    K* kin = keys; K* kout = keys_tmp; uint32_t* vin = vals; uint32_t* vout = vals_tmp;
+    int passes = (bits + 7) / 8;
+    if (passes & 1) ++passes;                             // even number of passes: the result lands in keys/vals
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, n, bpa, shift, hist.p);
+        hipLaunchKernelGGL(k_radix_scan, dim3(batch), dim3(1024), 0, stream, hist.p, 256 * bpa);
+        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, vin, kout, vout, n, bpa, shift, hist.p);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // hist is freed on return
+    return BVH_AMD_OK;
+}
+
+// d_ids: batch * n, overwritten with iota then sorted like std::sort with comp(i, j) = key(a,i) < key(a,j).
+template <typename T>
+int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, uint32_t astride, uint32_t istride, hipStream_t stream) {
+    if (n == 0 || batch == 0) return BVH_AMD_OK;
+    const uint32_t total = n * batch;
+    hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, stream, d_ids, n, total);
+    using U = typename Ord<T>::U;
+    DevBuf<uint32_t> ltab, rtab, vals_tmp;
+    DevBuf<SortSeg> seg_a, seg_b;
+    DevBuf<SortCounters> counters;
+    DevBuf<U> skeys, skeys_tmp;
+    const uint32_t seg_cap = total / 16 + batch + 2;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(ltab.alloc(total)); A(rtab.alloc(total)); A(vals_tmp.alloc(total)); A(seg_a.alloc(seg_cap)); A(seg_b.alloc(seg_cap));
+    A(counters.alloc(1)); A(skeys.alloc(total)); A(skeys_tmp.alloc(total));
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("std_sort_ids: hipMalloc: ") + hipGetErrorString(e));
+
+    if (n > 16) {
+        uint32_t lg = 0;
+        while ((uint64_t{2} << lg) <= n) ++lg;            // std::__lg(n) = floor(log2 n)
+        std::vector<SortSeg> roots(batch);
+        for (uint32_t a = 0; a < batch; ++a) roots[a] = SortSeg{ a * n, a * n + n, 2 * lg };
+        BVH_HIP_TRY(hipMemcpyAsync(seg_a.p, roots.data(), batch * sizeof(SortSeg), hipMemcpyHostToDevice, stream), BVH_AMD_ERR_HIP);
+        SortCtx<T> c;
+        c.ids = d_ids; c.keys = d_keys; c.n = n; c.astride = astride; c.istride = istride;
+        c.segs = seg_a.p; c.segs_next = seg_b.p; c.ltab = ltab.p; c.rtab = rtab.p; c.counters = counters.p; c.seg_cap = seg_cap;
+        uint32_t active = batch;
+        while (active) {
+            BVH_HIP_TRY(hipMemsetAsync(counters.p, 0, sizeof(SortCounters), stream), BVH_AMD_ERR_HIP);
+            hipLaunchKernelGGL(k_sort_partition<T>, dim3(active), dim3(kSortThreads), 0, stream, c);
+            BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+            SortCounters h;
+            BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+            BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+            if (h.next > seg_cap) return fail(BVH_AMD_ERR_OVERFLOW, "std_sort_ids: segment capacity exceeded");
+            active = h.next;
+            std::swap(c.segs, c.segs_next);
+        }
+    }
+    // __final_insertion_sort == stable sort by key of the current arrangement
+    hipLaunchKernelGGL(k_make_sort_keys<T>, dim3((total + 255) / 256), dim3(256), 0, stream, d_ids, d_keys, n, total, astride, istride, skeys.p);
+    return radix_sort_pairs<U>(skeys.p, d_ids, skeys_tmp.p, vals_tmp.p, n, batch, int(sizeof(U) * 8), stream);
+}
+
+template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t);
+template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t);
+template int std_sort_ids<float>(uint32_t*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+template int std_sort_ids<double>(uint32_t*, const double*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+
+} // namespace bvh_amd

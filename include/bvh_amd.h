@@ -182,6 +182,14 @@ BVH_AMD_API int bvh3f_intersect_rays_sphere(const struct bvh3f*, const float* d_
 BVH_AMD_API int bvh3d_intersect_rays_sphere(const struct bvh3d*, const double* d_sph4, const struct bvh_ray3d* d_rays,
     size_t n, unsigned flags, struct bvh_hit3d* d_hits, struct bvh_amd_counters* d_counters, void* stream);
 
+/* ---- building blocks exposed for unit tests (order-defining sorts) ----------------------- */
+/* d_ids_out[0..n) = the permutation libstdc++ 11's std::sort(iota, [&](i,j){ return keys[i] < keys[j]; }) produces,
+ * including the arrangement of equal keys (sweep_sah_builder.h:57-63 depends on it). */
+BVH_AMD_API int bvh_amd_std_sort_ids3f(const float* d_keys, size_t n, uint32_t* d_ids_out, void* stream);
+BVH_AMD_API int bvh_amd_std_sort_ids3d(const double* d_keys, size_t n, uint32_t* d_ids_out, void* stream);
+/* stable LSD radix sort of (key, value) pairs by the low `bits` bits of the key, in place */
+BVH_AMD_API int bvh_amd_radix_sort_pairs_u32(uint32_t* d_keys, uint32_t* d_vals, size_t n, int bits, void* stream);
+
 /* Name and average duration source for profiling: the kernel symbol the last intersect call used. */
 BVH_AMD_API const char* bvh_amd_last_kernel_name(void);
 

@@ -174,6 +174,14 @@ class CpuLib:
         self._fn("precompute_tris", self._sfx(dt))(_ptr(t), _ptr(p), n, _ptr(out))
         return out
 
+    def std_sort_ids(self, keys):
+        keys = np.ascontiguousarray(keys)
+        out = np.empty(len(keys), dtype=np.uint32)
+        f = getattr(self.dll, f"{self.prefix}_std_sort_ids{self._sfx(keys.dtype)}")
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_size_t, C.c_void_p]
+        f(_ptr(keys), len(keys), _ptr(out))
+        return out
+
     def sphere_bboxes(self, sph4):
         dt = sph4.dtype
         s4 = np.ascontiguousarray(sph4, dtype=dt).reshape(-1, 4)

@@ -935,6 +935,20 @@ extern "C" {
 ORC_IMPL(float, 3f)
 ORC_IMPL(double, 3d)
 
+// the order-defining primitive behind SweepSahBuilder's constructor (sweep_sah_builder.h:57-63)
+ORC_EXPORT void orc_std_sort_ids3f(const float* keys, size_t n, uint32_t* out) {
+    std::vector<size_t> ids(n);
+    std::iota(ids.begin(), ids.end(), size_t{0});
+    std::sort(ids.begin(), ids.end(), [&](size_t i, size_t j) { return keys[i] < keys[j]; });
+    for (size_t i = 0; i < n; ++i) out[i] = static_cast<uint32_t>(ids[i]);
+}
+ORC_EXPORT void orc_std_sort_ids3d(const double* keys, size_t n, uint32_t* out) {
+    std::vector<size_t> ids(n);
+    std::iota(ids.begin(), ids.end(), size_t{0});
+    std::sort(ids.begin(), ids.end(), [&](size_t i, size_t j) { return keys[i] < keys[j]; });
+    for (size_t i = 0; i < n; ++i) out[i] = static_cast<uint32_t>(ids[i]);
+}
+
 ORC_EXPORT int orc_hardware_threads(void) { return static_cast<int>(std::thread::hardware_concurrency()); }
 
 } // extern "C"
