@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <vector>
 
 namespace bvh_amd {
 
@@ -317,6 +318,229 @@ template <typename T> struct DevBuf {
     hipError_t alloc(size_t count) { return hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)); }
 };
 
+
+// ---- Phase A pieces shared by the binned and sweep builders -------------------------------------------
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_init_root(BuildCtx<T> c, bool init_iota) {
+    // ids = iota (binned_sah_builder.h:77) or the caller's order; root box = compute_bbox(0, n) in position order
+    // (top_down_sah_builder.h:80, :133-139)
+    __shared__ typename Ord<T>::U slo[3], shi[3];
+    if (threadIdx.x < 3) { slo[threadIdx.x] = Ord<T>::enc(Ord<T>::kMax); shi[threadIdx.x] = Ord<T>::enc(-Ord<T>::kMax); }
+    __syncthreads();
+    T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+    for (size_t i = blockIdx.x * size_t{256} + threadIdx.x; i < c.n; i += size_t{gridDim.x} * 256) {
+        size_t id = i;
+        if (init_iota) c.ids[i] = static_cast<uint32_t>(i);
+        else id = c.ids[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T a = c.bboxes[6 * id + k], b = c.bboxes[6 * id + 3 + k];
+            lo[k] = pick_min(lo[k], a);
+            hi[k] = pick_max(hi[k], b);
+            track_zero(&c.state[0].zlo[0][k], a, static_cast<uint32_t>(i));
+            track_zero(&c.state[0].zhi[0][k], b, static_cast<uint32_t>(i));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { atomicMin(&slo[k], Ord<T>::enc(lo[k])); atomicMax(&shi[k], Ord<T>::enc(hi[k])); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        // the root's key box lives in state[0].clo[0]/chi[0] until k_make_root decodes it
+        atomicMin(&c.state[0].clo[0][threadIdx.x], slo[threadIdx.x]);
+        atomicMax(&c.state[0].chi[0][threadIdx.x], shi[threadIdx.x]);
+    }
+}
+
+template <typename T>
+__global__ void k_prepare_root(BuildCtx<T> c) {
+    for (int k = 0; k < 3; ++k) {
+        c.state[0].clo[0][k] = Ord<T>::enc(Ord<T>::kMax); c.state[0].chi[0][k] = Ord<T>::enc(-Ord<T>::kMax);
+        c.state[0].zlo[0][k] = 0; c.state[0].zhi[0][k] = 0;
+    }
+    Counters z = {};
+    *c.counters = z;
+}
+
+template <typename T>
+__device__ void emit_child(const BuildCtx<T>& c, uint32_t id) {
+    // registers a freshly created node either as a big segment of the next level or as a Phase B root
+    ANode<T>& nd = c.nodes[id];
+    const uint32_t size = nd.end - nd.begin;
+    if (size > kSmall) {
+        nd.kind = KIND_BIG;
+        const uint32_t slot = atomicAdd(&c.counters->n_active_next, 1u);
+        const uint32_t nt = (size + kChunk - 1) / kChunk;
+        const uint32_t t0 = atomicAdd(&c.counters->n_tasks_next, nt);
+        if (slot >= c.slot_cap || t0 + nt > c.task_cap) { atomicOr(&c.counters->error, 1u); return; }
+        SlotState<T>& st = c.state_next[slot];
+        st.node = id; st.task0 = t0; st.ntasks = nt;
+        for (uint32_t t = 0; t < nt; ++t) {
+            Task tk;
+            tk.slot = slot;
+            tk.begin = nd.begin + t * kChunk;
+            tk.end = min(nd.end, tk.begin + kChunk);
+            c.tasks_next[t0 + t] = tk;
+        }
+    } else {
+        nd.kind = KIND_SMALL;
+        const uint32_t s = atomicAdd(&c.counters->n_small, 1u);
+        c.small_list[s] = id;
+    }
+}
+
+template <typename T>
+__global__ void k_make_root(BuildCtx<T> c) {
+    ANode<T>& r = c.nodes[0];
+    for (int k = 0; k < 3; ++k) {
+        r.lo[k] = decode_bound<T>(c.state[0].clo[0][k], c.state[0].zlo[0][k]);
+        r.hi[k] = decode_bound<T>(c.state[0].chi[0][k], c.state[0].zhi[0][k]);
+    }
+    r.begin = 0; r.end = c.n; r.child = kNone; r.parent = kNone; r.ic = 0; r.rank = 0;
+    c.counters->n_nodes = 1;
+    emit_child(c, 0);
+}
+
+// One block per active slot: reset its accumulators.
+template <typename T>
+__global__ void __launch_bounds__(64) k_init_slots(BuildCtx<T> c) {
+    const uint32_t slot = blockIdx.x;
+    const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
+    if (c.bins) {
+        SlotBins<T>& b = c.bins[slot];
+        for (int w = threadIdx.x; w < 3 * kBins * 3; w += 64) { (&b.lo[0][0][0])[w] = lo0; (&b.hi[0][0][0])[w] = hi0; }
+        for (int w = threadIdx.x; w < 3 * kBins; w += 64) (&b.cnt[0][0])[w] = 0;
+    }
+    SlotState<T>& st = c.state[slot];
+    if (threadIdx.x < 6) {
+        st.clo[threadIdx.x / 3][threadIdx.x % 3] = lo0; st.chi[threadIdx.x / 3][threadIdx.x % 3] = hi0;
+        st.zlo[threadIdx.x / 3][threadIdx.x % 3] = 0;   st.zhi[threadIdx.x / 3][threadIdx.x % 3] = 0;
+    }
+    if (threadIdx.x == 0) { st.m = 0; st.nviol = 0; st.mode = MODE_PARTITION; st.split = 0; }
+}
+
+// compute_bbox of both children (top_down_sah_builder.h:96-97, :133-139).
+template <typename T>
+__global__ void __launch_bounds__(256) k_child_bounds(BuildCtx<T> c) {
+    __shared__ typename Ord<T>::U slo[2][3], shi[2][3];
+    const Task tk = c.tasks[blockIdx.x];
+    SlotState<T>& st = c.state[tk.slot];
+    if (threadIdx.x < 6) { slo[threadIdx.x / 3][threadIdx.x % 3] = Ord<T>::enc(Ord<T>::kMax); shi[threadIdx.x / 3][threadIdx.x % 3] = Ord<T>::enc(-Ord<T>::kMax); }
+    __syncthreads();
+    const uint32_t split = st.split;
+    // the chunk lies on one side unless it straddles the split: reduce in registers per side first
+    T lo[2][3], hi[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[s][k] = Ord<T>::kMax; hi[s][k] = -Ord<T>::kMax; }
+    for (uint32_t pos = tk.begin + threadIdx.x; pos < tk.end; pos += 256) {
+        const uint32_t id = c.ids[pos];
+        const bool right = pos >= split;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T a = c.bboxes[6ull * id + k], b = c.bboxes[6ull * id + 3 + k];
+            track_zero(&st.zlo[right ? 1 : 0][k], a, pos);
+            track_zero(&st.zhi[right ? 1 : 0][k], b, pos);
+            if (right) { lo[1][k] = pick_min(lo[1][k], a); hi[1][k] = pick_max(hi[1][k], b); }
+            else       { lo[0][k] = pick_min(lo[0][k], a); hi[0][k] = pick_max(hi[0][k], b); }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            T a = lo[s][k], b = hi[s][k];
+            for (int off = 32; off > 0; off >>= 1) { a = pick_min(a, __shfl_xor(a, off)); b = pick_max(b, __shfl_xor(b, off)); }
+            if ((threadIdx.x & 63) == 0) { atomicMin(&slo[s][k], Ord<T>::enc(a)); atomicMax(&shi[s][k], Ord<T>::enc(b)); }
+        }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int s = threadIdx.x / 3, k = threadIdx.x % 3;
+        atomicMin(&st.clo[s][k], slo[s][k]);
+        atomicMax(&st.chi[s][k], shi[s][k]);
+    }
+}
+
+// Child creation with SATO order (top_down_sah_builder.h:91-113).
+template <typename T>
+__global__ void __launch_bounds__(64) k_finalize(BuildCtx<T> c, uint32_t n_active) {
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n_active) return;
+    const SlotState<T>& st = c.state[slot];
+    ANode<T>& nd = c.nodes[st.node];
+    T lo[2][3], hi[2][3];
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < 3; ++k) { lo[s][k] = decode_bound<T>(st.clo[s][k], st.zlo[s][k]); hi[s][k] = decode_bound<T>(st.chi[s][k], st.zhi[s][k]); }
+    uint32_t rb[2] = { nd.begin, st.split }, re[2] = { st.split, nd.end };
+    int first = 0;
+    if (half_area(lo[0], hi[0]) < half_area(lo[1], hi[1])) first = 1;                      // :105-108
+    const uint32_t child = atomicAdd(&c.counters->n_nodes, 2u);
+    if (child + 2 > c.node_cap) { atomicOr(&c.counters->error, 2u); return; }
+    nd.child = child;
+    nd.kind = KIND_INNER;
+    for (int w = 0; w < 2; ++w) {
+        const int s = w == 0 ? first : 1 - first;
+        ANode<T>& ch = c.nodes[child + w];
+        for (int k = 0; k < 3; ++k) { ch.lo[k] = lo[s][k]; ch.hi[k] = hi[s][k]; }
+        ch.begin = rb[s]; ch.end = re[s];
+        ch.child = kNone; ch.parent = st.node | (uint32_t(w) << 31); ch.ic = 0; ch.rank = 0;
+        emit_child(c, child + w);
+    }
+}
+
+
+// ---- host side shared by the builders ----------------------------------------------------------------------
+
+// Phase C: inner counts bottom-up, ranks top-down, then scatter of the Phase A nodes and the staged subtrees.
+template <typename T>
+int number_and_emit(BvhImpl<T>& out, const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, uint32_t n_nodes_a,
+                    uint32_t n_small, DevBuf<HostNode<T>>& final_nodes, hipStream_t stream)
+{
+    const size_t levels = level_start.size() - 1;
+    for (size_t l = levels; l-- > 0;) {
+        const uint32_t a = level_start[l], b = level_start[l + 1];
+        if (b > a) hipLaunchKernelGGL(k_count_inner<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
+    }
+    for (size_t l = 0; l < levels; ++l) {
+        const uint32_t a = level_start[l], b = level_start[l + 1];
+        if (b > a) hipLaunchKernelGGL(k_assign_ranks<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
+    }
+    ANode<T> root;
+    BVH_HIP_TRY(hipMemcpyAsync(&root, c.nodes, sizeof(root), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    const size_t total_nodes = 2 * size_t{root.ic} + 1;
+    BVH_HIP_TRY(final_nodes.alloc(total_nodes), BVH_AMD_ERR_HIP);
+    hipLaunchKernelGGL(k_emit_tree<T>, dim3((n_nodes_a + 255) / 256), dim3(256), 0, stream, c, n_nodes_a, final_nodes.p);
+    if (n_small) hipLaunchKernelGGL(k_emit_small<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, c, n_small, final_nodes.p);
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    out.nodes.resize(total_nodes);
+    return BVH_AMD_OK;
+}
+
+// Results: device copy (pair records + prim ids) and the host mirror. `d_ids` holds n prim ids in BVH order; with
+// take_ids the buffer itself becomes out.d_prim_ids (caller must then forget it).
+template <typename T>
+int finish_build(BvhImpl<T>& out, DevBuf<HostNode<T>>& final_nodes, uint32_t* d_ids, size_t n, hipStream_t stream, bool take_ids) {
+    const size_t total_nodes = out.nodes.size();
+    out.prim_ids.resize(n);
+    std::vector<uint32_t> ids_h(n);
+    BVH_HIP_TRY(hipMemcpyAsync(out.nodes.data(), final_nodes.p, total_nodes * sizeof(HostNode<T>), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipMemcpyAsync(ids_h.data(), d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    int rc = relayout_on_device(out, final_nodes.p, stream);
+    if (rc) return rc;
+    if (!out.d_work) BVH_HIP_TRY(hipMalloc(&out.d_work, 2 * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
+    if (out.d_prim_ids) { (void)hipFree(out.d_prim_ids); out.d_prim_ids = nullptr; }
+    if (take_ids) out.d_prim_ids = d_ids;
+    else {
+        BVH_HIP_TRY(hipMalloc(&out.d_prim_ids, std::max<size_t>(n, 1) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMemcpyAsync(out.d_prim_ids, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
+    }
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    for (size_t i = 0; i < n; ++i) out.prim_ids[i] = ids_h[i];
+    out.root_index = static_cast<uint32_t>(out.nodes[0].index);
+    return BVH_AMD_OK;
+}
 
 } // namespace bld
 } // namespace bvh_amd

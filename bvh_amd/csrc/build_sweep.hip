@@ -1,0 +1,527 @@
+// K8 — sweep-SAH top-down construction on gfx950, bit-exact with the reference's SweepSahBuilder
+// (sweep_sah_builder.h:50-138) under TopDownSahBuilder::build (top_down_sah_builder.h:74-139).
+//
+//  * the three centroid-sorted id arrays come from the exact std::sort emulation (sort_emul.hip); their
+//    tie arrangement decides which primitives a candidate plane separates;
+//  * per node and axis, the reference's right-to-left / left-to-right sweeps with chunked early-outs are a
+//    full evaluation: cost(i) = half_area(box[begin, i]) * (i + 1 - begin) + half_area(box[i + 1, end)) * (end - i - 1),
+//    argmin with strict `<`, lowest (axis, position) on ties (probe-verified): here a suffix and a
+//    prefix min/max scan (exact: min/max are associative) and an argmin reduction;
+//  * the other two axes are stable-partitioned by membership (std::stable_partition, :128-136);
+//  * big segments (> 64 primitives) run level-synchronously, one block per (segment, axis) for the scans and
+//    2048-primitive chunks for the per-position passes; segments <= 64 are finished by ONE wavefront that keeps
+//    the three orders as lane permutations in LDS; node numbering and emission are shared with the binned
+//    builder (build_common.h, Phase C).
+
+#include "build_common.h"
+
+namespace bvh_amd {
+
+using namespace bld;
+
+namespace {
+
+constexpr int kScanThreads = 512;
+
+template <typename T> struct AxisBest { T cost; uint32_t pos; uint32_t pad; };
+
+template <typename T>
+struct SweepCtx {
+    BuildCtx<T> b;                       // b.ids == ord[0]
+    uint32_t* ord[3];
+    uint32_t* ord_tmp;                   // 2 * n
+    uint32_t* marks;                     // per primitive id
+    T* cost_r;                           // 3 * n
+    AxisBest<T>* axis_best;              // slot_cap * 3
+    uint32_t* chunk_true2;               // 2 * task_cap
+};
+
+template <typename T> struct Box6 { T lo[3], hi[3]; };
+
+template <typename T> __device__ inline Box6<T> empty_box() {
+    Box6<T> b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { b.lo[k] = Ord<T>::kMax; b.hi[k] = -Ord<T>::kMax; }
+    return b;
+}
+template <typename T> __device__ inline Box6<T> join(const Box6<T>& a, const Box6<T>& o) {
+    Box6<T> r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.lo[k] = pick_min(a.lo[k], o.lo[k]); r.hi[k] = pick_max(a.hi[k], o.hi[k]); }
+    return r;
+}
+template <typename T> __device__ inline Box6<T> shfl_up_box(const Box6<T>& a, int off) {
+    Box6<T> r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.lo[k] = __shfl_up(a.lo[k], off); r.hi[k] = __shfl_up(a.hi[k], off); }
+    return r;
+}
+template <typename T> __device__ inline Box6<T> load_box(const T* bboxes, uint32_t id) {
+    Box6<T> r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.lo[k] = bboxes[6ull * id + k]; r.hi[k] = bboxes[6ull * id + 3 + k]; }
+    return r;
+}
+
+// Inclusive scan of one tile of kScanThreads boxes with a carry from earlier tiles. `valid` lanes beyond the
+// data contribute the empty box. Returns the inclusive value for this thread; updates carry (all threads).
+template <typename T>
+__device__ inline Box6<T> block_scan_boxes(Box6<T> v, Box6<T>& carry, T (*wtot)[6]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Box6<T> o = shfl_up_box(v, off);
+        if (lane >= off) v = join(o, v);
+    }
+    __syncthreads();                                        // wtot reuse across tiles
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { wtot[wave][k] = v.lo[k]; wtot[wave][3 + k] = v.hi[k]; }
+    }
+    __syncthreads();
+    Box6<T> pre = carry, tile = carry;
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        Box6<T> t;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t.lo[k] = wtot[w][k]; t.hi[k] = wtot[w][3 + k]; }
+        if (w < wave) pre = join(pre, t);
+        tile = join(tile, t);
+    }
+    carry = tile;
+    return join(pre, v);
+}
+
+// find_best_split for one (segment, axis): sweep_sah_builder.h:68-101 as full scans.
+template <typename T>
+__global__ void __launch_bounds__(kScanThreads) k_sweep_axis(SweepCtx<T> c) {
+    __shared__ T wtot[kScanThreads / 64][6];
+    __shared__ T wcost[kScanThreads / 64];
+    __shared__ uint32_t wpos[kScanThreads / 64];
+    const uint32_t slot = blockIdx.x / 3, axis = blockIdx.x % 3;
+    const SlotState<T>& st = c.b.state[slot];
+    const ANode<T>& nd = c.b.nodes[st.node];
+    const uint32_t b = nd.begin, e = nd.end;
+    const uint32_t* ord = c.ord[axis];
+    T* cost_r = c.cost_r + size_t{axis} * c.b.n;
+    // right-to-left: cost_r[i] = half_area(box[i, e)) * (e - i), i in (b, e)
+    Box6<T> carry = empty_box<T>();
+    for (uint32_t base = 0; base < e - b; base += kScanThreads) {
+        const uint32_t r = base + threadIdx.x;              // reversed index
+        const bool in = r < e - b;
+        const uint32_t pos = e - 1 - (in ? r : 0);
+        Box6<T> v = in ? load_box(c.b.bboxes, ord[pos]) : empty_box<T>();
+        v = block_scan_boxes(v, carry, wtot);
+        if (in && pos > b) cost_r[pos] = half_area(v.lo, v.hi) * static_cast<T>(e - pos);
+    }
+    __syncthreads();
+    // left-to-right: cost(i) = half_area(box[b, i]) * (i + 1 - b) + cost_r[i + 1], split position i + 1
+    carry = empty_box<T>();
+    T best = __builtin_inff();
+    uint32_t best_pos = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < e - b; base += kScanThreads) {
+        const uint32_t r = base + threadIdx.x;
+        const bool in = r < e - b;
+        const uint32_t pos = b + (in ? r : 0);
+        Box6<T> v = in ? load_box(c.b.bboxes, ord[pos]) : empty_box<T>();
+        v = block_scan_boxes(v, carry, wtot);
+        if (in && pos + 1 < e) {
+            const T cost = half_area(v.lo, v.hi) * static_cast<T>(pos + 1 - b) + cost_r[pos + 1];
+            if (cost < best) { best = cost; best_pos = pos + 1; }          // earlier positions win ties (strict <)
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T oc = __shfl_xor(best, off);
+        const uint32_t op = __shfl_xor(best_pos, off);
+        if (oc < best || (oc == best && op < best_pos)) { best = oc; best_pos = op; }
+    }
+    if (lane == 0) { wcost[wave] = best; wpos[wave] = best_pos; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kScanThreads / 64; ++w)
+            if (wcost[w] < best || (wcost[w] == best && wpos[w] < best_pos)) { best = wcost[w]; best_pos = wpos[w]; }
+        AxisBest<T> ab;
+        ab.cost = best; ab.pos = best_pos; ab.pad = 0;
+        c.axis_best[3 * slot + axis] = ab;
+    }
+}
+
+// try_split's decision (sweep_sah_builder.h:108-124)
+template <typename T>
+__global__ void __launch_bounds__(64) k_sweep_decide(SweepCtx<T> c, uint32_t n_active) {
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n_active) return;
+    SlotState<T>& st = c.b.state[slot];
+    const ANode<T>& nd = c.b.nodes[st.node];
+    const uint32_t size = nd.end - nd.begin;
+    const T stay = half_area(nd.lo, nd.hi) * (static_cast<T>(size) - T(1));
+    uint32_t pos = (nd.begin + nd.end + 1) / 2; T cost = stay; uint32_t axis = 0;     // :111
+    for (int k = 0; k < 3; ++k) {
+        const AxisBest<T> ab = c.axis_best[3 * slot + k];
+        if (ab.cost < cost) { cost = ab.cost; pos = ab.pos; axis = k; }
+    }
+    if (cost >= stay) {                                       // size > 64 > max_leaf_size: median on the widest axis (:122-123)
+        pos = (nd.begin + nd.end + 1) / 2;
+        axis = widest_axis(nd.lo, nd.hi);
+    }
+    st.split = pos;
+    st.axis = axis;
+    st.mode = MODE_PARTITION;
+}
+
+// mark_primitives (:103-106)
+template <typename T>
+__global__ void __launch_bounds__(256) k_sweep_mark(SweepCtx<T> c) {
+    const Task tk = c.b.tasks[blockIdx.x];
+    const SlotState<T>& st = c.b.state[tk.slot];
+    const uint32_t* ord = c.ord[st.axis];
+    for (uint32_t pos = tk.begin + threadIdx.x; pos < tk.end; pos += 256) c.marks[ord[pos]] = pos < st.split ? 1u : 0u;
+}
+
+__device__ inline uint32_t other_axis(uint32_t axis, uint32_t j) { return j == 0 ? (axis == 0 ? 1 : 0) : (axis == 2 ? 1 : 2); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_sweep_count(SweepCtx<T> c, uint32_t n_tasks) {
+    __shared__ uint32_t total;
+    const uint32_t task = blockIdx.x % n_tasks, j = blockIdx.x / n_tasks;
+    const Task tk = c.b.tasks[task];
+    const SlotState<T>& st = c.b.state[tk.slot];
+    const uint32_t* ord = c.ord[other_axis(st.axis, j)];
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t pos = tk.begin + threadIdx.x; pos < tk.end; pos += 256) mine += c.marks[ord[pos]];
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) c.chunk_true2[size_t{j} * c.b.task_cap + task] = total;
+}
+
+// std::stable_partition of the other axes (:129-136), out of place
+template <typename T>
+__global__ void __launch_bounds__(256) k_sweep_scatter(SweepCtx<T> c, uint32_t n_tasks) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t base_sh;
+    const uint32_t task = blockIdx.x % n_tasks, j = blockIdx.x / n_tasks;
+    const Task tk = c.b.tasks[task];
+    const SlotState<T>& st = c.b.state[tk.slot];
+    const ANode<T>& nd = c.b.nodes[st.node];
+    const uint32_t* ord = c.ord[other_axis(st.axis, j)];
+    uint32_t* out = c.ord_tmp + size_t{j} * c.b.n;
+    if (threadIdx.x == 0) base_sh = 0;
+    __syncthreads();
+    uint32_t before = 0;
+    const uint32_t* ct = c.chunk_true2 + size_t{j} * c.b.task_cap;
+    for (uint32_t t = st.task0 + threadIdx.x; t < task; t += 256) before += ct[t];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if ((threadIdx.x & 63) == 0 && before) atomicAdd(&base_sh, before);
+    __syncthreads();
+    uint32_t running = base_sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t tile = tk.begin; tile < tk.end; tile += 256) {
+        const uint32_t pos = tile + threadIdx.x;
+        const bool in = pos < tk.end;
+        const uint32_t id = in ? ord[pos] : 0;
+        const bool flag = in && c.marks[id] != 0;
+        const uint64_t bal = __ballot(flag);
+        if (lane == 0) wave_sum[wave] = __popcll(bal);
+        __syncthreads();
+        uint32_t excl = __popcll(bal & ((uint64_t{1} << lane) - 1)), tile_total = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) excl += wave_sum[w]; tile_total += wave_sum[w]; }
+        const uint32_t t_before = running + excl;             // marked elements in [begin, pos)
+        if (in) out[flag ? nd.begin + t_before : st.split + (pos - nd.begin - t_before)] = id;
+        running += tile_total;
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_sweep_copyback(SweepCtx<T> c, uint32_t n_tasks) {
+    const uint32_t task = blockIdx.x % n_tasks, j = blockIdx.x / n_tasks;
+    const Task tk = c.b.tasks[task];
+    const SlotState<T>& st = c.b.state[tk.slot];
+    uint32_t* ord = c.ord[other_axis(st.axis, j)];
+    const uint32_t* in = c.ord_tmp + size_t{j} * c.b.n;
+    for (uint32_t pos = tk.begin + threadIdx.x; pos < tk.end; pos += 256) ord[pos] = in[pos];
+}
+
+// =====================================================================================================
+// Segments <= 64 primitives: one wavefront, slot = lane holds a primitive, perm[k][position] = slot
+// =====================================================================================================
+
+template <typename T>
+struct WaveSweepLds {
+    uint32_t perm[3][kSmall];
+    uint32_t next[kSmall];
+    uint32_t markslot[kSmall];
+    T nbox[2 * kSmall][6];
+    uint32_t stack[kSmall + 4];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_small) {
+    __shared__ WaveSweepLds<T> lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_small) return;
+    WaveSweepLds<T>& L = lds_all[threadIdx.x >> 6];
+    ANode<T>& A = c.b.nodes[c.b.small_list[w]];
+    const uint32_t B = A.begin, s = A.end - A.begin;
+    HostNode<T>* stage = c.b.stage + 2ull * B;
+    const uint64_t lanes_below = (uint64_t{1} << lane) - 1;
+
+    // slot `lane` holds the primitive at position B + lane of the axis-0 order
+    uint32_t id = 0xFFFFFFFFu;
+    T blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0};
+    if (lane < int(s)) {
+        id = c.ord[0][B + lane];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { blo[k] = c.b.bboxes[6ull * id + k]; bhi[k] = c.b.bboxes[6ull * id + 3 + k]; }
+    }
+    L.perm[0][lane] = lane;
+    for (int k = 1; k < 3; ++k) {
+        const uint32_t want = lane < int(s) ? c.ord[k][B + lane] : 0xFFFFFFFEu;
+        uint32_t slot = lane;
+        for (uint32_t t = 0; t < s; ++t) if (__shfl(id, int(t)) == want) slot = t;
+        L.perm[k][lane] = slot;
+    }
+    if (lane < 3) { L.nbox[0][lane] = A.lo[lane]; L.nbox[0][3 + lane] = A.hi[lane]; }
+    if (lane == 0) L.stack[0] = pack_item(0, 0, s);
+    uint32_t sp = 1, ncount = 1;
+
+    while (sp > 0) {
+        wave_sync();
+        const uint32_t item = L.stack[--sp];
+        const uint32_t ln = item & 0xFF, lb = (item >> 8) & 0xFF, le = (item >> 16) & 0xFF;
+        const uint32_t cnt = le - lb;
+        T nlo[3], nhi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { nlo[k] = L.nbox[ln][k]; nhi[k] = L.nbox[ln][3 + k]; }
+        const bool in = uint32_t(lane) >= lb && uint32_t(lane) < le;      // lane as a POSITION
+        bool split = false;
+        uint32_t cut = 0;
+
+        if (cnt > c.b.min_leaf) {
+            const T stay = half_area(nlo, nhi) * (static_cast<T>(cnt) - T(1));
+            uint32_t best_pos = (B + lb + B + le + 1) / 2 - B; T best_cost = stay; uint32_t best_axis = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int src = L.perm[k][lane];
+                Box6<T> v;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { v.lo[q] = __shfl(blo[q], src); v.hi[q] = __shfl(bhi[q], src); }
+                if (!in) v = empty_box<T>();
+                // suffix scan (inclusive, towards higher positions) and prefix scan
+                Box6<T> suf = v, pre = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    Box6<T> o;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { o.lo[q] = __shfl_down(suf.lo[q], off); o.hi[q] = __shfl_down(suf.hi[q], off); }
+                    if (lane + off < 64) suf = join(o, suf);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { o.lo[q] = __shfl_up(pre.lo[q], off); o.hi[q] = __shfl_up(pre.hi[q], off); }
+                    if (lane >= off) pre = join(o, pre);
+                }
+                const T cr = half_area(suf.lo, suf.hi) * static_cast<T>(le - uint32_t(lane));    // cost of [lane, le)
+                const T cr_next = __shfl_down(cr, 1);
+                T cost = __builtin_inff();
+                uint32_t pos = 0xFFFFFFFFu;
+                if (in && uint32_t(lane) + 1 < le) {
+                    const T cl = half_area(pre.lo, pre.hi) * static_cast<T>(uint32_t(lane) + 1 - lb);
+                    const T tot = cl + cr_next;
+                    if (tot < cost) { cost = tot; pos = lane + 1; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const T oc = __shfl_xor(cost, off);
+                    const uint32_t op = __shfl_xor(pos, off);
+                    if (oc < cost || (oc == cost && op < pos)) { cost = oc; pos = op; }
+                }
+                if (cost < best_cost) { best_cost = cost; best_pos = pos; best_axis = k; }
+            }
+            bool do_split = true;
+            if (best_cost >= stay) {
+                if (cnt <= c.b.max_leaf) do_split = false;
+                else { best_pos = (B + lb + B + le + 1) / 2 - B; best_axis = widest_axis(nlo, nhi); }
+            }
+            if (do_split) {
+                // mark_primitives + stable_partition of the other two axes
+                L.markslot[L.perm[best_axis][lane]] = (in && uint32_t(lane) < best_pos) ? 1u : 0u;
+                wave_sync();
+                for (uint32_t k = 0; k < 3; ++k) {
+                    if (k == best_axis) continue;
+                    const uint32_t slot = L.perm[k][lane];
+                    const bool flag = in && L.markslot[slot] != 0;
+                    const uint64_t tmask = __ballot(flag), fmask = __ballot(in && !flag);
+                    if (in) L.next[flag ? lb + __popcll(tmask & lanes_below) : best_pos + __popcll(fmask & lanes_below)] = slot;
+                    wave_sync();
+                    if (in) L.perm[k][lane] = L.next[lane];
+                    wave_sync();
+                }
+                split = true;
+                cut = best_pos;
+            }
+        }
+
+        HostNode<T> rec;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rec.bounds[2 * k] = nlo[k]; rec.bounds[2 * k + 1] = nhi[k]; }
+        if (split) {
+            // compute_bbox of both children in axis-0 position order
+            const int src = L.perm[0][lane];
+            T plo[3], phi[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { plo[q] = __shfl(blo[q], src); phi[q] = __shfl(bhi[q], src); }
+            T lo[2][3], hi[2][3];
+            const bool left = in && uint32_t(lane) < cut, right = in && uint32_t(lane) >= cut;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[0][k] = left ? plo[k] : Ord<T>::kMax;  hi[0][k] = left ? phi[k] : -Ord<T>::kMax;
+                lo[1][k] = right ? plo[k] : Ord<T>::kMax; hi[1][k] = right ? phi[k] : -Ord<T>::kMax;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        lo[q][k] = pick_min(lo[q][k], __shfl_xor(lo[q][k], off));
+                        hi[q][k] = pick_max(hi[q][k], __shfl_xor(hi[q][k], off));
+                    }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {                  // sign of a zero bound = last zero in position order
+                    const bool side = q == 0 ? left : right;
+                    if (lo[q][k] == T(0)) {
+                        const uint64_t zm = __ballot(side && plo[k] == T(0));
+                        lo[q][k] = Ord<T>::zero(__shfl(Ord<T>::sign(plo[k]), 63 - __clzll(zm)));
+                    }
+                    if (hi[q][k] == T(0)) {
+                        const uint64_t zm = __ballot(side && phi[k] == T(0));
+                        hi[q][k] = Ord<T>::zero(__shfl(Ord<T>::sign(phi[k]), 63 - __clzll(zm)));
+                    }
+                }
+            const int first = half_area(lo[0], hi[0]) < half_area(lo[1], hi[1]) ? 1 : 0;
+            const uint32_t child = ncount;
+            ncount += 2;
+            const uint32_t rb[2] = { lb, cut }, re[2] = { cut, le };
+            if (lane < 3) {
+                L.nbox[child][lane] = lo[first][lane];         L.nbox[child][3 + lane] = hi[first][lane];
+                L.nbox[child + 1][lane] = lo[1 - first][lane]; L.nbox[child + 1][3 + lane] = hi[1 - first][lane];
+            }
+            uint32_t ia = pack_item(child, rb[first], re[first]), ib = pack_item(child + 1, rb[1 - first], re[1 - first]);
+            if (re[first] - rb[first] < re[1 - first] - rb[1 - first]) { const uint32_t t = ia; ia = ib; ib = t; }
+            if (lane == 0) { L.stack[sp] = ia; L.stack[sp + 1] = ib; }
+            sp += 2;
+            rec.index = static_cast<typename IndexOf<T>::Type>(child) << kCountBits;
+        } else {
+            rec.index = (static_cast<typename IndexOf<T>::Type>(B + lb) << kCountBits) | cnt;
+        }
+        if (lane == 0) stage[ln] = rec;
+    }
+    wave_sync();
+    // prim_ids = the axis-0 order (sweep_sah_builder.h:66)
+    const uint32_t out_id = __shfl(id, int(L.perm[0][lane]));
+    if (lane < int(s)) c.ord[0][B + lane] = out_id;
+    if (lane == 0) A.ic = (ncount - 1) / 2;
+}
+
+} // namespace
+
+// SweepSahBuilder::build on the device.
+template <typename T>
+int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
+                       hipStream_t stream)
+{
+    if (n >= (size_t{1} << 28)) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: more than 2^28 primitives");
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
+
+    DevBuf<uint32_t> ord;
+    BVH_HIP_TRY(ord.alloc(3 * n), BVH_AMD_ERR_HIP);
+    int rc = std_sort_ids<T>(ord.p, d_centers, n32, 3, 1, 3, stream);          // :57-63
+    if (rc) return rc;
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint32_t node_cap = attempt == 0 ? n32 / 8 + 1024 : 2 * n32 + 2;
+        const uint32_t slot_cap = n32 / (kSmall + 1) + 2;
+        const uint32_t task_cap = n32 / kChunk + slot_cap + 2;
+        DevBuf<uint32_t> ord_tmp, marks, chunk_true2, small_list;
+        DevBuf<T> cost_r;
+        DevBuf<AxisBest<T>> axis_best;
+        DevBuf<ANode<T>> nodes;
+        DevBuf<SlotState<T>> st_a, st_b;
+        DevBuf<Task> tk_a, tk_b;
+        DevBuf<HostNode<T>> stage, final_nodes;
+        DevBuf<Counters> counters;
+        hipError_t e = hipSuccess;
+        auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+        A(ord_tmp.alloc(2 * n)); A(marks.alloc(n)); A(chunk_true2.alloc(2 * size_t{task_cap})); A(small_list.alloc(node_cap));
+        A(cost_r.alloc(3 * n)); A(axis_best.alloc(3 * size_t{slot_cap})); A(nodes.alloc(node_cap));
+        A(st_a.alloc(slot_cap)); A(st_b.alloc(slot_cap)); A(tk_a.alloc(task_cap)); A(tk_b.alloc(task_cap));
+        A(stage.alloc(2 * n)); A(counters.alloc(1));
+        if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+
+        SweepCtx<T> sc;
+        BuildCtx<T>& c = sc.b;
+        c.bboxes = d_bboxes; c.centers = d_centers; c.ids = ord.p; c.n = n32;
+        c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
+        c.nodes = nodes.p; c.node_cap = node_cap; c.bins = nullptr; c.state = st_a.p; c.state_next = st_b.p; c.slot_cap = slot_cap;
+        c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = nullptr;
+        c.ltab = nullptr; c.rtab = nullptr; c.small_list = small_list.p; c.stage = stage.p; c.counters = counters.p;
+        for (int k = 0; k < 3; ++k) sc.ord[k] = ord.p + size_t{n} * k;
+        sc.ord_tmp = ord_tmp.p; sc.marks = marks.p; sc.cost_r = cost_r.p; sc.axis_best = axis_best.p; sc.chunk_true2 = chunk_true2.p;
+
+        hipLaunchKernelGGL(k_prepare_root<T>, dim3(1), dim3(1), 0, stream, c);
+        const unsigned root_grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 2048));
+        hipLaunchKernelGGL(k_init_root<T>, dim3(root_grid), dim3(256), 0, stream, c, false);
+        hipLaunchKernelGGL(k_make_root<T>, dim3(1), dim3(1), 0, stream, c);
+        Counters h;
+        BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+
+        std::vector<uint32_t> level_start{0, 1};
+        uint32_t n_active = h.n_active_next, n_tasks = h.n_tasks_next;
+        bool overflow = h.error != 0;
+        while (n_active > 0 && !overflow) {
+            std::swap(c.state, c.state_next);
+            std::swap(c.tasks, c.tasks_next);
+            BVH_HIP_TRY(hipMemsetAsync(&counters.p->n_active_next, 0, 2 * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
+            const unsigned slot_grid = (n_active + 63) / 64;
+            hipLaunchKernelGGL(k_init_slots<T>, dim3(n_active), dim3(64), 0, stream, c);
+            hipLaunchKernelGGL(k_sweep_axis<T>, dim3(3 * n_active), dim3(kScanThreads), 0, stream, sc);
+            hipLaunchKernelGGL(k_sweep_decide<T>, dim3(slot_grid), dim3(64), 0, stream, sc, n_active);
+            hipLaunchKernelGGL(k_sweep_mark<T>, dim3(n_tasks), dim3(256), 0, stream, sc);
+            hipLaunchKernelGGL(k_sweep_count<T>, dim3(2 * n_tasks), dim3(256), 0, stream, sc, n_tasks);
+            hipLaunchKernelGGL(k_sweep_scatter<T>, dim3(2 * n_tasks), dim3(256), 0, stream, sc, n_tasks);
+            hipLaunchKernelGGL(k_sweep_copyback<T>, dim3(2 * n_tasks), dim3(256), 0, stream, sc, n_tasks);
+            hipLaunchKernelGGL(k_child_bounds<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+            hipLaunchKernelGGL(k_finalize<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
+            BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+            BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+            BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+            overflow = h.error != 0;
+            level_start.push_back(h.n_nodes);
+            n_active = h.n_active_next;
+            n_tasks = h.n_tasks_next;
+        }
+        if (overflow) {
+            if (attempt == 0) continue;
+            return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
+        }
+        const uint32_t n_nodes_a = h.n_nodes, n_small = h.n_small;
+        if (n_small) hipLaunchKernelGGL(k_small_sweep<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, sc, n_small);
+        rc = number_and_emit<T>(out, c, level_start, n_nodes_a, n_small, final_nodes, stream);
+        if (rc) return rc;
+        return finish_build<T>(out, final_nodes, ord.p, n, stream, /*take_ids=*/false);
+    }
+    return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
+}
+
+template int build_sweep_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
+template int build_sweep_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
+
+} // namespace bvh_amd

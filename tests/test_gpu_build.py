@@ -107,4 +107,63 @@ def test_unsupported_modes_fail_loudly():
     tris = synth.soup(5000)
     bb, cc = bvh_amd.tri_bounds(tris)
     with pytest.raises(bvh_amd.BvhAmdError):
-        bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High))
+        bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
+
+
+# ---- sweep SAH (SweepSahBuilder, DefaultBuilder serial Medium) ----------------------------------------------
+
+def _gpu_sweep(bb, cc, **kw):
+    import bvh_amd
+    return bvh_amd.SweepSahBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium, **kw))
+
+
+@pytest.mark.parametrize("scene", ["cornell", "soup2k", "terrain2k", "soup2k_f64", "spheres2k_f64"])
+def test_sweep_matches_golden_stream(scene):
+    import bvh_amd
+    g = load_golden(scene)
+    assert _gpu_sweep(g["bboxes"], g["centers"]).serialize() == g["bvh_sweep"].tobytes()
+    bvh2 = bvh_amd.DefaultBuilder.build(g["bboxes"], g["centers"], bvh_amd.Config(quality=bvh_amd.Quality.Medium))
+    assert bvh2.serialize() == g["bvh_serial_med"].tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 9, 16, 17, 63, 64, 65, 66, 129, 1000, 2049, 4097, 30000])
+def test_sweep_sizes(orc, n):
+    tris = synth.soup(n, seed=n + 1, jitter=0.05)
+    bb, cc = orc.prep_tris(tris)
+    assert _gpu_sweep(bb, cc).serialize() == orc.build(bb, cc, builder=oracle.BUILDER_SWEEP).serialize()
+
+
+@pytest.mark.parametrize("scene,n", [("soup", 200_000), ("terrain", 200_000), ("sponza", 262_144), ("terrain", 1_000_000)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sweep_scenes(orc, scene, n, dtype):
+    if dtype == np.float64 and n > 200_000:
+        pytest.skip("covered by the float case")
+    tris = {"soup": lambda: synth.soup(n, dtype=dtype), "terrain": lambda: synth.terrain(n, dtype=dtype),
+            "sponza": lambda: synth.sponza_proxy(n, dtype=dtype)}[scene]()
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_SWEEP)
+    gpu = _gpu_sweep(bb, cc)
+    assert gpu.node_count == ref.node_count
+    assert gpu.serialize() == ref.serialize()
+
+
+@pytest.mark.parametrize("min_leaf,max_leaf", [(1, 1), (1, 4), (2, 8), (4, 4), (1, 15)])
+def test_sweep_leaf_limits(orc, min_leaf, max_leaf):
+    tris = synth.terrain(20000)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_SWEEP, min_leaf=min_leaf, max_leaf=max_leaf)
+    gpu = _gpu_sweep(bb, cc, min_leaf_size=min_leaf, max_leaf_size=max_leaf)
+    assert gpu.serialize() == ref.serialize()
+
+
+def test_sweep_degenerate_inputs(orc):
+    rng = np.random.default_rng(6)
+    base = synth.soup(40, seed=1, jitter=0.05)
+    cases = [np.repeat(base, 50, axis=0), np.repeat(base[:3], 400, axis=0), np.repeat(base[:1], 300, axis=0)]
+    t = synth.soup(5000, seed=2, jitter=0.03)
+    t[:, 2::3] = 0.5
+    cases.append((np.round(t * 8) / 8).astype(np.float32))
+    for tris in cases:
+        tris = np.ascontiguousarray(tris[rng.permutation(len(tris))])
+        bb, cc = orc.prep_tris(tris)
+        assert _gpu_sweep(bb, cc).serialize() == orc.build(bb, cc, builder=oracle.BUILDER_SWEEP).serialize()
