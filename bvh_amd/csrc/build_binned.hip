@@ -411,92 +411,203 @@ __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) 
 
 } // namespace
 
+// ---- host side ---------------------------------------------------------------------------------------------
+
+namespace {
+
+template <typename T>
+struct BinnedWs {
+    DevBuf<uint32_t> ids, chunk_true, ltab, rtab, small_list;
+    DevBuf<ANode<T>> nodes;
+    DevBuf<SlotBins<T>> bins;
+    DevBuf<SlotState<T>> st_a, st_b;
+    DevBuf<Task> tk_a, tk_b;
+    DevBuf<HostNode<T>> stage;
+    DevBuf<Counters> counters;
+
+    // capacities: typical on the first attempt, worst case (degenerate chains of big nodes) on retry
+    int alloc(BuildCtx<T>& c, uint32_t n, uint32_t roots, int attempt, bool own_ids) {
+        const uint32_t node_cap = (attempt == 0 ? n / 8 + 1024 : 2 * n + 2) + roots;
+        const uint32_t slot_cap = n / (kSmall + 1) + 2;
+        const uint32_t task_cap = n / kChunk + slot_cap + 2;
+        hipError_t e = hipSuccess;
+        auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+        if (own_ids) A(ids.alloc(n));
+        A(chunk_true.alloc(task_cap)); A(ltab.alloc(n)); A(rtab.alloc(n)); A(small_list.alloc(node_cap));
+        A(nodes.alloc(node_cap)); A(bins.alloc(slot_cap)); A(st_a.alloc(slot_cap)); A(st_b.alloc(slot_cap));
+        A(tk_a.alloc(task_cap)); A(tk_b.alloc(task_cap)); A(stage.alloc(2 * size_t{n})); A(counters.alloc(1));
+        if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+        if (own_ids) c.ids = ids.p;
+        c.n = n; c.nodes = nodes.p; c.node_cap = node_cap; c.bins = bins.p; c.state = st_a.p; c.state_next = st_b.p;
+        c.slot_cap = slot_cap; c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = chunk_true.p;
+        c.ltab = ltab.p; c.rtab = rtab.p; c.small_list = small_list.p; c.stage = stage.p; c.counters = counters.p;
+        return BVH_AMD_OK;
+    }
+};
+
+// Phase A levels + Phase B. Expects the roots already registered (state_next / tasks_next / counters) and `h` read back.
+template <typename T>
+int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_start, bool& overflow, hipStream_t stream) {
+    uint32_t n_active = h.n_active_next, n_tasks = h.n_tasks_next;
+    overflow = h.error != 0;
+    while (n_active > 0 && !overflow) {
+        std::swap(c.state, c.state_next);
+        std::swap(c.tasks, c.tasks_next);
+        BVH_HIP_TRY(hipMemsetAsync(&c.counters->n_active_next, 0, 2 * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
+        const unsigned slot_grid = (n_active + 63) / 64;
+        hipLaunchKernelGGL(k_init_slots<T>, dim3(n_active), dim3(64), 0, stream, c);
+        hipLaunchKernelGGL(k_bin<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+        hipLaunchKernelGGL(k_decide<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
+        hipLaunchKernelGGL(k_count<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+        hipLaunchKernelGGL(k_scatter<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+        hipLaunchKernelGGL(k_fallback<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
+        hipLaunchKernelGGL(k_swap<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+        hipLaunchKernelGGL(k_child_bounds<T>, dim3(n_tasks), dim3(256), 0, stream, c);
+        hipLaunchKernelGGL(k_finalize<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMemcpyAsync(&h, c.counters, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        overflow = h.error != 0;
+        level_start.push_back(h.n_nodes);
+        n_active = h.n_active_next;
+        n_tasks = h.n_tasks_next;
+    }
+    if (!overflow && h.n_small) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, stream, c, h.n_small);
+    return BVH_AMD_OK;
+}
+
+// Roots of a forest: tree g covers positions [group_begin[g], group_begin[g + 1]) of c.ids. One block per tree
+// computes compute_bbox over its range in position order (top_down_sah_builder.h:80, :133-139).
+template <typename T>
+__global__ void __launch_bounds__(256) k_forest_roots(BuildCtx<T> c, const uint32_t* group_begin) {
+    __shared__ typename Ord<T>::U slo[3], shi[3];
+    __shared__ uint32_t zlo[3], zhi[3];
+    const uint32_t g = blockIdx.x, b = group_begin[g], e = group_begin[g + 1];
+    if (threadIdx.x < 3) { slo[threadIdx.x] = Ord<T>::enc(Ord<T>::kMax); shi[threadIdx.x] = Ord<T>::enc(-Ord<T>::kMax); zlo[threadIdx.x] = 0; zhi[threadIdx.x] = 0; }
+    __syncthreads();
+    T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+    for (uint32_t pos = b + threadIdx.x; pos < e; pos += 256) {
+        const uint32_t id = c.ids[pos];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T lo_v = c.bboxes[6ull * id + k], hi_v = c.bboxes[6ull * id + 3 + k];
+            lo[k] = pick_min(lo[k], lo_v); hi[k] = pick_max(hi[k], hi_v);
+            track_zero(&zlo[k], lo_v, pos); track_zero(&zhi[k], hi_v, pos);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { atomicMin(&slo[k], Ord<T>::enc(lo[k])); atomicMax(&shi[k], Ord<T>::enc(hi[k])); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ANode<T>& r = c.nodes[g];
+        for (int k = 0; k < 3; ++k) { r.lo[k] = decode_bound<T>(slo[k], zlo[k]); r.hi[k] = decode_bound<T>(shi[k], zhi[k]); }
+        r.begin = b; r.end = e; r.child = kNone; r.parent = kNone; r.ic = 0; r.rank = 0; r.tree = g;
+        emit_child(c, g);
+    }
+}
+
+template <typename T>
+__global__ void k_forest_prepare(BuildCtx<T> c, uint32_t n_groups) {
+    Counters z = {};
+    z.n_nodes = n_groups;
+    *c.counters = z;
+}
+
+// tree_node_off[g] = sum of (2 * ic + 1) over earlier trees (g <= a few thousand: one lane)
+template <typename T>
+__global__ void k_forest_offsets(BuildCtx<T> c, uint32_t n_groups, uint32_t* tree_node_off) {
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) { tree_node_off[g] = run; run += 2 * c.nodes[g].ic + 1; }
+    tree_node_off[n_groups] = run;
+}
+
+} // namespace
+
 // BinnedSahBuilder::build on the device. On success `out` holds the host mirror and the device copy.
 template <typename T>
 int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
                         hipStream_t stream)
 {
     if (n >= (size_t{1} << 28)) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: more than 2^28 primitives");
-    const uint32_t n32 = static_cast<uint32_t>(n);
     BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
-
     for (int attempt = 0; attempt < 2; ++attempt) {
-        // capacities: typical first, worst case (degenerate chains of big nodes) on retry
-        const uint32_t node_cap = attempt == 0 ? n32 / 8 + 1024 : 2 * n32 + 2;
-        const uint32_t slot_cap = n32 / (kSmall + 1) + 2;
-        const uint32_t task_cap = n32 / kChunk + slot_cap + 2;
-        DevBuf<uint32_t> ids, chunk_true, ltab, rtab, small_list;
-        DevBuf<ANode<T>> nodes;
-        DevBuf<SlotBins<T>> bins;
-        DevBuf<SlotState<T>> st_a, st_b;
-        DevBuf<Task> tk_a, tk_b;
-        DevBuf<HostNode<T>> stage, final_nodes;
-        DevBuf<Counters> counters;
-        hipError_t e = hipSuccess;
-        auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-        A(ids.alloc(n)); A(chunk_true.alloc(task_cap)); A(ltab.alloc(n)); A(rtab.alloc(n)); A(small_list.alloc(node_cap));
-        A(nodes.alloc(node_cap)); A(bins.alloc(slot_cap)); A(st_a.alloc(slot_cap)); A(st_b.alloc(slot_cap));
-        A(tk_a.alloc(task_cap)); A(tk_b.alloc(task_cap)); A(stage.alloc(2 * n)); A(counters.alloc(1));
-        if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
-
+        BinnedWs<T> ws;
+        DevBuf<HostNode<T>> final_nodes;
         BuildCtx<T> c;
-        c.bboxes = d_bboxes; c.centers = d_centers; c.ids = ids.p; c.n = n32;
+        c.bboxes = d_bboxes; c.centers = d_centers;
         c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
-        c.nodes = nodes.p; c.node_cap = node_cap; c.bins = bins.p; c.state = st_a.p; c.state_next = st_b.p; c.slot_cap = slot_cap;
-        c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = chunk_true.p;
-        c.ltab = ltab.p; c.rtab = rtab.p; c.small_list = small_list.p; c.stage = stage.p; c.counters = counters.p;
-
-        // ---- root
+        int rc = ws.alloc(c, static_cast<uint32_t>(n), 1, attempt, true);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_prepare_root<T>, dim3(1), dim3(1), 0, stream, c);
         const unsigned root_grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 2048));
         hipLaunchKernelGGL(k_init_root<T>, dim3(root_grid), dim3(256), 0, stream, c, true);
-        {   // the root's children go to state_next/tasks_next; swap so they become the current level
-            BuildCtx<T> r = c;
-            hipLaunchKernelGGL(k_make_root<T>, dim3(1), dim3(1), 0, stream, r);
-        }
+        hipLaunchKernelGGL(k_make_root<T>, dim3(1), dim3(1), 0, stream, c);
         Counters h;
-        BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMemcpyAsync(&h, c.counters, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
         BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
-
         std::vector<uint32_t> level_start{0, 1};              // A-node id ranges per level
-        uint32_t n_active = h.n_active_next, n_tasks = h.n_tasks_next;
-        bool overflow = h.error != 0;
-        // ---- Phase A
-        while (n_active > 0 && !overflow) {
-            std::swap(c.state, c.state_next);
-            std::swap(c.tasks, c.tasks_next);
-            BVH_HIP_TRY(hipMemsetAsync(&counters.p->n_active_next, 0, 2 * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
-            const unsigned slot_grid = (n_active + 63) / 64;
-            hipLaunchKernelGGL(k_init_slots<T>, dim3(n_active), dim3(64), 0, stream, c);
-            hipLaunchKernelGGL(k_bin<T>, dim3(n_tasks), dim3(256), 0, stream, c);
-            hipLaunchKernelGGL(k_decide<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
-            hipLaunchKernelGGL(k_count<T>, dim3(n_tasks), dim3(256), 0, stream, c);
-            hipLaunchKernelGGL(k_scatter<T>, dim3(n_tasks), dim3(256), 0, stream, c);
-            hipLaunchKernelGGL(k_fallback<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
-            hipLaunchKernelGGL(k_swap<T>, dim3(n_tasks), dim3(256), 0, stream, c);
-            hipLaunchKernelGGL(k_child_bounds<T>, dim3(n_tasks), dim3(256), 0, stream, c);
-            hipLaunchKernelGGL(k_finalize<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
-            BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-            BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-            BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
-            overflow = h.error != 0;
-            level_start.push_back(h.n_nodes);
-            n_active = h.n_active_next;
-            n_tasks = h.n_tasks_next;
-        }
+        bool overflow = false;
+        rc = run_binned_phases(c, h, level_start, overflow, stream);
+        if (rc) return rc;
         if (overflow) {
             if (attempt == 0) continue;
             return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
         }
-        const uint32_t n_nodes_a = h.n_nodes, n_small = h.n_small;
+        rc = number_and_emit<T>(out, c, level_start, h.n_nodes, h.n_small, final_nodes, stream);
+        if (rc) return rc;
+        rc = finish_build<T>(out, final_nodes, ws.ids.p, n, stream, /*take_ids=*/true);
+        if (rc) return rc;
+        ws.ids.p = nullptr;                                   // handed over to `out`
+        return BVH_AMD_OK;
+    }
+    return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
+}
 
-        // ---- Phase B
-        if (n_small) hipLaunchKernelGGL(k_small<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, c, n_small);
-        int rc = number_and_emit<T>(out, c, level_start, n_nodes_a, n_small, final_nodes, stream);
+// One BinnedSahBuilder tree per group (MiniTreeBuilder::BuildTask::run, mini_tree_builder.h:122-139): d_ids holds the
+// groups' ids (ascending within a group) and is permuted in place; every tree is emitted standalone into `trees`
+// at tree_node_off[g] with leaf first_id relative to the group.
+template <typename T>
+int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* d_ids, uint32_t n, const uint32_t* d_group_begin,
+                               uint32_t n_groups, const bvh_build_config& cfg, DevBuf<HostNode<T>>& trees,
+                               DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream)
+{
+    DevBuf<uint32_t> sorted_ids;                              // a retry must start from the ascending order again
+    BVH_HIP_TRY(sorted_ids.alloc(n), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipMemcpyAsync(sorted_ids.p, d_ids, size_t{n} * 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt) BVH_HIP_TRY(hipMemcpyAsync(d_ids, sorted_ids.p, size_t{n} * 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
+        BinnedWs<T> ws;
+        BuildCtx<T> c;
+        c.bboxes = d_bboxes; c.centers = d_centers; c.ids = d_ids;
+        c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
+        int rc = ws.alloc(c, n, n_groups, attempt, false);
         if (rc) return rc;
-        rc = finish_build<T>(out, final_nodes, ids.p, n, stream, /*take_ids=*/true);
+        hipLaunchKernelGGL(k_forest_prepare<T>, dim3(1), dim3(1), 0, stream, c, n_groups);
+        hipLaunchKernelGGL(k_forest_roots<T>, dim3(n_groups), dim3(256), 0, stream, c, d_group_begin);
+        Counters h;
+        BVH_HIP_TRY(hipMemcpyAsync(&h, c.counters, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        std::vector<uint32_t> level_start{0, n_groups};
+        bool overflow = false;
+        rc = run_binned_phases(c, h, level_start, overflow, stream);
         if (rc) return rc;
-        ids.p = nullptr;                                      // handed over to `out`
+        if (overflow) {
+            if (attempt == 0) continue;
+            return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
+        }
+        rc = number_nodes<T>(c, level_start, stream);
+        if (rc) return rc;
+        BVH_HIP_TRY(tree_node_off.alloc(n_groups + 1), BVH_AMD_ERR_HIP);
+        hipLaunchKernelGGL(k_forest_offsets<T>, dim3(1), dim3(1), 0, stream, c, n_groups, tree_node_off.p);
+        BVH_HIP_TRY(hipMemcpyAsync(&total_nodes, tree_node_off.p + n_groups, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(trees.alloc(total_nodes), BVH_AMD_ERR_HIP);
+        c.tree_node_off = tree_node_off.p;
+        c.tree_begin = d_group_begin;
+        hipLaunchKernelGGL(k_emit_tree<T>, dim3((h.n_nodes + 255) / 256), dim3(256), 0, stream, c, h.n_nodes, trees.p);
+        if (h.n_small) hipLaunchKernelGGL(k_emit_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, stream, c, h.n_small, trees.p);
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // workspace dies here
         return BVH_AMD_OK;
     }
     return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
@@ -504,5 +615,9 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
 
 template int build_binned_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
 template int build_binned_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
+template int build_binned_forest_device<float>(const float*, const float*, uint32_t*, uint32_t, const uint32_t*, uint32_t,
+    const bvh_build_config&, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t);
+template int build_binned_forest_device<double>(const double*, const double*, uint32_t*, uint32_t, const uint32_t*, uint32_t,
+    const bvh_build_config&, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t);
 
 } // namespace bvh_amd

@@ -80,7 +80,7 @@ struct ANode {                           // Phase A tree node (BFS allocation or
     uint32_t kind;
     uint32_t ic;                         // inner nodes in this subtree (incl. itself)
     uint32_t rank;                       // pre-order rank among inner nodes, in the reference's processing order
-    uint32_t pad;
+    uint32_t tree;                       // which tree of a forest build (mini-trees); 0 for single-tree builds
 };
 
 template <typename T>
@@ -133,6 +133,10 @@ struct BuildCtx {
     uint32_t* small_list;
     HostNode<T>* stage;                  // 2n staged nodes of the Phase B subtrees
     Counters* counters;
+    // forest builds (mini-trees): every tree is emitted standalone (local node ids, local leaf first_id) at
+    // tree_node_off[tree]; tree_begin[tree] = first position of the tree's primitives. Null for single trees.
+    const uint32_t* tree_node_off = nullptr;
+    const uint32_t* tree_begin = nullptr;
 };
 
 // ---- libstdc++ std::partial_sort, replayed by one lane (stl_heap.h / stl_algo.h:1912-1919)
@@ -275,8 +279,9 @@ __global__ void __launch_bounds__(256) k_assign_ranks(BuildCtx<T> c, uint32_t fi
 
 template <typename T>
 __device__ inline uint32_t final_id(const BuildCtx<T>& c, const ANode<T>& nd) {
-    if (nd.parent == kNone) return 0;
-    return 1 + 2 * c.nodes[nd.parent & 0x7FFFFFFFu].rank + (nd.parent >> 31);
+    const uint32_t off = c.tree_node_off ? c.tree_node_off[nd.tree] : 0;
+    if (nd.parent == kNone) return off;
+    return off + 1 + 2 * c.nodes[nd.parent & 0x7FFFFFFFu].rank + (nd.parent >> 31);
 }
 
 template <typename T>
@@ -291,7 +296,8 @@ __global__ void __launch_bounds__(256) k_emit_tree(BuildCtx<T> c, uint32_t n_nod
         rec.index = static_cast<I>(1 + 2 * nd.rank) << kCountBits;
     } else {                                                  // KIND_SMALL: the staged subtree root
         const HostNode<T>& sr = c.stage[2ull * nd.begin];
-        rec.index = (sr.index & kCountMask) ? sr.index : ((sr.index >> kCountBits) + 2 * I(nd.rank)) << kCountBits;
+        const I rebase = static_cast<I>(c.tree_begin ? c.tree_begin[nd.tree] : 0) << kCountBits;
+        rec.index = (sr.index & kCountMask) ? sr.index - rebase : ((sr.index >> kCountBits) + 2 * I(nd.rank)) << kCountBits;
     }
     out[final_id(c, nd)] = rec;
 }
@@ -305,10 +311,13 @@ __global__ void __launch_bounds__(256) k_emit_small(BuildCtx<T> c, uint32_t n_sm
     using I = typename IndexOf<T>::Type;
     const uint32_t count = 2 * nd.ic;                         // staged nodes besides the root
     const HostNode<T>* stage = c.stage + 2ull * nd.begin;
+    const size_t off = c.tree_node_off ? c.tree_node_off[nd.tree] : 0;
+    const I rebase = static_cast<I>(c.tree_begin ? c.tree_begin[nd.tree] : 0) << kCountBits;
     for (uint32_t j = 1 + lane; j <= count; j += 64) {
         HostNode<T> rec = stage[j];
         if ((rec.index & kCountMask) == 0) rec.index = ((rec.index >> kCountBits) + 2 * I(nd.rank)) << kCountBits;
-        out[2ull * nd.rank + j] = rec;
+        else rec.index -= rebase;
+        out[off + 2ull * nd.rank + j] = rec;
     }
 }
 
@@ -396,7 +405,7 @@ __global__ void k_make_root(BuildCtx<T> c) {
         r.lo[k] = decode_bound<T>(c.state[0].clo[0][k], c.state[0].zlo[0][k]);
         r.hi[k] = decode_bound<T>(c.state[0].chi[0][k], c.state[0].zhi[0][k]);
     }
-    r.begin = 0; r.end = c.n; r.child = kNone; r.parent = kNone; r.ic = 0; r.rank = 0;
+    r.begin = 0; r.end = c.n; r.child = kNone; r.parent = kNone; r.ic = 0; r.rank = 0; r.tree = 0;
     c.counters->n_nodes = 1;
     emit_child(c, 0);
 }
@@ -484,7 +493,7 @@ __global__ void __launch_bounds__(64) k_finalize(BuildCtx<T> c, uint32_t n_activ
         ANode<T>& ch = c.nodes[child + w];
         for (int k = 0; k < 3; ++k) { ch.lo[k] = lo[s][k]; ch.hi[k] = hi[s][k]; }
         ch.begin = rb[s]; ch.end = re[s];
-        ch.child = kNone; ch.parent = st.node | (uint32_t(w) << 31); ch.ic = 0; ch.rank = 0;
+        ch.child = kNone; ch.parent = st.node | (uint32_t(w) << 31); ch.ic = 0; ch.rank = 0; ch.tree = nd.tree;
         emit_child(c, child + w);
     }
 }
@@ -494,8 +503,7 @@ __global__ void __launch_bounds__(64) k_finalize(BuildCtx<T> c, uint32_t n_activ
 
 // Phase C: inner counts bottom-up, ranks top-down, then scatter of the Phase A nodes and the staged subtrees.
 template <typename T>
-int number_and_emit(BvhImpl<T>& out, const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, uint32_t n_nodes_a,
-                    uint32_t n_small, DevBuf<HostNode<T>>& final_nodes, hipStream_t stream)
+int number_nodes(const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, hipStream_t stream)
 {
     const size_t levels = level_start.size() - 1;
     for (size_t l = levels; l-- > 0;) {
@@ -506,6 +514,15 @@ int number_and_emit(BvhImpl<T>& out, const BuildCtx<T>& c, const std::vector<uin
         const uint32_t a = level_start[l], b = level_start[l + 1];
         if (b > a) hipLaunchKernelGGL(k_assign_ranks<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
     }
+    return BVH_AMD_OK;
+}
+
+template <typename T>
+int number_and_emit(BvhImpl<T>& out, const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, uint32_t n_nodes_a,
+                    uint32_t n_small, DevBuf<HostNode<T>>& final_nodes, hipStream_t stream)
+{
+    int rc = number_nodes<T>(c, level_start, stream);
+    if (rc) return rc;
     ANode<T> root;
     BVH_HIP_TRY(hipMemcpyAsync(&root, c.nodes, sizeof(root), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);

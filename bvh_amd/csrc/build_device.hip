@@ -12,6 +12,9 @@ int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, s
                        hipStream_t stream);
 
 template <typename T>
+int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, hipStream_t stream);
+
+template <typename T>
 int build_on_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
                     bvh_amd_builder builder, hipStream_t stream)
 {
@@ -21,8 +24,10 @@ int build_on_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size
         return build_binned_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
     if (builder == BVH_AMD_BUILDER_SWEEP || (builder == BVH_AMD_BUILDER_DEFAULT_SERIAL && cfg.quality == BVH_BUILD_QUALITY_MEDIUM))
         return build_sweep_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
+    if (builder == BVH_AMD_BUILDER_DEFAULT_PARALLEL && cfg.quality != BVH_BUILD_QUALITY_HIGH)
+        return build_minitree_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
     return fail(BVH_AMD_ERR_UNSUPPORTED, "build: this builder/quality combination is not implemented on the device yet "
-                                         "(available: BinnedSahBuilder, SweepSahBuilder, DefaultBuilder serial Low/Medium)");
+                                         "(available: BinnedSahBuilder, SweepSahBuilder, DefaultBuilder serial Low/Medium, parallel Low/Medium)");
 }
 
 template int build_on_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, bvh_amd_builder, hipStream_t);

@@ -1,0 +1,430 @@
+// K1-K4, K7-K9 — MiniTreeBuilder (mini_tree_builder.h:47-310) on gfx950, bit-exact with the reference:
+//
+//   build_mini_trees (:160-205): centroid bounds -> 16^3 Morton grid cell per primitive -> greedy merge of adjacent
+//       cells up to parallel_threshold (when pruning is on) -> one BinnedSahBuilder tree per group over the group's
+//       ids in ascending order (:124). The reference's per-thread bin vectors + std::sort become one histogram,
+//       a one-lane merge over the 4096 cells and ONE stable radix sort by group id; all groups are then built
+//       simultaneously by the forest variant of the binned builder (build_binned.hip).
+//   prune_mini_trees (:207-247): area threshold from the serially summed root areas; per tree, the reference's
+//       explicit-stack DFS (second child first) cuts at nodes with half_area < threshold or leaves; each cut subtree
+//       is re-laid out by extract_bvh (bvh.h:92-122; right child first, children allocated at visit time, leaves'
+//       primitives re-packed in visit order). Here: one lane per tree / per cut replays those DFS orders, twice
+//       (count, then write) around exclusive scans that give every cut its node and primitive offsets.
+//   build_top_bvh (:249-310): SweepSahBuilder with leaf size 1 over the cut roots (build_sweep.hip), then the splice:
+//       top leaves become copies of the cut roots, tree i's nodes 1.. go to node_offsets[i] + j, its primitives to
+//       prim_offsets[i], indices rebased. The count pass already knows both offsets (a leaf-size-1 tree over m
+//       items has exactly 2m - 1 nodes), so the write pass stores straight into the final arrays.
+
+#include "build_common.h"
+
+namespace bvh_amd {
+
+using namespace bld;
+
+template <typename T>
+int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* d_ids, uint32_t n, const uint32_t* d_group_begin,
+                               uint32_t n_groups, const bvh_build_config& cfg, DevBuf<HostNode<T>>& trees,
+                               DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream);
+template <typename T>
+int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_leaf, uint32_t max_leaf,
+               DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& ord, size_t& total_nodes, hipStream_t stream);
+
+namespace {
+
+constexpr uint32_t kGridDim = 16, kCells = 4096;             // log2_grid_dim = 4 (:42)
+constexpr int kWalkStack = 160;
+
+template <typename T> struct Eps;
+template <> struct Eps<float>  { static constexpr float v = 1.1920928955078125e-07f; };
+template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
+
+template <typename T> __device__ inline T guarded_inverse(T x) {            // utils.h:59-63
+    return __builtin_fabs(x) <= Eps<T>::v ? static_cast<T>(__builtin_copysign(static_cast<double>(Ord<T>::kMax), static_cast<double>(x))) : T(1) / x;
+}
+
+struct MtScalars { uint32_t n_groups, n_cuts, error, pad; };
+
+template <typename T>
+__global__ void k_mt_prepare(typename Ord<T>::U* keybox, uint32_t* hist, MtScalars* sc) {
+    for (int k = threadIdx.x; k < 3; k += blockDim.x) { keybox[k] = Ord<T>::enc(Ord<T>::kMax); keybox[3 + k] = Ord<T>::enc(-Ord<T>::kMax); }
+    for (uint32_t i = threadIdx.x; i < kCells; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) { MtScalars z = {}; *sc = z; }
+}
+
+// center_bbox (:162-167)
+template <typename T>
+__global__ void __launch_bounds__(256) k_center_bounds(const T* centers, uint32_t n, typename Ord<T>::U* keybox) {
+    __shared__ typename Ord<T>::U slo[3], shi[3];
+    if (threadIdx.x < 3) { slo[threadIdx.x] = Ord<T>::enc(Ord<T>::kMax); shi[threadIdx.x] = Ord<T>::enc(-Ord<T>::kMax); }
+    __syncthreads();
+    T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+    for (size_t i = blockIdx.x * size_t{256} + threadIdx.x; i < n; i += size_t{gridDim.x} * 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const T v = centers[3 * i + k]; lo[k] = pick_min(lo[k], v); hi[k] = pick_max(hi[k], v); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { atomicMin(&slo[k], Ord<T>::enc(lo[k])); atomicMax(&shi[k], Ord<T>::enc(hi[k])); }
+    __syncthreads();
+    if (threadIdx.x < 3) { atomicMin(&keybox[threadIdx.x], slo[threadIdx.x]); atomicMax(&keybox[3 + threadIdx.x], shi[threadIdx.x]); }
+}
+
+__device__ inline uint32_t spread3(uint32_t v) {             // utils.h:104-115 for 4-bit inputs: bit k -> bit 3k
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+
+// grid cell of every primitive (:170-185) + cell histogram
+template <typename T>
+__global__ void __launch_bounds__(256) k_cells(const T* centers, uint32_t n, const typename Ord<T>::U* keybox, uint32_t* codes, uint32_t* hist) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T lo = Ord<T>::dec(keybox[k]), hi = Ord<T>::dec(keybox[3 + k]);
+        const T scale = static_cast<T>(kGridDim) * guarded_inverse(hi - lo);
+        const T shift = (-lo) * scale;
+        const T p = pick_max(Ord<T>::fma_(centers[3ull * i + k], scale, shift), T(0));
+        g[k] = p >= T(kGridDim - 1) ? kGridDim - 1 : static_cast<uint32_t>(p);
+    }
+    const uint32_t code = (spread3(g[0]) | (spread3(g[1]) << 1) | (spread3(g[2]) << 2)) & (kCells - 1);
+    codes[i] = code;
+    atomicAdd(&hist[code], 1u);
+}
+
+// merge_small_bins (:84-91) + remove_empty_bins (:93-96), one lane over the 4096 cells
+__global__ void k_merge_cells(const uint32_t* hist, int merge, uint32_t threshold, uint32_t* group_of, uint32_t* group_begin, MtScalars* sc) {
+    uint32_t groups = 0, run = 0;
+    for (uint32_t i = 0; i < kCells;) {
+        uint32_t acc = hist[i], j = i + 1;
+        if (merge)
+            for (; j < kCells && hist[j] + acc <= threshold; ++j) acc += hist[j];
+        if (acc) {
+            for (uint32_t q = i; q < j; ++q) group_of[q] = groups;
+            group_begin[groups] = run;
+            run += acc;
+            ++groups;
+        }
+        i = j;
+    }
+    group_begin[groups] = run;
+    sc->n_groups = groups;
+}
+
+__global__ void __launch_bounds__(256) k_group_keys(const uint32_t* codes, const uint32_t* group_of, uint32_t n, uint32_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = group_of[codes[i]];
+    vals[i] = i;
+}
+
+template <typename T> __device__ inline T node_half_area(const HostNode<T>& nd) {
+    const T d0 = nd.bounds[1] - nd.bounds[0], d1 = nd.bounds[3] - nd.bounds[2], d2 = nd.bounds[5] - nd.bounds[4];
+    return (d0 + d1) * d2 + d0 * d1;
+}
+template <typename T> __device__ inline bool node_is_leaf(const HostNode<T>& nd) { return (nd.index & kCountMask) != 0; }
+
+// avg_area summed in tree order (:209-213)
+template <typename T>
+__global__ void k_prune_threshold(const HostNode<T>* trees, const uint32_t* tree_off, uint32_t n_trees, T ratio, T* threshold) {
+    T avg = T(0);
+    for (uint32_t t = 0; t < n_trees; ++t) avg += node_half_area(trees[tree_off[t]]);
+    avg /= static_cast<T>(n_trees);
+    *threshold = avg * ratio;
+}
+
+// The cut DFS (:216-232): pass 0 counts the cuts of each tree, pass 1 writes them at cut_off[tree].
+template <typename T>
+__global__ void __launch_bounds__(64) k_prune_walk(const HostNode<T>* trees, const uint32_t* tree_off, uint32_t n_trees, const T* threshold,
+                                                   int pass, uint32_t* cut_count, const uint32_t* cut_off, uint2* cuts, MtScalars* sc) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n_trees) return;
+    const HostNode<T>* tree = trees + tree_off[t];
+    const T thr = *threshold;
+    uint32_t stack[kWalkStack];
+    int sp = 0;
+    stack[sp++] = 0;
+    uint32_t count = 0;
+    const uint32_t base = pass ? cut_off[t] : 0;
+    while (sp) {
+        const uint32_t id = stack[--sp];
+        const HostNode<T>& nd = tree[id];
+        if (node_half_area(nd) < thr || node_is_leaf(nd)) {
+            if (pass) cuts[base + count] = make_uint2(t, id);
+            ++count;
+        } else {
+            if (sp + 2 > kWalkStack) { atomicOr(&sc->error, 1u); break; }
+            const uint32_t f = static_cast<uint32_t>(nd.index >> kCountBits);
+            stack[sp++] = f;
+            stack[sp++] = f + 1;
+        }
+    }
+    if (!pass) cut_count[t] = count;
+}
+
+__global__ void __launch_bounds__(256) k_whole_trees_as_cuts(uint32_t n_trees, uint2* cuts) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n_trees) cuts[t] = make_uint2(t, 0);
+}
+
+// extract_bvh (bvh.h:92-122) per cut. pass 0: sizes (nodes - 1, prims); pass 1: write into the final arrays.
+template <typename T>
+struct ExtractArgs {
+    const HostNode<T>* trees; const uint32_t* tree_off; const uint32_t* group_begin; const uint32_t* ids;
+    const uint2* cuts; uint32_t n_cuts;
+    uint32_t* nodes_minus1; uint32_t* prims;                  // pass 0 outputs / pass 1 inputs are their exclusive scans
+    const uint32_t* node_off; const uint32_t* prim_off;
+    HostNode<T>* out_nodes; uint32_t* out_ids; HostNode<T>* cut_roots; T* top_boxes; T* top_centers;
+    uint32_t top_nodes;                                       // 2 * n_cuts - 1
+    MtScalars* sc;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_extract(ExtractArgs<T> a, int pass) {
+    using I = typename IndexOf<T>::Type;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n_cuts) return;
+    const uint2 cut = a.cuts[i];
+    const uint32_t t = cut.x, r = cut.y;
+    const HostNode<T>* tree = a.trees + a.tree_off[t];
+    const uint32_t gb = a.group_begin[t];
+    const uint32_t node_base = pass ? a.top_nodes - 1 + a.node_off[i] : 0;     // node_offsets[i] (:268)
+    const uint32_t prim_base = pass ? a.prim_off[i] : 0;                        // prim_offsets[i] (:269)
+    auto rebased = [&](HostNode<T> nd, uint32_t local_first) {                 // copy_node (:275-279)
+        const uint32_t cnt = static_cast<uint32_t>(nd.index & kCountMask);
+        nd.index = cnt ? ((static_cast<I>(prim_base + local_first) << kCountBits) | cnt) : (static_cast<I>(node_base + local_first) << kCountBits);
+        return nd;
+    };
+    uint32_t n_nodes = 1, n_prims = 0;
+    HostNode<T> root_rec;
+    if (r == 0) {                                             // the whole mini-tree moves (:239-240)
+        n_nodes = a.tree_off[t + 1] - a.tree_off[t];
+        n_prims = a.group_begin[t + 1] - gb;
+        if (pass) {
+            root_rec = rebased(tree[0], static_cast<uint32_t>(tree[0].index >> kCountBits));
+            for (uint32_t j = 1; j < n_nodes; ++j) a.out_nodes[node_base + j] = rebased(tree[j], static_cast<uint32_t>(tree[j].index >> kCountBits));
+            for (uint32_t p = 0; p < n_prims; ++p) a.out_ids[prim_base + p] = a.ids[gb + p];
+        }
+    } else {
+        uint2 stack[kWalkStack];
+        int sp = 0;
+        stack[sp++] = make_uint2(r, 0);
+        while (sp) {
+            const uint2 top = stack[--sp];
+            const HostNode<T> src = tree[top.x];
+            HostNode<T> rec;
+            if (node_is_leaf(src)) {
+                const uint32_t first = static_cast<uint32_t>(src.index >> kCountBits), cnt = static_cast<uint32_t>(src.index & kCountMask);
+                if (pass) {
+                    rec = rebased(src, n_prims);
+                    for (uint32_t q = 0; q < cnt; ++q) a.out_ids[prim_base + n_prims + q] = a.ids[gb + first + q];
+                }
+                n_prims += cnt;
+            } else {
+                if (sp + 2 > kWalkStack) { atomicOr(&a.sc->error, 1u); break; }
+                const uint32_t first = static_cast<uint32_t>(src.index >> kCountBits);
+                if (pass) rec = rebased(src, n_nodes);
+                stack[sp++] = make_uint2(first, n_nodes);
+                stack[sp++] = make_uint2(first + 1, n_nodes + 1);
+                n_nodes += 2;
+            }
+            if (pass) { if (top.y == 0) root_rec = rec; else a.out_nodes[node_base + top.y] = rec; }
+        }
+    }
+    if (!pass) { a.nodes_minus1[i] = n_nodes - 1; a.prims[i] = n_prims; return; }
+    a.cut_roots[i] = root_rec;
+    // the top-level builder's inputs (:251-256)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T lo = root_rec.bounds[2 * k], hi = root_rec.bounds[2 * k + 1];
+        a.top_boxes[6ull * i + k] = lo;
+        a.top_boxes[6ull * i + 3 + k] = hi;
+        a.top_centers[3ull * i + k] = (hi + lo) * T(0.5);    // bbox.h:30
+    }
+}
+
+// top nodes into the final array; top leaves become the cut roots (:282-288)
+template <typename T>
+__global__ void __launch_bounds__(256) k_splice_top(const HostNode<T>* top, const uint32_t* top_ids, uint32_t top_nodes, const HostNode<T>* cut_roots,
+                                                    HostNode<T>* out) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= top_nodes) return;
+    HostNode<T> nd = top[v];
+    if (node_is_leaf(nd)) nd = cut_roots[top_ids[static_cast<uint32_t>(nd.index >> kCountBits)]];
+    out[v] = nd;
+}
+
+// exclusive scan of a u32 array (two levels are enough for 2^28 elements with 4096-element blocks... three here)
+constexpr int kScanBlock = 4096;
+__global__ void __launch_bounds__(1024) k_scan_blocks(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums) {
+    __shared__ uint32_t part[1024];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? in[base + k] : 0; s += v[k]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t o = threadIdx.x >= unsigned(off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += o;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 1023 && block_sums) block_sums[blockIdx.x] = part[1023];
+}
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* out, uint32_t n, const uint32_t* block_offsets) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] += block_offsets[i / kScanBlock];
+}
+
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_host, hipStream_t stream) {
+    // out[i] = sum of in[0..i); total optionally returned to the host
+    if (n == 0) { if (total_host) *total_host = 0; return BVH_AMD_OK; }
+    const uint32_t blocks = (n + kScanBlock - 1) / kScanBlock;
+    DevBuf<uint32_t> sums, sums_scanned;
+    BVH_HIP_TRY(sums.alloc(blocks), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(sums_scanned.alloc(blocks), BVH_AMD_ERR_HIP);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(1024), 0, stream, in, out, n, sums.p);
+    uint32_t total = 0;
+    if (blocks > 1) {
+        int rc = exclusive_scan_u32(sums.p, sums_scanned.p, blocks, &total, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, sums_scanned.p);
+    } else if (total_host) {
+        BVH_HIP_TRY(hipMemcpyAsync(&total, sums.p, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    }
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    if (total_host) *total_host = total;
+    return BVH_AMD_OK;
+}
+
+} // namespace
+
+// MiniTreeBuilder::build on the device: final nodes (reference layout) + prim ids, both resident.
+template <typename T>
+int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T prune_ratio,
+                  DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& final_ids, size_t& total_nodes, hipStream_t stream)
+{
+    if (n >= (size_t{1} << 28)) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: more than 2^28 primitives");
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    using U = typename Ord<T>::U;
+    DevBuf<U> keybox;
+    DevBuf<uint32_t> hist, codes, group_of, group_begin, keys, ids, keys_tmp, vals_tmp;
+    DevBuf<MtScalars> scalars;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(keybox.alloc(6)); A(hist.alloc(kCells)); A(codes.alloc(n)); A(group_of.alloc(kCells)); A(group_begin.alloc(kCells + 1));
+    A(keys.alloc(n)); A(ids.alloc(n)); A(keys_tmp.alloc(n)); A(vals_tmp.alloc(n)); A(scalars.alloc(1));
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+
+    // ---- build_mini_trees
+    hipLaunchKernelGGL(k_mt_prepare<T>, dim3(1), dim3(256), 0, stream, keybox.p, hist.p, scalars.p);
+    const unsigned red_grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 2048));
+    hipLaunchKernelGGL(k_center_bounds<T>, dim3(red_grid), dim3(256), 0, stream, d_centers, n32, keybox.p);
+    hipLaunchKernelGGL(k_cells<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_centers, n32, keybox.p, codes.p, hist.p);
+    hipLaunchKernelGGL(k_merge_cells, dim3(1), dim3(1), 0, stream, hist.p, prune ? 1 : 0, static_cast<uint32_t>(cfg.parallel_threshold),
+                       group_of.p, group_begin.p, scalars.p);
+    hipLaunchKernelGGL(k_group_keys, dim3((n32 + 255) / 256), dim3(256), 0, stream, codes.p, group_of.p, n32, keys.p, ids.p);
+    int rc = radix_sort_pairs<uint32_t>(keys.p, ids.p, keys_tmp.p, vals_tmp.p, n32, 1, 12, stream);   // stable: ids ascending per group (:124)
+    if (rc) return rc;
+    MtScalars hs;
+    BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    const uint32_t n_trees = hs.n_groups;
+
+    DevBuf<HostNode<T>> trees;
+    DevBuf<uint32_t> tree_off;
+    uint32_t forest_nodes = 0;
+    rc = build_binned_forest_device<T>(d_bboxes, d_centers, ids.p, n32, group_begin.p, n_trees, cfg, trees, tree_off, forest_nodes, stream);
+    if (rc) return rc;
+
+    // ---- prune_mini_trees: the list of cuts (tree, node) in the reference's order
+    DevBuf<uint2> cuts;
+    uint32_t n_cuts = n_trees;
+    if (prune) {
+        DevBuf<T> threshold;
+        DevBuf<uint32_t> cut_count, cut_off;
+        BVH_HIP_TRY(threshold.alloc(1), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(cut_count.alloc(n_trees), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(cut_off.alloc(n_trees), BVH_AMD_ERR_HIP);
+        hipLaunchKernelGGL(k_prune_threshold<T>, dim3(1), dim3(1), 0, stream, trees.p, tree_off.p, n_trees, prune_ratio, threshold.p);
+        const unsigned tg = (n_trees + 63) / 64;
+        hipLaunchKernelGGL(k_prune_walk<T>, dim3(tg), dim3(64), 0, stream, trees.p, tree_off.p, n_trees, threshold.p, 0, cut_count.p,
+                           static_cast<const uint32_t*>(nullptr), static_cast<uint2*>(nullptr), scalars.p);
+        rc = exclusive_scan_u32(cut_count.p, cut_off.p, n_trees, &n_cuts, stream);
+        if (rc) return rc;
+        BVH_HIP_TRY(cuts.alloc(n_cuts), BVH_AMD_ERR_HIP);
+        hipLaunchKernelGGL(k_prune_walk<T>, dim3(tg), dim3(64), 0, stream, trees.p, tree_off.p, n_trees, threshold.p, 1, cut_count.p,
+                           cut_off.p, cuts.p, scalars.p);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    } else {
+        BVH_HIP_TRY(cuts.alloc(n_cuts), BVH_AMD_ERR_HIP);
+        hipLaunchKernelGGL(k_whole_trees_as_cuts, dim3((n_trees + 255) / 256), dim3(256), 0, stream, n_trees, cuts.p);
+    }
+
+    // ---- extract (sizes -> offsets -> write) and the top-level builder's inputs
+    DevBuf<uint32_t> nm1, np, node_off, prim_off;
+    DevBuf<HostNode<T>> cut_roots;
+    DevBuf<T> top_boxes, top_centers;
+    A(nm1.alloc(n_cuts)); A(np.alloc(n_cuts)); A(node_off.alloc(n_cuts)); A(prim_off.alloc(n_cuts)); A(cut_roots.alloc(n_cuts));
+    A(top_boxes.alloc(6 * size_t{n_cuts})); A(top_centers.alloc(3 * size_t{n_cuts})); A(final_ids.alloc(n));
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+    ExtractArgs<T> ea;
+    ea.trees = trees.p; ea.tree_off = tree_off.p; ea.group_begin = group_begin.p; ea.ids = ids.p; ea.cuts = cuts.p; ea.n_cuts = n_cuts;
+    ea.nodes_minus1 = nm1.p; ea.prims = np.p; ea.node_off = node_off.p; ea.prim_off = prim_off.p;
+    ea.out_nodes = nullptr; ea.out_ids = final_ids.p; ea.cut_roots = cut_roots.p; ea.top_boxes = top_boxes.p; ea.top_centers = top_centers.p;
+    ea.top_nodes = 2 * n_cuts - 1; ea.sc = scalars.p;
+    const unsigned cg = (n_cuts + 63) / 64;
+    hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 0);
+    uint32_t below = 0, prim_total = 0;
+    rc = exclusive_scan_u32(nm1.p, node_off.p, n_cuts, &below, stream);
+    if (rc) return rc;
+    rc = exclusive_scan_u32(np.p, prim_off.p, n_cuts, &prim_total, stream);
+    if (rc) return rc;
+    if (prim_total != n32) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree extraction lost primitives (walk stack overflow?)");
+    total_nodes = size_t{ea.top_nodes} + below;
+    BVH_HIP_TRY(final_nodes.alloc(total_nodes), BVH_AMD_ERR_HIP);
+    ea.out_nodes = final_nodes.p;
+    hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 1);
+    BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    if (hs.error) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree deeper than the pruning walk stack");
+
+    // ---- build_top_bvh: sweep SAH with one cut root per leaf, then the splice
+    DevBuf<HostNode<T>> top;
+    DevBuf<uint32_t> top_ord;
+    size_t top_count = 0;
+    rc = sweep_core<T>(top_boxes.p, top_centers.p, n_cuts, 1, 1, top, top_ord, top_count, stream);
+    if (rc) return rc;
+    if (top_count != ea.top_nodes) return fail(BVH_AMD_ERR_OVERFLOW, "build: unexpected top-level node count");
+    hipLaunchKernelGGL(k_splice_top<T>, dim3((ea.top_nodes + 255) / 256), dim3(256), 0, stream, top.p, top_ord.p, ea.top_nodes, cut_roots.p,
+                       final_nodes.p);
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
+}
+
+// DefaultBuilder::build(pool, ...) without the reinsertion pass (default_builder.h:41-42, :65-73).
+template <typename T>
+int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, hipStream_t stream) {
+    BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
+    DevBuf<HostNode<T>> final_nodes;
+    DevBuf<uint32_t> final_ids;
+    size_t total_nodes = 0;
+    const bool prune = cfg.quality != BVH_BUILD_QUALITY_LOW;
+    const T ratio = cfg.quality == BVH_BUILD_QUALITY_HIGH ? T(0.01) : T(0.1);
+    int rc = minitree_core<T>(d_bboxes, d_centers, n, cfg, prune, ratio, final_nodes, final_ids, total_nodes, stream);
+    if (rc) return rc;
+    out.nodes.resize(total_nodes);
+    rc = finish_build<T>(out, final_nodes, final_ids.p, n, stream, /*take_ids=*/true);
+    if (rc) return rc;
+    final_ids.p = nullptr;
+    return BVH_AMD_OK;
+}
+
+template int build_minitree_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
+template int build_minitree_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
+
+} // namespace bvh_amd

@@ -431,21 +431,22 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
 
 } // namespace
 
-// SweepSahBuilder::build on the device.
+// SweepSahBuilder core: nodes in the reference layout into `final_nodes`, prim ids (= the axis-0 order) in ord[0..n).
 template <typename T>
-int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
-                       hipStream_t stream)
+int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_leaf, uint32_t max_leaf,
+               DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& ord, size_t& total_nodes, hipStream_t stream)
 {
     if (n >= (size_t{1} << 28)) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: more than 2^28 primitives");
     const uint32_t n32 = static_cast<uint32_t>(n);
-    BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
-
-    DevBuf<uint32_t> ord;
     BVH_HIP_TRY(ord.alloc(3 * n), BVH_AMD_ERR_HIP);
     int rc = std_sort_ids<T>(ord.p, d_centers, n32, 3, 1, 3, stream);          // :57-63
     if (rc) return rc;
+    DevBuf<uint32_t> sorted;                                   // a capacity retry restarts from the sorted orders
+    BVH_HIP_TRY(sorted.alloc(3 * n), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipMemcpyAsync(sorted.p, ord.p, 3 * n * 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
 
     for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt) BVH_HIP_TRY(hipMemcpyAsync(ord.p, sorted.p, 3 * n * 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
         const uint32_t node_cap = attempt == 0 ? n32 / 8 + 1024 : 2 * n32 + 2;
         const uint32_t slot_cap = n32 / (kSmall + 1) + 2;
         const uint32_t task_cap = n32 / kChunk + slot_cap + 2;
@@ -455,7 +456,7 @@ int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, s
         DevBuf<ANode<T>> nodes;
         DevBuf<SlotState<T>> st_a, st_b;
         DevBuf<Task> tk_a, tk_b;
-        DevBuf<HostNode<T>> stage, final_nodes;
+        DevBuf<HostNode<T>> stage;
         DevBuf<Counters> counters;
         hipError_t e = hipSuccess;
         auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -468,7 +469,7 @@ int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, s
         SweepCtx<T> sc;
         BuildCtx<T>& c = sc.b;
         c.bboxes = d_bboxes; c.centers = d_centers; c.ids = ord.p; c.n = n32;
-        c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
+        c.min_leaf = min_leaf; c.max_leaf = max_leaf;
         c.nodes = nodes.p; c.node_cap = node_cap; c.bins = nullptr; c.state = st_a.p; c.state_next = st_b.p; c.slot_cap = slot_cap;
         c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = nullptr;
         c.ltab = nullptr; c.rtab = nullptr; c.small_list = small_list.p; c.stage = stage.p; c.counters = counters.p;
@@ -514,13 +515,34 @@ int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, s
         }
         const uint32_t n_nodes_a = h.n_nodes, n_small = h.n_small;
         if (n_small) hipLaunchKernelGGL(k_small_sweep<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, sc, n_small);
-        rc = number_and_emit<T>(out, c, level_start, n_nodes_a, n_small, final_nodes, stream);
+        BvhImpl<T> sizes;                                      // only its node vector length is used
+        rc = number_and_emit<T>(sizes, c, level_start, n_nodes_a, n_small, final_nodes, stream);
         if (rc) return rc;
-        return finish_build<T>(out, final_nodes, ord.p, n, stream, /*take_ids=*/false);
+        total_nodes = sizes.nodes.size();
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // workspace dies here
+        return BVH_AMD_OK;
     }
     return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
 }
 
+// SweepSahBuilder::build on the device.
+template <typename T>
+int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
+                       hipStream_t stream)
+{
+    BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
+    DevBuf<HostNode<T>> final_nodes;
+    DevBuf<uint32_t> ord;
+    size_t total_nodes = 0;
+    int rc = sweep_core<T>(d_bboxes, d_centers, n, static_cast<uint32_t>(cfg.min_leaf_size), static_cast<uint32_t>(cfg.max_leaf_size),
+                           final_nodes, ord, total_nodes, stream);
+    if (rc) return rc;
+    out.nodes.resize(total_nodes);
+    return finish_build<T>(out, final_nodes, ord.p, n, stream, /*take_ids=*/false);
+}
+
+template int sweep_core<float>(const float*, const float*, size_t, uint32_t, uint32_t, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, size_t&, hipStream_t);
+template int sweep_core<double>(const double*, const double*, size_t, uint32_t, uint32_t, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, size_t&, hipStream_t);
 template int build_sweep_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
 template int build_sweep_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
 

@@ -167,3 +167,45 @@ def test_sweep_degenerate_inputs(orc):
         tris = np.ascontiguousarray(tris[rng.permutation(len(tris))])
         bb, cc = orc.prep_tris(tris)
         assert _gpu_sweep(bb, cc).serialize() == orc.build(bb, cc, builder=oracle.BUILDER_SWEEP).serialize()
+
+
+# ---- mini-tree builder (DefaultBuilder with a thread pool, Low / Medium) ---------------------------------------
+
+def _gpu_parallel(bb, cc, quality, **kw):
+    import bvh_amd
+    return bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=quality, **kw), thread_pool=bvh_amd.ThreadPool())
+
+
+@pytest.mark.parametrize("scene", ["cornell", "soup2k", "terrain2k", "soup2k_f64", "spheres2k_f64"])
+@pytest.mark.parametrize("q,name", [(0, "parallel_low"), (1, "parallel_med")])
+def test_minitree_matches_golden_stream(scene, q, name):
+    import bvh_amd
+    g = load_golden(scene)
+    assert _gpu_parallel(g["bboxes"], g["centers"], bvh_amd.Quality(q)).serialize() == g[f"bvh_{name}"].tobytes()
+
+
+@pytest.mark.parametrize("scene,n", [("soup", 5000), ("soup", 200_000), ("terrain", 200_000), ("sponza", 262_144), ("soup", 1_000_000)])
+@pytest.mark.parametrize("q", [0, 1])
+def test_minitree_scenes(orc, scene, n, q):
+    import bvh_amd
+    tris = {"soup": lambda: synth.soup(n), "terrain": lambda: synth.terrain(n), "sponza": lambda: synth.sponza_proxy(n)}[scene]()
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=q)
+    gpu = _gpu_parallel(bb, cc, bvh_amd.Quality(q))
+    assert gpu.node_count == ref.node_count
+    assert gpu.serialize() == ref.serialize()
+
+
+def test_minitree_threshold_and_clustered_input(orc):
+    """A dense cluster puts most primitives into one grid cell (one big mini-tree) and parallel_threshold changes
+    the merge; both must follow the reference."""
+    import bvh_amd
+    a = synth.soup(30000, seed=3, jitter=0.001) * 0.01           # everything within 1% of the box
+    b = synth.soup(3000, seed=4, jitter=0.02)
+    tris = np.ascontiguousarray(np.concatenate([a, b]).astype(np.float32))
+    bb, cc = orc.prep_tris(tris)
+    for q in (0, 1):
+        for thr in (1024, 100, 5000):
+            ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=q, parallel_threshold=thr)
+            gpu = _gpu_parallel(bb, cc, bvh_amd.Quality(q), parallel_threshold=thr)
+            assert gpu.serialize() == ref.serialize(), (q, thr)
