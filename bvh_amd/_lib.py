@@ -52,6 +52,7 @@ _SIGS_T = {
     "bvh{S}_build_device": (_P, [_P, _P, _Z, _P, _I, _P]),
     "bvh{S}_from_nodes": (_P, [_P, _Z, _P, _Z]),
     "bvh{S}_destroy": (None, [_P]),
+    "bvh{S}_optimize": (None, [_P, _P]),
     "bvh{S}_save": (None, [_P, _P]),
     "bvh{S}_load": (_P, [_P]),
     "bvh{S}_serialize": (_Z, [_P, _P, _Z]),

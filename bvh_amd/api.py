@@ -140,6 +140,16 @@ class Bvh:
         t._bvh_keepalive = self
         return t
 
+    def optimize(self, thread_pool=None):
+        """ReinsertionOptimizer::optimize (reinsertion_optimizer.h:27-35), in place on the device."""
+        _torch()
+        _lib.load().bvh_amd_last_error()
+        before = self._lib.bvh_amd_last_error()
+        self._f("bvh{S}_optimize")(None, self._h)
+        err = self._lib.bvh_amd_last_error()
+        if err and err != before and b"optimize" in err:
+            raise _lib.BvhAmdError(err.decode())
+
     def get_root(self):
         return self.nodes[0]
 

@@ -9,7 +9,7 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
 
 template <typename T>
 int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
-                       hipStream_t stream);
+                       bool optimize, hipStream_t stream);
 
 template <typename T>
 int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, hipStream_t stream);
@@ -22,12 +22,11 @@ int build_on_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size
     if (builder == BVH_AMD_BUILDER_DEFAULT_PARALLEL && n < cfg.parallel_threshold) builder = BVH_AMD_BUILDER_DEFAULT_SERIAL;
     if (builder == BVH_AMD_BUILDER_BINNED || (builder == BVH_AMD_BUILDER_DEFAULT_SERIAL && cfg.quality == BVH_BUILD_QUALITY_LOW))
         return build_binned_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
-    if (builder == BVH_AMD_BUILDER_SWEEP || (builder == BVH_AMD_BUILDER_DEFAULT_SERIAL && cfg.quality == BVH_BUILD_QUALITY_MEDIUM))
-        return build_sweep_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
-    if (builder == BVH_AMD_BUILDER_DEFAULT_PARALLEL && cfg.quality != BVH_BUILD_QUALITY_HIGH)
-        return build_minitree_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
-    return fail(BVH_AMD_ERR_UNSUPPORTED, "build: this builder/quality combination is not implemented on the device yet "
-                                         "(available: BinnedSahBuilder, SweepSahBuilder, DefaultBuilder serial Low/Medium, parallel Low/Medium)");
+    if (builder == BVH_AMD_BUILDER_SWEEP) return build_sweep_device<T>(out, d_bboxes, d_centers, n, cfg, false, stream);
+    if (builder == BVH_AMD_BUILDER_DEFAULT_SERIAL)            // Medium: sweep; High: sweep + reinsertion (default_builder.h:56-60)
+        return build_sweep_device<T>(out, d_bboxes, d_centers, n, cfg, cfg.quality == BVH_BUILD_QUALITY_HIGH, stream);
+    if (builder == BVH_AMD_BUILDER_DEFAULT_PARALLEL) return build_minitree_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
+    return fail(BVH_AMD_ERR_ARG, "build: unknown builder");
 }
 
 template int build_on_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, bvh_amd_builder, hipStream_t);

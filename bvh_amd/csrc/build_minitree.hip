@@ -252,54 +252,6 @@ __global__ void __launch_bounds__(256) k_splice_top(const HostNode<T>* top, cons
     out[v] = nd;
 }
 
-// exclusive scan of a u32 array (two levels are enough for 2^28 elements with 4096-element blocks... three here)
-constexpr int kScanBlock = 4096;
-__global__ void __launch_bounds__(1024) k_scan_blocks(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums) {
-    __shared__ uint32_t part[1024];
-    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4;
-    uint32_t v[4], s = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? in[base + k] : 0; s += v[k]; }
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t o = threadIdx.x >= unsigned(off) ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += o;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
-    if (threadIdx.x == 1023 && block_sums) block_sums[blockIdx.x] = part[1023];
-}
-__global__ void __launch_bounds__(256) k_scan_add(uint32_t* out, uint32_t n, const uint32_t* block_offsets) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] += block_offsets[i / kScanBlock];
-}
-
-int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_host, hipStream_t stream) {
-    // out[i] = sum of in[0..i); total optionally returned to the host
-    if (n == 0) { if (total_host) *total_host = 0; return BVH_AMD_OK; }
-    const uint32_t blocks = (n + kScanBlock - 1) / kScanBlock;
-    DevBuf<uint32_t> sums, sums_scanned;
-    BVH_HIP_TRY(sums.alloc(blocks), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(sums_scanned.alloc(blocks), BVH_AMD_ERR_HIP);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(1024), 0, stream, in, out, n, sums.p);
-    uint32_t total = 0;
-    if (blocks > 1) {
-        int rc = exclusive_scan_u32(sums.p, sums_scanned.p, blocks, &total, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, sums_scanned.p);
-    } else if (total_host) {
-        BVH_HIP_TRY(hipMemcpyAsync(&total, sums.p, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-    }
-    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
-    if (total_host) *total_host = total;
-    return BVH_AMD_OK;
-}
-
 } // namespace
 
 // MiniTreeBuilder::build on the device: final nodes (reference layout) + prim ids, both resident.
@@ -406,7 +358,9 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     return BVH_AMD_OK;
 }
 
-// DefaultBuilder::build(pool, ...) without the reinsertion pass (default_builder.h:41-42, :65-73).
+template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+
+// DefaultBuilder::build(pool, ...): mini-trees, plus the reinsertion pass at Quality::High (default_builder.h:41-44, :65-73).
 template <typename T>
 int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, hipStream_t stream) {
     BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
@@ -417,6 +371,10 @@ int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers
     const T ratio = cfg.quality == BVH_BUILD_QUALITY_HIGH ? T(0.01) : T(0.1);
     int rc = minitree_core<T>(d_bboxes, d_centers, n, cfg, prune, ratio, final_nodes, final_ids, total_nodes, stream);
     if (rc) return rc;
+    if (cfg.quality == BVH_BUILD_QUALITY_HIGH) {
+        rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream);
+        if (rc) return rc;
+    }
     out.nodes.resize(total_nodes);
     rc = finish_build<T>(out, final_nodes, final_ids.p, n, stream, /*take_ids=*/true);
     if (rc) return rc;

@@ -526,9 +526,11 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
 }
 
 // SweepSahBuilder::build on the device.
+template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+
 template <typename T>
 int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
-                       hipStream_t stream)
+                       bool optimize, hipStream_t stream)
 {
     BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
     DevBuf<HostNode<T>> final_nodes;
@@ -537,13 +539,17 @@ int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, s
     int rc = sweep_core<T>(d_bboxes, d_centers, n, static_cast<uint32_t>(cfg.min_leaf_size), static_cast<uint32_t>(cfg.max_leaf_size),
                            final_nodes, ord, total_nodes, stream);
     if (rc) return rc;
+    if (optimize) {                                           // DefaultBuilder serial High (default_builder.h:58-60)
+        rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream);
+        if (rc) return rc;
+    }
     out.nodes.resize(total_nodes);
     return finish_build<T>(out, final_nodes, ord.p, n, stream, /*take_ids=*/false);
 }
 
 template int sweep_core<float>(const float*, const float*, size_t, uint32_t, uint32_t, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, size_t&, hipStream_t);
 template int sweep_core<double>(const double*, const double*, size_t, uint32_t, uint32_t, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, size_t&, hipStream_t);
-template int build_sweep_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
-template int build_sweep_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
+template int build_sweep_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, bool, hipStream_t);
+template int build_sweep_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, bool, hipStream_t);
 
 } // namespace bvh_amd

@@ -7,6 +7,9 @@
 
 namespace bvh_amd {
 
+template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
+
 namespace {
 thread_local std::string g_error;
 }
@@ -142,6 +145,26 @@ typename CTypes<T>::Bvh* load(FILE* f) {
 }
 
 template <typename T>
+int optimize(typename CTypes<T>::Bvh* bvh) {
+    if (!bvh) return fail(BVH_AMD_ERR_ARG, "optimize: null bvh");
+    BvhImpl<T>& b = *impl<T>(bvh);
+    if (b.nodes.empty()) return fail(BVH_AMD_ERR_ARG, "optimize: empty bvh");
+    HostNode<T>* d_nodes = nullptr;
+    const size_t bytes = b.nodes.size() * sizeof(HostNode<T>);
+    BVH_HIP_TRY(hipMalloc(&d_nodes, bytes), BVH_AMD_ERR_HIP);
+    hipError_t e = hipMemcpy(d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? reinsertion_optimize_device<T>(d_nodes, b.nodes.size(), nullptr) : fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
+    if (rc == BVH_AMD_OK) {
+        e = hipMemcpy(b.nodes.data(), d_nodes, bytes, hipMemcpyDeviceToHost);
+        rc = e == hipSuccess ? relayout_on_device<T>(b, d_nodes, nullptr) : fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
+        b.root_index = static_cast<uint32_t>(b.nodes[0].index);
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d_nodes);
+    return rc;
+}
+
+template <typename T>
 int intersect(const typename CTypes<T>::Bvh* bvh, int leaf, const T* d_prims, const typename CTypes<T>::Ray* d_rays, size_t n,
               unsigned flags, typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, void* stream)
 {
@@ -194,6 +217,7 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes<T>(nodes, nn, ids, np); }                                                                 \
     void bvh##S##_destroy(bvh##S* b) { delete impl<T>(b); }                                                         \
+    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(b); }                                                         \
     void bvh##S##_save(const bvh##S* b, FILE* f) { if (b && f) save<T>(*impl<T>(b), f); }                           \
     bvh##S* bvh##S##_load(FILE* f) { return f ? load<T>(f) : nullptr; }                                             \
     size_t bvh##S##_serialize(const bvh##S* b, void* out, size_t cap) { return b ? serialize<T>(*impl<T>(b), out, cap) : 0; } \

@@ -111,6 +111,9 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
 template <typename T>
 int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, uint32_t astride, uint32_t istride, hipStream_t stream);
 
+// out[i] = sum of in[0..i); the total is optionally returned to the host (synchronises the stream)
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_host, hipStream_t stream);
+
 // build_*.hip
 template <typename T>
 int build_on_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,

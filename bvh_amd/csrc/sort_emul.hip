@@ -219,7 +219,56 @@ __global__ void __launch_bounds__(256) k_iota(uint32_t* ids, uint32_t n, uint32_
     if (i < total) ids[i] = i % n;
 }
 
+// exclusive scan of a u32 array (two levels are enough for 2^28 elements with 4096-element blocks... three here)
+constexpr int kScanBlock = 4096;
+__global__ void __launch_bounds__(1024) k_scan_blocks(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums) {
+    __shared__ uint32_t part[1024];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? in[base + k] : 0; s += v[k]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t o = threadIdx.x >= unsigned(off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += o;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 1023 && block_sums) block_sums[blockIdx.x] = part[1023];
+}
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* out, uint32_t n, const uint32_t* block_offsets) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] += block_offsets[i / kScanBlock];
+}
+
 } // namespace
+
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_host, hipStream_t stream) {
+    // out[i] = sum of in[0..i); total optionally returned to the host
+    if (n == 0) { if (total_host) *total_host = 0; return BVH_AMD_OK; }
+    const uint32_t blocks = (n + kScanBlock - 1) / kScanBlock;
+    DevBuf<uint32_t> sums, sums_scanned;
+    BVH_HIP_TRY(sums.alloc(blocks), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(sums_scanned.alloc(blocks), BVH_AMD_ERR_HIP);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(1024), 0, stream, in, out, n, sums.p);
+    uint32_t total = 0;
+    if (blocks > 1) {
+        int rc = exclusive_scan_u32(sums.p, sums_scanned.p, blocks, &total, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, sums_scanned.p);
+    } else if (total_host) {
+        BVH_HIP_TRY(hipMemcpyAsync(&total, sums.p, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    }
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    if (total_host) *total_host = total;
+    return BVH_AMD_OK;
+}
+
 
 // Stable sort of `batch` independent arrays of n (key, value) pairs by the low `bits` bits of the key.
 // keys/vals are overwritten with the result; tmp buffers have the same sizes.

@@ -119,6 +119,12 @@ BVH_AMD_API struct bvh3d* bvh3d_from_nodes(const void* nodes, size_t node_count,
 BVH_AMD_API void bvh3f_destroy(struct bvh3f*);                                   /* c_api/bvh.h:130 */
 BVH_AMD_API void bvh3d_destroy(struct bvh3d*);                                   /* c_api/bvh.h:132 */
 
+/* ---- optimization (c_api/bvh.h:226-229): ReinsertionOptimizer::optimize on the device, in place. The pool
+ * argument is accepted for signature compatibility (the result does not depend on it in the reference either).
+ * On failure the BVH is left unchanged and bvh_amd_last_error() is set. */
+BVH_AMD_API void bvh3f_optimize(struct bvh_thread_pool*, struct bvh3f*);
+BVH_AMD_API void bvh3d_optimize(struct bvh_thread_pool*, struct bvh3d*);
+
 /* ---- serialization (c_api/bvh.h:136-144; byte format of Bvh::serialize, bvh.h:221-229) -------- */
 BVH_AMD_API void bvh3f_save(const struct bvh3f*, FILE*);
 BVH_AMD_API void bvh3d_save(const struct bvh3d*, FILE*);

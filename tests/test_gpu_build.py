@@ -102,12 +102,12 @@ def test_build_then_trace_matches_oracle(orc):
     assert hits.tobytes() == oh.tobytes()
 
 
-def test_unsupported_modes_fail_loudly():
+def test_bad_config_fails_loudly():
     import bvh_amd
-    tris = synth.soup(5000)
+    tris = synth.soup(500)
     bb, cc = bvh_amd.tri_bounds(tris)
     with pytest.raises(bvh_amd.BvhAmdError):
-        bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
+        bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(max_leaf_size=16))      # 4-bit primitive count
 
 
 # ---- sweep SAH (SweepSahBuilder, DefaultBuilder serial Medium) ----------------------------------------------
@@ -209,3 +209,47 @@ def test_minitree_threshold_and_clustered_input(orc):
             ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=q, parallel_threshold=thr)
             gpu = _gpu_parallel(bb, cc, bvh_amd.Quality(q), parallel_threshold=thr)
             assert gpu.serialize() == ref.serialize(), (q, thr)
+
+
+# ---- reinsertion optimizer / Quality::High --------------------------------------------------------------------
+
+@pytest.mark.parametrize("scene", ["cornell", "soup2k", "terrain2k", "soup2k_f64", "spheres2k_f64"])
+def test_high_quality_matches_golden_stream(scene):
+    import bvh_amd
+    g = load_golden(scene)
+    cfg = bvh_amd.Config(quality=bvh_amd.Quality.High)
+    assert bvh_amd.DefaultBuilder.build(g["bboxes"], g["centers"], cfg).serialize() == g["bvh_serial_high"].tobytes()
+    assert bvh_amd.DefaultBuilder.build(g["bboxes"], g["centers"], cfg, thread_pool=bvh_amd.ThreadPool()).serialize() \
+        == g["bvh_parallel_high"].tobytes()
+
+
+@pytest.mark.parametrize("scene,n", [("soup", 3), ("soup", 40), ("soup", 5000), ("terrain", 100_000), ("sponza", 262_144), ("soup", 300_000)])
+@pytest.mark.parametrize("parallel", [False, True])
+def test_high_quality_scenes(orc, scene, n, parallel):
+    import bvh_amd
+    tris = {"soup": lambda: synth.soup(n, jitter=0.01), "terrain": lambda: synth.terrain(n), "sponza": lambda: synth.sponza_proxy(n)}[scene]()
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL if parallel else oracle.BUILDER_DEFAULT_SERIAL,
+                    quality=oracle.QUALITY_HIGH)
+    gpu = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High),
+                                       thread_pool=bvh_amd.ThreadPool() if parallel else None)
+    assert gpu.serialize() == ref.serialize()
+
+
+def test_standalone_optimize_matches_reference(orc):
+    """bvhXX_optimize on an existing BVH (here: a binned tree, which reinsertion improves a lot), twice."""
+    import bvh_amd
+    tris = synth.sponza_proxy(60_000)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    gpu = bvh_amd.Bvh.from_nodes(ref.nodes(), ref.prim_ids())
+    for _ in range(2):
+        ref.optimize(-1)
+        gpu.optimize()
+        assert gpu.serialize() == ref.serialize()
+    # the optimised tree still traces identically
+    prims = bvh_amd.precompute_tris(tris, gpu.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    rays = synth.rays_closest(50_000, lo, hi)
+    hits = bvh_amd.hits_to_numpy(bvh_amd.intersect(gpu, prims, rays, robust=True))
+    assert hits.tobytes() == ref.intersect_tri(orc.precompute_tris(tris, ref.prim_ids()), rays, 0, 1, threads=8).tobytes()
