@@ -87,6 +87,9 @@ struct BvhImpl {
     uint32_t root_index = 0;                   // nodes[0].index narrowed to 32 bits
     // per-object scratch for batch launches
     unsigned long long* d_work = nullptr;      // [0] ray counter, [1] status word
+    // scratch of the optional ray-coherence sort (BVH_AMD_RAY_SORTED): keys, order, two temporaries, histograms
+    mutable uint32_t* d_sort = nullptr;
+    mutable size_t sort_cap = 0;
     ~BvhImpl();
 };
 
@@ -107,7 +110,9 @@ int launch_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t str
 
 // sort_emul.hip
 template <typename K>
-int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream);
+int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream,
+                     uint32_t* hist_buf = nullptr);
+size_t radix_sort_hist_words(uint32_t n, uint32_t batch);
 template <typename T>
 int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, uint32_t astride, uint32_t istride, hipStream_t stream);
 

@@ -272,12 +272,16 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* 
 
 // Stable sort of `batch` independent arrays of n (key, value) pairs by the low `bits` bits of the key.
 // keys/vals are overwritten with the result; tmp buffers have the same sizes.
+size_t radix_sort_hist_words(uint32_t n, uint32_t batch) { return size_t{batch} * 256 * ((n + kRadixTile - 1) / kRadixTile); }
+
 template <typename K>
-int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream) {
+int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream,
+                     uint32_t* hist_buf) {
     if (n == 0 || batch == 0) return BVH_AMD_OK;
     const uint32_t bpa = (n + kRadixTile - 1) / kRadixTile;
     DevBuf<uint32_t> hist;
-    BVH_HIP_TRY(hist.alloc(size_t{batch} * 256 * bpa), BVH_AMD_ERR_HIP);
+    if (hist_buf) hist.p = hist_buf;                          // caller-owned scratch: fully asynchronous
+    else BVH_HIP_TRY(hist.alloc(size_t{batch} * 256 * bpa), BVH_AMD_ERR_HIP);
     K* kin = keys; K* kout = keys_tmp; uint32_t* vin = vals; uint32_t* vout = vals_tmp;
     int passes = (bits + 7) / 8;
     if (passes & 1) ++passes;                             // even number of passes: the result lands in keys/vals
@@ -290,6 +294,7 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
         std::swap(vin, vout);
     }
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    if (hist_buf) { hist.p = nullptr; return BVH_AMD_OK; }
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // hist is freed on return
     return BVH_AMD_OK;
 }
@@ -339,8 +344,8 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
     return radix_sort_pairs<U>(skeys.p, d_ids, skeys_tmp.p, vals_tmp.p, n, batch, int(sizeof(U) * 8), stream);
 }
 
-template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t);
-template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t);
+template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*);
+template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*);
 template int std_sort_ids<float>(uint32_t*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 template int std_sort_ids<double>(uint32_t*, const double*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 

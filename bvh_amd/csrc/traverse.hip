@@ -18,14 +18,17 @@
 
 #include "common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace bvh_amd {
 
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kLdsDepth = 24;
-constexpr int kSpillDepth = 40;               // 24 + 40 = 64 = the reference's SmallStack capacity
-constexpr int kRefillThreshold = 16;          // refill when at least this many lanes of the wave are idle
+constexpr int kRefillThreshold = 32;          // refill when at least this many lanes of the wave are idle
+constexpr int kLeafThreshold = 32;            // run the leaf code when at least this many lanes wait at a leaf
 
 thread_local const char* g_last_kernel = "";
 
@@ -70,7 +73,10 @@ struct TraceArgs {
     unsigned long long n;
     unsigned long long* work;                  // [0] next ray ticket, [1] status (stack overflow)
     bvh_amd_counters* counters;
+    const uint32_t* order;                     // optional: ticket -> ray index (coherence sort); results are unaffected
     uint32_t root_index;
+    int refill_threshold;                      // refill when at least this many lanes are idle
+    int leaf_threshold;                        // leave the inner-node loop when this many lanes wait at a leaf
 };
 
 __device__ inline void load_pair(const PairNode<float>* p, float (&lb)[6], float (&rb)[6], uint32_t& li, uint32_t& ri) {
@@ -130,10 +136,24 @@ __device__ inline void store_hit(bvh_hit3d* out, uint32_t prim, double t, double
     q[1] = make_double2(u, v);
 }
 
+// Lanes of one wavefront hand data to each other through LDS without a workgroup barrier; LDS operations of a
+// wave execute in order, this only pins the compiler's ordering.
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// NOTE (measured, profiles/README.md): the L1 (TCP) processes ~1 lane-request per clock for divergent 16-byte loads, so
+// the four requests of a 64-byte pair record are the kernel's floor (4.9 G requests per 2^24-ray launch). A
+// quad-cooperative fetch (4 lanes x 16 B of one record per instruction + LDS transpose) was tried and is 3-4x SLOWER:
+// requests are charged per lane, not per line, and idle lanes then cost as much as active ones.
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
 __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
-    __shared__ uint32_t lds_stack[kLdsDepth * kBlock];
-    uint32_t spill[kSpillDepth];
+    constexpr int kDepth = kLdsDepth;
+    constexpr int kSpill = 64 - kDepth;            // kDepth + kSpill = 64 = the reference's SmallStack capacity
+    __shared__ uint32_t lds_stack[kDepth * kBlock];
+    uint32_t spill[kSpill];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const uint64_t lanes_below = (uint64_t{1} << lane) - 1;
@@ -150,15 +170,15 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
     unsigned long long n_pairs = 0, n_tests = 0, n_leaves = 0;
 
     auto push = [&](uint32_t v) {
-        if (sp < kLdsDepth) lds_stack[sp * kBlock + tid] = v;
-        else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = v;
+        if (sp < kDepth) lds_stack[sp * kBlock + tid] = v;
+        else if (sp < kDepth + kSpill) spill[sp - kDepth] = v;
         else overflow = true;
         ++sp;
     };
     auto pop = [&]() -> uint32_t {
         --sp;
-        if (sp < kLdsDepth) return lds_stack[sp * kBlock + tid];
-        if (sp < kLdsDepth + kSpillDepth) return spill[sp - kLdsDepth];
+        if (sp < kDepth) return lds_stack[sp * kBlock + tid];
+        if (sp < kDepth + kSpill) return spill[sp - kDepth];
         return 0u;
     };
 
@@ -166,14 +186,15 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
         // ---- refill idle slots with new rays (one atomic per wave) --------------------------------
         const uint64_t idle = __ballot(!have);
         const int n_idle = __popcll(idle);
-        if (!drained && (n_idle >= kRefillThreshold || n_idle == kWave)) {
+        if (!drained && (n_idle >= a.refill_threshold || n_idle == kWave)) {
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(a.work, static_cast<unsigned long long>(n_idle));
             base = __shfl(base, 0);
             if (base + n_idle >= a.n) drained = true;
             if (!have) {
-                const unsigned long long my = base + __popcll(idle & lanes_below);
-                if (my < a.n) {
+                const unsigned long long ticket = base + __popcll(idle & lanes_below);
+                if (ticket < a.n) {
+                    const unsigned long long my = a.order ? a.order[ticket] : ticket;
                     T r[8];
                     load_ray(a.rays + 8 * my, r);
 #pragma unroll
@@ -198,47 +219,58 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
         if (__ballot(have) == 0) break;
 
         // ---- inner nodes (bvh.h:132-150) ------------------------------------------------------------
-        while (have && !done && (top & kCountMask) == 0) {
+        // All lanes step together; a lane that reaches a leaf (or finishes) parks. The loop is left as soon as
+        // enough lanes are parked at leaves, so the leaf code runs for many lanes at once without anyone waiting
+        // for the slowest descent (the order of operations of each ray is unchanged).
+        for (;;) {
+            const bool inner = have && !done && (top & kCountMask) == 0;
+            const uint64_t inner_mask = __ballot(inner);
+            if (!inner_mask) break;
+            const int parked = __popcll(__ballot(have && !done && (top & kCountMask) != 0));
+            const int finished = __popcll(__ballot(!have || done));
+            if (parked >= a.leaf_threshold || (!drained && finished >= 2 * a.refill_threshold)) break;
             T lb[6], rb[6];
-            uint32_t li, ri;
-            load_pair(a.pairs + (top >> (kCountBits + 1)), lb, rb, li, ri);
-            if (Stats) ++n_pairs;
-            T l0 = tmin, l1 = tmax, r0 = tmin, r1 = tmax;               // node.h:105-117
+            uint32_t li = 0, ri = 0;
+            if (inner) {
+                load_pair(a.pairs + (top >> (kCountBits + 1)), lb, rb, li, ri);
+                if (Stats) ++n_pairs;
+                T l0 = tmin, l1 = tmax, r0 = tmin, r1 = tmax;               // node.h:105-117
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const T ln = oct[k] ? lb[2 * k + 1] : lb[2 * k], lf = oct[k] ? lb[2 * k] : lb[2 * k + 1];
-                const T rn = oct[k] ? rb[2 * k + 1] : rb[2 * k], rf = oct[k] ? rb[2 * k] : rb[2 * k + 1];
-                T la, lz, ra, rz;
-                if (Robust) {                                           // node.h:74-75
-                    la = (ln - org[k]) * inv[k]; lz = (lf - org[k]) * aux[k];
-                    ra = (rn - org[k]) * inv[k]; rz = (rf - org[k]) * aux[k];
-                } else {                                                // node.h:85-86
-                    la = Num<T>::fma_(ln, inv[k], aux[k]); lz = Num<T>::fma_(lf, inv[k], aux[k]);
-                    ra = Num<T>::fma_(rn, inv[k], aux[k]); rz = Num<T>::fma_(rf, inv[k], aux[k]);
+                for (int k = 0; k < 3; ++k) {
+                    const T ln = oct[k] ? lb[2 * k + 1] : lb[2 * k], lf = oct[k] ? lb[2 * k] : lb[2 * k + 1];
+                    const T rn = oct[k] ? rb[2 * k + 1] : rb[2 * k], rf = oct[k] ? rb[2 * k] : rb[2 * k + 1];
+                    T la, lz, ra, rz;
+                    if (Robust) {                                           // node.h:74-75
+                        la = (ln - org[k]) * inv[k]; lz = (lf - org[k]) * aux[k];
+                        ra = (rn - org[k]) * inv[k]; rz = (rf - org[k]) * aux[k];
+                    } else {                                                // node.h:85-86
+                        la = Num<T>::fma_(ln, inv[k], aux[k]); lz = Num<T>::fma_(lf, inv[k], aux[k]);
+                        ra = Num<T>::fma_(rn, inv[k], aux[k]); rz = Num<T>::fma_(rf, inv[k], aux[k]);
+                    }
+                    l0 = pick_max(la, l0); l1 = pick_min(lz, l1);
+                    r0 = pick_max(ra, r0); r1 = pick_min(rz, r1);
                 }
-                l0 = pick_max(la, l0); l1 = pick_min(lz, l1);
-                r0 = pick_max(ra, r0); r1 = pick_min(rz, r1);
-            }
-            const bool hl = l0 <= l1, hr = r0 <= r1;                    // bvh.h:177-180
-            if (hl) {
-                uint32_t near_i = li;
-                if (hr) {
-                    uint32_t far_i = ri;
-                    if (!Any && l0 > r0) { near_i = ri; far_i = li; }
-                    push(far_i);
+                const bool hl = l0 <= l1, hr = r0 <= r1;                    // bvh.h:177-180
+                if (hl) {
+                    uint32_t near_i = li;
+                    if (hr) {
+                        uint32_t far_i = ri;
+                        if (!Any && l0 > r0) { near_i = ri; far_i = li; }
+                        push(far_i);
+                    }
+                    top = near_i;
+                } else if (hr) {
+                    top = ri;
+                } else if (sp == 0) {
+                    done = true;
+                } else {
+                    top = pop();
                 }
-                top = near_i;
-            } else if (hr) {
-                top = ri;
-            } else if (sp == 0) {
-                done = true;
-            } else {
-                top = pop();
             }
         }
 
         // ---- leaf (bvh.h:152-155 + test/benchmark.cpp:281-291) ------------------------------------------
-        if (have && !done) {
+        if (have && !done && (top & kCountMask) != 0) {
             const uint32_t first = top >> kCountBits, count = top & kCountMask;
             if (Stats) ++n_leaves;
             for (uint32_t i = first; i < first + count; ++i) {
@@ -300,6 +332,29 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
             atomicAdd(&a.counters->leaves, n_leaves);
         }
     }
+}
+
+// Coherence key of a ray: Morton code of its origin cell (32^3 grid over the root box) above the direction octant.
+// Rays of one key start in the same cell and descend the same way first; any order gives the same per-ray results.
+template <typename T>
+__global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    T r[8];
+    load_ray(rays + 8ull * i, r);
+    const T q[3] = { (r[0] - lx) * sx, (r[1] - ly) * sy, (r[2] - lz) * sz };
+    uint32_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        T v = q[k];
+        v = v > T(0) ? v : T(0);
+        uint32_t c = v >= T(31) ? 31u : static_cast<uint32_t>(v);
+        uint32_t s = (c & 1u) | ((c & 2u) << 2) | ((c & 4u) << 4) | ((c & 8u) << 6) | ((c & 16u) << 8);
+        code |= s << k;
+    }
+    const uint32_t oct = (Num<T>::sign(r[3]) ? 1u : 0u) | (Num<T>::sign(r[4]) ? 2u : 0u) | (Num<T>::sign(r[5]) ? 4u : 0u);
+    keys[i] = (code << 3) | oct;
+    vals[i] = i;
 }
 
 struct Grid { int blocks = 0; };
@@ -366,6 +421,34 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     TraceArgs<T> args;
     args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
     args.n = n; args.work = b.d_work; args.counters = d_counters; args.root_index = b.root_index;
+    args.order = nullptr;
+    static const int refill_env = getenv("BVH_AMD_REFILL") ? atoi(getenv("BVH_AMD_REFILL")) : 0;   // tuning knobs
+    static const int leaf_env = getenv("BVH_AMD_LEAF") ? atoi(getenv("BVH_AMD_LEAF")) : 0;
+    args.refill_threshold = refill_env > 0 ? refill_env : kRefillThreshold;
+    args.leaf_threshold = leaf_env > 0 ? leaf_env : kLeafThreshold;
+    if ((flags & BVH_AMD_RAY_SORTED) && n > 4096 && n < (size_t{1} << 31)) {
+        const uint32_t n32 = static_cast<uint32_t>(n);
+        const size_t words = 4 * n + radix_sort_hist_words(n32, 1);
+        if (b.sort_cap < words) {
+            if (b.d_sort) (void)hipFree(b.d_sort);
+            b.d_sort = nullptr; b.sort_cap = 0;
+            BVH_HIP_TRY(hipMalloc(&b.d_sort, words * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
+            b.sort_cap = words;
+        }
+        uint32_t *keys = b.d_sort, *vals = keys + n, *kt = vals + n, *vt = kt + n, *hist = vt + n;
+        const HostNode<T>& root = b.nodes[0];
+        T lo[3], sc[3];
+        for (int k = 0; k < 3; ++k) {
+            const T ext = root.bounds[2 * k + 1] - root.bounds[2 * k];
+            lo[k] = root.bounds[2 * k];
+            sc[k] = ext > T(0) ? T(32) / ext : T(0);
+        }
+        hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2],
+                           keys, vals);
+        int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, 18, stream, hist);
+        if (rc) return rc;
+        args.order = vals;
+    }
     if (leaf_kind == LEAF_TRIANGLE) return dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream);
     return dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream);
 }

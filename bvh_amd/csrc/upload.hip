@@ -35,6 +35,7 @@ BvhImpl<T>::~BvhImpl() {
         if (d_pairs) (void)hipFree(d_pairs);
         if (d_prim_ids) (void)hipFree(d_prim_ids);
         if (d_work) (void)hipFree(d_work);
+        if (d_sort) (void)hipFree(d_sort);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
 }
