@@ -44,12 +44,14 @@ def parse_args():
     ap.add_argument("--workload", default="soup_1m", choices=sorted(WORKLOADS))
     ap.add_argument("--rays", type=int, default=1 << 24, help="rays per GPU per step")
     ap.add_argument("--fast", action="store_true", help="intersect_fast instead of the robust slab test")
+    ap.add_argument("--quality", default="high", choices=["low", "medium", "high"], help="DefaultBuilder quality of the traced BVH")
+    ap.add_argument("--serial-builder", action="store_true", help="DefaultBuilder without a thread pool (binned/sweep) instead of mini-trees")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rays of the CPU baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample):
+def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample, quality, serial):
     """The reference's CPU path (oracle/_ref when present, else the restatement) on a bounded sample of the same
     workload, all host threads; also a parity spot-check of the GPU result. Test infrastructure only."""
     import oracle
@@ -66,17 +68,20 @@ def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample):
     hits, cnt = cb.intersect_tri(prims, rays_sample, 0, robust, threads=threads, counters=True)
     dt = time.perf_counter() - t0
     parity = bool(hits.tobytes() == gpu_hits_sample.tobytes())
-    # CPU build of the same tree (single-threaded builder in the reference: BinnedSahBuilder)
+    # CPU build of the same tree with the reference's DefaultBuilder (thread pool = all host threads unless --serial-builder)
     bb, cc = lib.prep_tris(tris)
+    q = {"low": oracle.QUALITY_LOW, "medium": oracle.QUALITY_MEDIUM, "high": oracle.QUALITY_HIGH}[quality]
+    builder = oracle.BUILDER_DEFAULT_SERIAL if serial else oracle.BUILDER_DEFAULT_PARALLEL
+    lib.build(bb, cc, builder=builder, quality=q, threads=threads)              # warm-up
     t0 = time.perf_counter()
-    cb2 = lib.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    cb2 = lib.build(bb, cc, builder=builder, quality=q, threads=threads)
     bt = time.perf_counter() - t0
     same_tree = bool(cb2.serialize() == bvh.serialize())
     return {
         "value": round(len(rays_sample) / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": kind,
         "sample": f"first {len(rays_sample)} rays of rank 0's batch, same BVH, {threads} host threads "
                   f"(std::thread ray chunks around Bvh::intersect)",
-        "build_mtris_s": round(len(tris) / bt / 1e6, 3), "build_threads": 1,
+        "build_mtris_s": round(len(tris) / bt / 1e6, 3), "build_threads": 1 if serial else threads,
         "gpu_matches_cpu_hits": parity, "gpu_tree_equals_cpu_tree": same_tree,
         "P": round(float(cnt[0]) / len(rays_sample), 3), "T": round(float(cnt[1]) / len(rays_sample), 3),
     }
@@ -94,11 +99,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: bvh_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # BVH_AMD_BENCH_ONE_DEVICE=1 + BVH_AMD_BENCH_BACKEND=gloo: functional test of the N>1 path on a 1-GPU box
+    # (all ranks share cuda:0, collectives over gloo). The driver's runs use one GPU per rank and RCCL.
+    one_device = os.environ.get("BVH_AMD_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("BVH_AMD_BENCH_BACKEND", "nccl")
+    device_index = 0 if one_device else local_rank
+    torch.cuda.set_device(device_index)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     import bvh_amd
     from bvh_amd import synth
@@ -113,18 +126,22 @@ def main():
     if rank == 0:
         tris = getattr(synth, gen)(n_tris)
         d_tris = torch.from_numpy(tris).cuda()
-        cfg = bvh_amd.Config(quality=bvh_amd.Quality.Low)
-        bb, cc = bvh_amd.tri_bounds(d_tris)
-        bvh = bvh_amd.DefaultBuilder.build(bb, cc, cfg)                      # warm-up build (allocations, code load)
-        times = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+        pool = None if args.serial_builder else bvh_amd.ThreadPool()
+        builds = {}
+        for qname in ("low", "medium", "high"):                               # build Mtris/s of every DefaultBuilder mode
+            cfg = bvh_amd.Config(quality=bvh_amd.Quality[qname.capitalize()])
             bb, cc = bvh_amd.tri_bounds(d_tris)
-            bvh = bvh_amd.DefaultBuilder.build(bb, cc, cfg)                  # includes D2H of the host mirror
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
-        build_ms = sorted(times)[1] * 1e3
+            bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)   # warm-up build (allocations, code load)
+            times = []
+            for _ in range(3 if qname != "high" else 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                bb, cc = bvh_amd.tri_bounds(d_tris)
+                bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)   # includes D2H of the host mirror
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            builds[qname] = (sorted(times)[len(times) // 2] * 1e3, bvh_q)
+        build_ms, bvh = builds[args.quality]
         prims = bvh_amd.precompute_tris(d_tris, bvh.device_prim_ids())
     else:
         bvh, prims = None, None
@@ -132,7 +149,8 @@ def main():
         bvh, prims = broadcast_scene(bvh, prims, src=0)
     lo, hi = synth.scene_bounds(tris) if rank == 0 else (None, None)
     if distributed:
-        box = torch.tensor(np.stack([lo, hi]) if rank == 0 else np.zeros((2, 3)), dtype=torch.float64, device="cuda")
+        box = torch.tensor(np.stack([lo, hi]) if rank == 0 else np.zeros((2, 3)), dtype=torch.float64,
+                           device="cuda" if backend == "nccl" else "cpu")
         dist.broadcast(box, 0)
         lo, hi = box[0].cpu().numpy(), box[1].cpu().numpy()
 
@@ -169,7 +187,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))   # HIP events, launch stream
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -183,8 +201,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}; {'robust' if robust else 'fast'} traversal, "
-                                   f"DefaultBuilder serial Low (binned SAH) built on the GPU",
+            "config": {"workload": f"{args.workload}: {desc}; {'robust' if robust else 'fast'} traversal, DefaultBuilder "
+                                   f"{'serial' if args.serial_builder else 'with thread pool (mini-trees)'} Quality::{args.quality.capitalize()} "
+                                   f"built on the GPU (the reference's default configuration is thread pool + High)",
                        "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(args.rays),
                        "parallelism": f"rays sharded x{world}, BVH broadcast over RCCL" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -193,11 +212,14 @@ def main():
                          "kernel_ms": round(kernel_ms, 4), "bytes_per_ray": round(b_ray, 1),
                          "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)},
             "build": {"mtris_s": round(n_tris / (build_ms * 1e-3) / 1e6, 2), "ms": round(build_ms, 3),
-                      "what": "tri bounds + DefaultBuilder Low on device + D2H host mirror, median of 3"},
+                      "all_qualities_ms": {k: round(v[0], 3) for k, v in builds.items()},
+                      "all_qualities_mtris_s": {k: round(n_tris / (v[0] * 1e-3) / 1e6, 2) for k, v in builds.items()},
+                      "what": "tri bounds + DefaultBuilder on device + D2H host mirror; median of 3 (High: 1 run)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             ns = min(args.cpu_sample, args.rays)
-            out["cpu_baseline"] = cpu_baseline(tris, bvh, rays_h[:ns], int(robust), bvh_amd.hits_to_numpy(hits[:ns]))
+            out["cpu_baseline"] = cpu_baseline(tris, bvh, rays_h[:ns], int(robust), bvh_amd.hits_to_numpy(hits[:ns]),
+                                               args.quality, args.serial_builder)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

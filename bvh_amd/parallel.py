@@ -33,6 +33,11 @@ def broadcast_bytes(data, src: int = 0, device=None) -> bytes:
     return data if rank == src else buf.cpu().numpy().tobytes()
 
 
+def _coll_device():
+    import torch.distributed as dist
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
 def broadcast_tensor(t, shape_hint=None, src: int = 0, dtype=None, device=None):
     """Broadcasts a tensor whose shape only `src` knows."""
     import torch
@@ -65,7 +70,11 @@ def broadcast_scene(bvh, prims, src: int = 0):
     stream = broadcast_bytes(bvh.serialize() if rank == src else None, src)
     if rank != src:
         bvh = Bvh.deserialize(stream, dtype=dtype)
-    prims = broadcast_tensor(prims, src=src, dtype=torch.float64 if dtype == np.float64 else torch.float32)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    if dist.get_backend() == "nccl":
+        prims = broadcast_tensor(prims, src=src, dtype=tdt)
+    else:                                                     # CPU collectives (tests): stage through host memory
+        prims = broadcast_tensor(prims.cpu() if rank == src else None, src=src, dtype=tdt, device="cpu").cuda()
     return bvh, prims
 
 
