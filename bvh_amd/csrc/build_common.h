@@ -531,19 +531,19 @@ int number_and_emit(BvhImpl<T>& out, const BuildCtx<T>& c, const std::vector<uin
     hipLaunchKernelGGL(k_emit_tree<T>, dim3((n_nodes_a + 255) / 256), dim3(256), 0, stream, c, n_nodes_a, final_nodes.p);
     if (n_small) hipLaunchKernelGGL(k_emit_small<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, c, n_small, final_nodes.p);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-    out.nodes.resize(total_nodes);
+    out.node_count = total_nodes;
     return BVH_AMD_OK;
 }
 
-// Results: device copy (pair records + prim ids) and the host mirror. `d_ids` holds n prim ids in BVH order; with
-// take_ids the buffer itself becomes out.d_prim_ids (caller must then forget it).
+// Results: the device copy (reference-layout nodes, pair records, prim ids). The host mirror is filled lazily
+// (BvhImpl::sync_host). `d_ids` holds n prim ids in BVH order; with take_ids the buffer itself becomes out.d_prim_ids
+// (the caller must then forget it). final_nodes is always taken over.
 template <typename T>
 int finish_build(BvhImpl<T>& out, DevBuf<HostNode<T>>& final_nodes, uint32_t* d_ids, size_t n, hipStream_t stream, bool take_ids) {
-    const size_t total_nodes = out.nodes.size();
-    out.prim_ids.resize(n);
-    std::vector<uint32_t> ids_h(n);
-    BVH_HIP_TRY(hipMemcpyAsync(out.nodes.data(), final_nodes.p, total_nodes * sizeof(HostNode<T>), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipMemcpyAsync(ids_h.data(), d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    out.nodes.clear();                                        // out.node_count was set by the caller
+    out.prim_ids.clear();
+    out.prim_count = n;
+    out.host_valid = false;
     int rc = relayout_on_device(out, final_nodes.p, stream);
     if (rc) return rc;
     if (!out.d_work) BVH_HIP_TRY(hipMalloc(&out.d_work, 2 * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
@@ -553,9 +553,14 @@ int finish_build(BvhImpl<T>& out, DevBuf<HostNode<T>>& final_nodes, uint32_t* d_
         BVH_HIP_TRY(hipMalloc(&out.d_prim_ids, std::max<size_t>(n, 1) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
         BVH_HIP_TRY(hipMemcpyAsync(out.d_prim_ids, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
     }
+    HostNode<T> root;
+    BVH_HIP_TRY(hipMemcpyAsync(&root, final_nodes.p, sizeof(root), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
-    for (size_t i = 0; i < n; ++i) out.prim_ids[i] = ids_h[i];
-    out.root_index = static_cast<uint32_t>(out.nodes[0].index);
+    if (out.d_nodes) (void)hipFree(out.d_nodes);
+    out.d_nodes = final_nodes.p;
+    final_nodes.p = nullptr;
+    out.root_index = static_cast<uint32_t>(root.index);
+    for (int k = 0; k < 6; ++k) out.root_bounds[k] = root.bounds[k];
     return BVH_AMD_OK;
 }
 

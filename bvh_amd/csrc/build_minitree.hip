@@ -375,7 +375,7 @@ int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers
         rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream);
         if (rc) return rc;
     }
-    out.nodes.resize(total_nodes);
+    out.node_count = total_nodes;
     rc = finish_build<T>(out, final_nodes, final_ids.p, n, stream, /*take_ids=*/true);
     if (rc) return rc;
     final_ids.p = nullptr;

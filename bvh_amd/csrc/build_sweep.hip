@@ -518,7 +518,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         BvhImpl<T> sizes;                                      // only its node vector length is used
         rc = number_and_emit<T>(sizes, c, level_start, n_nodes_a, n_small, final_nodes, stream);
         if (rc) return rc;
-        total_nodes = sizes.nodes.size();
+        total_nodes = sizes.node_count;
         BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // workspace dies here
         return BVH_AMD_OK;
     }
@@ -543,7 +543,7 @@ int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, s
         rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream);
         if (rc) return rc;
     }
-    out.nodes.resize(total_nodes);
+    out.node_count = total_nodes;
     return finish_build<T>(out, final_nodes, ord.p, n, stream, /*take_ids=*/false);
 }
 

@@ -91,7 +91,7 @@ typename CTypes<T>::Bvh* from_nodes(const void* nodes, size_t nn, const size_t* 
 template <typename T>
 size_t stream_size(const BvhImpl<T>& b) {
     using I = typename IndexOf<T>::Type;
-    return 2 * sizeof(I) + b.nodes.size() * sizeof(HostNode<T>) + b.prim_ids.size() * sizeof(I);
+    return 2 * sizeof(I) + b.node_count * sizeof(HostNode<T>) + b.prim_count * sizeof(I);
 }
 
 template <typename T>
@@ -99,6 +99,7 @@ size_t serialize(const BvhImpl<T>& b, void* out, size_t cap) {
     using I = typename IndexOf<T>::Type;
     size_t need = stream_size(b);
     if (!out || cap < need) return need;
+    if (b.sync_host() != BVH_AMD_OK) return 0;
     auto p = static_cast<uint8_t*>(out);
     I hdr[2] = { static_cast<I>(b.nodes.size()), static_cast<I>(b.prim_ids.size()) };
     std::memcpy(p, hdr, sizeof(hdr)); p += sizeof(hdr);
@@ -148,20 +149,24 @@ template <typename T>
 int optimize(typename CTypes<T>::Bvh* bvh) {
     if (!bvh) return fail(BVH_AMD_ERR_ARG, "optimize: null bvh");
     BvhImpl<T>& b = *impl<T>(bvh);
-    if (b.nodes.empty()) return fail(BVH_AMD_ERR_ARG, "optimize: empty bvh");
-    HostNode<T>* d_nodes = nullptr;
-    const size_t bytes = b.nodes.size() * sizeof(HostNode<T>);
-    BVH_HIP_TRY(hipMalloc(&d_nodes, bytes), BVH_AMD_ERR_HIP);
-    hipError_t e = hipMemcpy(d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice);
-    int rc = e == hipSuccess ? reinsertion_optimize_device<T>(d_nodes, b.nodes.size(), nullptr) : fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
-    if (rc == BVH_AMD_OK) {
-        e = hipMemcpy(b.nodes.data(), d_nodes, bytes, hipMemcpyDeviceToHost);
-        rc = e == hipSuccess ? relayout_on_device<T>(b, d_nodes, nullptr) : fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
-        b.root_index = static_cast<uint32_t>(b.nodes[0].index);
+    if (b.node_count == 0) return fail(BVH_AMD_ERR_ARG, "optimize: empty bvh");
+    const size_t bytes = b.node_count * sizeof(HostNode<T>);
+    if (!b.d_nodes) {                                          // BVH came from the host (from_nodes / load): make it resident
+        BVH_HIP_TRY(hipMalloc(&b.d_nodes, bytes), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
+    } else if (b.host_valid) {                                 // the host mirror may have been edited through bvh_node* pointers
+        BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
     }
-    (void)hipDeviceSynchronize();
-    (void)hipFree(d_nodes);
-    return rc;
+    int rc = reinsertion_optimize_device<T>(b.d_nodes, b.node_count, nullptr);
+    if (rc) return rc;
+    rc = relayout_on_device<T>(b, b.d_nodes, nullptr);
+    if (rc) return rc;
+    HostNode<T> root;
+    BVH_HIP_TRY(hipMemcpy(&root, b.d_nodes, sizeof(root), hipMemcpyDeviceToHost), BVH_AMD_ERR_HIP);
+    b.root_index = static_cast<uint32_t>(root.index);
+    for (int k = 0; k < 6; ++k) b.root_bounds[k] = root.bounds[k];
+    if (b.host_valid) BVH_HIP_TRY(hipMemcpy(b.nodes.data(), b.d_nodes, bytes, hipMemcpyDeviceToHost), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
 }
 
 template <typename T>
@@ -222,10 +227,14 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_load(FILE* f) { return f ? load<T>(f) : nullptr; }                                             \
     size_t bvh##S##_serialize(const bvh##S* b, void* out, size_t cap) { return b ? serialize<T>(*impl<T>(b), out, cap) : 0; } \
     bvh##S* bvh##S##_deserialize(const void* bytes, size_t size) { return deserialize<T>(bytes, size); }            \
-    bvh_node##S* bvh##S##_get_node(bvh##S* b, size_t i) { return reinterpret_cast<bvh_node##S*>(&impl<T>(b)->nodes[i]); } \
-    size_t bvh##S##_get_prim_id(const bvh##S* b, size_t i) { return impl<T>(b)->prim_ids[i]; }                      \
-    size_t bvh##S##_get_prim_count(const bvh##S* b) { return impl<T>(b)->prim_ids.size(); }                         \
-    size_t bvh##S##_get_node_count(const bvh##S* b) { return impl<T>(b)->nodes.size(); }                            \
+    bvh_node##S* bvh##S##_get_node(bvh##S* b, size_t i) {                                                          \
+        if (impl<T>(b)->sync_host() != BVH_AMD_OK) return nullptr;                                                   \
+        return reinterpret_cast<bvh_node##S*>(&impl<T>(b)->nodes[i]); }                                              \
+    size_t bvh##S##_get_prim_id(const bvh##S* b, size_t i) {                                                        \
+        if (impl<T>(b)->sync_host() != BVH_AMD_OK) return BVH_INVALID_PRIM_ID;                                       \
+        return impl<T>(b)->prim_ids[i]; }                                                                            \
+    size_t bvh##S##_get_prim_count(const bvh##S* b) { return impl<T>(b)->prim_count; }                              \
+    size_t bvh##S##_get_node_count(const bvh##S* b) { return impl<T>(b)->node_count; }                              \
     bool bvh_node##S##_is_leaf(const bvh_node##S* n) { return (reinterpret_cast<const HostNode<T>*>(n)->index & kCountMask) != 0; } \
     size_t bvh_node##S##_get_prim_count(const bvh_node##S* n) { return reinterpret_cast<const HostNode<T>*>(n)->index & kCountMask; } \
     size_t bvh_node##S##_get_first_id(const bvh_node##S* n) { return reinterpret_cast<const HostNode<T>*>(n)->index >> kCountBits; } \
@@ -234,8 +243,10 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
         bvh_bbox##S r; r.min.x = h->bounds[0]; r.max.x = h->bounds[1]; r.min.y = h->bounds[2]; r.max.y = h->bounds[3]; \
         r.min.z = h->bounds[4]; r.max.z = h->bounds[5]; return r; }                                                 \
     void bvh##S##_copy_nodes(const bvh##S* b, void* out) {                                                          \
+        if (impl<T>(b)->sync_host() != BVH_AMD_OK) return;                                                           \
         std::memcpy(out, impl<T>(b)->nodes.data(), impl<T>(b)->nodes.size() * sizeof(HostNode<T>)); }               \
     void bvh##S##_copy_prim_ids(const bvh##S* b, size_t* out) {                                                     \
+        if (impl<T>(b)->sync_host() != BVH_AMD_OK) return;                                                           \
         std::memcpy(out, impl<T>(b)->prim_ids.data(), impl<T>(b)->prim_ids.size() * sizeof(size_t)); }              \
     const uint32_t* bvh##S##_device_prim_ids(const bvh##S* b) { return impl<T>(b)->d_prim_ids; }                    \
     int bvh_amd_tri_bounds##S(const T* t, size_t n, T* bb, T* cc, void* s) {                                        \

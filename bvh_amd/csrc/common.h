@@ -76,9 +76,15 @@ enum : int { BVH_AMD_OK = 0, BVH_AMD_ERR_HIP = -1, BVH_AMD_ERR_ARG = -2, BVH_AMD
 // ---- the object behind `struct bvh3f` / `struct bvh3d` ---------------------------------------------
 template <typename T>
 struct BvhImpl {
-    // host mirror, reference layout (authoritative for the accessor API)
-    std::vector<HostNode<T>> nodes;
-    std::vector<size_t> prim_ids;
+    // host mirror, reference layout (what the accessor API and serialize() read). After a device build it is filled
+    // lazily from d_nodes / d_prim_ids by sync_host(): GPU-resident workflows never pay the device-to-host copy.
+    mutable std::vector<HostNode<T>> nodes;
+    mutable std::vector<size_t> prim_ids;
+    mutable bool host_valid = true;
+    size_t node_count = 0, prim_count = 0;
+    HostNode<T>* d_nodes = nullptr;            // reference-layout nodes resident in HBM (device builds)
+    T root_bounds[6] = {0, 0, 0, 0, 0, 0};
+    int sync_host() const;
     // device copy
     int device = -1;
     PairNode<T>* d_pairs = nullptr;            // (node_count - 1) / 2 records

@@ -414,7 +414,7 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
 {
     if (n == 0) return BVH_AMD_OK;
     if (!d_prims || !d_rays || !d_hits) return fail(BVH_AMD_ERR_ARG, "intersect_rays: null device pointer");
-    if (b.nodes.empty() || !b.d_work) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device copy");
+    if (b.node_count == 0 || !b.d_work) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device copy");
     if (b.pair_count && !b.d_pairs) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device nodes");
     BVH_HIP_TRY(hipMemsetAsync(b.d_work, 0, 2 * sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
     if (d_counters) BVH_HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream), BVH_AMD_ERR_HIP);
@@ -436,11 +436,10 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
             b.sort_cap = words;
         }
         uint32_t *keys = b.d_sort, *vals = keys + n, *kt = vals + n, *vt = kt + n, *hist = vt + n;
-        const HostNode<T>& root = b.nodes[0];
         T lo[3], sc[3];
         for (int k = 0; k < 3; ++k) {
-            const T ext = root.bounds[2 * k + 1] - root.bounds[2 * k];
-            lo[k] = root.bounds[2 * k];
+            const T ext = b.root_bounds[2 * k + 1] - b.root_bounds[2 * k];
+            lo[k] = b.root_bounds[2 * k];
             sc[k] = ext > T(0) ? T(32) / ext : T(0);
         }
         hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2],

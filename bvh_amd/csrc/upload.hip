@@ -35,14 +35,32 @@ BvhImpl<T>::~BvhImpl() {
         if (d_pairs) (void)hipFree(d_pairs);
         if (d_prim_ids) (void)hipFree(d_prim_ids);
         if (d_work) (void)hipFree(d_work);
+        if (d_nodes) (void)hipFree(d_nodes);
         if (d_sort) (void)hipFree(d_sort);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
 }
 
 template <typename T>
+int BvhImpl<T>::sync_host() const {
+    if (host_valid) return BVH_AMD_OK;
+    int cur = -1;
+    BVH_HIP_TRY(hipGetDevice(&cur), BVH_AMD_ERR_HIP);
+    if (cur != device) BVH_HIP_TRY(hipSetDevice(device), BVH_AMD_ERR_HIP);
+    nodes.resize(node_count);
+    std::vector<uint32_t> ids(prim_count);
+    hipError_t e = hipMemcpy(nodes.data(), d_nodes, node_count * sizeof(HostNode<T>), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ids.data(), d_prim_ids, prim_count * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (cur != device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("sync_host: ") + hipGetErrorString(e));
+    prim_ids.assign(ids.begin(), ids.end());
+    host_valid = true;
+    return BVH_AMD_OK;
+}
+
+template <typename T>
 int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream) {
-    b.pair_count = (b.nodes.size() - 1) / 2;
+    b.pair_count = (b.node_count - 1) / 2;
     if (b.d_pairs) { (void)hipFree(b.d_pairs); b.d_pairs = nullptr; }
     if (b.pair_count) {
         BVH_HIP_TRY(hipMalloc(&b.d_pairs, b.pair_count * sizeof(PairNode<T>)), BVH_AMD_ERR_HIP);
@@ -57,6 +75,8 @@ int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t st
 template <typename T>
 int upload_bvh(BvhImpl<T>& b, hipStream_t stream) {
     if (b.nodes.empty()) return fail(BVH_AMD_ERR_ARG, "upload: empty BVH");
+    b.node_count = b.nodes.size(); b.prim_count = b.prim_ids.size(); b.host_valid = true;
+    for (int k = 0; k < 6; ++k) b.root_bounds[k] = b.nodes[0].bounds[k];
     if (b.nodes.size() % 2 == 0) return fail(BVH_AMD_ERR_ARG, "upload: node count must be odd (root + sibling pairs)");
     if (b.nodes.size() >= (size_t{1} << 28) || b.prim_ids.size() >= (size_t{1} << 28))
         return fail(BVH_AMD_ERR_UNSUPPORTED, "upload: more than 2^28 nodes/primitives (32-bit device indices)");
