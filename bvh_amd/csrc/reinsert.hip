@@ -23,7 +23,7 @@ namespace {
 constexpr int kSearchStack = 96;
 template <typename T> struct HeapCap;                       // heap entries kept in LDS (cost + id)
 template <> struct HeapCap<float>  { static constexpr uint32_t v = 16384; };
-template <> struct HeapCap<double> { static constexpr uint32_t v = 8192; };
+template <> struct HeapCap<double> { static constexpr uint32_t v = 8192; };   // 16-byte entries
 
 struct Move { uint32_t from, to; };
 struct ReScalars { uint32_t n_moves, error, pad[2]; };
@@ -51,89 +51,142 @@ __global__ void __launch_bounds__(256) k_parents_costs(const HostNode<T>* nodes,
 }
 
 // ---- find_candidates: libstdc++ heap algorithms with comp = std::greater on cost ---------------------------------
+// The whole wavefront works on ONE heap operation at a time, with wave-uniform control flow:
+//   * __adjust_heap (stl_heap.h:223-248) = walk the min-child path from the hole to a leaf, shift that path up one
+//     level, then __push_heap the saved value back up along the same path. The path is discovered FIVE LEVELS PER
+//     MEMORY ROUND-TRIP: the 62 descendants of the current hole are loaded by 62 lanes at once and the five child
+//     choices are made with readlane on registers. Path entry j stays in lane j, so the final layout
+//     (entries 1..m* move up, the value lands at path[m*], m* = deepest entry with !(cost > value)) is ONE parallel
+//     write round.
+//   * __push_heap (stl_heap.h:134-148) from the last position: the ancestor chain of a FIXED position is loaded by
+//     ~17 lanes at once; the shift is again one parallel write round.
+// Heap entries {cost, id}: the first 16 K (float) / 8 K (double) in LDS, the rest in HBM.
+template <typename T> struct Ent { T cost; uint32_t id; };
+
 template <typename T>
-struct HeapRef {
-    T* lc; uint32_t* li;                                     // LDS part
-    T* gc; uint32_t* gi;                                     // HBM part (indexed by absolute heap position)
-    uint32_t cap;
-    __device__ T cost(uint32_t i) const { return i < cap ? lc[i] : gc[i]; }
-    __device__ uint32_t id(uint32_t i) const { return i < cap ? li[i] : gi[i]; }
-    __device__ void set(uint32_t i, T c, uint32_t v) { if (i < cap) { lc[i] = c; li[i] = v; } else { gc[i] = c; gi[i] = v; } }
-    __device__ void move(uint32_t dst, uint32_t src) { set(dst, cost(src), id(src)); }
+struct WaveHeap {
+    Ent<T>* lds; Ent<T>* glob; uint32_t cap;
+    int cap_level;                                            // deepest level that lies completely in LDS
+    __device__ Ent<T> get(uint32_t i) const { return i < cap ? lds[i] : glob[i]; }
+    __device__ void set(uint32_t i, Ent<T> e) { if (i < cap) lds[i] = e; else glob[i] = e; }
 };
 
-template <typename T>
-__device__ void heap_push_up(HeapRef<T>& h, long hole, long top, T vc, uint32_t vi) {          // __push_heap
-    long parent = (hole - 1) / 2;
-    while (hole > top && h.cost(parent) > vc) {              // comp(parent, value) = parent.cost > value.cost
-        h.move(hole, parent);
-        hole = parent;
-        parent = (hole - 1) / 2;
-    }
-    h.set(hole, vc, vi);
+// Stores of this wave before its later loads. Memory instructions of ONE wave are processed in program order by the
+// LDS and by the vector memory pipeline (that is what makes store-then-load through a may-alias pointer work for a single
+// lane); lanes of the wave hand entries to each other through memory, so only the COMPILER must be kept from reordering
+// across the hand-off. No s_waitcnt is needed, which keeps store round-trips off the critical path.
+__device__ inline void heap_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
+__device__ inline float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ inline double lane_value(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(b), l), hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), l);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+__device__ inline uint32_t lane_value(uint32_t v, int l) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), l)); }
+
+// __adjust_heap(first, hole0, len, value) with comp(a, b) = a.cost > b.cost. All lanes call it with identical arguments.
 template <typename T>
-__device__ void heap_sift(HeapRef<T>& h, long hole, long len, T vc, uint32_t vi) {              // __adjust_heap
-    const long top = hole;
-    long second = hole;
-    while (second < (len - 1) / 2) {
-        second = 2 * (second + 1);
-        if (h.cost(second) > h.cost(second - 1)) second--;  // comp(second, second - 1)
-        h.move(hole, second);
-        hole = second;
+__device__ void wave_adjust_heap(WaveHeap<T>& h, uint32_t hole0, uint32_t len, Ent<T> value, int lane) {
+    uint32_t my_pos = hole0;                                  // lane j: position of path entry j (lane 0: the hole itself)
+    Ent<T> my_ent = value;                                    // lane j >= 1: the entry found there
+    uint32_t cur = hole0;
+    int depth = 0;                                            // path length so far
+    const uint32_t limit = (len - 1) / 2;                     // nodes below `limit` have two children
+    while (cur < limit) {
+        // lanes 1..62 load the descendants of `cur` down five levels (BFS order inside the subtree)
+        const int t = lane;
+        const int d = 31 - __clz(t + 1);
+        const uint32_t node = ((cur + 1) << d) - 1 + (static_cast<uint32_t>(t + 1) - (1u << d));
+        Ent<T> e; e.cost = T(0); e.id = 0;
+        if (t >= 1 && t <= 62 && node < len) e = h.get(node);
+        int r = 0;                                            // BFS index of the current hole inside the loaded subtree
+        // a round stops at the last LDS-resident level so that only one round per operation touches HBM
+        const int level = 31 - __clz(cur + 1);
+        const int steps = (level < h.cap_level && level + 5 > h.cap_level) ? h.cap_level - level : 5;   // >= 1
+        for (int step = 0; step < steps && cur < limit; ++step) {
+            const int c1 = 2 * r + 1, c2 = 2 * r + 2;
+            const T k1 = lane_value(e.cost, c1), k2 = lane_value(e.cost, c2);
+            const bool left = k2 > k1;                        // comp(second, second - 1): take the left child
+            r = left ? c1 : c2;
+            cur = left ? 2 * cur + 1 : 2 * cur + 2;
+            ++depth;
+            const T pc = lane_value(e.cost, r);
+            const uint32_t pi = lane_value(e.id, r);
+            if (lane == depth) { my_pos = cur; my_ent.cost = pc; my_ent.id = pi; }
+        }
     }
-    if ((len & 1) == 0 && second == (len - 2) / 2) {
-        second = 2 * (second + 1);
-        h.move(hole, second - 1);
-        hole = second - 1;
+    if ((len & 1u) == 0 && cur == (len - 2) / 2) {            // a last node with a single (left) child
+        const uint32_t child = 2 * cur + 1;
+        const Ent<T> e = h.get(child);
+        cur = child;
+        ++depth;
+        if (lane == depth) { my_pos = cur; my_ent = e; }
     }
-    heap_push_up(h, hole, top, vc, vi);
+    // __push_heap(first, hole = path[depth], top = hole0, value): entries below m* stay, 1..m* move up, value at path[m*]
+    const bool stays = lane >= 1 && lane <= depth && !(my_ent.cost > value.cost);
+    const uint64_t mask = __ballot(stays);
+    const int mstar = mask ? 63 - __clzll(static_cast<long long>(mask)) : 0;
+    const uint32_t up_pos = __shfl_up(my_pos, 1);             // position of path entry j - 1
+    if (lane >= 1 && lane <= mstar) h.set(up_pos, my_ent);
+    if (lane == mstar) h.set(my_pos, value);
+    heap_sync();
+}
+
+// __push_heap(first, hole = len - 1, top = 0, value)
+template <typename T>
+__device__ void wave_push_heap(WaveHeap<T>& h, uint32_t len, Ent<T> value, int lane) {
+    const uint32_t pos = lane == 0 ? len - 1 : (len >> lane) - 1;       // lane j: j-th ancestor of len - 1
+    const bool valid = lane >= 1 && (len >> lane) >= 1;
+    Ent<T> e; e.cost = T(0); e.id = 0;
+    if (valid) e = h.get(pos);
+    const uint64_t above = __ballot(valid && e.cost > value.cost) >> 1;   // bit j-1: ancestor j is moved down
+    const int moves = above == ~uint64_t{0} ? 64 : __ffsll(static_cast<long long>(~above)) - 1;   // leading run of ones
+    const uint32_t below_pos = __shfl_up(pos, 1);
+    if (lane >= 1 && lane <= moves) h.set(below_pos, e);
+    if (lane == moves) h.set(pos, value);
+    heap_sync();
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_nodes, uint32_t target, T* gc, uint32_t* gi, uint32_t* out_ids) {
+__global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_nodes, uint32_t target, Ent<T>* glob, uint32_t* out_ids) {
     extern __shared__ unsigned char heap_lds[];
-    const uint32_t cap = HeapCap<T>::v;
-    HeapRef<T> h;
-    h.lc = reinterpret_cast<T*>(heap_lds);
-    h.li = reinterpret_cast<uint32_t*>(heap_lds + size_t{cap} * sizeof(T));
-    h.gc = gc; h.gi = gi; h.cap = cap;
+    WaveHeap<T> h;
+    h.lds = reinterpret_cast<Ent<T>*>(heap_lds);
+    h.glob = glob;
+    h.cap = HeapCap<T>::v;
+    h.cap_level = 30 - __clz(static_cast<int>(HeapCap<T>::v));  // cap = 2^m entries: levels 0 .. m-1 are complete
     const int lane = threadIdx.x;
     const uint32_t head = min(n_nodes, target + 1);
     const uint32_t k = head - 1;                              // candidates 1 .. head-1  (:93-94)
-    for (uint32_t j = lane; j < k; j += 64) h.set(j, cost[j + 1], j + 1);
-    __syncthreads();
+    for (uint32_t j = lane; j < k; j += 64) { Ent<T> e; e.cost = cost[j + 1]; e.id = j + 1; h.set(j, e); }
+    heap_sync();
     if (k == 0) return;
-    if (lane == 0 && k >= 2) {                                // __make_heap
-        for (long parent = (long(k) - 2) / 2;; --parent) {
-            heap_sift(h, parent, long(k), h.cost(parent), h.id(parent));
+    if (k >= 2) {                                             // __make_heap (stl_heap.h:339-362)
+        for (uint32_t parent = (k - 2) / 2;; --parent) {
+            wave_adjust_heap(h, parent, k, h.get(parent), lane);
             if (parent == 0) break;
         }
     }
-    __syncthreads();
     for (uint32_t base = head; base < n_nodes; base += 64) {  // :96-103
         const uint32_t i = base + lane;
         const bool in = i < n_nodes;
         const T c = in ? cost[i] : T(0);
-        T hmin = h.cost(0);
-        hmin = __shfl(hmin, 0);
-        uint64_t mask = __ballot(in && hmin < c);             // the heap minimum only grows: a failed test stays failed
+        uint64_t mask = __ballot(in && h.get(0).cost < c);    // the heap minimum only grows: a failed test stays failed
         while (mask) {
             const int j = __ffsll(static_cast<long long>(mask)) - 1;
             mask &= mask - 1;
-            const T cj = __shfl(c, j);
-            if (lane == 0 && h.cost(0) < cj) {
-                if (k > 1) {                                   // std::pop_heap: value = heap[k-1]; heap[k-1] = heap[0]; sift
-                    const T vc = h.cost(k - 1); const uint32_t vi = h.id(k - 1);
-                    h.move(k - 1, 0);
-                    heap_sift(h, 0, long(k) - 1, vc, vi);
-                }
-                heap_push_up(h, long(k) - 1, 0, cj, base + j); // back() = {i, cost}; std::push_heap
+            const T cj = lane_value(c, j);
+            if (h.get(0).cost < cj) {
+                if (k > 1) wave_adjust_heap(h, 0u, k - 1, h.get(k - 1), lane);   // std::pop_heap
+                Ent<T> w; w.cost = cj; w.id = base + j;
+                wave_push_heap(h, k, w, lane);                // back() = {i, cost}; std::push_heap
             }
         }
     }
-    __syncthreads();
-    for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.id(j);
+    for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.get(j).id;
 }
 
 // ---- find_reinsertion (:107-188), one lane per candidate ----------------------------------------------------------------
@@ -267,25 +320,26 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
     const uint32_t head = std::min<uint32_t>(n, batch + 1), k = head - 1;
     if (k == 0) return BVH_AMD_OK;
 
-    DevBuf<uint32_t> parent, heap_i, cand, keep, off, order;
-    DevBuf<T> cost, heap_c, gains, neg_gain;
+    DevBuf<uint32_t> parent, cand, keep, off, order;
+    DevBuf<Ent<T>> heap_g;
+    DevBuf<T> cost, gains, neg_gain;
     DevBuf<Move> moves, kept;
     DevBuf<unsigned char> touched;
     DevBuf<ReScalars> scalars;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    A(parent.alloc(n)); A(heap_i.alloc(k)); A(cand.alloc(k)); A(keep.alloc(k)); A(off.alloc(k)); A(order.alloc(k));
-    A(cost.alloc(n)); A(heap_c.alloc(k)); A(gains.alloc(k)); A(neg_gain.alloc(k)); A(moves.alloc(k)); A(kept.alloc(k));
+    A(parent.alloc(n)); A(heap_g.alloc(k)); A(cand.alloc(k)); A(keep.alloc(k)); A(off.alloc(k)); A(order.alloc(k));
+    A(cost.alloc(n)); A(gains.alloc(k)); A(neg_gain.alloc(k)); A(moves.alloc(k)); A(kept.alloc(k));
     A(touched.alloc(n)); A(scalars.alloc(1));
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("optimize: hipMalloc: ") + hipGetErrorString(e));
     BVH_HIP_TRY(hipMemsetAsync(scalars.p, 0, sizeof(ReScalars), stream), BVH_AMD_ERR_HIP);
 
-    const size_t heap_lds = size_t{HeapCap<T>::v} * (sizeof(T) + sizeof(uint32_t));
+    const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>);
     BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(heap_lds)),
                 BVH_AMD_ERR_HIP);
     for (size_t it = 0; it < iterations; ++it) {
         hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, it == 0 ? 1 : 0);
-        hipLaunchKernelGGL(k_heap_select<T>, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_c.p, heap_i.p, cand.p);
+        hipLaunchKernelGGL(k_heap_select<T>, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
         BVH_HIP_TRY(hipMemsetAsync(touched.p, 0, n, stream), BVH_AMD_ERR_HIP);
         hipLaunchKernelGGL(k_search<T>, dim3((k + 63) / 64), dim3(64), 0, stream, d_nodes, parent.p, cand.p, k, moves.p, gains.p, keep.p, scalars.p);
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
