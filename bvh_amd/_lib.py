@@ -53,6 +53,13 @@ _SIGS_T = {
     "bvh{S}_from_nodes": (_P, [_P, _Z, _P, _Z]),
     "bvh{S}_destroy": (None, [_P]),
     "bvh{S}_optimize": (None, [_P, _P]),
+    "bvh{S}_refit": (None, [_P]),
+    "bvh{S}_sync_device": (_I, [_P]),
+    "bvh{S}_append_node": (None, [_P]),
+    "bvh{S}_remove_last_node": (None, [_P]),
+    "bvh_node{S}_set_prim_count": (None, [_P, _Z]),
+    "bvh_node{S}_set_first_id": (None, [_P, _Z]),
+    "bvh_node{S}_set_bbox": (None, [_P, _P]),
     "bvh{S}_save": (None, [_P, _P]),
     "bvh{S}_load": (_P, [_P]),
     "bvh{S}_serialize": (_Z, [_P, _P, _Z]),

@@ -150,6 +150,21 @@ class Bvh:
         if err and err != before and b"optimize" in err:
             raise _lib.BvhAmdError(err.decode())
 
+    def refit(self):
+        """Bvh::refit (bvh.h:211-218) on the device; pushes host-side node edits first."""
+        _torch()
+        self._f("bvh{S}_refit")(self._h)
+
+    def set_node_bbox(self, node_id: int, lo, hi):
+        """bvh_nodeXX_set_bbox on the host mirror (takes effect on the device at the next refit()/sync_device())."""
+        node = self._f("bvh{S}_get_node")(self._h, node_id)
+        ct = C.c_float if self._s == "3f" else C.c_double
+        bb = (ct * 6)(*[float(v) for v in list(lo) + list(hi)])
+        self._f("bvh_node{S}_set_bbox")(node, bb)
+
+    def sync_device(self):
+        _lib.check(self._f("bvh{S}_sync_device")(self._h), "sync_device")
+
     def get_root(self):
         return self.nodes[0]
 

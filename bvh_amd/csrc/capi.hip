@@ -8,6 +8,7 @@
 namespace bvh_amd {
 
 template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+template <typename T> int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
 template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
 
 namespace {
@@ -145,11 +146,13 @@ typename CTypes<T>::Bvh* load(FILE* f) {
     return deserialize<T>(buf.data(), buf.size());
 }
 
-template <typename T>
-int optimize(typename CTypes<T>::Bvh* bvh) {
-    if (!bvh) return fail(BVH_AMD_ERR_ARG, "optimize: null bvh");
+// Runs `op` (optimize / refit) on the resident reference-layout nodes, after pushing possible host-side edits, then
+// refreshes the traversal records and (if it was valid) the host mirror.
+template <typename T, typename Op>
+int on_resident_nodes(typename CTypes<T>::Bvh* bvh, Op op) {
+    if (!bvh) return fail(BVH_AMD_ERR_ARG, "null bvh");
     BvhImpl<T>& b = *impl<T>(bvh);
-    if (b.node_count == 0) return fail(BVH_AMD_ERR_ARG, "optimize: empty bvh");
+    if (b.node_count == 0) return fail(BVH_AMD_ERR_ARG, "empty bvh");
     const size_t bytes = b.node_count * sizeof(HostNode<T>);
     if (!b.d_nodes) {                                          // BVH came from the host (from_nodes / load): make it resident
         BVH_HIP_TRY(hipMalloc(&b.d_nodes, bytes), BVH_AMD_ERR_HIP);
@@ -157,7 +160,7 @@ int optimize(typename CTypes<T>::Bvh* bvh) {
     } else if (b.host_valid) {                                 // the host mirror may have been edited through bvh_node* pointers
         BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
     }
-    int rc = reinsertion_optimize_device<T>(b.d_nodes, b.node_count, nullptr);
+    int rc = op(b.d_nodes, b.node_count);
     if (rc) return rc;
     rc = relayout_on_device<T>(b, b.d_nodes, nullptr);
     if (rc) return rc;
@@ -167,6 +170,23 @@ int optimize(typename CTypes<T>::Bvh* bvh) {
     for (int k = 0; k < 6; ++k) b.root_bounds[k] = root.bounds[k];
     if (b.host_valid) BVH_HIP_TRY(hipMemcpy(b.nodes.data(), b.d_nodes, bytes, hipMemcpyDeviceToHost), BVH_AMD_ERR_HIP);
     return BVH_AMD_OK;
+}
+
+template <typename T> int optimize(typename CTypes<T>::Bvh* bvh) {
+    return on_resident_nodes<T>(bvh, [](HostNode<T>* d, size_t n) { return reinsertion_optimize_device<T>(d, n, nullptr); });
+}
+template <typename T> int refit(typename CTypes<T>::Bvh* bvh) {
+    return on_resident_nodes<T>(bvh, [](HostNode<T>* d, size_t n) { return refit_device<T>(d, n, nullptr); });
+}
+
+// Host-side edits (bvh_node* setters, append/remove) live in the mirror; this pushes them to the device copy.
+template <typename T> int sync_device(typename CTypes<T>::Bvh* bvh) {
+    if (!bvh) return fail(BVH_AMD_ERR_ARG, "sync_device: null bvh");
+    BvhImpl<T>& b = *impl<T>(bvh);
+    int rc = b.sync_host();
+    if (rc) return rc;
+    if (b.d_nodes) { (void)hipFree(b.d_nodes); b.d_nodes = nullptr; }
+    return upload_bvh<T>(b, nullptr);
 }
 
 template <typename T>
@@ -222,7 +242,25 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes<T>(nodes, nn, ids, np); }                                                                 \
     void bvh##S##_destroy(bvh##S* b) { delete impl<T>(b); }                                                         \
-    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(b); }                                                         \
+    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(b); }                                  \
+    void bvh##S##_refit(bvh##S* b) { (void)refit<T>(b); }                                                           \
+    int bvh##S##_sync_device(bvh##S* b) { return sync_device<T>(b); }                                                \
+    void bvh##S##_append_node(bvh##S* b) {                                                                          \
+        if (impl<T>(b)->sync_host() != BVH_AMD_OK) return;                                                           \
+        impl<T>(b)->nodes.emplace_back(); impl<T>(b)->node_count = impl<T>(b)->nodes.size(); }                       \
+    void bvh##S##_remove_last_node(bvh##S* b) {                                                                     \
+        if (impl<T>(b)->sync_host() != BVH_AMD_OK || impl<T>(b)->nodes.empty()) return;                              \
+        impl<T>(b)->nodes.pop_back(); impl<T>(b)->node_count = impl<T>(b)->nodes.size(); }                           \
+    void bvh_node##S##_set_prim_count(bvh_node##S* n, size_t c) {                                                   \
+        auto h = reinterpret_cast<HostNode<T>*>(n);                                                                 \
+        h->index = (h->index & ~static_cast<IndexOf<T>::Type>(kCountMask)) | (static_cast<IndexOf<T>::Type>(c) & kCountMask); } \
+    void bvh_node##S##_set_first_id(bvh_node##S* n, size_t f) {                                                     \
+        auto h = reinterpret_cast<HostNode<T>*>(n);                                                                 \
+        h->index = (static_cast<IndexOf<T>::Type>(f) << kCountBits) | (h->index & kCountMask); }                    \
+    void bvh_node##S##_set_bbox(bvh_node##S* n, const bvh_bbox##S* bb) {                                            \
+        auto h = reinterpret_cast<HostNode<T>*>(n);                                                                 \
+        h->bounds[0] = bb->min.x; h->bounds[1] = bb->max.x; h->bounds[2] = bb->min.y; h->bounds[3] = bb->max.y;     \
+        h->bounds[4] = bb->min.z; h->bounds[5] = bb->max.z; }                                                         \
     void bvh##S##_save(const bvh##S* b, FILE* f) { if (b && f) save<T>(*impl<T>(b), f); }                           \
     bvh##S* bvh##S##_load(FILE* f) { return f ? load<T>(f) : nullptr; }                                             \
     size_t bvh##S##_serialize(const bvh##S* b, void* out, size_t cap) { return b ? serialize<T>(*impl<T>(b), out, cap) : 0; } \

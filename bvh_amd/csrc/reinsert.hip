@@ -307,7 +307,54 @@ __global__ void k_apply(HostNode<T>* nodes, uint32_t* parent, unsigned char* tou
     }
 }
 
+// Bvh::refit (bvh.h:185-218): every inner box = left.bbox.extend(right.bbox), children before parents. One lane per
+// leaf climbs; the second child to arrive at a node computes it (agent-scope fences order the hand-off across XCDs).
+template <typename T>
+__global__ void __launch_bounds__(256) k_refit(HostNode<T>* nodes, const uint32_t* parent, uint32_t* arrived, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || i == 0 || !is_leaf(nodes[i])) return;
+    uint32_t cur = parent[i];
+    for (;;) {
+        __threadfence();                                      // release: this lane's box is visible before the ticket
+        if (atomicAdd(&arrived[cur], 1u) == 0) return;        // first child: the sibling's lane finishes this node
+        __threadfence();                                      // acquire: see the sibling's box
+        HostNode<T>& nd = nodes[cur];
+        const uint32_t f = first_of(nd);
+        const T* l = nodes[f].bounds;
+        const T* r = nodes[f + 1].bounds;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const T lo_l = __hip_atomic_load(&l[2 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), lo_r = __hip_atomic_load(&r[2 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const T hi_l = __hip_atomic_load(&l[2 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi_r = __hip_atomic_load(&r[2 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nd.bounds[2 * q], pick_min(lo_l, lo_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nd.bounds[2 * q + 1], pick_max(hi_l, hi_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (cur == 0) return;
+        cur = parent[cur];
+    }
+}
+
 } // namespace
+
+template <typename T>
+int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) {
+    const uint32_t n = static_cast<uint32_t>(node_count);
+    if (n < 3) return BVH_AMD_OK;
+    DevBuf<uint32_t> parent, arrived;
+    DevBuf<T> cost;
+    hipError_t e = parent.alloc(n);
+    if (e == hipSuccess) e = arrived.alloc(n);
+    if (e == hipSuccess) e = cost.alloc(n);
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("refit: hipMalloc: ") + hipGetErrorString(e));
+    BVH_HIP_TRY(hipMemsetAsync(arrived.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
+    hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, 1);
+    hipLaunchKernelGGL(k_refit<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, parent.p, arrived.p, n);
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
+}
+template int refit_device<float>(HostNode<float>*, size_t, hipStream_t);
+template int refit_device<double>(HostNode<double>*, size_t, hipStream_t);
 
 // ReinsertionOptimizer::optimize on device-resident nodes (reference layout), in place.
 template <typename T>

@@ -125,6 +125,25 @@ BVH_AMD_API void bvh3d_destroy(struct bvh3d*);                                  
 BVH_AMD_API void bvh3f_optimize(struct bvh_thread_pool*, struct bvh3f*);
 BVH_AMD_API void bvh3d_optimize(struct bvh_thread_pool*, struct bvh3d*);
 
+/* ---- refit and node editing (c_api/bvh.h:170-229). The setters, append and remove act on the host mirror exactly
+ * like the reference (node pointers alias the mirror and are invalidated by append). `bvhXX_refit` pushes the mirror
+ * to the device, recomputes every inner box bottom-up there (Bvh::refit, bvh.h:211-218) and refreshes both copies.
+ * After editing WITHOUT refit/optimize, call bvhXX_sync_device before tracing (additive; 0 on success). */
+BVH_AMD_API void bvh3f_refit(struct bvh3f*);
+BVH_AMD_API void bvh3d_refit(struct bvh3d*);
+BVH_AMD_API int bvh3f_sync_device(struct bvh3f*);
+BVH_AMD_API int bvh3d_sync_device(struct bvh3d*);
+BVH_AMD_API void bvh3f_append_node(struct bvh3f*);
+BVH_AMD_API void bvh3d_append_node(struct bvh3d*);
+BVH_AMD_API void bvh3f_remove_last_node(struct bvh3f*);
+BVH_AMD_API void bvh3d_remove_last_node(struct bvh3d*);
+BVH_AMD_API void bvh_node3f_set_prim_count(struct bvh_node3f*, size_t);
+BVH_AMD_API void bvh_node3d_set_prim_count(struct bvh_node3d*, size_t);
+BVH_AMD_API void bvh_node3f_set_first_id(struct bvh_node3f*, size_t);
+BVH_AMD_API void bvh_node3d_set_first_id(struct bvh_node3d*, size_t);
+BVH_AMD_API void bvh_node3f_set_bbox(struct bvh_node3f*, const struct bvh_bbox3f*);
+BVH_AMD_API void bvh_node3d_set_bbox(struct bvh_node3d*, const struct bvh_bbox3d*);
+
 /* ---- serialization (c_api/bvh.h:136-144; byte format of Bvh::serialize, bvh.h:221-229) -------- */
 BVH_AMD_API void bvh3f_save(const struct bvh3f*, FILE*);
 BVH_AMD_API void bvh3d_save(const struct bvh3d*, FILE*);

@@ -253,3 +253,50 @@ def test_standalone_optimize_matches_reference(orc):
     rays = synth.rays_closest(50_000, lo, hi)
     hits = bvh_amd.hits_to_numpy(bvh_amd.intersect(gpu, prims, rays, robust=True))
     assert hits.tobytes() == ref.intersect_tri(orc.precompute_tris(tris, ref.prim_ids()), rays, 0, 1, threads=8).tobytes()
+
+
+# ---- refit / node editing -------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_refit_matches_reference(orc, dtype):
+    """Bvh::refit after moving leaf boxes: every inner box recomputed bottom-up, bit-identical to the reference."""
+    import bvh_amd
+    tris = synth.soup(50_000, seed=13, jitter=0.02, dtype=dtype)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_MEDIUM)
+    nodes = ref.nodes().copy()
+    ids = ref.prim_ids()
+    rng = np.random.default_rng(3)
+    leaves = np.nonzero((nodes["index"] & 15) != 0)[0]
+    moved = rng.choice(leaves, size=len(leaves) // 3, replace=False)
+    shift = rng.normal(0, 0.05, size=(len(moved), 3)).astype(dtype)
+    nodes["bounds"][moved, 0::2] += shift
+    nodes["bounds"][moved, 1::2] += shift
+    nodes["bounds"][moved[:50], 0] = 0.0                       # exercise the +0 / -0 tie rule of robust_min
+    nodes["bounds"][moved[50:100], 0] = -0.0
+    a = orc.from_arrays(nodes, ids)
+    a.refit()
+    g = bvh_amd.Bvh.from_nodes(nodes, ids)
+    g.refit()
+    assert g.serialize() == a.serialize()
+    # the same through the node setters on the host mirror
+    g2 = bvh_amd.Bvh.from_nodes(ref.nodes(), ids)
+    for k in moved[:200]:
+        b = nodes["bounds"][k]
+        g2.set_node_bbox(int(k), b[0::2], b[1::2])
+    n2 = ref.nodes().copy()
+    n2["bounds"][moved[:200]] = nodes["bounds"][moved[:200]]
+    a2 = orc.from_arrays(n2, ids)
+    a2.refit()
+    g2.refit()
+    assert g2.serialize() == a2.serialize()
+
+
+def test_refit_on_device_built_tree_is_identity(orc):
+    import bvh_amd
+    tris = synth.terrain(30_000)
+    bb, cc = bvh_amd.tri_bounds(tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+    before = bvh.serialize()
+    bvh.refit()                                                # builder output already satisfies parent = union(children)
+    assert bvh.serialize() == before
