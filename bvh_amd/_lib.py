@@ -43,6 +43,11 @@ _SIGS = {
     "bvh_thread_pool_create": (_P, [_Z]),
     "bvh_thread_pool_destroy": (None, [_P]),
     "bvh_amd_gather": (_I, [_P, _P, _Z, _Z, _P, _P]),
+    "bvh_amd_device_alloc": (_P, [_Z]),
+    "bvh_amd_device_free": (None, [_P]),
+    "bvh_amd_copy_to_device": (_I, [_P, _P, _Z]),
+    "bvh_amd_copy_to_host": (_I, [_P, _P, _Z]),
+    "bvh_amd_synchronize": (_I, [_P]),
     "bvh_amd_std_sort_ids3f": (_I, [_P, _Z, _P, _P]),
     "bvh_amd_std_sort_ids3d": (_I, [_P, _Z, _P, _P]),
     "bvh_amd_radix_sort_pairs_u32": (_I, [_P, _P, _Z, _I, _P]),

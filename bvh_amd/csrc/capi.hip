@@ -228,6 +228,17 @@ int bvh_amd_device_name(int device, char* out, size_t cap) {
     return BVH_AMD_OK;
 }
 
+void* bvh_amd_device_alloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { set_error(std::string("device_alloc: ") + hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+void bvh_amd_device_free(void* p) { if (p) (void)hipFree(p); }
+int bvh_amd_copy_to_device(void* d, const void* h, size_t bytes) { BVH_HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP); return BVH_AMD_OK; }
+int bvh_amd_copy_to_host(void* h, const void* d, size_t bytes) { BVH_HIP_TRY(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost), BVH_AMD_ERR_HIP); return BVH_AMD_OK; }
+int bvh_amd_synchronize(void* stream) { BVH_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)), BVH_AMD_ERR_HIP); return BVH_AMD_OK; }
+
 bvh_thread_pool* bvh_thread_pool_create(size_t thread_count) {
     return reinterpret_cast<bvh_thread_pool*>(new ThreadPoolTag{thread_count});
 }

@@ -1,0 +1,376 @@
+// bvh::v2 — C++20 host-side mirror of madmann91/bvh's public interface for the hot path, over libbvh_amd.so.
+//
+// A program written against the reference headers keeps its types and calls:
+//
+//     using Node = bvh::v2::Node<float, 3>;
+//     bvh::v2::ThreadPool pool;
+//     auto bvh = bvh::v2::DefaultBuilder<Node>::build(pool, bboxes, centers, config);     // reference default_builder.h:33
+//     bvh.nodes, bvh.prim_ids, bvh.get_root().index ...                                     // reference bvh.h:17-89
+//
+// and runs the build on the MI355X (hand-written HIP kernels behind the C-ABI of include/bvh_amd.h). What differs:
+// the reference's per-ray `Bvh::intersect(ray, ..., leaf_fn)` takes a host lambda per leaf and cannot run on a GPU;
+// its batched equivalent is `bvh::v2::amd::intersect_batch<IsAnyHit, IsRobust>(bvh, prims, rays, hits)` with the
+// reference's own leaf intersectors (PrecomputedTri / Sphere). Only Dim == 3 exists on the device (2D: next round).
+// Layouts are bit-compatible with the reference (Vec, BBox, Ray, Node: SURVEY.md §8 sizes), which is what lets the
+// C-ABI take these arrays as they are. Errors throw bvh::v2::amd::Error (the reference has no error channel).
+#ifndef BVH_V2_BVH_AMD_HPP
+#define BVH_V2_BVH_AMD_HPP
+
+#include <array>
+#include <climits>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <span>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../bvh_amd.h"
+
+namespace bvh::v2 {
+
+// ---- vec.h / bbox.h / ray.h ---------------------------------------------------------------------------------------
+template <typename T, size_t N>
+struct Vec {
+    T values[N];
+    Vec() = default;
+    template <typename... Rest> Vec(T x, T y, Rest... rest) : values{ x, y, static_cast<T>(rest)... } {}
+    explicit Vec(T x) { for (auto& v : values) v = x; }
+    T& operator[](size_t i) { return values[i]; }
+    T operator[](size_t i) const { return values[i]; }
+};
+template <typename T, size_t N> Vec<T, N> operator+(const Vec<T, N>& a, const Vec<T, N>& b) { Vec<T, N> r; for (size_t i = 0; i < N; ++i) r[i] = a[i] + b[i]; return r; }
+template <typename T, size_t N> Vec<T, N> operator-(const Vec<T, N>& a, const Vec<T, N>& b) { Vec<T, N> r; for (size_t i = 0; i < N; ++i) r[i] = a[i] - b[i]; return r; }
+template <typename T, size_t N> Vec<T, N> operator*(const Vec<T, N>& a, T s) { Vec<T, N> r; for (size_t i = 0; i < N; ++i) r[i] = a[i] * s; return r; }
+template <typename T> Vec<T, 3> cross(const Vec<T, 3>& a, const Vec<T, 3>& b) {
+    return Vec<T, 3>(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+}
+
+template <typename T, size_t N>
+struct BBox {
+    Vec<T, N> min, max;
+    BBox() = default;
+    BBox(const Vec<T, N>& lo, const Vec<T, N>& hi) : min(lo), max(hi) {}
+    explicit BBox(const Vec<T, N>& p) : min(p), max(p) {}
+    BBox& extend(const BBox& o) {                             // reference bbox.h:22-27 (second operand wins ties)
+        for (size_t i = 0; i < N; ++i) { min[i] = min[i] < o.min[i] ? min[i] : o.min[i]; max[i] = max[i] > o.max[i] ? max[i] : o.max[i]; }
+        return *this;
+    }
+    BBox& extend(const Vec<T, N>& p) { return extend(BBox(p)); }
+    Vec<T, N> get_diagonal() const { return max - min; }
+    Vec<T, N> get_center() const { return (max + min) * static_cast<T>(0.5); }
+    T get_half_area() const {
+        auto d = get_diagonal();
+        if constexpr (N == 3) return (d[0] + d[1]) * d[2] + d[0] * d[1]; else return d[0] + d[1];
+    }
+    static BBox make_empty() { return BBox(Vec<T, N>(std::numeric_limits<T>::max()), Vec<T, N>(-std::numeric_limits<T>::max())); }
+};
+
+template <typename T, size_t N>
+struct Ray {
+    Vec<T, N> org, dir;
+    T tmin, tmax;
+    Ray() = default;
+    Ray(const Vec<T, N>& o, const Vec<T, N>& d, T t0 = 0, T t1 = std::numeric_limits<T>::max()) : org(o), dir(d), tmin(t0), tmax(t1) {}
+};
+
+// ---- index.h / node.h -------------------------------------------------------------------------------------------------
+template <size_t Bits, size_t PrimCountBits>
+struct Index {
+    using Type = std::conditional_t<Bits == 32, uint32_t, uint64_t>;
+    static constexpr Type max_prim_count = (Type{1} << PrimCountBits) - 1;
+    Type value;
+    Index() = default;
+    explicit Index(Type v) : value(v) {}
+    bool operator==(const Index&) const = default;
+    Type first_id() const { return value >> PrimCountBits; }
+    Type prim_count() const { return value & max_prim_count; }
+    bool is_leaf() const { return prim_count() != 0; }
+    bool is_inner() const { return !is_leaf(); }
+    static Index make_leaf(size_t first, size_t count) { return Index((static_cast<Type>(first) << PrimCountBits) | static_cast<Type>(count)); }
+    static Index make_inner(size_t first) { return Index(static_cast<Type>(first) << PrimCountBits); }
+};
+
+template <typename T, size_t Dim, size_t IndexBits = sizeof(T) * CHAR_BIT, size_t PrimCountBits = 4>
+struct Node {
+    using Scalar = T;
+    using Index = bvh::v2::Index<IndexBits, PrimCountBits>;
+    static constexpr size_t dimension = Dim;
+    std::array<T, Dim * 2> bounds;                            // {min_x, max_x, min_y, max_y, ...}  (reference node.h:31-37)
+    Index index;
+    bool operator==(const Node&) const = default;
+    bool is_leaf() const { return index.is_leaf(); }
+    BBox<T, Dim> get_bbox() const {
+        BBox<T, Dim> b;
+        for (size_t i = 0; i < Dim; ++i) { b.min[i] = bounds[2 * i]; b.max[i] = bounds[2 * i + 1]; }
+        return b;
+    }
+    void set_bbox(const BBox<T, Dim>& b) { for (size_t i = 0; i < Dim; ++i) { bounds[2 * i] = b.min[i]; bounds[2 * i + 1] = b.max[i]; } }
+};
+static_assert(sizeof(Node<float, 3>) == 28 && sizeof(Node<double, 3>) == 56, "layout must equal the reference's");
+static_assert(sizeof(BBox<float, 3>) == sizeof(bvh_bbox3f) && sizeof(Vec<float, 3>) == sizeof(bvh_vec3f) && sizeof(Ray<float, 3>) == sizeof(bvh_ray3f));
+static_assert(sizeof(BBox<double, 3>) == sizeof(bvh_bbox3d) && sizeof(Ray<double, 3>) == sizeof(bvh_ray3d));
+
+// ---- tri.h / sphere.h ----------------------------------------------------------------------------------------------------
+template <typename T, size_t N>
+struct Tri {
+    Vec<T, N> p0, p1, p2;
+    Tri() = default;
+    Tri(const Vec<T, N>& a, const Vec<T, N>& b, const Vec<T, N>& c) : p0(a), p1(b), p2(c) {}
+    BBox<T, N> get_bbox() const { return BBox<T, N>(p0).extend(p1).extend(p2); }
+    Vec<T, N> get_center() const { return (p0 + p1 + p2) * static_cast<T>(1. / 3.); }
+};
+template <typename T>
+struct PrecomputedTri {
+    Vec<T, 3> p0, e1, e2, n;
+    PrecomputedTri() = default;
+    PrecomputedTri(const Vec<T, 3>& a, const Vec<T, 3>& b, const Vec<T, 3>& c) : p0(a), e1(a - b), e2(c - a), n(cross(e1, e2)) {}
+    PrecomputedTri(const Tri<T, 3>& t) : PrecomputedTri(t.p0, t.p1, t.p2) {}
+};
+template <typename T, size_t N>
+struct Sphere {
+    Vec<T, N> center;
+    T radius;
+    Vec<T, N> get_center() const { return center; }
+    BBox<T, N> get_bbox() const { return BBox<T, N>(center - Vec<T, N>(radius), center + Vec<T, N>(radius)); }
+};
+
+// ---- thread_pool.h / executor.h / stack.h: kept for source compatibility; the GPU grid replaces the pool ----------------
+class ThreadPool {
+public:
+    explicit ThreadPool(size_t thread_count = 0) : count_(thread_count) {}
+    size_t get_thread_count() const { return count_; }
+private:
+    size_t count_;
+};
+struct SequentialExecutor {
+    template <typename Loop> void for_each(size_t begin, size_t end, const Loop& loop) { loop(begin, end); }
+};
+struct ParallelExecutor {                                     // host-side prep loops of the examples run inline
+    ThreadPool& thread_pool;
+    explicit ParallelExecutor(ThreadPool& pool, size_t = 1024) : thread_pool(pool) {}
+    template <typename Loop> void for_each(size_t begin, size_t end, const Loop& loop) { loop(begin, end); }
+};
+template <typename T, unsigned Capacity>
+struct SmallStack {                                           // reference stack.h:11-30 (the device kernel holds its own)
+    static constexpr unsigned capacity = Capacity;
+    T elems[Capacity];
+    unsigned size = 0;
+    bool is_empty() const { return size == 0; }
+    void push(const T& t) { elems[size++] = t; }
+    T pop() { return elems[--size]; }
+};
+
+namespace amd {
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+inline void check(int rc, const char* what) { if (rc != 0) throw Error(std::string(what) + ": " + bvh_amd_last_error()); }
+
+template <typename T> struct Api;
+template <> struct Api<float> {
+    using Handle = bvh3f; using CHit = bvh_hit3f;
+    static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3f_build(p, static_cast<const bvh_bbox3f*>(bb), static_cast<const bvh_vec3f*>(cc), n, c); }
+    static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3f_from_nodes(nodes, nn, ids, np); }
+    static void destroy(Handle* h) { bvh3f_destroy(h); }
+    static size_t node_count(const Handle* h) { return bvh3f_get_node_count(h); }
+    static size_t prim_count(const Handle* h) { return bvh3f_get_prim_count(h); }
+    static void copy_nodes(const Handle* h, void* out) { bvh3f_copy_nodes(h, out); }
+    static void copy_prim_ids(const Handle* h, size_t* out) { bvh3f_copy_prim_ids(h, out); }
+    static void optimize(Handle* h) { bvh3f_optimize(nullptr, h); }
+    static void refit(Handle* h) { bvh3f_refit(h); }
+    static const uint32_t* device_prim_ids(const Handle* h) { return bvh3f_device_prim_ids(h); }
+    static int precompute(const void* t9, const uint32_t* perm, size_t n, void* out) { return bvh_amd_precompute_tris3f(static_cast<const float*>(t9), perm, n, static_cast<float*>(out), nullptr); }
+    static int trace_tri(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3f_intersect_rays_tri(h, static_cast<const float*>(prims), static_cast<const bvh_ray3f*>(rays), n, f, static_cast<bvh_hit3f*>(hits), nullptr, nullptr); }
+    static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3f_intersect_rays_sphere(h, static_cast<const float*>(prims), static_cast<const bvh_ray3f*>(rays), n, f, static_cast<bvh_hit3f*>(hits), nullptr, nullptr); }
+};
+template <> struct Api<double> {
+    using Handle = bvh3d; using CHit = bvh_hit3d;
+    static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3d_build(p, static_cast<const bvh_bbox3d*>(bb), static_cast<const bvh_vec3d*>(cc), n, c); }
+    static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3d_from_nodes(nodes, nn, ids, np); }
+    static void destroy(Handle* h) { bvh3d_destroy(h); }
+    static size_t node_count(const Handle* h) { return bvh3d_get_node_count(h); }
+    static size_t prim_count(const Handle* h) { return bvh3d_get_prim_count(h); }
+    static void copy_nodes(const Handle* h, void* out) { bvh3d_copy_nodes(h, out); }
+    static void copy_prim_ids(const Handle* h, size_t* out) { bvh3d_copy_prim_ids(h, out); }
+    static void optimize(Handle* h) { bvh3d_optimize(nullptr, h); }
+    static void refit(Handle* h) { bvh3d_refit(h); }
+    static const uint32_t* device_prim_ids(const Handle* h) { return bvh3d_device_prim_ids(h); }
+    static int precompute(const void* t9, const uint32_t* perm, size_t n, void* out) { return bvh_amd_precompute_tris3d(static_cast<const double*>(t9), perm, n, static_cast<double*>(out), nullptr); }
+    static int trace_tri(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3d_intersect_rays_tri(h, static_cast<const double*>(prims), static_cast<const bvh_ray3d*>(rays), n, f, static_cast<bvh_hit3d*>(hits), nullptr, nullptr); }
+    static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3d_intersect_rays_sphere(h, static_cast<const double*>(prims), static_cast<const bvh_ray3d*>(rays), n, f, static_cast<bvh_hit3d*>(hits), nullptr, nullptr); }
+};
+
+// RAII device array (HBM of the current HIP device)
+template <typename T>
+class DeviceArray {
+public:
+    DeviceArray() = default;
+    explicit DeviceArray(size_t n) : size_(n), ptr_(static_cast<T*>(bvh_amd_device_alloc(n * sizeof(T)))) { if (!ptr_) throw Error(bvh_amd_last_error()); }
+    DeviceArray(std::span<const T> host) : DeviceArray(host.size()) { check(bvh_amd_copy_to_device(ptr_, host.data(), host.size_bytes()), "copy_to_device"); }
+    DeviceArray(DeviceArray&& o) noexcept : size_(o.size_), ptr_(o.ptr_) { o.ptr_ = nullptr; o.size_ = 0; }
+    DeviceArray& operator=(DeviceArray&& o) noexcept { if (this != &o) { bvh_amd_device_free(ptr_); ptr_ = o.ptr_; size_ = o.size_; o.ptr_ = nullptr; o.size_ = 0; } return *this; }
+    ~DeviceArray() { bvh_amd_device_free(ptr_); }
+    T* data() const { return ptr_; }
+    size_t size() const { return size_; }
+    void download(std::span<T> out) const { check(bvh_amd_copy_to_host(out.data(), ptr_, out.size_bytes()), "copy_to_host"); }
+private:
+    size_t size_ = 0;
+    T* ptr_ = nullptr;
+};
+
+// One record per ray; prim = BVH-order primitive index (the `i` of the reference's leaf lambda), invalid on a miss.
+template <typename T> struct Hit;
+template <> struct Hit<float>  { uint32_t prim; float t, u, v; static constexpr uint32_t invalid = BVH_AMD_INVALID; };
+template <> struct Hit<double> { uint32_t prim; uint32_t pad; double t, u, v; static constexpr uint32_t invalid = BVH_AMD_INVALID; };
+static_assert(sizeof(Hit<float>) == sizeof(bvh_hit3f) && sizeof(Hit<double>) == sizeof(bvh_hit3d));
+
+} // namespace amd
+
+// ---- bvh.h ----------------------------------------------------------------------------------------------------------------
+template <typename Node> class ReinsertionOptimizer;
+
+template <typename Node>
+struct Bvh {
+    using Index = typename Node::Index;
+    using Scalar = typename Node::Scalar;
+    using Ray = bvh::v2::Ray<Scalar, Node::dimension>;
+    static_assert(Node::dimension == 3, "bvh_amd: only 3D BVHs exist on the device in this round");
+
+    std::vector<Node> nodes;                                  // host mirror, reference layout (bvh.h:22-23)
+    std::vector<size_t> prim_ids;
+
+    Bvh() = default;
+    Bvh(Bvh&&) = default;
+    Bvh& operator=(Bvh&&) = default;
+    bool operator==(const Bvh& o) const { return nodes == o.nodes && prim_ids == o.prim_ids; }
+    const Node& get_root() const { return nodes[0]; }
+    static bool is_left_sibling(size_t id) { return id % 2 == 1; }
+    static size_t get_sibling_id(size_t id) { return is_left_sibling(id) ? id + 1 : id - 1; }
+
+    // Bvh::refit (reference bvh.h:211-218) on the device; `nodes` may have been edited by the caller.
+    void refit() { push(); amd::Api<Scalar>::refit(device_.get()); pull(); }
+
+    // the device-resident twin (built by DefaultBuilder, or uploaded on demand)
+    typename amd::Api<Scalar>::Handle* device() const {
+        if (!device_) const_cast<Bvh*>(this)->push();
+        return device_.get();
+    }
+    void adopt(typename amd::Api<Scalar>::Handle* h) {
+        device_ = std::shared_ptr<typename amd::Api<Scalar>::Handle>(h, [](auto* p) { amd::Api<Scalar>::destroy(p); });
+        pull();
+    }
+
+private:
+    std::shared_ptr<typename amd::Api<Scalar>::Handle> device_;
+    void push() {                                             // host mirror -> device
+        auto* h = amd::Api<Scalar>::from_nodes(nodes.data(), nodes.size(), prim_ids.data(), prim_ids.size());
+        if (!h) throw amd::Error(bvh_amd_last_error());
+        device_ = std::shared_ptr<typename amd::Api<Scalar>::Handle>(h, [](auto* p) { amd::Api<Scalar>::destroy(p); });
+    }
+    void pull() {                                             // device -> host mirror
+        nodes.resize(amd::Api<Scalar>::node_count(device_.get()));
+        prim_ids.resize(amd::Api<Scalar>::prim_count(device_.get()));
+        amd::Api<Scalar>::copy_nodes(device_.get(), nodes.data());
+        amd::Api<Scalar>::copy_prim_ids(device_.get(), prim_ids.data());
+    }
+    template <typename N> friend class ReinsertionOptimizer;
+};
+
+// ---- default_builder.h ----------------------------------------------------------------------------------------------------
+template <typename Node>
+class DefaultBuilder {
+    using Scalar = typename Node::Scalar;
+    using Vec = bvh::v2::Vec<Scalar, Node::dimension>;
+    using BBox = bvh::v2::BBox<Scalar, Node::dimension>;
+public:
+    enum class Quality { Low, Medium, High };
+    struct Config {
+        size_t min_leaf_size = 1;
+        size_t max_leaf_size = 8;
+        Quality quality = Quality::High;
+        size_t parallel_threshold = 1024;
+    };
+    // with a thread pool: the reference's mini-tree builder semantics (default_builder.h:33-46)
+    [[nodiscard]] static Bvh<Node> build(ThreadPool& pool, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config = {}) {
+        return run(reinterpret_cast<bvh_thread_pool*>(&pool), bboxes, centers, config);
+    }
+    // without: the serial builders' semantics (default_builder.h:49-62)
+    [[nodiscard]] static Bvh<Node> build(std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config = {}) {
+        return run(nullptr, bboxes, centers, config);
+    }
+private:
+    static Bvh<Node> run(bvh_thread_pool* pool, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config) {
+        bvh_build_config c;
+        c.quality = static_cast<bvh_build_quality>(config.quality);
+        c.min_leaf_size = config.min_leaf_size; c.max_leaf_size = config.max_leaf_size; c.parallel_threshold = config.parallel_threshold;
+        auto* h = amd::Api<Scalar>::build(pool, bboxes.data(), centers.data(), bboxes.size(), &c);
+        if (!h) throw amd::Error(bvh_amd_last_error());
+        Bvh<Node> bvh;
+        bvh.adopt(h);
+        return bvh;
+    }
+};
+
+// ---- reinsertion_optimizer.h ------------------------------------------------------------------------------------------------
+template <typename Node>
+class ReinsertionOptimizer {
+public:
+    static void optimize(ThreadPool&, Bvh<Node>& bvh) { optimize(bvh); }
+    static void optimize(Bvh<Node>& bvh) {
+        bvh.push();
+        amd::Api<typename Node::Scalar>::optimize(bvh.device_.get());
+        bvh.pull();
+    }
+};
+
+namespace amd {
+
+// PrecomputedTri of tris[bvh.prim_ids[i]] for every BVH-order slot i, resident in HBM (test/simple_example.cpp:57-65).
+template <typename Node>
+DeviceArray<PrecomputedTri<typename Node::Scalar>> permuted_triangles(const Bvh<Node>& bvh, std::span<const Tri<typename Node::Scalar, 3>> tris) {
+    using T = typename Node::Scalar;
+    DeviceArray<Tri<T, 3>> d_tris(tris);
+    DeviceArray<PrecomputedTri<T>> out(tris.size());
+    check(Api<T>::precompute(d_tris.data(), Api<T>::device_prim_ids(bvh.device()), tris.size(), out.data()), "precompute_tris");
+    check(bvh_amd_synchronize(nullptr), "synchronize");
+    return out;
+}
+
+// Bvh::intersect<IsAnyHit, IsRobust> (reference bvh.h:160-182) for a batch of rays with the closest/any-hit triangle
+// leaf loop of test/benchmark.cpp:281-291. Host spans in, host spans out (device-pointer overload below).
+template <bool IsAnyHit, bool IsRobust, typename Node>
+void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<PrecomputedTri<typename Node::Scalar>>& prims,
+                     const DeviceArray<Ray<typename Node::Scalar, 3>>& rays, DeviceArray<Hit<typename Node::Scalar>>& hits) {
+    using T = typename Node::Scalar;
+    const unsigned flags = (IsAnyHit ? unsigned(BVH_AMD_RAY_ANY_HIT) : 0u) | (IsRobust ? unsigned(BVH_AMD_RAY_ROBUST) : 0u);
+    check(Api<T>::trace_tri(bvh.device(), prims.data(), rays.data(), rays.size(), flags, hits.data()), "intersect_rays_tri");
+}
+template <bool IsAnyHit, bool IsRobust, typename Node>
+void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<PrecomputedTri<typename Node::Scalar>>& prims,
+                     std::span<const Ray<typename Node::Scalar, 3>> rays, std::span<Hit<typename Node::Scalar>> hits) {
+    using T = typename Node::Scalar;
+    DeviceArray<Ray<T, 3>> d_rays(rays);
+    DeviceArray<Hit<T>> d_hits(rays.size());
+    intersect_batch<IsAnyHit, IsRobust>(bvh, prims, d_rays, d_hits);
+    d_hits.download(hits);
+}
+// spheres: hit.t = t0, hit.u = t1 of Sphere::intersect (reference sphere.h:32-49); `spheres` in BVH order
+template <bool IsAnyHit, bool IsRobust, typename Node>
+void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<Sphere<typename Node::Scalar, 3>>& spheres,
+                     std::span<const Ray<typename Node::Scalar, 3>> rays, std::span<Hit<typename Node::Scalar>> hits) {
+    using T = typename Node::Scalar;
+    const unsigned flags = (IsAnyHit ? unsigned(BVH_AMD_RAY_ANY_HIT) : 0u) | (IsRobust ? unsigned(BVH_AMD_RAY_ROBUST) : 0u);
+    DeviceArray<Ray<T, 3>> d_rays(rays);
+    DeviceArray<Hit<T>> d_hits(rays.size());
+    check(Api<T>::trace_sphere(bvh.device(), spheres.data(), d_rays.data(), rays.size(), flags, d_hits.data()), "intersect_rays_sphere");
+    d_hits.download(hits);
+}
+
+} // namespace amd
+} // namespace bvh::v2
+
+#endif

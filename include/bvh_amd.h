@@ -93,6 +93,13 @@ BVH_AMD_API const char* bvh_amd_version(void);
 BVH_AMD_API int bvh_amd_device_count(void);            /* < 0 on HIP failure */
 BVH_AMD_API int bvh_amd_device_name(int device, char* out, size_t cap);
 
+/* Device memory helpers (thin wrappers over hipMalloc / hipMemcpy) so that C and C++ callers need no HIP headers. */
+BVH_AMD_API void* bvh_amd_device_alloc(size_t bytes);                         /* NULL on failure */
+BVH_AMD_API void bvh_amd_device_free(void* d_ptr);
+BVH_AMD_API int bvh_amd_copy_to_device(void* d_dst, const void* h_src, size_t bytes);
+BVH_AMD_API int bvh_amd_copy_to_host(void* h_dst, const void* d_src, size_t bytes);
+BVH_AMD_API int bvh_amd_synchronize(void* stream);
+
 /* ---- thread pool (c_api/bvh.h:90-91). Kept for signature compatibility; the GPU grid replaces it.
  * A non-NULL pool selects the reference's *parallel* builder semantics (mini-trees). ------------- */
 BVH_AMD_API struct bvh_thread_pool* bvh_thread_pool_create(size_t thread_count);
