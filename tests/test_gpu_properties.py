@@ -1,0 +1,115 @@
+"""-m gpu: BASELINE.json's full sizes through size-independent properties (no oracle at these sizes).
+
+Builder (10M-triangle procedural mesh, config 4): structural invariants of a reference-layout BVH —
+odd node count, siblings adjacent, every primitive in exactly one leaf, leaf sizes within the 4-bit count,
+parent box == union(children) bit-exactly (A.4: every builder output has it; refit must be the identity),
+SATO order for the builders that do not reinsert.
+Traversal (1M-tri scene): ray-permutation invariance, any-hit => closest-hit and t_closest <= t_any,
+counters of a split batch sum to the counters of the whole batch, robust misses no hit the fast test finds."""
+import numpy as np
+import pytest
+
+from bvh_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_structure(bvh, n_prims, sato=True):
+    nodes = bvh.nodes
+    ids = bvh.prim_ids
+    N = len(nodes)
+    assert N % 2 == 1 and bvh.node_count == N
+    idx = nodes["index"].astype(np.int64)
+    cnt = idx & 15
+    first = idx >> 4
+    inner = cnt == 0
+    # every non-root node is the child of exactly one inner node; children are adjacent pairs starting at odd ids
+    kids = first[inner]
+    assert (kids % 2 == 1).all() and (kids + 1 < N).all()
+    seen = np.zeros(N, dtype=np.int32)
+    np.add.at(seen, kids, 1)
+    np.add.at(seen, kids + 1, 1)
+    assert seen[0] == 0 and (seen[1:] == 1).all()
+    # leaves partition [0, n) of prim_ids and prim_ids is a permutation
+    lf, lc = first[~inner], cnt[~inner]
+    assert lc.sum() == n_prims and (lc >= 1).all() and (lc <= 15).all()
+    order = np.argsort(lf)
+    assert lf[order][0] == 0 and (lf[order][1:] == (lf[order] + lc[order])[:-1]).all()
+    assert len(ids) == n_prims and (np.sort(ids) == np.arange(n_prims, dtype=ids.dtype)).all()
+    # parent box == union of child boxes, bit-exactly
+    b = nodes["bounds"]
+    lo = np.minimum(b[kids][:, 0::2], b[kids + 1][:, 0::2])
+    hi = np.maximum(b[kids][:, 1::2], b[kids + 1][:, 1::2])
+    assert (b[inner][:, 0::2] == lo).all() and (b[inner][:, 1::2] == hi).all()
+    if sato:                                                  # first child has the larger-or-equal half area
+        d = (b[:, 1::2] - b[:, 0::2]).astype(b.dtype)
+        ha = (d[:, 0] + d[:, 1]) * d[:, 2] + d[:, 0] * d[:, 1]
+        assert (ha[kids] >= ha[kids + 1]).all()
+
+
+@pytest.mark.parametrize("mode", ["serial_low", "parallel_medium"])
+def test_10m_triangle_build_invariants(mode):
+    import bvh_amd
+    import torch
+    n = 10_000_000
+    tris = torch.from_numpy(synth.procedural_10m(n)).cuda()
+    bb, cc = bvh_amd.tri_bounds(tris)
+    if mode == "serial_low":
+        bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Low))
+    else:
+        bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+    _check_structure(bvh, n)
+    before = bvh.serialize()
+    bvh.refit()
+    assert bvh.serialize() == before                          # idempotence: builder boxes are already tight
+    # the tree is usable: a ray aimed at a primitive's centroid from 0.25 away hits something no farther than that
+    sample = torch.randint(0, n, (200_000,), device="cuda")
+    c = cc[sample]
+    org = c + torch.tensor([0.0, 0.0, 0.25], device="cuda")
+    rays = torch.cat([org, torch.tensor([0.0, 0.0, -1.0], device="cuda").expand(len(c), 3),
+                      torch.zeros(len(c), 1, device="cuda"), torch.full((len(c), 1), 3.0e38, device="cuda")], dim=1).contiguous()
+    prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+    hits = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, prims, rays, robust=True))
+    ok = (hits["prim"] != bvh_amd.INVALID) & (hits["t"] <= 0.25 * (1 + 1e-4))
+    assert ok.mean() > 0.999                                  # (triangles seen edge-on by the probe ray may be missed)
+
+
+def test_high_quality_1m_invariants_and_traversal_properties():
+    import bvh_amd
+    import torch
+    n = 1_000_000
+    tris_h = synth.soup(n)
+    tris = torch.from_numpy(tris_h).cuda()
+    bb, cc = bvh_amd.tri_bounds(tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
+    _check_structure(bvh, n, sato=False)                      # reinsertion does not restore SATO order
+    prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris_h)
+    nr = 4_000_000
+    rays = torch.from_numpy(synth.rays_closest(nr, lo, hi)).cuda()
+    closest, c_all = bvh_amd.intersect(bvh, prims, rays, robust=True, counters=True)
+    closest = closest.clone()
+    # permutation invariance
+    perm = torch.randperm(nr, device="cuda")
+    shuffled = bvh_amd.intersect(bvh, prims, rays[perm].contiguous(), robust=True)
+    assert bool((shuffled.view(torch.int32) == closest[perm].view(torch.int32)).all())
+    # the coherence-sorted launch returns the same records
+    sorted_run = bvh_amd.intersect(bvh, prims, rays, robust=True, sort_rays=True)
+    assert bool((sorted_run.view(torch.int32) == closest.view(torch.int32)).all())
+    # counters are additive over a split of the batch
+    _, c_a = bvh_amd.intersect(bvh, prims, rays[: nr // 3].contiguous(), robust=True, counters=True)
+    _, c_b = bvh_amd.intersect(bvh, prims, rays[nr // 3:].contiguous(), robust=True, counters=True)
+    assert bool((c_a + c_b == c_all).all())
+    # any-hit is consistent with closest-hit
+    anyh = bvh_amd.intersect(bvh, prims, rays, any_hit=True, robust=True)
+    hc = closest.view(torch.int32)[:, 0] != -1
+    ha = anyh.view(torch.int32)[:, 0] != -1
+    assert bool((hc == ha).all())
+    assert bool((closest[:, 1][hc] <= anyh[:, 1][ha]).all())
+    # Ize's robust test never misses what the fast test finds
+    fast = bvh_amd.intersect(bvh, prims, rays, robust=False)
+    hf = fast.view(torch.int32)[:, 0] != -1
+    assert bool((hc | ~hf).all())
+    both = hc & hf
+    rel = (closest[:, 1][both] - fast[:, 1][both]).abs() / closest[:, 1][both].abs().clamp_min(1e-30)
+    assert float((rel > 1e-5).float().mean()) < 1e-4
