@@ -99,10 +99,17 @@ print("rank", rank, "ok")
 
 
 def test_two_rank_broadcast_and_sharding_gloo(tmp_path):
+    import socket
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29591", str(script)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    for attempt in range(2):                                  # a fresh free port each time (rendezvous ports can linger)
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            break
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
