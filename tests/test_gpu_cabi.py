@@ -1,0 +1,103 @@
+"""-m gpu: the reference-named C entry points called exactly as a C program would (host pointers, opaque handles, FILE*),
+checked against the oracle / golden streams."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from bvh_amd import synth
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from bvh_amd import _lib
+    return _lib, _lib.load()
+
+
+@pytest.mark.parametrize("sfx,scene", [("3f", "soup2k"), ("3d", "soup2k_f64")])
+@pytest.mark.parametrize("quality,pool,key", [(0, False, "serial_low"), (1, False, "serial_med"), (2, False, "serial_high"),
+                                               (0, True, "parallel_low"), (1, True, "parallel_med"), (2, True, "parallel_high")])
+def test_bvhXX_build_host_pointers(sfx, scene, quality, pool, key, tmp_path):
+    L, dll = _lib()
+    g = load_golden(scene)
+    bb = np.ascontiguousarray(g["bboxes"])
+    cc = np.ascontiguousarray(g["centers"])
+    cfg = L.BuildConfig(quality, 1, 8, 1024)
+    tp = dll.bvh_thread_pool_create(4) if pool else None
+    h = getattr(dll, f"bvh{sfx}_build")(tp, bb.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), len(bb), C.byref(cfg))
+    assert h, L.last_error()
+    try:
+        want = g[f"bvh_{key}"].tobytes()
+        n = getattr(dll, f"bvh{sfx}_serialize")(h, None, 0)
+        buf = C.create_string_buffer(n)
+        getattr(dll, f"bvh{sfx}_serialize")(h, buf, n)
+        assert buf.raw == want
+        # accessors on the (lazily filled) host mirror
+        nn = getattr(dll, f"bvh{sfx}_get_node_count")(h)
+        npr = getattr(dll, f"bvh{sfx}_get_prim_count")(h)
+        node_dt = oracle.NODEF if sfx == "3f" else oracle.NODED
+        idx_dt = np.dtype("<u4" if sfx == "3f" else "<u8")
+        ref_nodes = np.frombuffer(want, dtype=node_dt, count=nn, offset=2 * idx_dt.itemsize)
+        ref_ids = np.frombuffer(want, dtype=idx_dt, count=npr, offset=2 * idx_dt.itemsize + nn * node_dt.itemsize)
+        assert nn == len(ref_nodes) and npr == len(bb)
+        for i in (0, 1, nn // 2, nn - 1):
+            node = getattr(dll, f"bvh{sfx}_get_node")(h, i)
+            leaf = getattr(dll, f"bvh_node{sfx}_is_leaf")(node)
+            cnt = getattr(dll, f"bvh_node{sfx}_get_prim_count")(node)
+            first = getattr(dll, f"bvh_node{sfx}_get_first_id")(node)
+            box = getattr(dll, f"bvh_node{sfx}_get_bbox")(node)
+            ri = int(ref_nodes["index"][i])
+            assert leaf == ((ri & 15) != 0) and cnt == (ri & 15) and first == (ri >> 4)
+            got = np.array(list(box.v), dtype=ref_nodes["bounds"].dtype)         # {min xyz, max xyz}
+            assert (got[:3] == ref_nodes["bounds"][i][0::2]).all() and (got[3:] == ref_nodes["bounds"][i][1::2]).all()
+        for i in (0, npr // 3, npr - 1):
+            assert getattr(dll, f"bvh{sfx}_get_prim_id")(h, i) == int(ref_ids[i])
+        # FILE* round trip in the reference's byte format (c_api/bvh.h:136-144)
+        libc = C.CDLL(None)
+        libc.fopen.restype, libc.fopen.argtypes = C.c_void_p, [C.c_char_p, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        path = str(tmp_path / "bvh.bin").encode()
+        f = libc.fopen(path, b"wb")
+        getattr(dll, f"bvh{sfx}_save")(h, f)
+        libc.fclose(f)
+        assert open(path, "rb").read() == want
+        f = libc.fopen(path, b"rb")
+        h2 = getattr(dll, f"bvh{sfx}_load")(f)
+        libc.fclose(f)
+        assert h2
+        n2 = getattr(dll, f"bvh{sfx}_serialize")(h2, None, 0)
+        buf2 = C.create_string_buffer(n2)
+        getattr(dll, f"bvh{sfx}_serialize")(h2, buf2, n2)
+        assert buf2.raw == want
+        getattr(dll, f"bvh{sfx}_destroy")(h2)
+    finally:
+        getattr(dll, f"bvh{sfx}_destroy")(h)
+        if tp:
+            dll.bvh_thread_pool_destroy(tp)
+
+
+def test_null_config_means_reference_defaults(orc):
+    """config == NULL: DefaultBuilder::Config{} = High, leaves 1..8, threshold 1024 (c_api/bvh_impl.h:37-47)."""
+    L, dll = _lib()
+    tris = synth.soup(3000, seed=17, jitter=0.03)
+    bb, cc = orc.prep_tris(tris)
+    h = dll.bvh3f_build(None, bb.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), len(bb), None)
+    assert h, L.last_error()
+    n = dll.bvh3f_serialize(h, None, 0)
+    buf = C.create_string_buffer(n)
+    dll.bvh3f_serialize(h, buf, n)
+    dll.bvh3f_destroy(h)
+    assert buf.raw == orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_SERIAL, quality=oracle.QUALITY_HIGH).serialize()
+
+
+def test_errors_are_reported_not_swallowed():
+    L, dll = _lib()
+    assert not dll.bvh3f_build(None, None, None, 0, None)
+    assert "empty" in L.last_error()
+    assert dll.bvh3f_intersect_rays_tri(None, None, None, 10, 0, None, None, None) != 0
+    assert not dll.bvh3f_deserialize(b"\x01\x00", 2)
+    assert "truncated" in L.last_error()

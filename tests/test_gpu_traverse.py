@@ -145,3 +145,37 @@ def test_edge_cases(orc):
             oh = ob.intersect_tri(oprims, base[:n], 0, robust)
             assert h.tobytes() == oh.tobytes(), (n, robust)
     torch.cuda.synchronize()
+
+
+def test_cornell_render_ppm_md5(orc):
+    """End to end: the reference's ctest `benchmark cornell_box.obj --eye 0 1 2 --dir 0 0 -1 --up 0 1 0` writes render.ppm with
+    md5 96f6bbdc03d7f750fdb833993e9f8538 for every quality. Here: device build (pool, High), device
+    traversal (fast, closest), then the eyelight shading of test/benchmark.cpp:363-371 and its PPM writer (:250-255)."""
+    import hashlib
+    import bvh_amd
+    g = load_golden("cornell")
+    tris = g["prims"]
+    bb, cc = bvh_amd.tri_bounds(tris)
+    for q in (bvh_amd.Quality.Low, bvh_amd.Quality.High):
+        bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=q), thread_pool=bvh_amd.ThreadPool())
+        ids = bvh.prim_ids
+        prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+        W = H = 1024
+        rays = synth.rays_pinhole(W, H, (0, 1, 2), (0, 0, -1), (0, 1, 0))
+        h = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=False))
+        hit = h["prim"] != bvh_amd.INVALID
+        assert int(hit.sum()) == 1027152
+        # eyelight: |dot(normalize(tri.n), ray.dir)| with the reference's float order of operations
+        f = np.float32
+        pt = orc.precompute_tris(tris)                                  # original order; n = columns 9..11
+        orig = ids[np.minimum(h["prim"], len(ids) - 1)].astype(np.int64)
+        n = pt[orig][:, 9:12].astype(f)
+        ln = np.sqrt(((f(0) + n[:, 0] * n[:, 0]) + n[:, 1] * n[:, 1]) + n[:, 2] * n[:, 2], dtype=f)
+        nn = n * (f(1) / ln)[:, None]
+        d = rays[:, 3:6]
+        dot = ((f(0) + nn[:, 0] * d[:, 0]) + nn[:, 1] * d[:, 1]) + nn[:, 2] * d[:, 2]
+        inten = np.where(hit, np.abs(dot), f(0)).astype(f)
+        pix = np.minimum(np.maximum(0, (inten * f(256)).astype(np.int32)), 255).astype(np.uint8)
+        img = np.repeat(pix.reshape(H, W, 1), 3, axis=2)
+        ppm = f"P6 {W} {H} 255\n".encode() + img[::-1].tobytes()        # rows written from j = height down to 1
+        assert hashlib.md5(ppm).hexdigest() == "96f6bbdc03d7f750fdb833993e9f8538"
