@@ -87,6 +87,21 @@ def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample, quality, seria
     }
 
 
+def pmc_traffic_gbs(args, robust, kernel_ms):
+    """roofline.traffic: HBM-side bytes per launch of the traced kernel from the SEPARATE rocprofv3 --pmc passes of this
+    same command (FETCH_SIZE and WRITE_SIZE cannot be collected inside a timed run), committed as
+    profiles/pmc_traffic.json, divided by the live kernel time -> GB/s like `achieved`. None when no pass was recorded
+    for this exact workload / quality / ray count."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    key = f"{args.workload}|{args.quality}|{'serial' if args.serial_builder else 'pool'}|{'robust' if robust else 'fast'}|{args.rays}"
+    rec = json.load(open(path)).get(key)
+    if rec is None:
+        return None
+    return round((rec["fetch_kb"] + rec["write_kb"]) * 1024.0 / (kernel_ms * 1e-3) / 1e9, 1)
+
+
 def main():
     args = parse_args()
     import torch
@@ -196,6 +211,7 @@ def main():
         total_rays = args.rays * world * args.steps
         value = total_rays / elapsed / 1e6
         achieved = b_ray * args.rays / (kernel_ms * 1e-3) / 1e9
+        traffic = pmc_traffic_gbs(args, robust, kernel_ms)
         out = {
             "metric": "Mrays/s closest-hit (1M-tri scene)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,7 +223,7 @@ def main():
                        "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(args.rays),
                        "parallelism": f"rays sharded x{world}, BVH broadcast over RCCL" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": bvh_amd._lib.load().bvh_amd_last_kernel_name().decode(),
                          "kernel_ms": round(kernel_ms, 4), "bytes_per_ray": round(b_ray, 1),
                          "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)},
