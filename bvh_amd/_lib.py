@@ -38,6 +38,7 @@ _SIGS = {
     "bvh_amd_last_error": (C.c_char_p, []),
     "bvh_amd_version": (C.c_char_p, []),
     "bvh_amd_last_kernel_name": (C.c_char_p, []),
+    "bvh_amd_reinsertion_stats": (None, [C.POINTER(C.c_uint)]),
     "bvh_amd_device_count": (_I, []),
     "bvh_amd_device_name": (_I, [_I, C.c_char_p, _Z]),
     "bvh_thread_pool_create": (_P, [_Z]),

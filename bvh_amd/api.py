@@ -314,6 +314,13 @@ def hits_to_numpy(hits) -> np.ndarray:
     return a.view(HITF if a.dtype == np.float32 else HITD).reshape(-1)
 
 
+def reinsertion_stats():
+    """(fast, exact) ReinsertionOptimizer iterations run so far in this process (include/bvh_amd.h: bvh_amd_reinsertion_stats)."""
+    out = (C.c_uint * 2)()
+    _lib.load().bvh_amd_reinsertion_stats(out)
+    return int(out[0]), int(out[1])
+
+
 def std_sort_ids(keys):
     """ids sorted exactly like libstdc++'s std::sort(iota, by keys[i] < keys[j]) incl. tie arrangement (int32 tensor)."""
     torch = _torch()

@@ -8,6 +8,7 @@
 namespace bvh_amd {
 
 template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+void reinsertion_stats(unsigned out[2]);
 template <typename T> int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
 template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
 
@@ -213,6 +214,7 @@ extern "C" {
 const char* bvh_amd_last_error(void) { return g_error.c_str(); }
 const char* bvh_amd_version(void) { return "bvh_amd 0.1 (gfx950)"; }
 const char* bvh_amd_last_kernel_name(void) { return last_kernel_name(); }
+void bvh_amd_reinsertion_stats(unsigned out[2]) { if (out) reinsertion_stats(out); }
 
 int bvh_amd_device_count(void) {
     int n = 0;

@@ -3,16 +3,35 @@
 // Per iteration (3 by default, batch = 5 % of the nodes):
 //   find_candidates (:88-105)  top-k nodes by half-area through a min-heap whose ARRAY LAYOUT (not just its set) is the
 //                              input order of everything downstream, so libstdc++'s make_heap / pop_heap / push_heap are
-//                              replayed exactly (stl_heap.h:134-148, :223-266, :339-362). It is inherently
-//                              sequential: one wavefront runs it — 64 lanes stream and pre-filter the costs (only values
-//                              above the current heap minimum can enter, and the minimum only grows), lane 0 sifts; the top
-//                              16 K entries of the heap live in LDS, the rest in HBM.
+//                              replayed exactly (stl_heap.h:134-148, :223-266, :339-362). make_heap is
+//                              level-parallel (one launch per heap level); the replacement loop is inherently sequential
+//                              and runs on ONE wavefront, organised around what bounds a lone wave (instruction count and
+//                              memory latency): the top 14 heap levels live in LDS, five levels are resolved per LDS round
+//                              trip, the ancestor chain of the last position lives in registers, and the HBM part of each
+//                              sift-down is deferred and executed 64 at a time (see the comments further down).
 //   find_reinsertion (:107-188) one lane per candidate: the reference's branch-and-bound walk with its explicit stack
 //                              (same push order, same strict comparisons), read-only on the tree.
 //   remove_if + std::sort by gain, descending (:254-256): stable compaction (scan) + the exact std::sort emulation on the
 //                              negated gains (sort_emul.hip) — equal gains are common and their order decides conflicts.
 //   greedy apply (:258-265)    sequential by nature (live parents, touched flags, refits up both paths): one lane.
+//
+// FAST PATH (default). The heap layout only matters through (1) which of several equal-cost nodes straddling the
+// top-k threshold survive and (2) the order std::sort leaves equal gains in, and (2) only matters when two equal-gain
+// reinsertions that are both still applicable touch a common node (non-conflicting reinsertions commute: disjoint
+// slots, and every refit path ends consistent bottom-up). So each iteration first runs WITHOUT the replay:
+// top-k by a radix sort of the costs, gains sorted by a radix sort, and k_apply verifies, group of equal gains by group,
+// that the applicable members have pairwise disjoint conflict sets. The moment (1) or (2) could make the layout
+// matter the iteration is rolled back (nodes restored from a device copy) and redone with the exact replay
+// (k_heap_select + std::sort emulation). Results are bit-identical to the reference either way. In practice the layout
+// matters often: a node X whose best target is its "uncle" Y usually comes with Y -> X at exactly the same gain, and the two
+// share nodes, so on the 1M-triangle soup two of three iterations need the replay (~250 ms each; a fast iteration ~4 ms).
+// BVH_AMD_REINSERT=exact forces the replay, BVH_AMD_REINSERT_DEBUG=1 reports why an iteration fell back.
 #include "build_common.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 namespace bvh_amd {
 
@@ -21,12 +40,13 @@ using namespace bld;
 namespace {
 
 constexpr int kSearchStack = 96;
-template <typename T> struct HeapCap;                       // heap entries kept in LDS (cost + id)
-template <> struct HeapCap<float>  { static constexpr uint32_t v = 16384; };
-template <> struct HeapCap<double> { static constexpr uint32_t v = 8192; };   // 16-byte entries
+template <typename T> struct HeapLevels;                    // complete heap levels kept in LDS (cost + id per entry)
+template <> struct HeapLevels<float>  { static constexpr int v = 14; };       // 16383 entries of 8 bytes
+template <> struct HeapLevels<double> { static constexpr int v = 13; };       //  8191 entries of 16 bytes
+template <typename T> struct HeapCap { static constexpr uint32_t v = (1u << HeapLevels<T>::v) - 1; };
 
 struct Move { uint32_t from, to; };
-struct ReScalars { uint32_t n_moves, error, pad[2]; };
+struct ReScalars { uint32_t n_moves, error, ambiguous, pad; };
 
 template <typename T> __device__ inline T ha6(const T* b) {                  // bounds = {minx,maxx,miny,maxy,minz,maxz}
     const T d0 = b[1] - b[0], d1 = b[3] - b[2], d2 = b[5] - b[4];
@@ -60,15 +80,24 @@ __global__ void __launch_bounds__(256) k_parents_costs(const HostNode<T>* nodes,
 //     write round.
 //   * __push_heap (stl_heap.h:134-148) from the last position: the ancestor chain of a FIXED position is loaded by
 //     ~17 lanes at once; the shift is again one parallel write round.
-// Heap entries {cost, id}: the first 16 K (float) / 8 K (double) in LDS, the rest in HBM.
+// Heap entries {cost, id}: the first 14 (float) / 13 (double) levels in LDS, the rest in HBM.
 template <typename T> struct Ent { T cost; uint32_t id; };
 
+// The two halves of the heap are addressed through explicitly address-space-qualified pointers: a generic pointer that
+// may be either makes the compiler emit FLAT loads/stores, and flat accesses force an s_waitcnt on every outstanding HBM
+// store before the next load (measured: 2.4 us per replacement, most of it waiting for store acknowledgements).
 template <typename T>
 struct WaveHeap {
-    Ent<T>* lds; Ent<T>* glob; uint32_t cap;
+    using LdsEnt = __attribute__((address_space(3))) Ent<T>;
+    using GlobEnt = __attribute__((address_space(1))) Ent<T>;
+    LdsEnt* lds; GlobEnt* glob; uint32_t cap;
     int cap_level;                                            // deepest level that lies completely in LDS
-    __device__ Ent<T> get(uint32_t i) const { return i < cap ? lds[i] : glob[i]; }
-    __device__ void set(uint32_t i, Ent<T> e) { if (i < cap) lds[i] = e; else glob[i] = e; }
+    __device__ Ent<T> get_lds(uint32_t i) const { Ent<T> e; e.cost = lds[i].cost; e.id = lds[i].id; return e; }
+    __device__ Ent<T> get_glob(uint32_t i) const { Ent<T> e; e.cost = glob[i].cost; e.id = glob[i].id; return e; }
+    __device__ void set_lds(uint32_t i, Ent<T> e) { lds[i].cost = e.cost; lds[i].id = e.id; }
+    __device__ void set_glob(uint32_t i, Ent<T> e) { glob[i].cost = e.cost; glob[i].id = e.id; }
+    __device__ Ent<T> get(uint32_t i) const { return i < cap ? get_lds(i) : get_glob(i); }
+    __device__ void set(uint32_t i, Ent<T> e) { if (i < cap) set_lds(i, e); else set_glob(i, e); }
 };
 
 // Stores of this wave before its later loads. Memory instructions of ONE wave are processed in program order by the
@@ -87,106 +116,407 @@ __device__ inline double lane_value(double v, int l) {
 }
 __device__ inline uint32_t lane_value(uint32_t v, int l) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), l)); }
 
-// __adjust_heap(first, hole0, len, value) with comp(a, b) = a.cost > b.cost. All lanes call it with identical arguments.
+// lane i <- lane i + 1 (DPP wave_shl:1, a VALU move; __shfl_down would go through the LDS crossbar and its latency)
+__device__ inline uint32_t from_next_lane(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x130, 0xf, 0xf, false));
+}
+__device__ inline float from_next_lane(float v) { return __uint_as_float(from_next_lane(__float_as_uint(v))); }
+__device__ inline double from_next_lane(double v) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    const unsigned long long r = (static_cast<unsigned long long>(from_next_lane(static_cast<uint32_t>(b >> 32))) << 32) | from_next_lane(static_cast<uint32_t>(b));
+    return __longlong_as_double(static_cast<long long>(r));
+}
+
+// The ancestor chain of the last heap position k-1 (the only positions __push_heap(first, k-1, 0, w) can touch, and where
+// std::pop_heap takes its value from). Lane j holds ancestor j: position (k >> j) - 1, lane 0 = k-1 itself. Chain entries
+// beyond the LDS part of the heap live in REGISTERS for the whole replacement loop (their HBM copies go stale), so that
+// neither the value a pop starts from nor the push that follows waits on HBM.
 template <typename T>
-__device__ void wave_adjust_heap(WaveHeap<T>& h, uint32_t hole0, uint32_t len, Ent<T> value, int lane) {
-    uint32_t my_pos = hole0;                                  // lane j: position of path entry j (lane 0: the hole itself)
-    Ent<T> my_ent = value;                                    // lane j >= 1: the entry found there
-    uint32_t cur = hole0;
-    int depth = 0;                                            // path length so far
-    const uint32_t limit = (len - 1) / 2;                     // nodes below `limit` have two children
-    while (cur < limit) {
-        // lanes 1..62 load the descendants of `cur` down five levels (BFS order inside the subtree)
-        const int t = lane;
-        const int d = 31 - __clz(t + 1);
-        const uint32_t node = ((cur + 1) << d) - 1 + (static_cast<uint32_t>(t + 1) - (1u << d));
-        Ent<T> e; e.cost = T(0); e.id = 0;
-        if (t >= 1 && t <= 62 && node < len) e = h.get(node);
-        int r = 0;                                            // BFS index of the current hole inside the loaded subtree
-        // a round stops at the last LDS-resident level so that only one round per operation touches HBM
-        const int level = 31 - __clz(cur + 1);
-        const int steps = (level < h.cap_level && level + 5 > h.cap_level) ? h.cap_level - level : 5;   // >= 1
-        for (int step = 0; step < steps && cur < limit; ++step) {
-            const int c1 = 2 * r + 1, c2 = 2 * r + 2;
-            const T k1 = lane_value(e.cost, c1), k2 = lane_value(e.cost, c2);
-            const bool left = k2 > k1;                        // comp(second, second - 1): take the left child
-            r = left ? c1 : c2;
-            cur = left ? 2 * cur + 1 : 2 * cur + 2;
-            ++depth;
-            const T pc = lane_value(e.cost, r);
-            const uint32_t pi = lane_value(e.id, r);
-            if (lane == depth) { my_pos = cur; my_ent.cost = pc; my_ent.id = pi; }
-        }
+struct Chain {
+    Ent<T> reg;                                               // authoritative when `bottom`
+    uint32_t pos; bool on, bottom;
+    uint32_t k; int top_level;                                // level of position k-1
+    __device__ void init(const WaveHeap<T>& h, uint32_t k_, int lane) {
+        k = k_;
+        top_level = 31 - __clz(static_cast<int>(k_));
+        on = lane <= top_level;
+        pos = on ? (k_ >> lane) - 1 : 0;
+        bottom = on && pos >= h.cap;
+        reg.cost = T(0); reg.id = 0;
     }
-    if ((len & 1u) == 0 && cur == (len - 2) / 2) {            // a last node with a single (left) child
-        const uint32_t child = 2 * cur + 1;
-        const Ent<T> e = h.get(child);
-        cur = child;
-        ++depth;
-        if (lane == depth) { my_pos = cur; my_ent = e; }
+    __device__ void load(const WaveHeap<T>& h) { if (bottom) reg = h.get_glob(pos); }
+    __device__ void flush(WaveHeap<T>& h) { if (bottom) h.set_glob(pos, reg); heap_sync(); }
+    __device__ bool holds(uint32_t p, int level) const { return level <= top_level && (k >> (top_level - level)) - 1 == p; }   // wave-uniform
+};
+
+// ---- __adjust_heap(first, hole0, len, value) with comp(a, b) = a.cost > b.cost, by the whole wavefront ------------------
+// All lanes call these with identical (wave-uniform) arguments. The min-child path is discovered FIVE LEVELS PER MEMORY
+// ROUND-TRIP: the 62 descendants of the current hole are loaded by 62 lanes at once and the child choices are made with
+// readlane on registers. Path entry j is kept by lane j, so the result (entries 1..m* move up one level, the value lands
+// at path[m*], m* = deepest entry with !(cost > value)) is one parallel write round.
+//
+// Because a heap is sorted along every root-to-leaf path, {j : !(cost_j > value)} is a prefix of the path: the upper part
+// of a path can be finalised before the lower part is known. The replacement loop uses that to split each pop into
+//   top    levels that live in LDS: done at once; if every entry met so far moves up, the hole arrives at the last LDS
+//          level and is handed over as a task (position, value); the LDS entry there is marked as an open hole;
+//   bottom the rest of the path in HBM. Tasks in different subtrees are independent, so they are DEFERRED: up to 64 of them
+//          are collected (one per lane) and then sifted down all at once, one lane per task, so the HBM latency of the
+//          deep levels is paid once per batch instead of once per replacement. A later pop that is about to read an open
+//          hole (it shows up among the entries of the last LDS level it loads) resolves the batch first.
+template <typename T>
+struct PathState {
+    uint32_t my_pos; Ent<T> my_ent;                           // lane j: position / old entry of path entry j (lane 0: the hole)
+    uint32_t cur; int depth;
+};
+
+// (a round never straddles the LDS/HBM boundary: it either ends at the last LDS level or starts at or below it, so the
+// two kinds of loads never target the same registers under complementary lane masks, which would serialise them)
+template <typename T>
+__device__ inline Ent<T> load_round(const WaveHeap<T>& h, uint32_t cur, int steps, uint32_t len, bool lds_round, int lane) {
+    const int d = 31 - __clz(lane + 1);                       // lanes 1..62: descendants of `cur` in BFS order
+    const uint32_t node = ((cur + 1) << d) - 1 + (static_cast<uint32_t>(lane + 1) - (1u << d));
+    Ent<T> e; e.cost = T(0); e.id = 0;
+    if (lane >= 1 && lane <= 62 && d <= steps && node < len) { if (lds_round) e = h.get_lds(node); else e = h.get_glob(node); }
+    return e;
+}
+
+template <typename T>
+__device__ inline void walk_round(const Ent<T>& e, int steps, uint32_t limit, PathState<T>& p, int lane) {
+    int r = 0;                                                // BFS index of the current hole inside the loaded subtree
+    for (int step = 0; step < steps && p.cur < limit; ++step) {
+        const int c1 = 2 * r + 1, c2 = 2 * r + 2;
+        const T k1 = lane_value(e.cost, c1), k2 = lane_value(e.cost, c2);
+        const bool left = k2 > k1;                            // comp(second, second - 1): take the left child
+        r = left ? c1 : c2;
+        p.cur = left ? 2 * p.cur + 1 : 2 * p.cur + 2;
+        ++p.depth;
+        const T pc = lane_value(e.cost, r);
+        const uint32_t pi = lane_value(e.id, r);
+        if (lane == p.depth) { p.my_pos = p.cur; p.my_ent.cost = pc; p.my_ent.id = pi; }
     }
-    // __push_heap(first, hole = path[depth], top = hole0, value): entries below m* stay, 1..m* move up, value at path[m*]
-    const bool stays = lane >= 1 && lane <= depth && !(my_ent.cost > value.cost);
+}
+
+// entries 1..m* move up; the value lands at path[m*] unless `defer_value` and m* == depth (the hole is handed on). Returns m* == depth.
+template <bool LdsOnly, typename T>
+__device__ inline bool write_path(WaveHeap<T>& h, const PathState<T>& p, Ent<T> value, bool defer_value, int lane) {
+    const bool stays = lane >= 1 && lane <= p.depth && !(p.my_ent.cost > value.cost);
     const uint64_t mask = __ballot(stays);
     const int mstar = mask ? 63 - __clzll(static_cast<long long>(mask)) : 0;
-    const uint32_t up_pos = __shfl_up(my_pos, 1);             // position of path entry j - 1
-    if (lane >= 1 && lane <= mstar) h.set(up_pos, my_ent);
-    if (lane == mstar) h.set(my_pos, value);
+    const uint32_t up_pos = __shfl_up(p.my_pos, 1);           // position of path entry j - 1
+    const bool open = mstar == p.depth;
+    if constexpr (LdsOnly) {                                  // (the top part never leaves LDS: no HBM instruction at all)
+        if (lane >= 1 && lane <= mstar) h.set_lds(up_pos, p.my_ent);
+        if (lane == mstar && !(defer_value && open)) h.set_lds(p.my_pos, value);
+    } else {
+        if (lane >= 1 && lane <= mstar) h.set(up_pos, p.my_ent);
+        if (lane == mstar && !(defer_value && open)) h.set(p.my_pos, value);
+    }
     heap_sync();
+    return open;
 }
 
-// __push_heap(first, hole = len - 1, top = 0, value)
+// The complete operation from `hole0` by the whole wave (used for the rare chain-crossing paths).
+// Returns true when the chain registers were flushed because the path ran along the chain into the HBM part of the heap:
+// the caller reloads them afterwards.
 template <typename T>
-__device__ void wave_push_heap(WaveHeap<T>& h, uint32_t len, Ent<T> value, int lane) {
-    const uint32_t pos = lane == 0 ? len - 1 : (len >> lane) - 1;       // lane j: j-th ancestor of len - 1
-    const bool valid = lane >= 1 && (len >> lane) >= 1;
-    Ent<T> e; e.cost = T(0); e.id = 0;
-    if (valid) e = h.get(pos);
-    const uint64_t above = __ballot(valid && e.cost > value.cost) >> 1;   // bit j-1: ancestor j is moved down
-    const int moves = above == ~uint64_t{0} ? 64 : __ffsll(static_cast<long long>(~above)) - 1;   // leading run of ones
-    const uint32_t below_pos = __shfl_up(pos, 1);
-    if (lane >= 1 && lane <= moves) h.set(below_pos, e);
-    if (lane == moves) h.set(pos, value);
-    heap_sync();
+__device__ bool wave_adjust_heap(WaveHeap<T>& h, Chain<T>& chain, uint32_t hole0, uint32_t len, Ent<T> value, int lane) {
+    PathState<T> p;
+    p.my_pos = hole0; p.my_ent = value; p.cur = hole0; p.depth = 0;
+    bool flushed = false;
+    const uint32_t limit = (len - 1) / 2;                     // nodes below `limit` have two children
+    while (p.cur < limit) {
+        // a round stops at the last LDS-resident level so that only one round per operation touches HBM
+        const int level = 31 - __clz(p.cur + 1);
+        const int steps = (level < h.cap_level && level + 5 > h.cap_level) ? h.cap_level - level : 5;   // >= 1
+        if (!flushed && level + steps > h.cap_level && chain.holds(p.cur, level)) { chain.flush(h); flushed = true; }
+        const Ent<T> e = load_round(h, p.cur, steps, len, level < h.cap_level, lane);
+        walk_round(e, steps, limit, p, lane);
+    }
+    if ((len & 1u) == 0 && p.cur == (len - 2) / 2) {          // a last node with a single (left) child
+        const uint32_t child = 2 * p.cur + 1;
+        Ent<T> e;
+        if (child < h.cap) e = h.get_lds(child); else e = h.get_glob(child);     // wave-uniform
+        p.cur = child;
+        ++p.depth;
+        if (lane == p.depth) { p.my_pos = p.cur; p.my_ent = e; }
+    }
+    write_path<false>(h, p, value, false, lane);
+    return flushed;
 }
 
+constexpr uint32_t kStreamChunk = 512;                     // node costs fetched per HBM round trip of the replacement loop
+constexpr uint32_t kOpenHole = 0xffffffffu;                // id of an LDS entry whose content is owed by a deferred task
+
+// Top part of a pop from the root: walks the LDS levels only. Returns true when the hole has to continue below the last LDS
+// level; then `hand_pos` is where it stands (all path entries above it have moved up, `value` is not stored yet).
+template <typename T, typename Resolve>
+__device__ bool top_adjust(WaveHeap<T>& h, uint32_t len, Ent<T> value, int lane, uint32_t& hand_pos, Resolve resolve_tasks) {
+    PathState<T> p;
+    p.my_pos = 0; p.my_ent = value; p.cur = 0; p.depth = 0;
+    const uint32_t limit = (len - 1) / 2;
+    int level = 0;
+    while (p.cur < limit && level < h.cap_level) {
+        const int steps = min(5, h.cap_level - level);
+        Ent<T> e = load_round(h, p.cur, steps, len, true, lane);
+        if (level + steps == h.cap_level && __ballot(e.id == kOpenHole)) {      // an entry of the last LDS level is still owed
+            resolve_tasks();
+            e = load_round(h, p.cur, steps, len, true, lane);
+        }
+        walk_round(e, steps, limit, p, lane);
+        level = 31 - __clz(p.cur + 1);
+    }
+    const bool single = (len & 1u) == 0 && p.cur == (len - 2) / 2;
+    const bool below = level >= h.cap_level && (p.cur < limit || single);
+    if (!below && single) {                                   // the heap ends inside the LDS levels
+        const uint32_t child = 2 * p.cur + 1;
+        const Ent<T> e = h.get_lds(child);
+        p.cur = child;
+        ++p.depth;
+        if (lane == p.depth) { p.my_pos = p.cur; p.my_ent = e; }
+    }
+    const bool open = write_path<true>(h, p, value, below, lane);
+    hand_pos = p.cur;
+    return below && open;
+}
+
+// The same top part for heaps that extend below the LDS levels (len >= cap: every node above the last LDS level has both
+// children), written for instruction count, which is what a single wave is bound by (the generic version above spends
+// ~1200 clocks per five-level round on readlane chains). BFS node `lane` of the subtree under the hole loads BOTH its
+// children with one LDS instruction and chooses between them, all nodes at once; the path is then five dependent readlanes
+// ("pointer jumping" through the choices), and every path node itself stores its chosen child's entry (or the value,
+// at the first node whose chosen child is greater) into its own position, so no entry travels between lanes.
+template <typename T, typename Resolve>
+__device__ bool fast_top_adjust(WaveHeap<T>& h, Ent<T> value, int lane, uint32_t& hand_pos, T& root_cost, Resolve resolve_tasks) {
+    uint32_t cur = 0;
+    const int d = 31 - __clz(lane + 1);
+    const uint32_t in_level = static_cast<uint32_t>(lane + 1) - (1u << d);
+    for (int level = 0; level < h.cap_level;) {
+        const int steps = min(5, h.cap_level - level);
+        const uint32_t node = ((cur + 1) << d) - 1 + in_level;            // heap position of BFS node `lane`
+        const bool inner = lane < (1 << steps) - 1;
+        Ent<T> c1{}, c2{};
+        if (inner) { c1 = h.get_lds(2 * node + 1); c2 = h.get_lds(2 * node + 2); }
+        if (level + steps == h.cap_level && __ballot(inner && (c1.id == kOpenHole || c2.id == kOpenHole))) {
+            resolve_tasks();                                               // an entry of the last LDS level is still owed
+            if (inner) { c1 = h.get_lds(2 * node + 1); c2 = h.get_lds(2 * node + 2); }
+        }
+        const bool left = c2.cost > c1.cost;                               // comp(second, second - 1): take the left child
+        const Ent<T> chosen = left ? c1 : c2;
+        const uint32_t chosen_pos = left ? 2 * node + 1 : 2 * node + 2;
+        const int next = left ? 2 * lane + 1 : 2 * lane + 2;
+        int r = 0;
+        uint64_t path = 1;                                                 // BFS indices of the path nodes of this round
+        for (int sidx = 1; sidx < steps; ++sidx) { r = __builtin_amdgcn_readlane(next, r); path |= uint64_t{1} << r; }
+        const bool on_path = (path >> lane) & 1u;
+        const uint64_t greater = __ballot(on_path && chosen.cost > value.cost);
+        if (level == 0) root_cost = (greater & 1u) ? value.cost : lane_value(chosen.cost, 0);
+        if (greater) {                                                     // the value lands inside this round
+            const int landing = __ffsll(static_cast<long long>(greater)) - 1;      // shallowest such node (BFS order)
+            if (on_path && lane < landing) h.set_lds(node, chosen);
+            if (lane == landing) h.set_lds(node, value);
+            heap_sync();
+            return false;
+        }
+        if (on_path) h.set_lds(node, chosen);
+        heap_sync();
+        cur = lane_value(chosen_pos, r);
+        level += steps;
+    }
+    hand_pos = cur;
+    return true;
+}
+
+// __push_heap(first, hole = k - 1, top = 0, w) on the chain: ancestors greater than w move down one place, w lands above them
+// Returns how many ancestors moved (== chain.top_level when w became the new root).
+template <typename T>
+__device__ int wave_push_chain(WaveHeap<T>& h, Chain<T>& chain, Ent<T> w, int lane) {
+    Ent<T> e = chain.reg;
+    if (chain.on && !chain.bottom && lane >= 1) e = h.get_lds(chain.pos);
+    const bool valid = chain.on && lane >= 1;
+    const uint64_t above = __ballot(valid && e.cost > w.cost) >> 1;       // bit j-1: ancestor j is moved down
+    const int moves = above == ~uint64_t{0} ? 64 : __ffsll(static_cast<long long>(~above)) - 1;   // leading run of ones
+    Ent<T> below; below.cost = from_next_lane(e.cost); below.id = from_next_lane(e.id);             // ancestor j + 1
+    if (chain.on && lane <= moves) {
+        const Ent<T> nv = lane == moves ? w : below;
+        if (chain.bottom) chain.reg = nv; else h.set_lds(chain.pos, nv);
+    }
+    heap_sync();
+    return moves;
+}
+
+// literal __adjust_heap by ONE lane on the HBM copy (level-parallel make_heap below)
+template <typename T>
+__device__ void lane_adjust_heap(Ent<T>* a, uint32_t hole, uint32_t len, Ent<T> value) {
+    const uint32_t top = hole;
+    uint32_t child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (a[child].cost > a[child - 1].cost) --child;
+        a[hole] = a[child];
+        hole = child;
+    }
+    if ((len & 1u) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[hole] = a[child - 1];
+        hole = child - 1;
+    }
+    while (hole > top) {
+        const uint32_t parent = (hole - 1) / 2;
+        if (!(a[parent].cost > value.cost)) break;
+        a[hole] = a[parent];
+        hole = parent;
+    }
+    a[hole] = value;
+}
+
+// the same by one lane on the LDS + HBM heap of the replacement loop (deferred bottom tasks: the hole is an LDS entry,
+// everything below it is in HBM)
+template <typename T>
+__device__ void lane_adjust_heap(WaveHeap<T>& h, uint32_t hole, uint32_t len, Ent<T> value) {
+    const uint32_t top = hole;
+    uint32_t child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        const Ent<T> r = h.get_glob(child), l = h.get_glob(child - 1);
+        Ent<T> take = r;
+        if (r.cost > l.cost) { --child; take = l; }
+        h.set(hole, take);
+        hole = child;
+    }
+    if ((len & 1u) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h.set(hole, h.get_glob(child - 1));
+        hole = child - 1;
+    }
+    while (hole > top) {
+        const uint32_t parent = (hole - 1) / 2;
+        const Ent<T> pe = h.get(parent);
+        if (!(pe.cost > value.cost)) break;
+        h.set(hole, pe);
+        hole = parent;
+    }
+    h.set(hole, value);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_heap_fill(const T* cost, uint32_t k, Ent<T>* glob) {      // candidates 1 .. k  (:93-94)
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < k) { Ent<T> e; e.cost = cost[j + 1]; e.id = j + 1; glob[j] = e; }
+}
+
+// __make_heap (stl_heap.h:339-362) calls __adjust_heap for parent = (k-2)/2 down to 0. Calls on one heap level work in
+// disjoint subtrees and only depend on the calls below them, so one launch per level (deepest first), one lane per
+// node, reproduces the sequential result.
+template <typename T>
+__global__ void __launch_bounds__(64) k_make_heap_level(Ent<T>* glob, uint32_t k, uint32_t first, uint32_t count) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < count) lane_adjust_heap(glob, first + i, k, glob[first + i]);
+}
+
+// The replacement loop (:96-103). `glob` holds the finished make_heap; the top of the heap is staged into LDS.
 template <typename T>
 __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_nodes, uint32_t target, Ent<T>* glob, uint32_t* out_ids) {
     extern __shared__ unsigned char heap_lds[];
     WaveHeap<T> h;
-    h.lds = reinterpret_cast<Ent<T>*>(heap_lds);
-    h.glob = glob;
+    h.lds = (typename WaveHeap<T>::LdsEnt*)heap_lds;
+    h.glob = (typename WaveHeap<T>::GlobEnt*)glob;
+    auto* stage = (__attribute__((address_space(3))) T*)(heap_lds + size_t{HeapCap<T>::v} * sizeof(Ent<T>));   // costs of the current chunk
     h.cap = HeapCap<T>::v;
-    h.cap_level = 30 - __clz(static_cast<int>(HeapCap<T>::v));  // cap = 2^m entries: levels 0 .. m-1 are complete
+    h.cap_level = HeapLevels<T>::v - 1;
     const int lane = threadIdx.x;
     const uint32_t head = min(n_nodes, target + 1);
-    const uint32_t k = head - 1;                              // candidates 1 .. head-1  (:93-94)
-    for (uint32_t j = lane; j < k; j += 64) { Ent<T> e; e.cost = cost[j + 1]; e.id = j + 1; h.set(j, e); }
-    heap_sync();
+    const uint32_t k = head - 1;
     if (k == 0) return;
-    if (k >= 2) {                                             // __make_heap (stl_heap.h:339-362)
-        for (uint32_t parent = (k - 2) / 2;; --parent) {
-            wave_adjust_heap(h, parent, k, h.get(parent), lane);
-            if (parent == 0) break;
+    for (uint32_t j = lane; j < min(k, h.cap); j += 64) h.set_lds(j, h.get_glob(j));
+    heap_sync();
+    Chain<T> chain;
+    chain.init(h, k, lane);
+    chain.load(h);
+    // deferred bottom tasks: lane i keeps task i
+    uint32_t n_tasks = 0; uint32_t task_pos = 0; Ent<T> task_value{};
+    auto resolve_tasks = [&]() {
+        if (n_tasks) {
+            if (static_cast<uint32_t>(lane) < n_tasks) lane_adjust_heap(h, task_pos, k - 1, task_value);
+            heap_sync();
+            n_tasks = 0;
         }
-    }
-    for (uint32_t base = head; base < n_nodes; base += 64) {  // :96-103
-        const uint32_t i = base + lane;
-        const bool in = i < n_nodes;
-        const T c = in ? cost[i] : T(0);
-        uint64_t mask = __ballot(in && h.get(0).cost < c);    // the heap minimum only grows: a failed test stays failed
-        while (mask) {
-            const int j = __ffsll(static_cast<long long>(mask)) - 1;
-            mask &= mask - 1;
-            const T cj = lane_value(c, j);
-            if (h.get(0).cost < cj) {
-                if (k > 1) wave_adjust_heap(h, 0u, k - 1, h.get(k - 1), lane);   // std::pop_heap
-                Ent<T> w; w.cost = cj; w.id = base + j;
-                wave_push_heap(h, k, w, lane);                // back() = {i, cost}; std::push_heap
+    };
+    T root_cost = h.lds[0].cost;                              // cost of the heap minimum, tracked in a register
+    const bool last_in_regs = k - 1 >= h.cap;                 // position k-1 (chain lane 0) is register-resident
+    for (uint32_t chunk = head; chunk < n_nodes; chunk += kStreamChunk) {   // :96-103, kStreamChunk costs per HBM round trip
+        bool any = false;
+#pragma unroll
+        for (uint32_t q = 0; q < kStreamChunk / 64; ++q) {
+            const uint32_t i = chunk + q * 64 + lane;
+            const T c_hbm = i < n_nodes ? cost[i] : T(0);
+            any = any || (i < n_nodes && root_cost < c_hbm);  // the heap minimum only grows: a failed test stays failed
+            stage[q * 64 + lane] = c_hbm;                     // through LDS: the loop below then holds no register that depends
+        }                                                     // on an HBM load (the compiler would wait on ALL of them)
+        if (!__ballot(any)) continue;
+        heap_sync();
+        for (uint32_t q = 0; q < kStreamChunk / 64; ++q) {
+            const uint32_t base = chunk + q * 64;
+            if (base >= n_nodes) break;
+            const T c = stage[q * 64 + lane];
+            uint64_t mask = __ballot(base + lane < n_nodes && root_cost < c);
+            while (mask) {
+                const int j = __ffsll(static_cast<long long>(mask)) - 1;
+                mask &= mask - 1;
+                const T cj = lane_value(c, j);
+                if (root_cost < cj) {
+                    if (k > 1) {                                  // std::pop_heap: the value at k-1 sinks in from the root
+                        Ent<T> v;
+                        if (last_in_regs) { v.cost = lane_value(chain.reg.cost, 0); v.id = lane_value(chain.reg.id, 0); }
+                        else v = h.get_lds(k - 1);
+                        uint32_t hand = 0;
+                        bool handed;
+                        if (k - 1 >= h.cap) handed = fast_top_adjust(h, v, lane, hand, root_cost, resolve_tasks);
+                        else { handed = top_adjust(h, k - 1, v, lane, hand, resolve_tasks); root_cost = h.lds[0].cost; }
+                        if (handed) {
+                            if (chain.holds(hand, h.cap_level)) {     // the path follows the chain into HBM (rare): at once, by the wave
+                                if (wave_adjust_heap(h, chain, hand, k - 1, v, lane)) chain.load(h);
+                            } else {
+                                if (static_cast<uint32_t>(lane) == n_tasks) { task_pos = hand; task_value = v; }
+                                if (lane == 0) h.lds[hand].id = kOpenHole;
+                                heap_sync();
+                                if (++n_tasks == 64) resolve_tasks();
+                            }
+                        }
+                    }
+                    Ent<T> w; w.cost = cj; w.id = base + j;
+                    if (wave_push_chain(h, chain, w, lane) == chain.top_level) root_cost = cj;   // back() = {i, cost}; std::push_heap
+                }
             }
         }
     }
+    resolve_tasks();
+    chain.flush(h);
     for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.get(j).id;
+}
+
+// ---- fast path: top-k by cost without the heap (valid when no tie straddles the threshold) --------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_cost_keys(const T* cost, uint32_t n, typename Ord<T>::U* keys, uint32_t* ids) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;        // entry i <-> node i + 1 (the root is never a candidate, :93)
+    if (i + 1 >= n) return;
+    T c = cost[i + 1];
+    if (c == T(0)) c = T(0);                                  // -0 == +0 for operator<
+    keys[i] = ~Ord<T>::enc(c);                                // ascending radix sort = descending cost
+    ids[i] = i + 1;
+}
+
+template <typename U>
+__global__ void k_check_threshold(const U* sorted_keys, uint32_t k, uint32_t count, ReScalars* sc) {
+    // the k-th and (k+1)-th largest costs are equal: which of them the reference's heap keeps depends on its layout
+    if (k < count && sorted_keys[k - 1] == sorted_keys[k]) sc->ambiguous = 1u;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gain_keys(const T* neg_gain, uint32_t m, typename Ord<T>::U* keys, uint32_t* order) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    keys[i] = Ord<T>::enc(neg_gain[i]);                       // gains are > 0: no zero to canonicalise
+    order[i] = i;
 }
 
 // ---- find_reinsertion (:107-188), one lane per candidate ----------------------------------------------------------------
@@ -283,27 +613,55 @@ __device__ void refit_upwards(HostNode<T>* nodes, const uint32_t* parent, uint32
 }
 
 template <typename T>
-__global__ void k_apply(HostNode<T>* nodes, uint32_t* parent, unsigned char* touched, const Move* moves, const uint32_t* order, uint32_t m) {
+__device__ inline void apply_move(HostNode<T>* nodes, uint32_t* parent, unsigned char* touched, const Move mv) {
     using I = typename IndexOf<T>::Type;
-    for (uint32_t j = 0; j < m; ++j) {
-        const Move mv = moves[order[j]];
-        const uint32_t from = mv.from, to = mv.to;
-        const uint32_t hot[5] = { to, from, sibling_of(from), parent[to], parent[from] };     // get_conflicts (:227-234)
-        bool clash = false;
-        for (int q = 0; q < 5; ++q) clash = clash || touched[hot[q]];
-        if (clash) continue;
-        for (int q = 0; q < 5; ++q) touched[hot[q]] = 1;
-        const uint32_t sib = sibling_of(from), par = parent[from];
-        const HostNode<T> sib_node = nodes[sib], dst_node = nodes[to];
-        nodes[to].index = static_cast<I>(left_of(from)) << kCountBits;
-        nodes[sib] = dst_node;
-        nodes[par] = sib_node;
-        if (!is_leaf(dst_node)) { parent[first_of(dst_node)] = sib; parent[first_of(dst_node) + 1] = sib; }
-        if (!is_leaf(sib_node)) { parent[first_of(sib_node)] = par; parent[first_of(sib_node) + 1] = par; }
-        parent[sib] = to;
-        parent[from] = to;
-        refit_upwards(nodes, parent, to);
-        refit_upwards(nodes, parent, par);
+    const uint32_t from = mv.from, to = mv.to;
+    const uint32_t hot[5] = { to, from, sibling_of(from), parent[to], parent[from] };     // get_conflicts (:227-234)
+    bool clash = false;
+    for (int q = 0; q < 5; ++q) clash = clash || touched[hot[q]];
+    if (clash) return;
+    for (int q = 0; q < 5; ++q) touched[hot[q]] = 1;
+    const uint32_t sib = sibling_of(from), par = parent[from];
+    const HostNode<T> sib_node = nodes[sib], dst_node = nodes[to];
+    nodes[to].index = static_cast<I>(left_of(from)) << kCountBits;
+    nodes[sib] = dst_node;
+    nodes[par] = sib_node;
+    if (!is_leaf(dst_node)) { parent[first_of(dst_node)] = sib; parent[first_of(dst_node) + 1] = sib; }
+    if (!is_leaf(sib_node)) { parent[first_of(sib_node)] = par; parent[first_of(sib_node) + 1] = par; }
+    parent[sib] = to;
+    parent[from] = to;
+    refit_upwards(nodes, parent, to);
+    refit_upwards(nodes, parent, par);
+}
+
+// check_ties (fast path): `order` is sorted by gain but equal gains are in an arbitrary order. A group of equal gains is
+// order-independent iff its still-applicable members (no clash with what earlier groups touched) have pairwise disjoint
+// conflict sets (evaluated on the live parents at the start of the group: applying one such member changes parent[] only
+// below nodes of its own conflict set). Otherwise: flag and stop, the host rolls the iteration back.
+template <typename T>
+__global__ void k_apply(HostNode<T>* nodes, uint32_t* parent, unsigned char* touched, const Move* moves, const uint32_t* order,
+                        const T* neg_gain, uint32_t m, int check_ties, uint32_t* group_mark, uint32_t gid_base, ReScalars* sc) {
+    uint32_t gid = gid_base;
+    for (uint32_t j = 0; j < m;) {
+        uint32_t e = j + 1;
+        if (check_ties) {
+            const T g = neg_gain[order[j]];
+            while (e < m && neg_gain[order[e]] == g) ++e;
+            if (e - j > 1) {
+                ++gid;
+                for (uint32_t q = j; q < e; ++q) {
+                    const Move mv = moves[order[q]];
+                    const uint32_t hot[5] = { mv.to, mv.from, sibling_of(mv.from), parent[mv.to], parent[mv.from] };
+                    bool clash = false, shared = false;
+                    for (int h = 0; h < 5; ++h) { clash = clash || touched[hot[h]]; shared = shared || group_mark[hot[h]] == gid; }
+                    if (clash) continue;
+                    if (shared) { sc->ambiguous = 1u; return; }
+                    for (int h = 0; h < 5; ++h) group_mark[hot[h]] = gid;
+                }
+            }
+        }
+        for (uint32_t q = j; q < e; ++q) apply_move(nodes, parent, touched, moves[order[q]]);
+        j = e;
     }
 }
 
@@ -356,9 +714,14 @@ int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) {
 template int refit_device<float>(HostNode<float>*, size_t, hipStream_t);
 template int refit_device<double>(HostNode<double>*, size_t, hipStream_t);
 
+static std::atomic<unsigned> g_fast_iterations{0}, g_exact_iterations{0};
+
+void reinsertion_stats(unsigned out[2]) { out[0] = g_fast_iterations.load(); out[1] = g_exact_iterations.load(); }
+
 // ReinsertionOptimizer::optimize on device-resident nodes (reference layout), in place.
 template <typename T>
 int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) {
+    using U = typename Ord<T>::U;
     const uint32_t n = static_cast<uint32_t>(node_count);
     if (n < 2) return BVH_AMD_OK;
     const T ratio = static_cast<T>(0.05);                     // Config (:19-25)
@@ -366,39 +729,113 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
     const uint32_t batch = static_cast<uint32_t>(std::max<size_t>(1, static_cast<size_t>(static_cast<T>(node_count) * ratio)));   // :238-239
     const uint32_t head = std::min<uint32_t>(n, batch + 1), k = head - 1;
     if (k == 0) return BVH_AMD_OK;
+    const char* mode = std::getenv("BVH_AMD_REINSERT");
+    const bool always_exact = mode && std::strcmp(mode, "exact") == 0;
 
-    DevBuf<uint32_t> parent, cand, keep, off, order;
+    DevBuf<uint32_t> parent, cand, keep, off, order, group_mark, ids, ids_tmp, hist;
     DevBuf<Ent<T>> heap_g;
     DevBuf<T> cost, gains, neg_gain;
+    DevBuf<U> keys, keys_tmp;
     DevBuf<Move> moves, kept;
     DevBuf<unsigned char> touched;
     DevBuf<ReScalars> scalars;
+    DevBuf<HostNode<T>> backup;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(parent.alloc(n)); A(heap_g.alloc(k)); A(cand.alloc(k)); A(keep.alloc(k)); A(off.alloc(k)); A(order.alloc(k));
     A(cost.alloc(n)); A(gains.alloc(k)); A(neg_gain.alloc(k)); A(moves.alloc(k)); A(kept.alloc(k));
     A(touched.alloc(n)); A(scalars.alloc(1));
+    if (!always_exact) {
+        A(group_mark.alloc(n)); A(ids.alloc(n)); A(ids_tmp.alloc(n)); A(keys.alloc(n)); A(keys_tmp.alloc(n));
+        A(hist.alloc(radix_sort_hist_words(n, 1))); A(backup.alloc(n));
+    }
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("optimize: hipMalloc: ") + hipGetErrorString(e));
     BVH_HIP_TRY(hipMemsetAsync(scalars.p, 0, sizeof(ReScalars), stream), BVH_AMD_ERR_HIP);
+    if (!always_exact) BVH_HIP_TRY(hipMemsetAsync(group_mark.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
 
-    const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>);
+    const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>) + kStreamChunk * sizeof(T);
     BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(heap_lds)),
                 BVH_AMD_ERR_HIP);
+    auto read_scalars = [&](ReScalars& hs) -> int {
+        BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        return BVH_AMD_OK;
+    };
+    auto clear_ambiguous = [&]() -> int {
+        BVH_HIP_TRY(hipMemsetAsync(&scalars.p->ambiguous, 0, 4, stream), BVH_AMD_ERR_HIP);
+        return BVH_AMD_OK;
+    };
+    bool parents_valid = false;
     for (size_t it = 0; it < iterations; ++it) {
-        hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, it == 0 ? 1 : 0);
-        hipLaunchKernelGGL(k_heap_select<T>, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
-        BVH_HIP_TRY(hipMemsetAsync(touched.p, 0, n, stream), BVH_AMD_ERR_HIP);
-        hipLaunchKernelGGL(k_search<T>, dim3((k + 63) / 64), dim3(64), 0, stream, d_nodes, parent.p, cand.p, k, moves.p, gains.p, keep.p, scalars.p);
-        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-        uint32_t m = 0;
-        int rc = exclusive_scan_u32(keep.p, off.p, k, &m, stream);
-        if (rc) return rc;
-        if (m == 0) continue;
-        hipLaunchKernelGGL(k_compact<T>, dim3((k + 255) / 256), dim3(256), 0, stream, moves.p, gains.p, keep.p, off.p, k, kept.p, neg_gain.p);
-        rc = std_sort_ids<T>(order.p, neg_gain.p, m, 1, 0, 1, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_apply<T>, dim3(1), dim3(1), 0, stream, d_nodes, parent.p, touched.p, kept.p, order.p, m);
-        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        bool exact = always_exact;
+        for (;;) {                                            // at most two rounds: fast, then (if the layout matters) exact
+            hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, parents_valid ? 0 : 1);
+            parents_valid = true;
+            ReScalars hs;
+            int rc;
+            if (exact) {
+                hipLaunchKernelGGL(k_heap_fill<T>, dim3((k + 255) / 256), dim3(256), 0, stream, cost.p, k, heap_g.p);
+                if (k >= 2) {
+                    const uint32_t last_parent = (k - 2) / 2;
+                    int level = 0;
+                    while ((uint64_t{2} << level) - 2 < last_parent) ++level;          // level of last_parent
+                    for (; level >= 0; --level) {
+                        const uint32_t first = (1u << level) - 1;
+                        const uint32_t count = std::min<uint32_t>((2u << level) - 2, last_parent) - first + 1;
+                        hipLaunchKernelGGL(k_make_heap_level<T>, dim3((count + 63) / 64), dim3(64), 0, stream, heap_g.p, k, first, count);
+                    }
+                }
+                hipLaunchKernelGGL(k_heap_select<T>, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
+            } else {
+                BVH_HIP_TRY(hipMemcpyAsync(backup.p, d_nodes, size_t{n} * sizeof(HostNode<T>), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
+                hipLaunchKernelGGL(k_cost_keys<T>, dim3((n + 255) / 256), dim3(256), 0, stream, cost.p, n, keys.p, ids.p);
+                rc = radix_sort_pairs<U>(keys.p, ids.p, keys_tmp.p, ids_tmp.p, n - 1, 1, int(sizeof(U) * 8), stream, hist.p);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_check_threshold<U>, dim3(1), dim3(1), 0, stream, keys.p, k, n - 1, scalars.p);
+                BVH_HIP_TRY(hipMemcpyAsync(cand.p, ids.p, size_t{k} * 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
+            }
+            BVH_HIP_TRY(hipMemsetAsync(touched.p, 0, n, stream), BVH_AMD_ERR_HIP);
+            hipLaunchKernelGGL(k_search<T>, dim3((k + 63) / 64), dim3(64), 0, stream, d_nodes, parent.p, cand.p, k, moves.p, gains.p, keep.p, scalars.p);
+            BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+            uint32_t m = 0;
+            rc = exclusive_scan_u32(keep.p, off.p, k, &m, stream);
+            if (rc) return rc;
+            if (!exact) {
+                if ((rc = read_scalars(hs))) return rc;
+                if (hs.ambiguous) {                           // nothing was modified yet
+                    if (std::getenv("BVH_AMD_REINSERT_DEBUG")) std::fprintf(stderr, "[bvh_amd] reinsertion iteration %zu: tie at the top-k threshold -> exact replay\n", it);
+                    if ((rc = clear_ambiguous())) return rc;
+                    exact = true;
+                    continue;
+                }
+            }
+            if (m != 0) {
+                hipLaunchKernelGGL(k_compact<T>, dim3((k + 255) / 256), dim3(256), 0, stream, moves.p, gains.p, keep.p, off.p, k, kept.p, neg_gain.p);
+                if (exact) {
+                    rc = std_sort_ids<T>(order.p, neg_gain.p, m, 1, 0, 1, stream);
+                } else {
+                    hipLaunchKernelGGL(k_gain_keys<T>, dim3((m + 255) / 256), dim3(256), 0, stream, neg_gain.p, m, keys.p, order.p);
+                    rc = radix_sort_pairs<U>(keys.p, order.p, keys_tmp.p, ids_tmp.p, m, 1, int(sizeof(U) * 8), stream, hist.p);
+                }
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_apply<T>, dim3(1), dim3(1), 0, stream, d_nodes, parent.p, touched.p, kept.p, order.p, neg_gain.p, m,
+                                   exact ? 0 : 1, group_mark.p, static_cast<uint32_t>(it) * (k + 1), scalars.p);
+                BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+                if (!exact) {
+                    if ((rc = read_scalars(hs))) return rc;
+                    if (hs.ambiguous) {                       // roll the iteration back and replay it exactly
+                        if (std::getenv("BVH_AMD_REINSERT_DEBUG")) std::fprintf(stderr, "[bvh_amd] reinsertion iteration %zu: equal gains with shared nodes -> exact replay\n", it);
+                        BVH_HIP_TRY(hipMemcpyAsync(d_nodes, backup.p, size_t{n} * sizeof(HostNode<T>), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
+                        if ((rc = clear_ambiguous())) return rc;
+                        parents_valid = false;
+                        exact = true;
+                        continue;
+                    }
+                }
+            }
+            (exact ? g_exact_iterations : g_fast_iterations).fetch_add(1);
+            break;
+        }
     }
     ReScalars hs;
     BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);

@@ -224,6 +224,10 @@ BVH_AMD_API int bvh_amd_radix_sort_pairs_u32(uint32_t* d_keys, uint32_t* d_vals,
 
 /* Name and average duration source for profiling: the kernel symbol the last intersect call used. */
 BVH_AMD_API const char* bvh_amd_last_kernel_name(void);
+/* ReinsertionOptimizer iterations run so far in this process: out[0] = through the heap-free fast path, out[1] = through the
+ * exact replay of the reference's candidate heap + std::sort (taken when ties make their layout matter).
+ * Both produce the reference's result bit for bit; BVH_AMD_REINSERT=exact in the environment forces the replay. */
+BVH_AMD_API void bvh_amd_reinsertion_stats(unsigned out[2]);
 
 #ifdef __cplusplus
 }

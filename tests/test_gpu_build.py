@@ -236,6 +236,39 @@ def test_high_quality_scenes(orc, scene, n, parallel):
     assert gpu.serialize() == ref.serialize()
 
 
+def _lattice(n_side, dtype=np.float32):
+    """identical triangles on a power-of-two lattice: node costs and reinsertion gains tie massively"""
+    g = np.arange(n_side, dtype=dtype)
+    org = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 1, 3)
+    tri = np.array([[0.0, 0.0, 0.0], [0.5, 0.0, 0.25], [0.0, 0.5, 0.25]], dtype=dtype)
+    return np.ascontiguousarray((org + tri[None]).reshape(-1, 9))
+
+
+@pytest.mark.parametrize("scene", ["soup", "terrain", "lattice", "lattice_f64", "dup"])
+def test_reinsertion_fast_path_and_exact_replay_agree_with_reference(orc, scene, monkeypatch):
+    """The heap-free fast path must either prove the candidate-heap layout irrelevant or fall back to the exact replay;
+    both, and the forced replay, give the reference's bytes. The soup takes the fast path, the lattice (ties everywhere) the replay."""
+    import bvh_amd
+    tris = {"soup": lambda: synth.soup(60_000, jitter=0.01), "terrain": lambda: synth.terrain(60_000),
+            "lattice": lambda: _lattice(32), "lattice_f64": lambda: _lattice(24, np.float64),
+            "dup": lambda: np.concatenate([synth.soup(20_000), synth.soup(20_000)])}[scene]()      # every primitive twice
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_SERIAL, quality=oracle.QUALITY_HIGH).serialize()
+    cfg = bvh_amd.Config(quality=bvh_amd.Quality.High)
+    f0, e0 = bvh_amd.reinsertion_stats()
+    assert bvh_amd.DefaultBuilder.build(bb, cc, cfg).serialize() == ref
+    f1, e1 = bvh_amd.reinsertion_stats()
+    assert (f1 - f0) + (e1 - e0) == 3
+    if scene == "soup":
+        assert f1 - f0 == 3
+    if scene.startswith("lattice"):
+        assert e1 - e0 >= 1
+    monkeypatch.setenv("BVH_AMD_REINSERT", "exact")
+    assert bvh_amd.DefaultBuilder.build(bb, cc, cfg).serialize() == ref
+    f2, e2 = bvh_amd.reinsertion_stats()
+    assert (f2 - f1, e2 - e1) == (0, 3)
+
+
 def test_standalone_optimize_matches_reference(orc):
     """bvhXX_optimize on an existing BVH (here: a binned tree, which reinsertion improves a lot), twice."""
     import bvh_amd

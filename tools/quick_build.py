@@ -17,4 +17,4 @@ for name, q, pool in [("serial Low (binned)", 0, False), ("serial Medium (sweep)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         b = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=bvh_amd.ThreadPool() if pool else None)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    print(f"{scene} n={n} {name:28s} nodes={b.node_count:8d}  best {min(ts)*1e3:9.2f} ms  ({n/min(ts)/1e6:7.2f} Mtris/s)  all={[round(t*1e3,1) for t in ts]}", flush=True)
+    print(f"{scene} n={n} {name:28s} nodes={b.node_count:8d}  best {min(ts)*1e3:9.2f} ms  ({n/min(ts)/1e6:7.2f} Mtris/s)  all={[round(t*1e3,1) for t in ts]}  reinsertion fast/exact iterations so far={bvh_amd.reinsertion_stats()}", flush=True)
