@@ -285,45 +285,54 @@ __device__ bool top_adjust(WaveHeap<T>& h, uint32_t len, Ent<T> value, int lane,
 // children with one LDS instruction and chooses between them, all nodes at once; the path is then five dependent readlanes
 // ("pointer jumping" through the choices), and every path node itself stores its chosen child's entry (or the value,
 // at the first node whose chosen child is greater) into its own position, so no entry travels between lanes.
-template <typename T, typename Resolve>
-__device__ bool fast_top_adjust(WaveHeap<T>& h, Ent<T> value, int lane, uint32_t& hand_pos, T& root_cost, Resolve resolve_tasks) {
-    uint32_t cur = 0;
-    const int d = 31 - __clz(lane + 1);
-    const uint32_t in_level = static_cast<uint32_t>(lane + 1) - (1u << d);
-    for (int level = 0; level < h.cap_level;) {
-        const int steps = min(5, h.cap_level - level);
-        const uint32_t node = ((cur + 1) << d) - 1 + in_level;            // heap position of BFS node `lane`
-        const bool inner = lane < (1 << steps) - 1;
-        Ent<T> c1{}, c2{};
-        if (inner) { c1 = h.get_lds(2 * node + 1); c2 = h.get_lds(2 * node + 2); }
-        if (level + steps == h.cap_level && __ballot(inner && (c1.id == kOpenHole || c2.id == kOpenHole))) {
+// (the rounds are unrolled at compile time: 5 + 5 + 3 levels for float, 5 + 5 + 2 for double)
+template <typename T, int Level, typename Resolve>
+__device__ inline bool fast_top_round(WaveHeap<T>& h, Ent<T> value, int lane, uint32_t cur, int d, uint32_t in_level,
+                                      uint32_t& hand_pos, T& root_cost, Resolve& resolve_tasks) {
+    constexpr int kCapLevel = HeapLevels<T>::v - 1;
+    constexpr int kSteps = kCapLevel - Level < 5 ? kCapLevel - Level : 5;
+    const uint32_t node = ((cur + 1) << d) - 1 + in_level;                // heap position of BFS node `lane`
+    const bool inner = lane < (1 << kSteps) - 1;
+    Ent<T> c1{}, c2{};
+    if (inner) { c1 = h.get_lds(2 * node + 1); c2 = h.get_lds(2 * node + 2); }
+    if constexpr (Level + kSteps == kCapLevel) {
+        if (__ballot(inner && (c1.id == kOpenHole || c2.id == kOpenHole))) {
             resolve_tasks();                                               // an entry of the last LDS level is still owed
             if (inner) { c1 = h.get_lds(2 * node + 1); c2 = h.get_lds(2 * node + 2); }
         }
-        const bool left = c2.cost > c1.cost;                               // comp(second, second - 1): take the left child
-        const Ent<T> chosen = left ? c1 : c2;
-        const uint32_t chosen_pos = left ? 2 * node + 1 : 2 * node + 2;
-        const int next = left ? 2 * lane + 1 : 2 * lane + 2;
-        int r = 0;
-        uint64_t path = 1;                                                 // BFS indices of the path nodes of this round
-        for (int sidx = 1; sidx < steps; ++sidx) { r = __builtin_amdgcn_readlane(next, r); path |= uint64_t{1} << r; }
-        const bool on_path = (path >> lane) & 1u;
-        const uint64_t greater = __ballot(on_path && chosen.cost > value.cost);
-        if (level == 0) root_cost = (greater & 1u) ? value.cost : lane_value(chosen.cost, 0);
-        if (greater) {                                                     // the value lands inside this round
-            const int landing = __ffsll(static_cast<long long>(greater)) - 1;      // shallowest such node (BFS order)
-            if (on_path && lane < landing) h.set_lds(node, chosen);
-            if (lane == landing) h.set_lds(node, value);
-            heap_sync();
-            return false;
-        }
-        if (on_path) h.set_lds(node, chosen);
-        heap_sync();
-        cur = lane_value(chosen_pos, r);
-        level += steps;
     }
-    hand_pos = cur;
+    const bool left = c2.cost > c1.cost;                                   // comp(second, second - 1): take the left child
+    const Ent<T> chosen = left ? c1 : c2;
+    const uint32_t chosen_pos = left ? 2 * node + 1 : 2 * node + 2;
+    const int next = left ? 2 * lane + 1 : 2 * lane + 2;
+    int r = 0;
+    uint64_t path = 1;                                                     // BFS indices of the path nodes of this round
+#pragma unroll
+    for (int sidx = 1; sidx < kSteps; ++sidx) { r = __builtin_amdgcn_readlane(next, r); path |= uint64_t{1} << r; }
+    const bool on_path = (path >> lane) & 1u;
+    const uint64_t greater = __ballot(on_path && chosen.cost > value.cost);
+    if constexpr (Level == 0) root_cost = (greater & 1u) ? value.cost : lane_value(chosen.cost, 0);
+    if (greater) {                                                         // the value lands inside this round
+        const int landing = __ffsll(static_cast<long long>(greater)) - 1;  // shallowest such node (BFS order)
+        if (on_path && lane < landing) h.set_lds(node, chosen);
+        if (lane == landing) h.set_lds(node, value);
+        heap_sync();
+        return false;
+    }
+    if (on_path) h.set_lds(node, chosen);
+    heap_sync();
+    const uint32_t below = lane_value(chosen_pos, r);
+    if constexpr (Level + kSteps < kCapLevel)
+        return fast_top_round<T, Level + kSteps>(h, value, lane, below, d, in_level, hand_pos, root_cost, resolve_tasks);
+    hand_pos = below;
     return true;
+}
+
+template <typename T, typename Resolve>
+__device__ inline bool fast_top_adjust(WaveHeap<T>& h, Ent<T> value, int lane, uint32_t& hand_pos, T& root_cost, Resolve resolve_tasks) {
+    const int d = 31 - __clz(lane + 1);
+    const uint32_t in_level = static_cast<uint32_t>(lane + 1) - (1u << d);
+    return fast_top_round<T, 0>(h, value, lane, 0u, d, in_level, hand_pos, root_cost, resolve_tasks);
 }
 
 // __push_heap(first, hole = k - 1, top = 0, w) on the chain: ancestors greater than w move down one place, w lands above them
