@@ -44,6 +44,10 @@ _SIGS = {
     "bvh_thread_pool_create": (_P, [_Z]),
     "bvh_thread_pool_destroy": (None, [_P]),
     "bvh_amd_gather": (_I, [_P, _P, _Z, _Z, _P, _P]),
+    "bvh_amd_pinhole_rays3f": (_I, [_P, _P, _P, _Z, _Z, _P, _P]),
+    "bvh_amd_pinhole_rays3d": (_I, [_P, _P, _P, _Z, _Z, _P, _P]),
+    "bvh_amd_shade_eyelight3f": (_I, [_P, _P, _P, _Z, _P, _P]),
+    "bvh_amd_shade_eyelight3d": (_I, [_P, _P, _P, _Z, _P, _P]),
     "bvh_amd_device_alloc": (_P, [_Z]),
     "bvh_amd_device_free": (None, [_P]),
     "bvh_amd_copy_to_device": (_I, [_P, _P, _Z]),
@@ -57,6 +61,7 @@ _SIGS_T = {
     "bvh{S}_build": (_P, [_P, _P, _P, _Z, _P]),
     "bvh{S}_build_device": (_P, [_P, _P, _Z, _P, _I, _P]),
     "bvh{S}_from_nodes": (_P, [_P, _Z, _P, _Z]),
+    "bvh{S}_extract": (_P, [_P, _Z]),
     "bvh{S}_destroy": (None, [_P]),
     "bvh{S}_optimize": (None, [_P, _P]),
     "bvh{S}_refit": (None, [_P]),

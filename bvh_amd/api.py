@@ -181,6 +181,11 @@ class Bvh:
         _torch()
         return Bvh(getattr(lib, f"bvh{s}_deserialize")(data, len(data)), s)
 
+    def extract_bvh(self, root_id: int) -> "Bvh":
+        """Bvh::extract_bvh (bvh.h:92-122): the subtree under node `root_id` as its own BVH (device op)."""
+        h = getattr(_lib.load(), f"bvh{self._s}_extract")(self._h, int(root_id))
+        return Bvh(h, self._s)
+
     @staticmethod
     def from_nodes(nodes: np.ndarray, prim_ids: np.ndarray) -> "Bvh":
         s = "3f" if nodes.dtype.itemsize == 28 else "3d"
@@ -270,6 +275,30 @@ def sphere_bounds(sph4):
     _lib.check(getattr(_lib.load(), f"bvh_amd_sphere_bounds{s}")(t.data_ptr(), t.shape[0], bb.data_ptr(), cc.data_ptr(), _stream()),
                "sphere_bounds")
     return bb, cc
+
+
+def pinhole_rays(width: int, height: int, eye, direction, up, dtype=np.float32):
+    """Primary rays of the reference's benchmark camera (test/benchmark.cpp:343-359), generated on the device: (h*w, 8)."""
+    torch = _torch()
+    dt = np.dtype(dtype)
+    s = _suffix(torch.float32 if dt == np.float32 else torch.float64)
+    arr = [np.ascontiguousarray(np.asarray(v, dtype=dt).reshape(3)) for v in (eye, direction, up)]
+    out = torch.empty((width * height, 8), dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda")
+    _lib.check(getattr(_lib.load(), f"bvh_amd_pinhole_rays{s}")(arr[0].ctypes.data_as(C.c_void_p), arr[1].ctypes.data_as(C.c_void_p),
+                                                              arr[2].ctypes.data_as(C.c_void_p), width, height, out.data_ptr(), _stream()),
+               "pinhole_rays")
+    return out
+
+
+def shade_eyelight(prims12, rays, hits):
+    """Eyelight shading of test/benchmark.cpp:363-371 on the device -> (n, 3) uint8."""
+    torch = _torch()
+    p, r = _dev(prims12, 12), _dev(rays, 8)
+    s = _suffix(p.dtype)
+    out = torch.empty((r.shape[0], 3), dtype=torch.uint8, device=p.device)
+    _lib.check(getattr(_lib.load(), f"bvh_amd_shade_eyelight{s}")(p.data_ptr(), r.data_ptr(), hits.data_ptr(), r.shape[0], out.data_ptr(), _stream()),
+               "shade_eyelight")
+    return out
 
 
 def gather(records, perm):

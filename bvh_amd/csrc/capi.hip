@@ -9,6 +9,8 @@ namespace bvh_amd {
 
 template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
 void reinsertion_stats(unsigned out[2]);
+template <typename T>
+int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_count, const uint32_t* d_ids, size_t root_id, hipStream_t stream);
 template <typename T> int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
 template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
 
@@ -147,12 +149,9 @@ typename CTypes<T>::Bvh* load(FILE* f) {
     return deserialize<T>(buf.data(), buf.size());
 }
 
-// Runs `op` (optimize / refit) on the resident reference-layout nodes, after pushing possible host-side edits, then
-// refreshes the traversal records and (if it was valid) the host mirror.
-template <typename T, typename Op>
-int on_resident_nodes(typename CTypes<T>::Bvh* bvh, Op op) {
-    if (!bvh) return fail(BVH_AMD_ERR_ARG, "null bvh");
-    BvhImpl<T>& b = *impl<T>(bvh);
+// The reference-layout nodes resident on the device, with possible host-side edits pushed.
+template <typename T>
+int make_nodes_resident(BvhImpl<T>& b) {
     if (b.node_count == 0) return fail(BVH_AMD_ERR_ARG, "empty bvh");
     const size_t bytes = b.node_count * sizeof(HostNode<T>);
     if (!b.d_nodes) {                                          // BVH came from the host (from_nodes / load): make it resident
@@ -161,7 +160,19 @@ int on_resident_nodes(typename CTypes<T>::Bvh* bvh, Op op) {
     } else if (b.host_valid) {                                 // the host mirror may have been edited through bvh_node* pointers
         BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
     }
-    int rc = op(b.d_nodes, b.node_count);
+    return BVH_AMD_OK;
+}
+
+// Runs `op` (optimize / refit) on the resident reference-layout nodes, then refreshes the traversal records and (if it was
+// valid) the host mirror.
+template <typename T, typename Op>
+int on_resident_nodes(typename CTypes<T>::Bvh* bvh, Op op) {
+    if (!bvh) return fail(BVH_AMD_ERR_ARG, "null bvh");
+    BvhImpl<T>& b = *impl<T>(bvh);
+    int rc = make_nodes_resident<T>(b);
+    if (rc) return rc;
+    const size_t bytes = b.node_count * sizeof(HostNode<T>);
+    rc = op(b.d_nodes, b.node_count);
     if (rc) return rc;
     rc = relayout_on_device<T>(b, b.d_nodes, nullptr);
     if (rc) return rc;
@@ -171,6 +182,16 @@ int on_resident_nodes(typename CTypes<T>::Bvh* bvh, Op op) {
     for (int k = 0; k < 6; ++k) b.root_bounds[k] = root.bounds[k];
     if (b.host_valid) BVH_HIP_TRY(hipMemcpy(b.nodes.data(), b.d_nodes, bytes, hipMemcpyDeviceToHost), BVH_AMD_ERR_HIP);
     return BVH_AMD_OK;
+}
+
+template <typename T> typename CTypes<T>::Bvh* extract(typename CTypes<T>::Bvh* bvh, size_t root_id) {
+    if (!bvh) { set_error("extract: null bvh"); return nullptr; }
+    BvhImpl<T>& b = *impl<T>(bvh);
+    if (make_nodes_resident<T>(b)) return nullptr;
+    if (!b.d_prim_ids) { set_error("extract: the BVH has no device prim ids"); return nullptr; }
+    auto out = std::make_unique<BvhImpl<T>>();
+    if (extract_device<T>(*out, b.d_nodes, b.node_count, b.d_prim_ids, root_id, nullptr)) return nullptr;
+    return reinterpret_cast<typename CTypes<T>::Bvh*>(out.release());
 }
 
 template <typename T> int optimize(typename CTypes<T>::Bvh* bvh) {
@@ -252,6 +273,7 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_build_device(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,              \
                                   enum bvh_amd_builder builder, void* stream) {                                     \
         return build_device<T>(d_bb, d_cc, n, cfg, builder, stream); }                                              \
+    bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return extract<T>(b, root_id); }                          \
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes<T>(nodes, nn, ids, np); }                                                                 \
     void bvh##S##_destroy(bvh##S* b) { delete impl<T>(b); }                                                         \
@@ -331,6 +353,19 @@ int bvh_amd_radix_sort_pairs_u32(uint32_t* d_keys, uint32_t* d_vals, size_t n, i
     (void)hipFree(kt);
     if (vt) (void)hipFree(vt);
     return rc;
+}
+
+int bvh_amd_pinhole_rays3f(const float eye[3], const float dir[3], const float up[3], size_t w, size_t h, bvh_ray3f* d_rays, void* stream) {
+    return launch_pinhole_rays<float>(eye, dir, up, w, h, reinterpret_cast<float*>(d_rays), static_cast<hipStream_t>(stream));
+}
+int bvh_amd_pinhole_rays3d(const double eye[3], const double dir[3], const double up[3], size_t w, size_t h, bvh_ray3d* d_rays, void* stream) {
+    return launch_pinhole_rays<double>(eye, dir, up, w, h, reinterpret_cast<double*>(d_rays), static_cast<hipStream_t>(stream));
+}
+int bvh_amd_shade_eyelight3f(const float* d_tris12, const bvh_ray3f* d_rays, const bvh_hit3f* d_hits, size_t n, uint8_t* d_rgb, void* stream) {
+    return launch_shade_eyelight<float>(d_tris12, reinterpret_cast<const float*>(d_rays), d_hits, n, d_rgb, static_cast<hipStream_t>(stream));
+}
+int bvh_amd_shade_eyelight3d(const double* d_tris12, const bvh_ray3d* d_rays, const bvh_hit3d* d_hits, size_t n, uint8_t* d_rgb, void* stream) {
+    return launch_shade_eyelight<double>(d_tris12, reinterpret_cast<const double*>(d_rays), d_hits, n, d_rgb, static_cast<hipStream_t>(stream));
 }
 
 int bvh_amd_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t stride, void* d_out, void* stream) {

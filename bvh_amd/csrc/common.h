@@ -114,6 +114,11 @@ template <typename T> int launch_precompute_tris(const T* d_tris9, const uint32_
 template <typename T> int launch_sphere_bounds(const T* d_sph4, size_t n, T* d_bb, T* d_cc, hipStream_t s);
 int launch_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t stride, void* d_out, hipStream_t s);
 
+// render.hip
+template <typename T> int launch_pinhole_rays(const T eye[3], const T dir[3], const T up[3], size_t width, size_t height, T* d_rays, hipStream_t s);
+template <typename T>
+int launch_shade_eyelight(const T* d_tris12, const T* d_rays, const typename HitOf<T>::Type* d_hits, size_t n, uint8_t* d_rgb, hipStream_t s);
+
 // sort_emul.hip
 template <typename K>
 int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream,

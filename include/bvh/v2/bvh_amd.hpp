@@ -180,6 +180,7 @@ template <> struct Api<float> {
     static size_t prim_count(const Handle* h) { return bvh3f_get_prim_count(h); }
     static void copy_nodes(const Handle* h, void* out) { bvh3f_copy_nodes(h, out); }
     static void copy_prim_ids(const Handle* h, size_t* out) { bvh3f_copy_prim_ids(h, out); }
+    static Handle* extract(Handle* h, size_t root_id) { return bvh3f_extract(h, root_id); }
     static void optimize(Handle* h) { bvh3f_optimize(nullptr, h); }
     static void refit(Handle* h) { bvh3f_refit(h); }
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh3f_device_prim_ids(h); }
@@ -196,6 +197,7 @@ template <> struct Api<double> {
     static size_t prim_count(const Handle* h) { return bvh3d_get_prim_count(h); }
     static void copy_nodes(const Handle* h, void* out) { bvh3d_copy_nodes(h, out); }
     static void copy_prim_ids(const Handle* h, size_t* out) { bvh3d_copy_prim_ids(h, out); }
+    static Handle* extract(Handle* h, size_t root_id) { return bvh3d_extract(h, root_id); }
     static void optimize(Handle* h) { bvh3d_optimize(nullptr, h); }
     static void refit(Handle* h) { bvh3d_refit(h); }
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh3d_device_prim_ids(h); }
@@ -250,6 +252,15 @@ struct Bvh {
     const Node& get_root() const { return nodes[0]; }
     static bool is_left_sibling(size_t id) { return id % 2 == 1; }
     static size_t get_sibling_id(size_t id) { return is_left_sibling(id) ? id + 1 : id - 1; }
+
+    // Bvh::extract_bvh (reference bvh.h:92-122) on the device
+    [[nodiscard]] Bvh extract_bvh(size_t root_id) const {
+        auto* h = amd::Api<Scalar>::extract(device(), root_id);
+        if (!h) throw amd::Error(bvh_amd_last_error());
+        Bvh out;
+        out.adopt(h);
+        return out;
+    }
 
     // Bvh::refit (reference bvh.h:211-218) on the device; `nodes` may have been edited by the caller.
     void refit() { push(); amd::Api<Scalar>::refit(device_.get()); pull(); }

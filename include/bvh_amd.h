@@ -123,6 +123,11 @@ BVH_AMD_API struct bvh3d* bvh3d_build_device(const double* d_bboxes, const doubl
 BVH_AMD_API struct bvh3f* bvh3f_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
 BVH_AMD_API struct bvh3d* bvh3d_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
 
+/* Additive: Bvh::extract_bvh(root_id) (src/bvh/v2/bvh.h:92-122) on the device: the subtree under `root_id` as its own BVH,
+ * node order and re-packed prim ids exactly as the reference lays them out. NULL + bvh_amd_last_error() on failure. */
+BVH_AMD_API struct bvh3f* bvh3f_extract(struct bvh3f* bvh, size_t root_id);
+BVH_AMD_API struct bvh3d* bvh3d_extract(struct bvh3d* bvh, size_t root_id);
+
 BVH_AMD_API void bvh3f_destroy(struct bvh3f*);                                   /* c_api/bvh.h:130 */
 BVH_AMD_API void bvh3d_destroy(struct bvh3d*);                                   /* c_api/bvh.h:132 */
 
@@ -201,6 +206,20 @@ BVH_AMD_API int bvh_amd_sphere_bounds3f(const float* d_sph4, size_t n, float* d_
 BVH_AMD_API int bvh_amd_sphere_bounds3d(const double* d_sph4, size_t n, double* d_bboxes, double* d_centers, void* stream);
 /* out[i] = in[perm[i]] for records of `stride` bytes (multiple of 4). */
 BVH_AMD_API int bvh_amd_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t stride, void* d_out, void* stream);
+
+/* The renderer of the reference's benchmark (test/benchmark.cpp:340-371) around the batch traversal: primary rays of its
+ * pinhole camera, row-major (y, x): Ray(eye, normalize(dir) + u * right + v * up), u = 2x/w - 1, v = 2y/h - 1 (:343-359);
+ * eye/dir/up are HOST float[3]. */
+BVH_AMD_API int bvh_amd_pinhole_rays3f(const float eye[3], const float dir[3], const float up[3], size_t width, size_t height,
+    struct bvh_ray3f* d_rays, void* stream);
+BVH_AMD_API int bvh_amd_pinhole_rays3d(const double eye[3], const double dir[3], const double up[3], size_t width, size_t height,
+    struct bvh_ray3d* d_rays, void* stream);
+/* ... and its eyelight shading (:363-371): rgb[3i..3i+2] = clamp(int(|dot(normalize(tri.n), ray.dir)| * 256), 0, 255), 0 for a
+ * miss. d_tris12 = the BVH-ordered PrecomputedTri array the rays were traced against. */
+BVH_AMD_API int bvh_amd_shade_eyelight3f(const float* d_tris12, const struct bvh_ray3f* d_rays, const struct bvh_hit3f* d_hits, size_t n,
+    uint8_t* d_rgb, void* stream);
+BVH_AMD_API int bvh_amd_shade_eyelight3d(const double* d_tris12, const struct bvh_ray3d* d_rays, const struct bvh_hit3d* d_hits, size_t n,
+    uint8_t* d_rgb, void* stream);
 
 /* ---- batched traversal: Bvh::intersect<IsAnyHit, IsRobust> (bvh.h:160-182) for n rays ---------- */
 /* d_prims are in BVH order (prims[i] belongs to prim_ids[i]), like the reference's permuted

@@ -70,6 +70,10 @@ class CpuBvh:
         self.lib._fn("serialize", self.s)(self.h, _ptr(buf), n)
         return buf.tobytes()
 
+    def extract(self, root_id: int) -> "CpuBvh":
+        """Bvh::extract_bvh(root_id) (bvh.h:92-122)."""
+        return CpuBvh(self.lib, self.lib._fn("extract", self.s)(self.h, root_id), self.s)
+
     def optimize(self, threads: int = -1):
         """ReinsertionOptimizer::optimize; threads < 0 = SequentialExecutor overload."""
         self.lib._fn("optimize", self.s)(self.h, threads)
@@ -111,6 +115,7 @@ class CpuLib:
         "from_arrays": (C.c_void_p, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
         "serialize": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "optimize": (None, [C.c_void_p, C.c_int]),
+        "extract": (C.c_void_p, [C.c_void_p, C.c_size_t]),
         "refit": (None, [C.c_void_p]),
         "prep_tris": (None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
         "precompute_tris": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -920,6 +920,8 @@ extern "C" {
     ORC_EXPORT size_t orc_serialize##S(const void* h, uint8_t* out, size_t cap) {                       \
         return serialize_tree<T>(*static_cast<const Tree<T>*>(h), out, cap); }                          \
     ORC_EXPORT void orc_optimize##S(void* h, int /*threads*/) { optimize_tree<T>(*static_cast<Tree<T>*>(h)); } \
+    ORC_EXPORT void* orc_extract##S(const void* h, size_t root) {                                        \
+        return new Tree<T>(extract_subtree<T>(*static_cast<const Tree<T>*>(h), root)); }                 \
     ORC_EXPORT void orc_refit##S(void* h) { refit_tree<T>(*static_cast<Tree<T>*>(h)); }                 \
     ORC_EXPORT void orc_prep_tris##S(const T* t9, size_t n, T* bb, T* cc) { tri_bounds_and_centers<T>(t9, n, bb, cc); } \
     ORC_EXPORT void orc_precompute_tris##S(const T* t9, const uint64_t* perm, size_t n, T* out12) {     \

@@ -287,6 +287,8 @@ extern "C" {
     ORC_EXPORT size_t ref_serialize##S(const void* h, uint8_t* out, size_t cap) {                       \
         return serialize<T>(static_cast<const Bvh3<T>*>(h), out, cap); }                                \
     ORC_EXPORT void ref_optimize##S(void* h, int threads) { optimize<T>(static_cast<Bvh3<T>*>(h), threads); } \
+    ORC_EXPORT void* ref_extract##S(const void* h, size_t root) {                                       \
+        return new Bvh3<T>(static_cast<const Bvh3<T>*>(h)->extract_bvh(root)); }                        \
     ORC_EXPORT void ref_refit##S(void* h) { static_cast<Bvh3<T>*>(h)->refit(); }                        \
     ORC_EXPORT void ref_prep_tris##S(const T* t9, size_t n, T* bb, T* cc) { prep_tris<T>(t9, n, bb, cc); } \
     ORC_EXPORT void ref_precompute_tris##S(const T* t9, const uint64_t* perm, size_t n, T* out12) {     \

@@ -288,6 +288,38 @@ def test_standalone_optimize_matches_reference(orc):
     assert hits.tobytes() == ref.intersect_tri(orc.precompute_tris(tris, ref.prim_ids()), rays, 0, 1, threads=8).tobytes()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_extract_bvh_matches_reference(orc, dtype):
+    """Bvh::extract_bvh(root_id) as a device op: node order (right child first, children allocated at visit time) and the
+    re-packed prim ids equal the reference's, for subtrees of a device-built tree and of a host-supplied tree."""
+    import bvh_amd
+    tris = synth.sponza_proxy(40_000).astype(dtype)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_MEDIUM)
+    gpu = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+    assert gpu.serialize() == ref.serialize()
+    nodes = ref.nodes()
+    leaf = int(np.flatnonzero(nodes["index"] & 15)[0])
+    for root in (1, 2, 5, 6, 1000, 1001, leaf, ref.node_count - 1, 0):
+        if root == 0:
+            continue                                          # (the reference asserts root_id != 0)
+        sub = gpu.extract_bvh(root)
+        want = ref.extract(root)
+        assert sub.serialize() == want.serialize(), root
+        assert sub.node_count == want.node_count and sub.prim_count == want.prim_count
+    hosted = bvh_amd.Bvh.from_nodes(ref.nodes(), ref.prim_ids())
+    assert hosted.extract_bvh(2).serialize() == ref.extract(2).serialize()
+    # an extracted subtree is a complete BVH: it traces like the reference's
+    sub, want = gpu.extract_bvh(1), ref.extract(1)
+    prims = bvh_amd.precompute_tris(tris, sub.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    rays = synth.rays_closest(20_000, lo, hi).astype(dtype)
+    hits = bvh_amd.hits_to_numpy(bvh_amd.intersect(sub, prims, rays, robust=True))
+    assert hits.tobytes() == want.intersect_tri(orc.precompute_tris(tris, want.prim_ids()), rays, 0, 1, threads=4).tobytes()
+    with pytest.raises(bvh_amd.BvhAmdError):
+        gpu.extract_bvh(gpu.node_count)
+
+
 # ---- refit / node editing -------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -179,3 +179,9 @@ def test_cornell_render_ppm_md5(orc):
         img = np.repeat(pix.reshape(H, W, 1), 3, axis=2)
         ppm = f"P6 {W} {H} 255\n".encode() + img[::-1].tobytes()        # rows written from j = height down to 1
         assert hashlib.md5(ppm).hexdigest() == "96f6bbdc03d7f750fdb833993e9f8538"
+        # the same with the camera and the shading on the device: nothing but the PPM rows leaves HBM
+        d_rays = bvh_amd.pinhole_rays(W, H, (0, 1, 2), (0, 0, -1), (0, 1, 0))
+        assert d_rays.cpu().numpy().tobytes() == rays.tobytes()
+        d_hits = bvh_amd.intersect(bvh, prims, d_rays, any_hit=False, robust=False)
+        d_img = bvh_amd.shade_eyelight(prims, d_rays, d_hits).cpu().numpy().reshape(H, W, 3)
+        assert hashlib.md5(f"P6 {W} {H} 255\n".encode() + d_img[::-1].tobytes()).hexdigest() == "96f6bbdc03d7f750fdb833993e9f8538"
