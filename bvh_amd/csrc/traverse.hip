@@ -26,7 +26,7 @@ namespace bvh_amd {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kLdsDepth = 24;
+constexpr int kLdsDepth = 20;
 constexpr int kRefillThreshold = 32;          // refill when at least this many lanes of the wave are idle
 constexpr int kLeafThreshold = 32;            // run the leaf code when at least this many lanes wait at a leaf
 
