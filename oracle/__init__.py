@@ -28,7 +28,11 @@ HITF = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 HITD = np.dtype([("prim", "<u4"), ("pad", "<u4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8")])
 NODEF = np.dtype([("bounds", "<f4", (6,)), ("index", "<u4")])
 NODED = np.dtype([("bounds", "<f8", (6,)), ("index", "<u8")])
+NODE2F = np.dtype([("bounds", "<f4", (4,)), ("index", "<u4")])      # Node<float, 2>: {minx,maxx,miny,maxy}, index (20 bytes)
+NODE2D = np.dtype([("bounds", "<f8", (4,)), ("index", "<u8")])      # Node<double, 2> (40 bytes)
 assert HITF.itemsize == 16 and HITD.itemsize == 32 and NODEF.itemsize == 28 and NODED.itemsize == 56
+assert NODE2F.itemsize == 20 and NODE2D.itemsize == 40
+NODE_DTYPES = {"3f": NODEF, "3d": NODED, "2f": NODE2F, "2d": NODE2D}
 
 
 def _ptr(a):
@@ -55,7 +59,7 @@ class CpuBvh:
         return self.lib._fn("prim_count", self.s)(self.h)
 
     def nodes(self) -> np.ndarray:
-        out = np.empty(self.node_count, dtype=NODEF if self.s == "3f" else NODED)
+        out = np.empty(self.node_count, dtype=NODE_DTYPES[self.s])
         self.lib._fn("get_nodes", self.s)(self.h, _ptr(out))
         return out
 
@@ -88,10 +92,11 @@ class CpuBvh:
         return self._intersect("intersect_sphere", sph4, rays8, any_hit, robust, threads, counters)
 
     def _intersect(self, name, prims, rays8, any_hit, robust, threads, counters):
-        dt = np.float32 if self.s == "3f" else np.float64
+        dt = np.float32 if self.s[1] == "f" else np.float64
+        dim = int(self.s[0])
         prims = np.ascontiguousarray(prims, dtype=dt)
-        rays8 = np.ascontiguousarray(rays8, dtype=dt).reshape(-1, 8)
-        out = np.empty(len(rays8), dtype=HITF if self.s == "3f" else HITD)
+        rays8 = np.ascontiguousarray(rays8, dtype=dt).reshape(-1, 2 * dim + 2)      # {org[dim], dir[dim], tmin, tmax}
+        out = np.empty(len(rays8), dtype=HITF if self.s[1] == "f" else HITD)
         cnt = np.zeros(3, dtype=np.uint64)
         self.lib._fn(name, self.s)(self.h, _ptr(prims), _ptr(rays8), len(rays8), int(any_hit), int(robust),
                                    int(threads), _ptr(out), _ptr(cnt))
@@ -136,8 +141,8 @@ class CpuLib:
         return f
 
     @staticmethod
-    def _sfx(dtype):
-        return "3f" if np.dtype(dtype) == np.float32 else "3d"
+    def _sfx(dtype, dim=3):
+        return f"{dim}f" if np.dtype(dtype) == np.float32 else f"{dim}d"
 
     def hardware_threads(self) -> int:
         return int(getattr(self.dll, f"{self.prefix}_hardware_threads")())
@@ -145,9 +150,10 @@ class CpuLib:
     def build(self, bboxes, centers, builder=BUILDER_DEFAULT_SERIAL, quality=QUALITY_HIGH, min_leaf=1,
               max_leaf=8, parallel_threshold=1024, threads=0) -> CpuBvh:
         dt = bboxes.dtype
-        s = self._sfx(dt)
-        bboxes = np.ascontiguousarray(bboxes, dtype=dt).reshape(-1, 6)
-        centers = np.ascontiguousarray(centers, dtype=dt).reshape(-1, 3)
+        dim = np.asarray(centers).shape[-1]                   # (n, 3) centers + (n, 6) boxes, or (n, 2) + (n, 4) {min, max}
+        s = self._sfx(dt, dim)
+        bboxes = np.ascontiguousarray(bboxes, dtype=dt).reshape(-1, 2 * dim)
+        centers = np.ascontiguousarray(centers, dtype=dt).reshape(-1, dim)
         assert len(bboxes) == len(centers) and len(bboxes) > 0
         h = self._fn("build", s)(_ptr(bboxes), _ptr(centers), len(bboxes), builder, quality, min_leaf, max_leaf,
                                  parallel_threshold, threads)
@@ -156,7 +162,7 @@ class CpuLib:
         return CpuBvh(self, h, s)
 
     def from_arrays(self, nodes: np.ndarray, prim_ids: np.ndarray) -> CpuBvh:
-        s = "3f" if nodes.dtype.itemsize == 28 else "3d"
+        s = {28: "3f", 56: "3d", 20: "2f", 40: "2d"}[nodes.dtype.itemsize]
         nodes = np.ascontiguousarray(nodes)
         ids = np.ascontiguousarray(prim_ids, dtype=np.uint64)
         h = self._fn("from_arrays", s)(_ptr(nodes), len(nodes), _ptr(ids), len(ids))
@@ -188,11 +194,13 @@ class CpuLib:
         return out
 
     def sphere_bboxes(self, sph4):
+        """(n, 4) spheres {center, radius} or (n, 3) circles -> bboxes (n, 2 dim) {min, max}, centers (n, dim)."""
         dt = sph4.dtype
-        s4 = np.ascontiguousarray(sph4, dtype=dt).reshape(-1, 4)
-        bb = np.empty((len(s4), 6), dtype=dt)
-        cc = np.empty((len(s4), 3), dtype=dt)
-        self._fn("sphere_bboxes", self._sfx(dt))(_ptr(s4), len(s4), _ptr(bb), _ptr(cc))
+        dim = np.asarray(sph4).shape[-1] - 1
+        s4 = np.ascontiguousarray(sph4, dtype=dt).reshape(-1, dim + 1)
+        bb = np.empty((len(s4), 2 * dim), dtype=dt)
+        cc = np.empty((len(s4), dim), dtype=dt)
+        self._fn("sphere_bboxes", self._sfx(dt, dim))(_ptr(s4), len(s4), _ptr(bb), _ptr(cc))
         return bb, cc
 
 

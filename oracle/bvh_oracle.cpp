@@ -45,6 +45,13 @@ template <typename T> struct Traits;
 template <> struct Traits<float>  { using Index = uint32_t; using Hit = orc_hitf; };
 template <> struct Traits<double> { using Index = uint64_t; using Hit = orc_hitd; };
 
+// Dimension of the problem being restated: 3, or 2 for the `2f` / `2d` families (Node<T, 2>, c_api/bvh.cpp:7-10). Storage stays
+// three wide (z = 0 everywhere) and every algorithmic loop over axes runs to g_dim, so the 2D entry points below are thin
+// wrappers that pad their inputs and narrow their outputs. Test infrastructure: a plain global, set by DimScope for the
+// duration of one exported call (worker threads started inside the call see it); calls are not re-entrant across dimensions.
+static int g_dim = 3;
+struct DimScope { int saved; explicit DimScope(int d) : saved(g_dim) { g_dim = d; } ~DimScope() { g_dim = saved; } };
+
 constexpr unsigned kCountBits = 4;       // node.h:22 PrimCountBits
 constexpr size_t   kBins = 8;            // binned_sah_builder.h:19 BinCount
 
@@ -66,24 +73,24 @@ struct Box {
     T lo[3], hi[3];
     static Box empty() {                                     // bbox.h:40-44
         Box b;
-        for (int k = 0; k < 3; ++k) { b.lo[k] = std::numeric_limits<T>::max(); b.hi[k] = -std::numeric_limits<T>::max(); }
+        for (int k = 0; k < 3; ++k) { b.lo[k] = k < g_dim ? std::numeric_limits<T>::max() : T(0); b.hi[k] = k < g_dim ? -std::numeric_limits<T>::max() : T(0); }
         return b;
     }
     void grow(const Box& o) {                                // bbox.h:22-26: accumulated value is the first operand
-        for (int k = 0; k < 3; ++k) { lo[k] = pick_min(lo[k], o.lo[k]); hi[k] = pick_max(hi[k], o.hi[k]); }
+        for (int k = 0; k < g_dim; ++k) { lo[k] = pick_min(lo[k], o.lo[k]); hi[k] = pick_max(hi[k], o.hi[k]); }
     }
     void grow_point(const T* p) {                            // bbox.h:18-20
-        for (int k = 0; k < 3; ++k) { lo[k] = pick_min(lo[k], p[k]); hi[k] = pick_max(hi[k], p[k]); }
+        for (int k = 0; k < g_dim; ++k) { lo[k] = pick_min(lo[k], p[k]); hi[k] = pick_max(hi[k], p[k]); }
     }
-    T half_area() const {                                    // bbox.h:32-38 (3D form)
+    T half_area() const {                                    // bbox.h:32-38
         T d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+        if (g_dim == 2) return d0 + d1;
         return (d0 + d1) * d2 + d0 * d1;
     }
     int largest_axis() const {                               // vec.h:23-33: first maximum wins, NaN never wins
         T d[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] };
         int axis = 0;
-        if (d[1] > d[axis]) axis = 1;
-        if (d[2] > d[axis]) axis = 2;
+        for (int k = 1; k < g_dim; ++k) if (d[k] > d[axis]) axis = k;
         return axis;
     }
 };
@@ -193,13 +200,13 @@ struct BinnedSplitter {
     bool try_split(const Box<T>& nb, size_t b, size_t e, size_t& cut) {    // :128-156
         Slot slots[3][kBins];
         T scale[3], shift[3];
-        for (int k = 0; k < 3; ++k) {                        // :88-89
+        for (int k = 0; k < g_dim; ++k) {                        // :88-89
             scale[k] = T(kBins) / (nb.hi[k] - nb.lo[k]);
             shift[k] = (-nb.lo[k]) * scale[k];
         }
         for (size_t i = b; i < e; ++i) {                     // :91-98
             size_t p = order[i];
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < g_dim; ++k) {
                 T pos = fused(centers[3 * p + k], scale[k], shift[k]);
                 size_t s = std::min(kBins - 1, static_cast<size_t>(pick_max(pos, T(0))));
                 slots[k][s].box.grow(boxes[p]);
@@ -208,7 +215,7 @@ struct BinnedSplitter {
         }
         int wide = nb.largest_axis();
         size_t best_bin = kBins / 2; T best_cost = std::numeric_limits<T>::max(); int best_axis = wide;   // :132-133
-        for (int k = 0; k < 3; ++k) {                        // :101-116
+        for (int k = 0; k < g_dim; ++k) {                        // :101-116
             Slot acc;
             T right_cost[kBins];
             for (size_t i = kBins - 1; i > 0; --i) {
@@ -259,7 +266,7 @@ struct SweepSplitter {
     SweepSplitter(const Box<T>* b, const T* c, size_t n, LeafLimits l)
         : boxes(b), centers(c), lim(l), goes_left(n), suffix_cost(n)
     {
-        for (int k = 0; k < 3; ++k) {                        // :57-63
+        for (int k = 0; k < g_dim; ++k) {                        // :57-63
             sorted[k].resize(n);
             std::iota(sorted[k].begin(), sorted[k].end(), size_t{0});
             std::sort(sorted[k].begin(), sorted[k].end(),
@@ -295,7 +302,7 @@ struct SweepSplitter {
     bool try_split(const Box<T>& nb, size_t b, size_t e, size_t& cut) {    // :108-139
         T stay_cost = nb.half_area() * (static_cast<T>(e - b) - T(1));
         size_t best_pos = (b + e + 1) / 2; T best_cost = stay_cost; int best_axis = 0;
-        for (int k = 0; k < 3; ++k) scan_axis(k, b, e, best_pos, best_cost, best_axis);
+        for (int k = 0; k < g_dim; ++k) scan_axis(k, b, e, best_pos, best_cost, best_axis);
         if (best_cost >= stay_cost) {
             if (e - b <= lim.max_leaf) return false;
             best_pos = (b + e + 1) / 2;                      // :122-123 median on the widest axis
@@ -303,7 +310,7 @@ struct SweepSplitter {
         }
         for (size_t i = b; i < best_pos; ++i) goes_left[sorted[best_axis][i]] = true;   // :103-106
         for (size_t i = best_pos; i < e; ++i) goes_left[sorted[best_axis][i]] = false;
-        for (int k = 0; k < 3; ++k) {                        // :129-136
+        for (int k = 0; k < g_dim; ++k) {                        // :129-136
             if (k == best_axis) continue;
             std::stable_partition(sorted[k].begin() + b, sorted[k].begin() + e,
                 [&](size_t i) { return bool(goes_left[i]); });
@@ -713,7 +720,8 @@ void sphere_bounds(const T* s4, size_t n, T* bb, T* cc) {
 // Single-ray traversal (bvh.h:125-182, node.h:59-117, ray.h:29-48) and leaf tests
 // ---------------------------------------------------------------------------------------------
 
-template <typename T> inline T dot3(const T* a, const T* b) {   // vec.h:98-100: ((0 + a0 b0) + a1 b1) + a2 b2
+template <typename T> inline T dot3(const T* a, const T* b) {   // vec.h:98-100: ((0 + a0 b0) + a1 b1) [+ a2 b2]
+    if (g_dim == 2) return (T(0) + a[0] * b[0]) + a[1] * b[1];
     return ((T(0) + a[0] * b[0]) + a[1] * b[1]) + a[2] * b[2];
 }
 
@@ -775,7 +783,7 @@ void trace_one(const Tree<T>& tree, const T* prims, RayState<T>& ray, typename T
     using Index = typename Traits<T>::Index;
     T inv[3], inv_org[3], inv_pad[3];
     unsigned oct[3];
-    for (int k = 0; k < 3; ++k) {                            // bvh.h:162-165
+    for (int k = 0; k < g_dim; ++k) {                            // bvh.h:162-165
         inv[k] = Robust ? T(1) / ray.dir[k] : guarded_inverse(ray.dir[k]);
         inv_org[k] = (-inv[k]) * ray.org[k];
         inv_pad[k] = nudge_ulps(inv[k], 2);
@@ -783,7 +791,7 @@ void trace_one(const Tree<T>& tree, const T* prims, RayState<T>& ray, typename T
     }
     auto slab = [&](const NodeRec<T>& node, T& t0, T& t1) { // node.h:68-88, :105-117
         t0 = ray.tmin; t1 = ray.tmax;
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < g_dim; ++k) {
             T near_b = node.bounds[2 * k + oct[k]], far_b = node.bounds[2 * k + 1 - oct[k]];
             T a, b;
             if (Robust) { a = (near_b - ray.org[k]) * inv[k]; b = (far_b - ray.org[k]) * inv_pad[k]; }
@@ -936,6 +944,106 @@ extern "C" {
 
 ORC_IMPL(float, 3f)
 ORC_IMPL(double, 3d)
+
+} // extern "C"
+
+// ---- the 2D families: pad to the three-wide internal storage, run with g_dim = 2, narrow the results -----------------------
+namespace {
+
+template <typename T> struct Node2Rec { T bounds[4]; typename Traits<T>::Index index; };   // Node<T, 2> (node.h:31-37)
+static_assert(sizeof(Node2Rec<float>) == 20 && sizeof(Node2Rec<double>) == 40);
+
+template <typename T>
+void narrow_nodes(const Tree<T>& t, Node2Rec<T>* out) {
+    for (size_t i = 0; i < t.nodes.size(); ++i) {
+        for (int k = 0; k < 4; ++k) out[i].bounds[k] = t.nodes[i].bounds[k];
+        out[i].index = t.nodes[i].index;
+    }
+}
+
+template <typename T>
+Tree<T>* build2(const T* bboxes4, const T* centers2, size_t n, int builder, int quality, size_t min_leaf, size_t max_leaf, size_t par_threshold) {
+    // DefaultBuilder(pool) above parallel_threshold runs the mini-tree builder, which reads p[2] of a 2D vector
+    // (mini_tree_builder.h:183): undefined behaviour in the reference, refused here
+    if (!n || (builder == ORC_BUILDER_DEFAULT_PARALLEL && n >= par_threshold)) return nullptr;
+    std::vector<T> bb(6 * n), cc(3 * n);
+    for (size_t i = 0; i < n; ++i) {                          // {min[2], max[2]} -> {min[3], max[3]} with z = 0
+        bb[6 * i + 0] = bboxes4[4 * i + 0]; bb[6 * i + 1] = bboxes4[4 * i + 1]; bb[6 * i + 2] = T(0);
+        bb[6 * i + 3] = bboxes4[4 * i + 2]; bb[6 * i + 4] = bboxes4[4 * i + 3]; bb[6 * i + 5] = T(0);
+        cc[3 * i + 0] = centers2[2 * i + 0]; cc[3 * i + 1] = centers2[2 * i + 1]; cc[3 * i + 2] = T(0);
+    }
+    DimScope dim(2);
+    return new Tree<T>(build_dispatch<T>(bb.data(), cc.data(), n, builder, quality, LeafLimits{min_leaf, max_leaf}, par_threshold));
+}
+
+template <typename T>
+size_t serialize2(const Tree<T>& t, uint8_t* out, size_t cap) {           // bvh.h:221-229 with 20/40-byte nodes
+    using Index = typename Traits<T>::Index;
+    const size_t need = 2 * sizeof(Index) + t.nodes.size() * sizeof(Node2Rec<T>) + t.prim_ids.size() * sizeof(Index);
+    if (!out || cap < need) return need;
+    Index hdr[2] = { static_cast<Index>(t.nodes.size()), static_cast<Index>(t.prim_ids.size()) };
+    std::memcpy(out, hdr, sizeof(hdr));
+    out += sizeof(hdr);
+    std::vector<Node2Rec<T>> narrow(t.nodes.size());
+    narrow_nodes(t, narrow.data());
+    std::memcpy(out, narrow.data(), narrow.size() * sizeof(Node2Rec<T>));
+    out += narrow.size() * sizeof(Node2Rec<T>);
+    for (size_t p : t.prim_ids) { Index v = static_cast<Index>(p); std::memcpy(out, &v, sizeof(v)); out += sizeof(v); }
+    return need;
+}
+
+template <typename T>
+void trace2(const Tree<T>& tree, const T* circles3, const T* rays6, size_t n, int any, int robust, int threads,
+            typename Traits<T>::Hit* out, uint64_t* counters) {
+    size_t np = tree.prim_ids.size();
+    std::vector<T> sph(4 * np), rays(8 * n);
+    for (size_t i = 0; i < np; ++i) { sph[4 * i] = circles3[3 * i]; sph[4 * i + 1] = circles3[3 * i + 1]; sph[4 * i + 2] = T(0); sph[4 * i + 3] = circles3[3 * i + 2]; }
+    for (size_t i = 0; i < n; ++i) {                           // {org[2], dir[2], tmin, tmax}
+        const T* q = rays6 + 6 * i; T* r = rays.data() + 8 * i;
+        r[0] = q[0]; r[1] = q[1]; r[2] = T(0); r[3] = q[2]; r[4] = q[3]; r[5] = T(0); r[6] = q[4]; r[7] = q[5];
+    }
+    DimScope dim(2);
+    trace_all<T, Leaf::Sphere>(tree, sph.data(), rays.data(), n, any, robust, threads, out, counters);
+}
+
+} // namespace
+
+extern "C" {
+
+#define ORC_IMPL2(T, S)                                                                                 \
+    ORC_EXPORT void* orc_build##S(const T* bboxes4, const T* centers2, size_t n, int builder, int quality, \
+        size_t min_leaf, size_t max_leaf, size_t par_threshold, int /*threads*/) {                      \
+        return build2<T>(bboxes4, centers2, n, builder, quality, min_leaf, max_leaf, par_threshold); }  \
+    ORC_EXPORT void orc_destroy##S(void* h) { delete static_cast<Tree<T>*>(h); }                        \
+    ORC_EXPORT size_t orc_node_count##S(const void* h) { return static_cast<const Tree<T>*>(h)->nodes.size(); } \
+    ORC_EXPORT size_t orc_prim_count##S(const void* h) { return static_cast<const Tree<T>*>(h)->prim_ids.size(); } \
+    ORC_EXPORT void orc_get_nodes##S(const void* h, void* out) {                                        \
+        narrow_nodes<T>(*static_cast<const Tree<T>*>(h), static_cast<Node2Rec<T>*>(out)); }             \
+    ORC_EXPORT void orc_get_prim_ids##S(const void* h, uint64_t* out) {                                 \
+        auto t = static_cast<const Tree<T>*>(h); for (size_t i = 0; i < t->prim_ids.size(); ++i) out[i] = t->prim_ids[i]; } \
+    ORC_EXPORT void* orc_from_arrays##S(const void* nodes, size_t nn, const uint64_t* ids, size_t np) { \
+        auto t = new Tree<T>; t->nodes.resize(nn);                                                       \
+        auto src = static_cast<const Node2Rec<T>*>(nodes);                                               \
+        for (size_t i = 0; i < nn; ++i) {                                                                \
+            for (int k = 0; k < 4; ++k) t->nodes[i].bounds[k] = src[i].bounds[k];                        \
+            t->nodes[i].bounds[4] = t->nodes[i].bounds[5] = T(0); t->nodes[i].index = src[i].index; }    \
+        t->prim_ids.assign(ids, ids + np); return t; }                                                  \
+    ORC_EXPORT size_t orc_serialize##S(const void* h, uint8_t* out, size_t cap) {                       \
+        return serialize2<T>(*static_cast<const Tree<T>*>(h), out, cap); }                              \
+    ORC_EXPORT void orc_optimize##S(void* h, int /*threads*/) { DimScope dim(2); optimize_tree<T>(*static_cast<Tree<T>*>(h)); } \
+    ORC_EXPORT void* orc_extract##S(const void* h, size_t root) {                                        \
+        DimScope dim(2); return new Tree<T>(extract_subtree<T>(*static_cast<const Tree<T>*>(h), root)); } \
+    ORC_EXPORT void orc_refit##S(void* h) { DimScope dim(2); refit_tree<T>(*static_cast<Tree<T>*>(h)); } \
+    ORC_EXPORT void orc_sphere_bboxes##S(const T* c3, size_t n, T* bb4, T* cc2) {                       \
+        for (size_t i = 0; i < n; ++i) for (int k = 0; k < 2; ++k) {      /* sphere.h:24-27 */           \
+            bb4[4 * i + k] = c3[3 * i + k] - c3[3 * i + 2]; bb4[4 * i + 2 + k] = c3[3 * i + k] + c3[3 * i + 2]; \
+            cc2[2 * i + k] = c3[3 * i + k]; } }                                                          \
+    ORC_EXPORT void orc_intersect_sphere##S(const void* h, const T* circles3, const T* rays6, size_t nrays, \
+        int any, int robust, int threads, Traits<T>::Hit* out, uint64_t* counters) {                    \
+        trace2<T>(*static_cast<const Tree<T>*>(h), circles3, rays6, nrays, any, robust, threads, out, counters); }
+
+ORC_IMPL2(float, 2f)
+ORC_IMPL2(double, 2d)
 
 // the order-defining primitive behind SweepSahBuilder's constructor (sweep_sah_builder.h:57-63)
 ORC_EXPORT void orc_std_sort_ids3f(const float* keys, size_t n, uint32_t* out) {

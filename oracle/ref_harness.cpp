@@ -46,25 +46,31 @@ using namespace bvh::v2;
 
 template <typename T> using Node3 = Node<T, 3>;
 template <typename T> using Bvh3 = Bvh<Node3<T>>;
+template <typename T, size_t D> using BvhN = Bvh<Node<T, D>>;   // D = 2: the `2f` / `2d` families of the C API (c_api/bvh.cpp:7-10)
 
-template <typename T>
-Bvh3<T>* build(const T* bboxes, const T* centers, size_t n, int builder, int quality,
-               size_t min_leaf, size_t max_leaf, size_t par_threshold, int threads)
+template <typename T, size_t D>
+BvhN<T, D>* build(const T* bboxes, const T* centers, size_t n, int builder, int quality,
+                  size_t min_leaf, size_t max_leaf, size_t par_threshold, int threads)
 {
-    using N = Node3<T>;
-    std::vector<BBox<T, 3>> bb(n);
-    std::vector<Vec<T, 3>> cc(n);
+    using N = Node<T, D>;
+    std::vector<BBox<T, D>> bb(n);                            // bboxes: n x {min[D], max[D]}, centers: n x D
+    std::vector<Vec<T, D>> cc(n);
     for (size_t i = 0; i < n; ++i) {
-        bb[i] = BBox<T, 3>(Vec<T, 3>(bboxes[6 * i + 0], bboxes[6 * i + 1], bboxes[6 * i + 2]),
-                           Vec<T, 3>(bboxes[6 * i + 3], bboxes[6 * i + 4], bboxes[6 * i + 5]));
-        cc[i] = Vec<T, 3>(centers[3 * i + 0], centers[3 * i + 1], centers[3 * i + 2]);
+        for (size_t k = 0; k < D; ++k) {
+            bb[i].min[k] = bboxes[2 * D * i + k];
+            bb[i].max[k] = bboxes[2 * D * i + D + k];
+            cc[i][k] = centers[D * i + k];
+        }
     }
     typename DefaultBuilder<N>::Config cfg;
     cfg.quality = static_cast<typename DefaultBuilder<N>::Quality>(quality);
     cfg.min_leaf_size = min_leaf;
     cfg.max_leaf_size = max_leaf;
     cfg.parallel_threshold = par_threshold;
-    auto out = std::make_unique<Bvh3<T>>();
+    auto out = std::make_unique<BvhN<T, D>>();
+    // (with D = 2 the mini-tree builder reads p[2] of a 2D vector, mini_tree_builder.h:183: undefined behaviour. The harness
+    //  only lets DefaultBuilder(pool) through below parallel_threshold, where it is the serial builder, default_builder.h:38-39)
+    if (D == 2 && builder == ORC_BUILDER_DEFAULT_PARALLEL && n >= par_threshold) return nullptr;
     switch (builder) {
     case ORC_BUILDER_DEFAULT_SERIAL:
         *out = DefaultBuilder<N>::build(bb, cc, cfg);
@@ -86,17 +92,17 @@ Bvh3<T>* build(const T* bboxes, const T* centers, size_t n, int builder, int qua
     return out.release();
 }
 
-template <typename T>
-void get_nodes(const Bvh3<T>* b, void* out) {
-    static_assert(sizeof(Node3<float>) == 28 && sizeof(Node3<double>) == 56);
-    std::memcpy(out, b->nodes.data(), b->nodes.size() * sizeof(Node3<T>));
+template <typename T, size_t D>
+void get_nodes(const BvhN<T, D>* b, void* out) {
+    static_assert(sizeof(Node3<float>) == 28 && sizeof(Node3<double>) == 56 && sizeof(Node<float, 2>) == 20 && sizeof(Node<double, 2>) == 40);
+    std::memcpy(out, b->nodes.data(), b->nodes.size() * sizeof(Node<T, D>));
 }
 
-template <typename T>
-Bvh3<T>* from_arrays(const void* nodes, size_t nn, const uint64_t* prim_ids, size_t np) {
-    auto b = std::make_unique<Bvh3<T>>();
+template <typename T, size_t D>
+BvhN<T, D>* from_arrays(const void* nodes, size_t nn, const uint64_t* prim_ids, size_t np) {
+    auto b = std::make_unique<BvhN<T, D>>();
     b->nodes.resize(nn);
-    std::memcpy(b->nodes.data(), nodes, nn * sizeof(Node3<T>));
+    std::memcpy(b->nodes.data(), nodes, nn * sizeof(Node<T, D>));
     b->prim_ids.assign(prim_ids, prim_ids + np);
     return b.release();
 }
@@ -110,8 +116,8 @@ struct VecStream : OutputStream {
     }
 };
 
-template <typename T>
-size_t serialize(const Bvh3<T>* b, uint8_t* out, size_t cap) {
+template <typename T, size_t D>
+size_t serialize(const BvhN<T, D>* b, uint8_t* out, size_t cap) {
     VecStream s;
     b->serialize(s);
     if (out && cap >= s.bytes.size())
@@ -119,13 +125,13 @@ size_t serialize(const Bvh3<T>* b, uint8_t* out, size_t cap) {
     return s.bytes.size();
 }
 
-template <typename T>
-void optimize(Bvh3<T>* b, int threads) {
+template <typename T, size_t D>
+void optimize(BvhN<T, D>* b, int threads) {
     if (threads < 0) {
-        ReinsertionOptimizer<Node3<T>>::optimize(*b);
+        ReinsertionOptimizer<Node<T, D>>::optimize(*b);
     } else {
         ThreadPool pool(static_cast<size_t>(threads));
-        ReinsertionOptimizer<Node3<T>>::optimize(pool, *b);
+        ReinsertionOptimizer<Node<T, D>>::optimize(pool, *b);
     }
 }
 
@@ -157,16 +163,18 @@ void precompute_tris(const T* t9, const uint64_t* perm, size_t n, T* out12) {
     }
 }
 
-template <typename T>
-void sphere_bboxes(const T* s4, size_t n, T* bboxes, T* centers) {
+template <typename T, size_t D>
+void sphere_bboxes(const T* sph, size_t n, T* bboxes, T* centers) {      // sph: n x {center[D], radius}
     for (size_t i = 0; i < n; ++i) {
-        Sphere<T, 3> s(Vec<T, 3>(s4[4 * i + 0], s4[4 * i + 1], s4[4 * i + 2]), s4[4 * i + 3]);
+        Vec<T, D> ctr;
+        for (size_t k = 0; k < D; ++k) ctr[k] = sph[(D + 1) * i + k];
+        Sphere<T, D> s(ctr, sph[(D + 1) * i + D]);
         auto bb = s.get_bbox();
         auto c = s.get_center();
-        for (int k = 0; k < 3; ++k) {
-            bboxes[6 * i + k] = bb.min[k];
-            bboxes[6 * i + 3 + k] = bb.max[k];
-            centers[3 * i + k] = c[k];
+        for (size_t k = 0; k < D; ++k) {
+            bboxes[2 * D * i + k] = bb.min[k];
+            bboxes[2 * D * i + D + k] = bb.max[k];
+            centers[D * i + k] = c[k];
         }
     }
 }
@@ -190,19 +198,21 @@ void parallel_chunks(size_t n, int threads, F&& fn) {
 
 // The leaf lambda below is the closest-hit / any-hit pattern of test/benchmark.cpp:277-298 and
 // test/simple_example.cpp:81-92 (permuted primitives: the BVH-order index i addresses prims[i]).
-template <typename T, bool Any, bool Robust, typename Prim, typename LeafTest>
-void intersect_all(const Bvh3<T>* b, const Prim* prims, const T* rays8, size_t nrays, int threads,
+template <typename T, size_t D, bool Any, bool Robust, typename Prim, typename LeafTest>
+void intersect_all(const BvhN<T, D>* b, const Prim* prims, const T* rays8, size_t nrays, int threads,
                    typename HitOf<T>::Type* out, uint64_t* counters, LeafTest&& leaf_test)
 {
     std::vector<uint64_t> cnt(3 * std::max(threads, 1), 0);
     parallel_chunks(nrays, threads, [&](size_t rb, size_t re, int slot) {
         uint64_t pairs = 0, tests = 0, leaves = 0;
         for (size_t r = rb; r < re; ++r) {
-            const T* q = rays8 + 8 * r;
-            Ray<T, 3> ray(Vec<T, 3>(q[0], q[1], q[2]), Vec<T, 3>(q[3], q[4], q[5]), q[6], q[7]);
+            const T* q = rays8 + (2 * D + 2) * r;                 // {org[D], dir[D], tmin, tmax}
+            Vec<T, D> org, dir;
+            for (size_t k = 0; k < D; ++k) { org[k] = q[k]; dir[k] = q[D + k]; }
+            Ray<T, D> ray(org, dir, q[2 * D], q[2 * D + 1]);
             typename HitOf<T>::Type h{};
-            h.prim = ORC_INVALID; h.t = q[7]; h.u = 0; h.v = 0;
-            SmallStack<typename Bvh3<T>::Index, 64> stack;
+            h.prim = ORC_INVALID; h.t = q[2 * D + 1]; h.u = 0; h.v = 0;
+            SmallStack<typename BvhN<T, D>::Index, 64> stack;
             b->template intersect<Any, Robust>(ray, b->get_root().index, stack,
                 [&](size_t begin, size_t end) {
                     ++leaves;
@@ -212,7 +222,7 @@ void intersect_all(const Bvh3<T>* b, const Prim* prims, const T* rays8, size_t n
                     }
                     return h.prim != ORC_INVALID;
                 },
-                [&](const Node3<T>&, const Node3<T>&) { ++pairs; });
+                [&](const Node<T, D>&, const Node<T, D>&) { ++pairs; });
             out[r] = h;
         }
         cnt[3 * slot + 0] += pairs; cnt[3 * slot + 1] += tests; cnt[3 * slot + 2] += leaves;
@@ -230,7 +240,7 @@ void intersect_tri(const Bvh3<T>* b, const T* tris12, const T* rays8, size_t nra
                    typename HitOf<T>::Type* out, uint64_t* counters)
 {
     auto prims = reinterpret_cast<const PrecomputedTri<T>*>(tris12);
-    intersect_all<T, Any, Robust>(b, prims, rays8, nrays, threads, out, counters,
+    intersect_all<T, 3, Any, Robust>(b, prims, rays8, nrays, threads, out, counters,
         [](const PrecomputedTri<T>& tri, Ray<T, 3>& ray, size_t i, typename HitOf<T>::Type& h) {
             if (auto hit = tri.intersect(ray)) {
                 std::tie(ray.tmax, h.u, h.v) = *hit;
@@ -240,14 +250,14 @@ void intersect_tri(const Bvh3<T>* b, const T* tris12, const T* rays8, size_t nra
         });
 }
 
-template <typename T, bool Any, bool Robust>
-void intersect_sphere(const Bvh3<T>* b, const T* sph4, const T* rays8, size_t nrays, int threads,
+template <typename T, size_t D, bool Any, bool Robust>
+void intersect_sphere(const BvhN<T, D>* b, const T* sph, const T* rays, size_t nrays, int threads,
                       typename HitOf<T>::Type* out, uint64_t* counters)
 {
-    auto prims = reinterpret_cast<const Sphere<T, 3>*>(sph4);
-    static_assert(sizeof(Sphere<T, 3>) == 4 * sizeof(T));
-    intersect_all<T, Any, Robust>(b, prims, rays8, nrays, threads, out, counters,
-        [](const Sphere<T, 3>& s, Ray<T, 3>& ray, size_t i, typename HitOf<T>::Type& h) {
+    auto prims = reinterpret_cast<const Sphere<T, D>*>(sph);
+    static_assert(sizeof(Sphere<T, D>) == (D + 1) * sizeof(T));
+    intersect_all<T, D, Any, Robust>(b, prims, rays, nrays, threads, out, counters,
+        [](const Sphere<T, D>& s, Ray<T, D>& ray, size_t i, typename HitOf<T>::Type& h) {
             if (auto hit = s.intersect(ray)) {
                 ray.tmax = hit->first;
                 h.t = hit->first;
@@ -271,40 +281,54 @@ struct Dispatch;
 
 extern "C" {
 
-#define REF_IMPL(T, S)                                                                                  \
+#define DISPATCH_SPHERE(T, D, any, robust, ...)                             \
+    do {                                                                    \
+        if (any) { if (robust) intersect_sphere<T, D, true, true>(__VA_ARGS__); else intersect_sphere<T, D, true, false>(__VA_ARGS__); } \
+        else     { if (robust) intersect_sphere<T, D, false, true>(__VA_ARGS__); else intersect_sphere<T, D, false, false>(__VA_ARGS__); } \
+    } while (0)
+
+/* everything that exists for every dimension (D = 2: bboxes n x 4, centers n x 2, nodes 20/40 bytes, spheres n x 3, rays n x 6) */
+#define REF_IMPL(T, D, S)                                                                               \
     ORC_EXPORT void* ref_build##S(const T* bboxes, const T* centers, size_t n, int builder,            \
         int quality, size_t min_leaf, size_t max_leaf, size_t par_threshold, int threads) {            \
-        return build<T>(bboxes, centers, n, builder, quality, min_leaf, max_leaf, par_threshold, threads); } \
-    ORC_EXPORT void ref_destroy##S(void* h) { delete static_cast<Bvh3<T>*>(h); }                        \
-    ORC_EXPORT size_t ref_node_count##S(const void* h) { return static_cast<const Bvh3<T>*>(h)->nodes.size(); } \
-    ORC_EXPORT size_t ref_prim_count##S(const void* h) { return static_cast<const Bvh3<T>*>(h)->prim_ids.size(); } \
-    ORC_EXPORT void ref_get_nodes##S(const void* h, void* out) { get_nodes<T>(static_cast<const Bvh3<T>*>(h), out); } \
+        return build<T, D>(bboxes, centers, n, builder, quality, min_leaf, max_leaf, par_threshold, threads); } \
+    ORC_EXPORT void ref_destroy##S(void* h) { delete static_cast<BvhN<T, D>*>(h); }                     \
+    ORC_EXPORT size_t ref_node_count##S(const void* h) { return static_cast<const BvhN<T, D>*>(h)->nodes.size(); } \
+    ORC_EXPORT size_t ref_prim_count##S(const void* h) { return static_cast<const BvhN<T, D>*>(h)->prim_ids.size(); } \
+    ORC_EXPORT void ref_get_nodes##S(const void* h, void* out) { get_nodes<T, D>(static_cast<const BvhN<T, D>*>(h), out); } \
     ORC_EXPORT void ref_get_prim_ids##S(const void* h, uint64_t* out) {                                \
-        auto b = static_cast<const Bvh3<T>*>(h);                                                        \
+        auto b = static_cast<const BvhN<T, D>*>(h);                                                     \
         for (size_t i = 0; i < b->prim_ids.size(); ++i) out[i] = b->prim_ids[i]; }                      \
     ORC_EXPORT void* ref_from_arrays##S(const void* nodes, size_t nn, const uint64_t* ids, size_t np) { \
-        return from_arrays<T>(nodes, nn, ids, np); }                                                    \
+        return from_arrays<T, D>(nodes, nn, ids, np); }                                                 \
     ORC_EXPORT size_t ref_serialize##S(const void* h, uint8_t* out, size_t cap) {                       \
-        return serialize<T>(static_cast<const Bvh3<T>*>(h), out, cap); }                                \
-    ORC_EXPORT void ref_optimize##S(void* h, int threads) { optimize<T>(static_cast<Bvh3<T>*>(h), threads); } \
+        return serialize<T, D>(static_cast<const BvhN<T, D>*>(h), out, cap); }                          \
+    ORC_EXPORT void ref_optimize##S(void* h, int threads) { optimize<T, D>(static_cast<BvhN<T, D>*>(h), threads); } \
     ORC_EXPORT void* ref_extract##S(const void* h, size_t root) {                                       \
-        return new Bvh3<T>(static_cast<const Bvh3<T>*>(h)->extract_bvh(root)); }                        \
-    ORC_EXPORT void ref_refit##S(void* h) { static_cast<Bvh3<T>*>(h)->refit(); }                        \
+        return new BvhN<T, D>(static_cast<const BvhN<T, D>*>(h)->extract_bvh(root)); }                  \
+    ORC_EXPORT void ref_refit##S(void* h) { static_cast<BvhN<T, D>*>(h)->refit(); }                     \
+    ORC_EXPORT void ref_sphere_bboxes##S(const T* sph, size_t n, T* bb, T* cc) { sphere_bboxes<T, D>(sph, n, bb, cc); } \
+    ORC_EXPORT void ref_intersect_sphere##S(const void* h, const T* sph, const T* rays, size_t nrays,   \
+        int any, int robust, int threads, HitOf<T>::Type* out, uint64_t* counters) {                    \
+        DISPATCH_SPHERE(T, D, any, robust, static_cast<const BvhN<T, D>*>(h), sph, rays, nrays,         \
+                        threads, out, counters); }
+
+/* triangles exist in 3D only (tri.h:30-74) */
+#define REF_IMPL_TRI(T, S)                                                                              \
     ORC_EXPORT void ref_prep_tris##S(const T* t9, size_t n, T* bb, T* cc) { prep_tris<T>(t9, n, bb, cc); } \
     ORC_EXPORT void ref_precompute_tris##S(const T* t9, const uint64_t* perm, size_t n, T* out12) {     \
         precompute_tris<T>(t9, perm, n, out12); }                                                       \
-    ORC_EXPORT void ref_sphere_bboxes##S(const T* s4, size_t n, T* bb, T* cc) { sphere_bboxes<T>(s4, n, bb, cc); } \
     ORC_EXPORT void ref_intersect_tri##S(const void* h, const T* tris12, const T* rays8, size_t nrays,  \
         int any, int robust, int threads, HitOf<T>::Type* out, uint64_t* counters) {                    \
         DISPATCH4(intersect_tri, T, any, robust, static_cast<const Bvh3<T>*>(h), tris12, rays8, nrays,  \
-                  threads, out, counters); }                                                            \
-    ORC_EXPORT void ref_intersect_sphere##S(const void* h, const T* sph4, const T* rays8, size_t nrays, \
-        int any, int robust, int threads, HitOf<T>::Type* out, uint64_t* counters) {                    \
-        DISPATCH4(intersect_sphere, T, any, robust, static_cast<const Bvh3<T>*>(h), sph4, rays8, nrays, \
                   threads, out, counters); }
 
-REF_IMPL(float, 3f)
-REF_IMPL(double, 3d)
+REF_IMPL(float, 3, 3f)
+REF_IMPL(double, 3, 3d)
+REF_IMPL(float, 2, 2f)
+REF_IMPL(double, 2, 2d)
+REF_IMPL_TRI(float, 3f)
+REF_IMPL_TRI(double, 3d)
 
 ORC_EXPORT int ref_hardware_threads(void) { return static_cast<int>(std::thread::hardware_concurrency()); }
 
