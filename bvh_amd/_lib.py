@@ -32,6 +32,14 @@ class BBox3d(C.Structure):
     _fields_ = [("v", C.c_double * 6)]
 
 
+class BBox2f(C.Structure):
+    _fields_ = [("v", C.c_float * 4)]
+
+
+class BBox2d(C.Structure):
+    _fields_ = [("v", C.c_double * 4)]
+
+
 # name -> (restype, argtypes); `{S}` expands to 3f / 3d
 _P, _Z, _I, _U = C.c_void_p, C.c_size_t, C.c_int, C.c_uint
 _SIGS = {
@@ -93,11 +101,14 @@ _SIGS_T = {
 }
 
 
+_ONLY_3D = ("bvh_amd_tri_bounds{S}", "bvh_amd_precompute_tris{S}", "bvh{S}_intersect_rays_tri")     # tri.h is 3D only
+
+
 def exported_symbols():
     """Every symbol include/bvh_amd.h declares."""
     names = list(_SIGS)
-    for s in ("3f", "3d"):
-        names += [k.format(S=s) for k in _SIGS_T]
+    for s in ("3f", "3d", "2f", "2d"):
+        names += [k.format(S=s) for k in _SIGS_T if s[0] == "3" or k not in _ONLY_3D]
         names += [f"bvh_node{s}_get_bbox"]
     return names
 
@@ -116,12 +127,16 @@ def load():
     for name, (res, args) in _SIGS.items():
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
-    for s in ("3f", "3d"):
+    for s in ("3f", "3d", "2f", "2d"):
         for name, (res, args) in _SIGS_T.items():
+            if s[0] == "2" and name in _ONLY_3D:
+                continue
             f = getattr(lib, name.format(S=s))
             f.restype, f.argtypes = res, args
     lib.bvh_node3f_get_bbox.restype, lib.bvh_node3f_get_bbox.argtypes = BBox3f, [_P]
     lib.bvh_node3d_get_bbox.restype, lib.bvh_node3d_get_bbox.argtypes = BBox3d, [_P]
+    lib.bvh_node2f_get_bbox.restype, lib.bvh_node2f_get_bbox.argtypes = BBox2f, [_P]
+    lib.bvh_node2d_get_bbox.restype, lib.bvh_node2d_get_bbox.argtypes = BBox2d, [_P]
     _lib = lib
     return lib
 

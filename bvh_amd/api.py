@@ -14,6 +14,9 @@ HITF = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 HITD = np.dtype([("prim", "<u4"), ("pad", "<u4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8")])
 NODEF = np.dtype([("bounds", "<f4", (6,)), ("index", "<u4")])     # reference node.h:31-37
 NODED = np.dtype([("bounds", "<f8", (6,)), ("index", "<u8")])
+NODE2F = np.dtype([("bounds", "<f4", (4,)), ("index", "<u4")])    # Node<float, 2>: {minx,maxx,miny,maxy}, index
+NODE2D = np.dtype([("bounds", "<f8", (4,)), ("index", "<u8")])
+_NODE_DTYPES = {"3f": NODEF, "3d": NODED, "2f": NODE2F, "2d": NODE2D}
 
 
 class Quality(enum.IntEnum):          # default_builder.h:21
@@ -61,12 +64,14 @@ def _torch():
     return torch
 
 
-def _suffix(dtype) -> str:
+def _suffix(dtype, dim: int = 3) -> str:
     import torch
+    if dim not in (2, 3):
+        raise ValueError("BVHs are 2- or 3-dimensional")
     if dtype in (torch.float32, np.float32, np.dtype(np.float32)):
-        return "3f"
+        return f"{dim}f"
     if dtype in (torch.float64, np.float64, np.dtype(np.float64)):
-        return "3d"
+        return f"{dim}d"
     raise TypeError(f"unsupported scalar type {dtype}")
 
 
@@ -88,7 +93,7 @@ def _stream():
 
 
 class Bvh:
-    """bvh::v2::Bvh<Node<T,3>> (bvh.h:17-89): host mirror in the reference layout + device-resident copy."""
+    """bvh::v2::Bvh<Node<T,3>> or Bvh<Node<T,2>> (bvh.h:17-89): host mirror in the reference layout + device-resident copy."""
 
     def __init__(self, handle, suffix: str):
         if not handle:
@@ -106,7 +111,11 @@ class Bvh:
 
     @property
     def dtype(self):
-        return np.float32 if self._s == "3f" else np.float64
+        return np.float32 if self._s[1] == "f" else np.float64
+
+    @property
+    def dim(self) -> int:
+        return int(self._s[0])
 
     @property
     def node_count(self) -> int:
@@ -118,7 +127,7 @@ class Bvh:
 
     @property
     def nodes(self) -> np.ndarray:
-        out = np.empty(self.node_count, dtype=NODEF if self._s == "3f" else NODED)
+        out = np.empty(self.node_count, dtype=_NODE_DTYPES[self._s])
         self._f("bvh{S}_copy_nodes")(self._h, out.ctypes.data_as(C.c_void_p))
         return out
 
@@ -158,8 +167,8 @@ class Bvh:
     def set_node_bbox(self, node_id: int, lo, hi):
         """bvh_nodeXX_set_bbox on the host mirror (takes effect on the device at the next refit()/sync_device())."""
         node = self._f("bvh{S}_get_node")(self._h, node_id)
-        ct = C.c_float if self._s == "3f" else C.c_double
-        bb = (ct * 6)(*[float(v) for v in list(lo) + list(hi)])
+        ct = C.c_float if self._s[1] == "f" else C.c_double
+        bb = (ct * (2 * self.dim))(*[float(v) for v in list(lo) + list(hi)])
         self._f("bvh_node{S}_set_bbox")(node, bb)
 
     def sync_device(self):
@@ -175,8 +184,8 @@ class Bvh:
         return buf.raw
 
     @staticmethod
-    def deserialize(data: bytes, dtype=np.float32) -> "Bvh":   # bvh.h:231-243
-        s = _suffix(np.dtype(dtype))
+    def deserialize(data: bytes, dtype=np.float32, dim: int = 3) -> "Bvh":   # bvh.h:231-243
+        s = _suffix(np.dtype(dtype), dim)
         lib = _lib.load()
         _torch()
         return Bvh(getattr(lib, f"bvh{s}_deserialize")(data, len(data)), s)
@@ -188,7 +197,7 @@ class Bvh:
 
     @staticmethod
     def from_nodes(nodes: np.ndarray, prim_ids: np.ndarray) -> "Bvh":
-        s = "3f" if nodes.dtype.itemsize == 28 else "3d"
+        s = {28: "3f", 56: "3d", 20: "2f", 40: "2d"}[nodes.dtype.itemsize]
         lib = _lib.load()
         _torch()
         nodes = np.ascontiguousarray(nodes)
@@ -199,11 +208,12 @@ class Bvh:
 
 def _build(bboxes, centers, config: Config, builder: _Builder) -> Bvh:
     lib = _lib.load()
-    bb = _dev(bboxes, 6)
-    cc = _dev(centers, 3)
+    dim = int(np.shape(centers)[-1])                          # (n,6) + (n,3), or (n,4) {min.x,min.y,max.x,max.y} + (n,2)
+    bb = _dev(bboxes, 2 * dim)
+    cc = _dev(centers, dim)
     if bb.dtype != cc.dtype or bb.shape[0] != cc.shape[0]:
-        raise ValueError("bboxes (n,6) and centers (n,3) must agree in dtype and length")
-    s = _suffix(bb.dtype)
+        raise ValueError("bboxes (n, 2 dim) and centers (n, dim) must agree in dtype and length")
+    s = _suffix(bb.dtype, dim)
     cfg = config._c()
     h = getattr(lib, f"bvh{s}_build_device")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), int(builder), _stream())
     return Bvh(h, s)
@@ -267,11 +277,14 @@ def precompute_tris(tris9, perm=None):
 
 
 def sphere_bounds(sph4):
+    """Sphere::get_bbox / get_center (sphere.h:24-27): (n,4) spheres {center, radius} -> (n,6), (n,3); (n,3) circles
+    {center.x, center.y, radius} -> (n,4) {min.x,min.y,max.x,max.y}, (n,2)."""
     torch = _torch()
-    t = _dev(sph4, 4)
-    s = _suffix(t.dtype)
-    bb = torch.empty((t.shape[0], 6), dtype=t.dtype, device=t.device)
-    cc = torch.empty((t.shape[0], 3), dtype=t.dtype, device=t.device)
+    dim = int(np.shape(sph4)[-1]) - 1
+    t = _dev(sph4, dim + 1)
+    s = _suffix(t.dtype, dim)
+    bb = torch.empty((t.shape[0], 2 * dim), dtype=t.dtype, device=t.device)
+    cc = torch.empty((t.shape[0], dim), dtype=t.dtype, device=t.device)
     _lib.check(getattr(_lib.load(), f"bvh_amd_sphere_bounds{s}")(t.data_ptr(), t.shape[0], bb.data_ptr(), cc.data_ptr(), _stream()),
                "sphere_bounds")
     return bb, cc
@@ -320,9 +333,11 @@ def intersect(bvh: Bvh, prims, rays, any_hit: bool = False, robust: bool = False
     torch = _torch()
     lib = _lib.load()
     s = bvh._s
-    dt = torch.float32 if s == "3f" else torch.float64
-    r = _dev(rays, 8)
+    dt = torch.float32 if s[1] == "f" else torch.float64
+    r = _dev(rays, 2 * bvh.dim + 2)                           # {org, dir, tmin, tmax}
     p = _dev(prims)
+    if bvh.dim == 2:
+        leaf = "sphere"                                       # circles {center.x, center.y, radius}: the only 2D leaf (sphere.h)
     if r.dtype != dt or p.dtype != dt:
         raise TypeError("prims/rays dtype must match the BVH scalar type")
     n = r.shape[0]

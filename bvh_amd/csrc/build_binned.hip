@@ -85,18 +85,18 @@ __global__ void __launch_bounds__(64) k_decide(BuildCtx<T> c, uint32_t n_active)
     SlotState<T>& st = c.state[slot];
     const ANode<T>& nd = c.nodes[st.node];
     const SlotBins<T>& b = c.bins[slot];
-    const int wide = widest_axis(nd.lo, nd.hi);
+    const int wide = widest_axis(nd.lo, nd.hi, c.dim);
     uint32_t best_bin = kBins / 2; T best_cost = Ord<T>::kMax; int best_axis = wide;     // :132-133
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < c.dim; ++k) {
         T cost; uint32_t bin;
         sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
             for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(b.lo[k][i][j]); hi[j] = Ord<T>::dec(b.hi[k][i][j]); }
             n = b.cnt[k][i];
-        }, cost, bin);
+        }, cost, bin, c.dim);
         if (cost < best_cost) { best_cost = cost; best_bin = bin; best_axis = k; }
     }
     const uint32_t size = nd.end - nd.begin;
-    const T stay = half_area(nd.lo, nd.hi) * (static_cast<T>(size) - T(1));              // split_heuristic.h:36-38
+    const T stay = half_area(nd.lo, nd.hi, c.dim) * (static_cast<T>(size) - T(1));       // split_heuristic.h:36-38
     st.wide = wide;
     st.axis = best_axis;
     if (best_cost >= stay) {
@@ -280,25 +280,26 @@ __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) 
             }
             // ---- find_best_split: lane k sweeps axis k
             wave_sync();
-            if (lane < 3) {
+            if (lane < c.dim) {
                 T cost; uint32_t bin;
                 const int k = lane;
                 sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
                     for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(L.lo[k][i][j]); hi[j] = Ord<T>::dec(L.hi[k][i][j]); }
                     n = L.cnt[k][i];
-                }, cost, bin);
+                }, cost, bin, c.dim);
                 L.axis_cost[k] = cost;
                 L.axis_bin[k] = bin;
             }
             wave_sync();
-            const int wide = widest_axis(nlo, nhi);
+            const int wide = widest_axis(nlo, nhi, c.dim);
             uint32_t best_bin = kBins / 2; T best_cost = Ord<T>::kMax; int best_axis = wide;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
+                if (k >= c.dim) continue;
                 const T cst = L.axis_cost[k];
                 if (cst < best_cost) { best_cost = cst; best_bin = L.axis_bin[k]; best_axis = k; }
             }
-            const T stay = half_area(nlo, nhi) * (static_cast<T>(cnt) - T(1));
+            const T stay = half_area(nlo, nhi, c.dim) * (static_cast<T>(cnt) - T(1));
             bool fallback = false;
             if (best_cost >= stay) {
                 if (cnt > c.max_leaf) fallback = true;        // else: leaf
@@ -387,7 +388,7 @@ __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) 
                         hi[q][k] = Ord<T>::zero(__shfl(Ord<T>::sign(bhi[k]), 63 - __clzll(zm)));
                     }
                 }
-            const int first = half_area(lo[0], hi[0]) < half_area(lo[1], hi[1]) ? 1 : 0;   // SATO
+            const int first = half_area(lo[0], hi[0], c.dim) < half_area(lo[1], hi[1], c.dim) ? 1 : 0;   // SATO
             const uint32_t child = ncount;
             ncount += 2;
             const uint32_t rb[2] = { lb, cut }, re[2] = { cut, le };
@@ -536,6 +537,7 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
         BuildCtx<T> c;
         c.bboxes = d_bboxes; c.centers = d_centers;
         c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
+        c.dim = out.dim;
         int rc = ws.alloc(c, static_cast<uint32_t>(n), 1, attempt, true);
         if (rc) return rc;
         hipLaunchKernelGGL(k_prepare_root<T>, dim3(1), dim3(1), 0, stream, c);

@@ -53,15 +53,19 @@ template <> struct Ord<double> {
 template <typename T> __device__ inline T pick_min(T a, T b) { return a < b ? a : b; }    // utils.h:41-43
 template <typename T> __device__ inline T pick_max(T a, T b) { return a > b ? a : b; }
 
-template <typename T> __device__ inline T half_area(const T* lo, const T* hi) {            // bbox.h:32-38
+// 2D builds (`2f` / `2d` families, Node<T, 2>) run the same kernels on three-wide data with z = 0 everywhere: the z lanes of
+// every box stay (+0, +0) and are inert; only the DECISIONS know the dimension: the half area (bbox.h:32-38: d0 + d1 in
+// 2D), the widest axis, and which axes are candidates for a split.
+template <typename T> __device__ inline T half_area(const T* lo, const T* hi, int dim = 3) {   // bbox.h:32-38
     T d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+    if (dim == 2) return d0 + d1;
     return (d0 + d1) * d2 + d0 * d1;
 }
-template <typename T> __device__ inline int widest_axis(const T* lo, const T* hi) {        // vec.h:23-33
+template <typename T> __device__ inline int widest_axis(const T* lo, const T* hi, int dim = 3) {   // vec.h:23-33
     T d[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] };
     int axis = 0;
     if (d[1] > d[axis]) axis = 1;
-    if (d[2] > d[axis]) axis = 2;
+    if (dim > 2 && d[2] > d[axis]) axis = 2;
     return axis;
 }
 // min(BinCount - 1, size_t(max(pos, 0)))  (binned_sah_builder.h:94-95); NaN -> 0, +inf saturates to 7.
@@ -118,6 +122,7 @@ struct BuildCtx {
     uint32_t* ids;
     uint32_t n;
     uint32_t min_leaf, max_leaf;
+    int dim = 3;                         // 2: Node<T, 2> semantics on z = 0 data (see half_area)
     ANode<T>* nodes;
     uint32_t node_cap;
     SlotBins<T>* bins;
@@ -198,7 +203,7 @@ __device__ void partial_sort_replay(uint32_t* a, long middle, long last, KeyFn k
 // Starts from (FLT_MAX, -) and reports the first strict minimum; combining axes 0,1,2 with strict `<`
 // afterwards equals the reference's carried `best_split`.
 template <typename T, typename LoadBin>
-__device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin) {
+__device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin, int dim) {
     T right_cost[kBins];
     {
         T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
@@ -210,7 +215,7 @@ __device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin
 #pragma unroll
             for (int k = 0; k < 3; ++k) { lo[k] = pick_min(lo[k], blo[k]); hi[k] = pick_max(hi[k], bhi[k]); }
             cnt += bc;
-            right_cost[i] = half_area(lo, hi) * static_cast<T>(cnt);
+            right_cost[i] = half_area(lo, hi, dim) * static_cast<T>(cnt);
         }
     }
     best_cost = Ord<T>::kMax;
@@ -224,7 +229,7 @@ __device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin
 #pragma unroll
         for (int k = 0; k < 3; ++k) { lo[k] = pick_min(lo[k], blo[k]); hi[k] = pick_max(hi[k], bhi[k]); }
         cnt += bc;
-        T cost = half_area(lo, hi) * static_cast<T>(cnt) + right_cost[i + 1];
+        T cost = half_area(lo, hi, dim) * static_cast<T>(cnt) + right_cost[i + 1];
         if (cost < best_cost) { best_cost = cost; best_bin = i + 1; }
     }
 }
@@ -483,7 +488,7 @@ __global__ void __launch_bounds__(64) k_finalize(BuildCtx<T> c, uint32_t n_activ
         for (int k = 0; k < 3; ++k) { lo[s][k] = decode_bound<T>(st.clo[s][k], st.zlo[s][k]); hi[s][k] = decode_bound<T>(st.chi[s][k], st.zhi[s][k]); }
     uint32_t rb[2] = { nd.begin, st.split }, re[2] = { st.split, nd.end };
     int first = 0;
-    if (half_area(lo[0], hi[0]) < half_area(lo[1], hi[1])) first = 1;                      // :105-108
+    if (half_area(lo[0], hi[0], c.dim) < half_area(lo[1], hi[1], c.dim)) first = 1;        // :105-108
     const uint32_t child = atomicAdd(&c.counters->n_nodes, 2u);
     if (child + 2 > c.node_cap) { atomicOr(&c.counters->error, 2u); return; }
     nd.child = child;
@@ -558,6 +563,7 @@ int finish_build(BvhImpl<T>& out, DevBuf<HostNode<T>>& final_nodes, uint32_t* d_
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
     if (out.d_nodes) (void)hipFree(out.d_nodes);
     out.d_nodes = final_nodes.p;
+    out.d_nodes_count = out.node_count;
     final_nodes.p = nullptr;
     out.root_index = static_cast<uint32_t>(root.index);
     for (int k = 0; k < 6; ++k) out.root_bounds[k] = root.bounds[k];

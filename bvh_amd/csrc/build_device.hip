@@ -25,7 +25,14 @@ int build_on_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size
     if (builder == BVH_AMD_BUILDER_SWEEP) return build_sweep_device<T>(out, d_bboxes, d_centers, n, cfg, false, stream);
     if (builder == BVH_AMD_BUILDER_DEFAULT_SERIAL)            // Medium: sweep; High: sweep + reinsertion (default_builder.h:56-60)
         return build_sweep_device<T>(out, d_bboxes, d_centers, n, cfg, cfg.quality == BVH_BUILD_QUALITY_HIGH, stream);
-    if (builder == BVH_AMD_BUILDER_DEFAULT_PARALLEL) return build_minitree_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
+    if (builder == BVH_AMD_BUILDER_DEFAULT_PARALLEL) {
+        // 2D: the reference's mini-tree builder reads p[2] of a 2D vector (mini_tree_builder.h:183), undefined behaviour
+        // that no implementation can reproduce; refused loudly instead of guessed
+        if (out.dim == 2)
+            return fail(BVH_AMD_ERR_UNSUPPORTED, "build: 2D BVHs have no defined thread-pool build at or above parallel_threshold "
+                                                  "(the reference reads the third component of 2D points); pass pool = NULL");
+        return build_minitree_device<T>(out, d_bboxes, d_centers, n, cfg, stream);
+    }
     return fail(BVH_AMD_ERR_ARG, "build: unknown builder");
 }
 

@@ -27,7 +27,7 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
                                DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream);
 template <typename T>
 int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_leaf, uint32_t max_leaf,
-               DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& ord, size_t& total_nodes, hipStream_t stream);
+               DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& ord, size_t& total_nodes, hipStream_t stream, int dim);
 
 namespace {
 
@@ -348,7 +348,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     DevBuf<HostNode<T>> top;
     DevBuf<uint32_t> top_ord;
     size_t top_count = 0;
-    rc = sweep_core<T>(top_boxes.p, top_centers.p, n_cuts, 1, 1, top, top_ord, top_count, stream);
+    rc = sweep_core<T>(top_boxes.p, top_centers.p, n_cuts, 1, 1, top, top_ord, top_count, stream, 3);
     if (rc) return rc;
     if (top_count != ea.top_nodes) return fail(BVH_AMD_ERR_OVERFLOW, "build: unexpected top-level node count");
     hipLaunchKernelGGL(k_splice_top<T>, dim3((ea.top_nodes + 255) / 256), dim3(256), 0, stream, top.p, top_ord.p, ea.top_nodes, cut_roots.p,
@@ -358,7 +358,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     return BVH_AMD_OK;
 }
 
-template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim);
 
 // DefaultBuilder::build(pool, ...): mini-trees, plus the reinsertion pass at Quality::High (default_builder.h:41-44, :65-73).
 template <typename T>
@@ -372,7 +372,7 @@ int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers
     int rc = minitree_core<T>(d_bboxes, d_centers, n, cfg, prune, ratio, final_nodes, final_ids, total_nodes, stream);
     if (rc) return rc;
     if (cfg.quality == BVH_BUILD_QUALITY_HIGH) {
-        rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream);
+        rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream, 3);
         if (rc) return rc;
     }
     out.node_count = total_nodes;

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kScanThreads) k_sweep_axis(SweepCtx<T> c) {
         const uint32_t pos = e - 1 - (in ? r : 0);
         Box6<T> v = in ? load_box(c.b.bboxes, ord[pos]) : empty_box<T>();
         v = block_scan_boxes(v, carry, wtot);
-        if (in && pos > b) cost_r[pos] = half_area(v.lo, v.hi) * static_cast<T>(e - pos);
+        if (in && pos > b) cost_r[pos] = half_area(v.lo, v.hi, c.b.dim) * static_cast<T>(e - pos);
     }
     __syncthreads();
     // left-to-right: cost(i) = half_area(box[b, i]) * (i + 1 - b) + cost_r[i + 1], split position i + 1
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(kScanThreads) k_sweep_axis(SweepCtx<T> c) {
         Box6<T> v = in ? load_box(c.b.bboxes, ord[pos]) : empty_box<T>();
         v = block_scan_boxes(v, carry, wtot);
         if (in && pos + 1 < e) {
-            const T cost = half_area(v.lo, v.hi) * static_cast<T>(pos + 1 - b) + cost_r[pos + 1];
+            const T cost = half_area(v.lo, v.hi, c.b.dim) * static_cast<T>(pos + 1 - b) + cost_r[pos + 1];
             if (cost < best) { best = cost; best_pos = pos + 1; }          // earlier positions win ties (strict <)
         }
     }
@@ -155,15 +155,15 @@ __global__ void __launch_bounds__(64) k_sweep_decide(SweepCtx<T> c, uint32_t n_a
     SlotState<T>& st = c.b.state[slot];
     const ANode<T>& nd = c.b.nodes[st.node];
     const uint32_t size = nd.end - nd.begin;
-    const T stay = half_area(nd.lo, nd.hi) * (static_cast<T>(size) - T(1));
+    const T stay = half_area(nd.lo, nd.hi, c.b.dim) * (static_cast<T>(size) - T(1));
     uint32_t pos = (nd.begin + nd.end + 1) / 2; T cost = stay; uint32_t axis = 0;     // :111
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < c.b.dim; ++k) {
         const AxisBest<T> ab = c.axis_best[3 * slot + k];
         if (ab.cost < cost) { cost = ab.cost; pos = ab.pos; axis = k; }
     }
     if (cost >= stay) {                                       // size > 64 > max_leaf_size: median on the widest axis (:122-123)
         pos = (nd.begin + nd.end + 1) / 2;
-        axis = widest_axis(nd.lo, nd.hi);
+        axis = widest_axis(nd.lo, nd.hi, c.b.dim);
     }
     st.split = pos;
     st.axis = axis;
@@ -303,10 +303,11 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
         uint32_t cut = 0;
 
         if (cnt > c.b.min_leaf) {
-            const T stay = half_area(nlo, nhi) * (static_cast<T>(cnt) - T(1));
+            const T stay = half_area(nlo, nhi, c.b.dim) * (static_cast<T>(cnt) - T(1));
             uint32_t best_pos = (B + lb + B + le + 1) / 2 - B; T best_cost = stay; uint32_t best_axis = 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
+                if (k >= c.b.dim) continue;                   // (wave-uniform)
                 const int src = L.perm[k][lane];
                 Box6<T> v;
 #pragma unroll
@@ -324,12 +325,12 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
                     for (int q = 0; q < 3; ++q) { o.lo[q] = __shfl_up(pre.lo[q], off); o.hi[q] = __shfl_up(pre.hi[q], off); }
                     if (lane >= off) pre = join(o, pre);
                 }
-                const T cr = half_area(suf.lo, suf.hi) * static_cast<T>(le - uint32_t(lane));    // cost of [lane, le)
+                const T cr = half_area(suf.lo, suf.hi, c.b.dim) * static_cast<T>(le - uint32_t(lane));    // cost of [lane, le)
                 const T cr_next = __shfl_down(cr, 1);
                 T cost = __builtin_inff();
                 uint32_t pos = 0xFFFFFFFFu;
                 if (in && uint32_t(lane) + 1 < le) {
-                    const T cl = half_area(pre.lo, pre.hi) * static_cast<T>(uint32_t(lane) + 1 - lb);
+                    const T cl = half_area(pre.lo, pre.hi, c.b.dim) * static_cast<T>(uint32_t(lane) + 1 - lb);
                     const T tot = cl + cr_next;
                     if (tot < cost) { cost = tot; pos = lane + 1; }
                 }
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
             bool do_split = true;
             if (best_cost >= stay) {
                 if (cnt <= c.b.max_leaf) do_split = false;
-                else { best_pos = (B + lb + B + le + 1) / 2 - B; best_axis = widest_axis(nlo, nhi); }
+                else { best_pos = (B + lb + B + le + 1) / 2 - B; best_axis = widest_axis(nlo, nhi, c.b.dim); }
             }
             if (do_split) {
                 // mark_primitives + stable_partition of the other two axes
@@ -404,7 +405,7 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
                         hi[q][k] = Ord<T>::zero(__shfl(Ord<T>::sign(phi[k]), 63 - __clzll(zm)));
                     }
                 }
-            const int first = half_area(lo[0], hi[0]) < half_area(lo[1], hi[1]) ? 1 : 0;
+            const int first = half_area(lo[0], hi[0], c.b.dim) < half_area(lo[1], hi[1], c.b.dim) ? 1 : 0;
             const uint32_t child = ncount;
             ncount += 2;
             const uint32_t rb[2] = { lb, cut }, re[2] = { cut, le };
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
 // SweepSahBuilder core: nodes in the reference layout into `final_nodes`, prim ids (= the axis-0 order) in ord[0..n).
 template <typename T>
 int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_leaf, uint32_t max_leaf,
-               DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& ord, size_t& total_nodes, hipStream_t stream)
+               DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& ord, size_t& total_nodes, hipStream_t stream, int dim)
 {
     if (n >= (size_t{1} << 28)) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: more than 2^28 primitives");
     const uint32_t n32 = static_cast<uint32_t>(n);
@@ -470,6 +471,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         BuildCtx<T>& c = sc.b;
         c.bboxes = d_bboxes; c.centers = d_centers; c.ids = ord.p; c.n = n32;
         c.min_leaf = min_leaf; c.max_leaf = max_leaf;
+        c.dim = dim;
         c.nodes = nodes.p; c.node_cap = node_cap; c.bins = nullptr; c.state = st_a.p; c.state_next = st_b.p; c.slot_cap = slot_cap;
         c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = nullptr;
         c.ltab = nullptr; c.rtab = nullptr; c.small_list = small_list.p; c.stage = stage.p; c.counters = counters.p;
@@ -526,7 +528,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
 }
 
 // SweepSahBuilder::build on the device.
-template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim);
 
 template <typename T>
 int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
@@ -537,18 +539,18 @@ int build_sweep_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, s
     DevBuf<uint32_t> ord;
     size_t total_nodes = 0;
     int rc = sweep_core<T>(d_bboxes, d_centers, n, static_cast<uint32_t>(cfg.min_leaf_size), static_cast<uint32_t>(cfg.max_leaf_size),
-                           final_nodes, ord, total_nodes, stream);
+                           final_nodes, ord, total_nodes, stream, out.dim);
     if (rc) return rc;
     if (optimize) {                                           // DefaultBuilder serial High (default_builder.h:58-60)
-        rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream);
+        rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream, out.dim);
         if (rc) return rc;
     }
     out.node_count = total_nodes;
     return finish_build<T>(out, final_nodes, ord.p, n, stream, /*take_ids=*/false);
 }
 
-template int sweep_core<float>(const float*, const float*, size_t, uint32_t, uint32_t, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, size_t&, hipStream_t);
-template int sweep_core<double>(const double*, const double*, size_t, uint32_t, uint32_t, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, size_t&, hipStream_t);
+template int sweep_core<float>(const float*, const float*, size_t, uint32_t, uint32_t, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, size_t&, hipStream_t, int);
+template int sweep_core<double>(const double*, const double*, size_t, uint32_t, uint32_t, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, size_t&, hipStream_t, int);
 template int build_sweep_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, bool, hipStream_t);
 template int build_sweep_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, bool, hipStream_t);
 

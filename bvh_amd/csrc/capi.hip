@@ -7,7 +7,7 @@
 
 namespace bvh_amd {
 
-template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim);
 void reinsertion_stats(unsigned out[2]);
 template <typename T>
 int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_count, const uint32_t* d_ids, size_t root_id, hipStream_t stream);
@@ -153,9 +153,16 @@ typename CTypes<T>::Bvh* load(FILE* f) {
 template <typename T>
 int make_nodes_resident(BvhImpl<T>& b) {
     if (b.node_count == 0) return fail(BVH_AMD_ERR_ARG, "empty bvh");
+    if (b.dim == 2 && b.host_valid && b.nodes2_valid) b.widen_host();    // 2D: the caller edits the narrow mirror
     const size_t bytes = b.node_count * sizeof(HostNode<T>);
+    if (b.d_nodes && b.d_nodes_count != b.node_count) {        // nodes were appended / removed on the host
+        (void)hipFree(b.d_nodes);
+        b.d_nodes = nullptr;
+    }
     if (!b.d_nodes) {                                          // BVH came from the host (from_nodes / load): make it resident
+        if (!b.host_valid || b.nodes.size() != b.node_count) return fail(BVH_AMD_ERR_ARG, "the BVH has neither a resident nor a host copy of its nodes");
         BVH_HIP_TRY(hipMalloc(&b.d_nodes, bytes), BVH_AMD_ERR_HIP);
+        b.d_nodes_count = b.node_count;
         BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
     } else if (b.host_valid) {                                 // the host mirror may have been edited through bvh_node* pointers
         BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
@@ -166,9 +173,9 @@ int make_nodes_resident(BvhImpl<T>& b) {
 // Runs `op` (optimize / refit) on the resident reference-layout nodes, then refreshes the traversal records and (if it was
 // valid) the host mirror.
 template <typename T, typename Op>
-int on_resident_nodes(typename CTypes<T>::Bvh* bvh, Op op) {
-    if (!bvh) return fail(BVH_AMD_ERR_ARG, "null bvh");
-    BvhImpl<T>& b = *impl<T>(bvh);
+int on_resident_nodes(BvhImpl<T>* pb, Op op) {
+    if (!pb) return fail(BVH_AMD_ERR_ARG, "null bvh");
+    BvhImpl<T>& b = *pb;
     int rc = make_nodes_resident<T>(b);
     if (rc) return rc;
     const size_t bytes = b.node_count * sizeof(HostNode<T>);
@@ -181,34 +188,169 @@ int on_resident_nodes(typename CTypes<T>::Bvh* bvh, Op op) {
     b.root_index = static_cast<uint32_t>(root.index);
     for (int k = 0; k < 6; ++k) b.root_bounds[k] = root.bounds[k];
     if (b.host_valid) BVH_HIP_TRY(hipMemcpy(b.nodes.data(), b.d_nodes, bytes, hipMemcpyDeviceToHost), BVH_AMD_ERR_HIP);
+    b.nodes2_valid = false;
     return BVH_AMD_OK;
 }
 
-template <typename T> typename CTypes<T>::Bvh* extract(typename CTypes<T>::Bvh* bvh, size_t root_id) {
-    if (!bvh) { set_error("extract: null bvh"); return nullptr; }
-    BvhImpl<T>& b = *impl<T>(bvh);
+template <typename T> BvhImpl<T>* extract(BvhImpl<T>* pb, size_t root_id) {
+    if (!pb) { set_error("extract: null bvh"); return nullptr; }
+    BvhImpl<T>& b = *pb;
     if (make_nodes_resident<T>(b)) return nullptr;
     if (!b.d_prim_ids) { set_error("extract: the BVH has no device prim ids"); return nullptr; }
     auto out = std::make_unique<BvhImpl<T>>();
+    out->dim = b.dim;
     if (extract_device<T>(*out, b.d_nodes, b.node_count, b.d_prim_ids, root_id, nullptr)) return nullptr;
-    return reinterpret_cast<typename CTypes<T>::Bvh*>(out.release());
+    return out.release();
 }
 
-template <typename T> int optimize(typename CTypes<T>::Bvh* bvh) {
-    return on_resident_nodes<T>(bvh, [](HostNode<T>* d, size_t n) { return reinsertion_optimize_device<T>(d, n, nullptr); });
+template <typename T> int optimize(BvhImpl<T>* b) {
+    const int dim = b ? b->dim : 3;
+    return on_resident_nodes<T>(b, [dim](HostNode<T>* d, size_t n) { return reinsertion_optimize_device<T>(d, n, nullptr, dim); });
 }
-template <typename T> int refit(typename CTypes<T>::Bvh* bvh) {
-    return on_resident_nodes<T>(bvh, [](HostNode<T>* d, size_t n) { return refit_device<T>(d, n, nullptr); });
+template <typename T> int refit(BvhImpl<T>* b) {
+    return on_resident_nodes<T>(b, [](HostNode<T>* d, size_t n) { return refit_device<T>(d, n, nullptr); });
 }
 
 // Host-side edits (bvh_node* setters, append/remove) live in the mirror; this pushes them to the device copy.
-template <typename T> int sync_device(typename CTypes<T>::Bvh* bvh) {
-    if (!bvh) return fail(BVH_AMD_ERR_ARG, "sync_device: null bvh");
-    BvhImpl<T>& b = *impl<T>(bvh);
-    int rc = b.sync_host();
+template <typename T> int sync_device(BvhImpl<T>* pb) {
+    if (!pb) return fail(BVH_AMD_ERR_ARG, "sync_device: null bvh");
+    BvhImpl<T>& b = *pb;
+    int rc = b.dim == 2 ? b.sync_host2() : b.sync_host();
     if (rc) return rc;
+    if (b.dim == 2) b.widen_host();
     if (b.d_nodes) { (void)hipFree(b.d_nodes); b.d_nodes = nullptr; }
     return upload_bvh<T>(b, nullptr);
+}
+
+// ---- the 2D families (c_api/bvh.cpp:7-10): the same BvhImpl with dim = 2; inputs are widened to z = 0 on the device, the
+// host mirror the caller sees is BvhImpl::nodes2 in the reference's 20/40-byte layout ------------------------------------------
+template <typename T> struct CTypes2;
+template <> struct CTypes2<float>  { using Bvh = bvh2f; using Node = bvh_node2f; using BBox = bvh_bbox2f; using Vec = bvh_vec2f; using Ray = bvh_ray2f; };
+template <> struct CTypes2<double> { using Bvh = bvh2d; using Node = bvh_node2d; using BBox = bvh_bbox2d; using Vec = bvh_vec2d; using Ray = bvh_ray2d; };
+template <typename T> BvhImpl<T>* impl2(typename CTypes2<T>::Bvh* b) { return reinterpret_cast<BvhImpl<T>*>(b); }
+template <typename T> const BvhImpl<T>* impl2(const typename CTypes2<T>::Bvh* b) { return reinterpret_cast<const BvhImpl<T>*>(b); }
+template <typename T> typename CTypes2<T>::Bvh* handle2(BvhImpl<T>* b) { return reinterpret_cast<typename CTypes2<T>::Bvh*>(b); }
+
+template <typename T>
+typename CTypes2<T>::Bvh* build2_device(const T* d_bb4, const T* d_cc2, size_t n, const bvh_build_config* config, bvh_amd_builder builder, void* stream) {
+    if (!d_bb4 || !d_cc2 || n == 0) { set_error("build: empty input (the reference's behaviour is undefined for 0 primitives)"); return nullptr; }
+    bvh_build_config cfg = config ? *config : default_config();
+    if (cfg.min_leaf_size < 1 || cfg.min_leaf_size > cfg.max_leaf_size || cfg.max_leaf_size > 15) {
+        set_error("build: need 1 <= min_leaf_size <= max_leaf_size <= 15 (4-bit primitive count, index.h:38)");
+        return nullptr;
+    }
+    T *d_bb6 = nullptr, *d_cc3 = nullptr;
+    BVH_HIP_TRY_PTR(hipMalloc(&d_bb6, n * 6 * sizeof(T)));
+    hipError_t e = hipMalloc(&d_cc3, n * 3 * sizeof(T));
+    auto b = std::make_unique<BvhImpl<T>>();
+    b->dim = 2;
+    int rc = e == hipSuccess ? launch_widen_inputs<T>(d_bb4, d_cc2, n, d_bb6, d_cc3, static_cast<hipStream_t>(stream))
+                             : fail(BVH_AMD_ERR_HIP, std::string("build: ") + hipGetErrorString(e));
+    if (rc == BVH_AMD_OK) rc = build_on_device<T>(*b, d_bb6, d_cc3, n, cfg, builder, static_cast<hipStream_t>(stream));
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    (void)hipFree(d_bb6);
+    if (d_cc3) (void)hipFree(d_cc3);
+    return rc == BVH_AMD_OK ? handle2<T>(b.release()) : nullptr;
+}
+
+template <typename T>
+typename CTypes2<T>::Bvh* build2_host(bvh_thread_pool* pool, const typename CTypes2<T>::BBox* bboxes, const typename CTypes2<T>::Vec* centers, size_t n,
+                                      const bvh_build_config* config) {
+    if (!bboxes || !centers || n == 0) { set_error("build: empty input"); return nullptr; }
+    static_assert(sizeof(typename CTypes2<T>::BBox) == 4 * sizeof(T) && sizeof(typename CTypes2<T>::Vec) == 2 * sizeof(T));
+    T *d_bb = nullptr, *d_cc = nullptr;
+    BVH_HIP_TRY_PTR(hipMalloc(&d_bb, n * 4 * sizeof(T)));
+    hipError_t e = hipMalloc(&d_cc, n * 2 * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpy(d_bb, bboxes, n * 4 * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cc, centers, n * 2 * sizeof(T), hipMemcpyHostToDevice);
+    typename CTypes2<T>::Bvh* out = nullptr;
+    if (e == hipSuccess)
+        out = build2_device<T>(d_bb, d_cc, n, config, pool ? BVH_AMD_BUILDER_DEFAULT_PARALLEL : BVH_AMD_BUILDER_DEFAULT_SERIAL, nullptr);
+    else
+        set_error(std::string("build: ") + hipGetErrorString(e));
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d_bb);
+    if (d_cc) (void)hipFree(d_cc);
+    return out;
+}
+
+template <typename T>
+BvhImpl<T>* adopt_nodes2(const HostNode2<T>* nodes, size_t nn, std::vector<size_t>&& ids) {
+    auto b = std::make_unique<BvhImpl<T>>();
+    b->dim = 2;
+    b->nodes2.assign(nodes, nodes + nn);
+    b->widen_host();
+    b->prim_ids = std::move(ids);
+    if (upload_bvh<T>(*b, nullptr) != BVH_AMD_OK) return nullptr;
+    b->nodes2_valid = true;
+    return b.release();
+}
+
+template <typename T>
+typename CTypes2<T>::Bvh* from_nodes2(const void* nodes, size_t nn, const size_t* prim_ids, size_t np) {
+    if (!nodes || nn == 0 || (!prim_ids && np)) { set_error("from_nodes: null/empty input"); return nullptr; }
+    return handle2<T>(adopt_nodes2<T>(static_cast<const HostNode2<T>*>(nodes), nn, std::vector<size_t>(prim_ids, prim_ids + np)));
+}
+
+template <typename T>
+size_t stream_size2(const BvhImpl<T>& b) {
+    using I = typename IndexOf<T>::Type;
+    return 2 * sizeof(I) + b.node_count * sizeof(HostNode2<T>) + b.prim_count * sizeof(I);
+}
+
+template <typename T>
+size_t serialize2(const BvhImpl<T>& b, void* out, size_t cap) {           // bvh.h:221-229 with Node<T, 2> records
+    using I = typename IndexOf<T>::Type;
+    const size_t need = stream_size2(b);
+    if (!out || cap < need) return need;
+    if (b.sync_host2() != BVH_AMD_OK) return 0;
+    auto p = static_cast<uint8_t*>(out);
+    I hdr[2] = { static_cast<I>(b.nodes2.size()), static_cast<I>(b.prim_ids.size()) };
+    std::memcpy(p, hdr, sizeof(hdr)); p += sizeof(hdr);
+    std::memcpy(p, b.nodes2.data(), b.nodes2.size() * sizeof(HostNode2<T>)); p += b.nodes2.size() * sizeof(HostNode2<T>);
+    for (size_t id : b.prim_ids) { I v = static_cast<I>(id); std::memcpy(p, &v, sizeof(v)); p += sizeof(v); }
+    return need;
+}
+
+template <typename T>
+typename CTypes2<T>::Bvh* deserialize2(const void* bytes, size_t size) {
+    using I = typename IndexOf<T>::Type;
+    if (!bytes || size < 2 * sizeof(I)) { set_error("deserialize: truncated stream"); return nullptr; }
+    auto p = static_cast<const uint8_t*>(bytes);
+    I hdr[2];
+    std::memcpy(hdr, p, sizeof(hdr)); p += sizeof(hdr);
+    const size_t nn = hdr[0], np = hdr[1];
+    if (size < 2 * sizeof(I) + nn * sizeof(HostNode2<T>) + np * sizeof(I)) { set_error("deserialize: truncated stream"); return nullptr; }
+    std::vector<HostNode2<T>> nodes(nn);
+    std::memcpy(nodes.data(), p, nn * sizeof(HostNode2<T>)); p += nn * sizeof(HostNode2<T>);
+    std::vector<size_t> ids(np);
+    for (size_t i = 0; i < np; ++i) { I v; std::memcpy(&v, p, sizeof(v)); p += sizeof(v); ids[i] = static_cast<size_t>(v); }
+    return handle2<T>(adopt_nodes2<T>(nodes.data(), nn, std::move(ids)));
+}
+
+template <typename T>
+typename CTypes2<T>::Bvh* load2(FILE* f) {
+    using I = typename IndexOf<T>::Type;
+    I hdr[2] = {0, 0};
+    if (fread(hdr, sizeof(I), 2, f) != 2) { set_error("load: truncated stream"); return nullptr; }
+    std::vector<uint8_t> buf(2 * sizeof(I) + size_t(hdr[0]) * sizeof(HostNode2<T>) + size_t(hdr[1]) * sizeof(I));
+    std::memcpy(buf.data(), hdr, sizeof(hdr));
+    const size_t rest = buf.size() - sizeof(hdr);
+    if (fread(buf.data() + sizeof(hdr), 1, rest, f) != rest) { set_error("load: truncated stream"); return nullptr; }
+    return deserialize2<T>(buf.data(), buf.size());
+}
+
+template <typename T>
+int intersect2(const typename CTypes2<T>::Bvh* bvh, const T* d_circles3, const typename CTypes2<T>::Ray* d_rays, size_t n, unsigned flags,
+               typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, void* stream) {
+    if (!bvh) return fail(BVH_AMD_ERR_ARG, "intersect_rays: null bvh");
+    static_assert(sizeof(typename CTypes2<T>::Ray) == 6 * sizeof(T));
+    const BvhImpl<T>& b = *impl2<T>(bvh);
+    int cur = -1;
+    BVH_HIP_TRY(hipGetDevice(&cur), BVH_AMD_ERR_HIP);
+    if (cur != b.device) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH lives on another device than the current one");
+    return launch_traverse<T>(b, LEAF_SPHERE, d_circles3, reinterpret_cast<const T*>(d_rays), n, flags, d_hits, d_counters,
+                              static_cast<hipStream_t>(stream));
 }
 
 template <typename T>
@@ -273,13 +415,13 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_build_device(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,              \
                                   enum bvh_amd_builder builder, void* stream) {                                     \
         return build_device<T>(d_bb, d_cc, n, cfg, builder, stream); }                                              \
-    bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return extract<T>(b, root_id); }                          \
+    bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return handle<T>(extract<T>(impl<T>(b), root_id)); }      \
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes<T>(nodes, nn, ids, np); }                                                                 \
     void bvh##S##_destroy(bvh##S* b) { delete impl<T>(b); }                                                         \
-    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(b); }                                  \
-    void bvh##S##_refit(bvh##S* b) { (void)refit<T>(b); }                                                           \
-    int bvh##S##_sync_device(bvh##S* b) { return sync_device<T>(b); }                                                \
+    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(impl<T>(b)); }                         \
+    void bvh##S##_refit(bvh##S* b) { (void)refit<T>(impl<T>(b)); }                                                  \
+    int bvh##S##_sync_device(bvh##S* b) { return sync_device<T>(impl<T>(b)); }                                       \
     void bvh##S##_append_node(bvh##S* b) {                                                                          \
         if (impl<T>(b)->sync_host() != BVH_AMD_OK) return;                                                           \
         impl<T>(b)->nodes.emplace_back(); impl<T>(b)->node_count = impl<T>(b)->nodes.size(); }                       \
@@ -337,6 +479,72 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
 
 BVH_AMD_IMPL(float, 3f)
 BVH_AMD_IMPL(double, 3d)
+
+#define BVH_AMD_IMPL2(T, S)                                                                                         \
+    bvh##S* bvh##S##_build(bvh_thread_pool* pool, const bvh_bbox##S* bb, const bvh_vec##S* cc, size_t n,            \
+                           const bvh_build_config* cfg) { return build2_host<T>(pool, bb, cc, n, cfg); }            \
+    bvh##S* bvh##S##_build_device(const T* d_bb4, const T* d_cc2, size_t n, const bvh_build_config* cfg,            \
+                                  enum bvh_amd_builder builder, void* stream) {                                     \
+        return build2_device<T>(d_bb4, d_cc2, n, cfg, builder, stream); }                                           \
+    bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return handle2<T>(extract<T>(impl2<T>(b), root_id)); }    \
+    bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
+        return from_nodes2<T>(nodes, nn, ids, np); }                                                                \
+    void bvh##S##_destroy(bvh##S* b) { delete impl2<T>(b); }                                                        \
+    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(impl2<T>(b)); }                        \
+    void bvh##S##_refit(bvh##S* b) { (void)refit<T>(impl2<T>(b)); }                                                 \
+    int bvh##S##_sync_device(bvh##S* b) { return sync_device<T>(impl2<T>(b)); }                                      \
+    void bvh##S##_append_node(bvh##S* b) {                                                                          \
+        if (impl2<T>(b)->sync_host2() != BVH_AMD_OK) return;                                                         \
+        impl2<T>(b)->nodes2.emplace_back(); impl2<T>(b)->node_count = impl2<T>(b)->nodes2.size(); }                  \
+    void bvh##S##_remove_last_node(bvh##S* b) {                                                                     \
+        if (impl2<T>(b)->sync_host2() != BVH_AMD_OK || impl2<T>(b)->nodes2.empty()) return;                          \
+        impl2<T>(b)->nodes2.pop_back(); impl2<T>(b)->node_count = impl2<T>(b)->nodes2.size(); }                      \
+    void bvh_node##S##_set_prim_count(bvh_node##S* n, size_t c) {                                                   \
+        auto h = reinterpret_cast<HostNode2<T>*>(n);                                                                \
+        h->index = (h->index & ~static_cast<IndexOf<T>::Type>(kCountMask)) | (static_cast<IndexOf<T>::Type>(c) & kCountMask); } \
+    void bvh_node##S##_set_first_id(bvh_node##S* n, size_t f) {                                                     \
+        auto h = reinterpret_cast<HostNode2<T>*>(n);                                                                \
+        h->index = (static_cast<IndexOf<T>::Type>(f) << kCountBits) | (h->index & kCountMask); }                    \
+    void bvh_node##S##_set_bbox(bvh_node##S* n, const bvh_bbox##S* bb) {                                            \
+        auto h = reinterpret_cast<HostNode2<T>*>(n);                                                                \
+        h->bounds[0] = bb->min.x; h->bounds[1] = bb->max.x; h->bounds[2] = bb->min.y; h->bounds[3] = bb->max.y; }   \
+    void bvh##S##_save(const bvh##S* b, FILE* f) {                                                                  \
+        if (!b || !f) return;                                                                                        \
+        std::vector<uint8_t> buf(stream_size2(*impl2<T>(b)));                                                        \
+        serialize2(*impl2<T>(b), buf.data(), buf.size());                                                            \
+        fwrite(buf.data(), 1, buf.size(), f); }                                                                      \
+    bvh##S* bvh##S##_load(FILE* f) { return f ? load2<T>(f) : nullptr; }                                            \
+    size_t bvh##S##_serialize(const bvh##S* b, void* out, size_t cap) { return b ? serialize2<T>(*impl2<T>(b), out, cap) : 0; } \
+    bvh##S* bvh##S##_deserialize(const void* bytes, size_t size) { return deserialize2<T>(bytes, size); }           \
+    bvh_node##S* bvh##S##_get_node(bvh##S* b, size_t i) {                                                          \
+        if (impl2<T>(b)->sync_host2() != BVH_AMD_OK) return nullptr;                                                 \
+        return reinterpret_cast<bvh_node##S*>(&impl2<T>(b)->nodes2[i]); }                                            \
+    size_t bvh##S##_get_prim_id(const bvh##S* b, size_t i) {                                                        \
+        if (impl2<T>(b)->sync_host() != BVH_AMD_OK) return BVH_INVALID_PRIM_ID;                                      \
+        return impl2<T>(b)->prim_ids[i]; }                                                                           \
+    size_t bvh##S##_get_prim_count(const bvh##S* b) { return impl2<T>(b)->prim_count; }                             \
+    size_t bvh##S##_get_node_count(const bvh##S* b) { return impl2<T>(b)->node_count; }                             \
+    bool bvh_node##S##_is_leaf(const bvh_node##S* n) { return (reinterpret_cast<const HostNode2<T>*>(n)->index & kCountMask) != 0; } \
+    size_t bvh_node##S##_get_prim_count(const bvh_node##S* n) { return reinterpret_cast<const HostNode2<T>*>(n)->index & kCountMask; } \
+    size_t bvh_node##S##_get_first_id(const bvh_node##S* n) { return reinterpret_cast<const HostNode2<T>*>(n)->index >> kCountBits; } \
+    bvh_bbox##S bvh_node##S##_get_bbox(const bvh_node##S* n) {                                                      \
+        auto h = reinterpret_cast<const HostNode2<T>*>(n);                                                          \
+        bvh_bbox##S r; r.min.x = h->bounds[0]; r.max.x = h->bounds[1]; r.min.y = h->bounds[2]; r.max.y = h->bounds[3]; return r; } \
+    void bvh##S##_copy_nodes(const bvh##S* b, void* out) {                                                          \
+        if (impl2<T>(b)->sync_host2() != BVH_AMD_OK) return;                                                         \
+        std::memcpy(out, impl2<T>(b)->nodes2.data(), impl2<T>(b)->nodes2.size() * sizeof(HostNode2<T>)); }          \
+    void bvh##S##_copy_prim_ids(const bvh##S* b, size_t* out) {                                                     \
+        if (impl2<T>(b)->sync_host() != BVH_AMD_OK) return;                                                          \
+        std::memcpy(out, impl2<T>(b)->prim_ids.data(), impl2<T>(b)->prim_ids.size() * sizeof(size_t)); }            \
+    const uint32_t* bvh##S##_device_prim_ids(const bvh##S* b) { return impl2<T>(b)->d_prim_ids; }                   \
+    int bvh_amd_sphere_bounds##S(const T* c3, size_t n, T* bb4, T* cc2, void* s) {                                  \
+        return launch_circle_bounds<T>(c3, n, bb4, cc2, static_cast<hipStream_t>(s)); }                             \
+    int bvh##S##_intersect_rays_sphere(const bvh##S* b, const T* circles, const bvh_ray##S* rays, size_t n, unsigned flags, \
+                                       HitOf<T>::Type* hits, bvh_amd_counters* cnt, void* s) {                      \
+        return intersect2<T>(b, circles, rays, n, flags, hits, cnt, s); }
+
+BVH_AMD_IMPL2(float, 2f)
+BVH_AMD_IMPL2(double, 2d)
 
 int bvh_amd_std_sort_ids3f(const float* d_keys, size_t n, uint32_t* d_ids_out, void* stream) {
     return std_sort_ids<float>(d_ids_out, d_keys, static_cast<uint32_t>(n), 1, 0, 1, static_cast<hipStream_t>(stream));

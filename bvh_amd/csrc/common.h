@@ -29,6 +29,13 @@ struct HostNode {
 };
 static_assert(sizeof(HostNode<float>) == 28 && sizeof(HostNode<double>) == 56);
 
+template <typename T>
+struct HostNode2 {                             // Node<T, 2> (node.h:31-37): what bvh2f_get_node / _save / _serialize expose
+    T bounds[4];                               // {minx,maxx,miny,maxy}
+    typename IndexOf<T>::Type index;
+};
+static_assert(sizeof(HostNode2<float>) == 20 && sizeof(HostNode2<double>) == 40);
+
 // ---- device traversal record: both children of one inner node in one aligned line ------------
 // The reference fetches nodes[first_id] and nodes[first_id + 1] (bvh.h:133-134), 2 x 28 B that start at
 // byte 28 * odd and straddle cache lines. On the device the sibling pair p = (first_id - 1) / 2 is one
@@ -82,7 +89,16 @@ struct BvhImpl {
     mutable std::vector<size_t> prim_ids;
     mutable bool host_valid = true;
     size_t node_count = 0, prim_count = 0;
+    // 3, or 2 for the `2f` / `2d` families (Node<T, 2>): everything on the device stays three wide with z = 0 (inert), only the
+    // decisions (half area, widest axis, split candidates, slab test, circle test) know the dimension. The host mirror of
+    // a 2D BVH is `nodes2` in the reference's 20/40-byte layout; `nodes` then only stages transfers.
+    int dim = 3;
+    mutable std::vector<HostNode2<T>> nodes2;
+    mutable bool nodes2_valid = false;         // nodes2 mirrors `nodes` (it goes stale whenever `nodes` is refreshed from the device)
+    int sync_host2() const;                    // sync_host() + nodes -> nodes2
+    void widen_host() const;                   // nodes2 -> nodes (z = 0): the caller may have edited nodes2 through bvh_node2X pointers
     HostNode<T>* d_nodes = nullptr;            // reference-layout nodes resident in HBM (device builds)
+    size_t d_nodes_count = 0;                  // its capacity in nodes (append/remove_last_node change node_count on the host)
     T root_bounds[6] = {0, 0, 0, 0, 0, 0};
     int sync_host() const;
     // device copy
@@ -113,6 +129,8 @@ template <typename T> int launch_tri_bounds(const T* d_tris9, size_t n, T* d_bb,
 template <typename T> int launch_precompute_tris(const T* d_tris9, const uint32_t* d_perm, size_t n, T* d_out, hipStream_t s);
 template <typename T> int launch_sphere_bounds(const T* d_sph4, size_t n, T* d_bb, T* d_cc, hipStream_t s);
 int launch_gather(const void* d_in, const uint32_t* d_perm, size_t n, size_t stride, void* d_out, hipStream_t s);
+template <typename T> int launch_circle_bounds(const T* d_circles3, size_t n, T* d_bb4, T* d_cc2, hipStream_t s);
+template <typename T> int launch_widen_inputs(const T* d_bb4, const T* d_cc2, size_t n, T* d_bb6, T* d_cc3, hipStream_t s);
 
 // render.hip
 template <typename T> int launch_pinhole_rays(const T eye[3], const T dir[3], const T up[3], size_t width, size_t height, T* d_rays, hipStream_t s);

@@ -69,9 +69,47 @@ __global__ void __launch_bounds__(256) gather_kernel(const uint32_t* in, const u
     }
 }
 
+// ---- 2D families: circles, and the three-wide staging of 2D inputs (z = 0) the builders run on ------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) circle_bounds_kernel(const T* c3, size_t n, T* bb4, T* cc2) {
+    const size_t i = blockIdx.x * size_t{256} + threadIdx.x;
+    if (i >= n) return;
+    const T x = c3[3 * i], y = c3[3 * i + 1], r = c3[3 * i + 2];          // Sphere<T, 2>::get_bbox / get_center (sphere.h:24-27)
+    bb4[4 * i + 0] = x - r; bb4[4 * i + 1] = y - r; bb4[4 * i + 2] = x + r; bb4[4 * i + 3] = y + r;
+    cc2[2 * i + 0] = x; cc2[2 * i + 1] = y;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) widen_inputs_kernel(const T* bb4, const T* cc2, size_t n, T* bb6, T* cc3) {
+    const size_t i = blockIdx.x * size_t{256} + threadIdx.x;
+    if (i >= n) return;
+    bb6[6 * i + 0] = bb4[4 * i + 0]; bb6[6 * i + 1] = bb4[4 * i + 1]; bb6[6 * i + 2] = T(0);    // {min.x, min.y, 0, max.x, max.y, 0}
+    bb6[6 * i + 3] = bb4[4 * i + 2]; bb6[6 * i + 4] = bb4[4 * i + 3]; bb6[6 * i + 5] = T(0);
+    cc3[3 * i + 0] = cc2[2 * i + 0]; cc3[3 * i + 1] = cc2[2 * i + 1]; cc3[3 * i + 2] = T(0);
+}
+
 inline unsigned blocks_for(size_t n) { return static_cast<unsigned>((n + 255) / 256); }
 
 } // namespace
+
+template <typename T>
+int launch_circle_bounds(const T* d_circles3, size_t n, T* d_bb4, T* d_cc2, hipStream_t s) {
+    if (!n) return BVH_AMD_OK;
+    hipLaunchKernelGGL(circle_bounds_kernel<T>, dim3(blocks_for(n)), dim3(256), 0, s, d_circles3, n, d_bb4, d_cc2);
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
+}
+template <typename T>
+int launch_widen_inputs(const T* d_bb4, const T* d_cc2, size_t n, T* d_bb6, T* d_cc3, hipStream_t s) {
+    if (!n) return BVH_AMD_OK;
+    hipLaunchKernelGGL(widen_inputs_kernel<T>, dim3(blocks_for(n)), dim3(256), 0, s, d_bb4, d_cc2, n, d_bb6, d_cc3);
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
+}
+template int launch_circle_bounds<float>(const float*, size_t, float*, float*, hipStream_t);
+template int launch_circle_bounds<double>(const double*, size_t, double*, double*, hipStream_t);
+template int launch_widen_inputs<float>(const float*, const float*, size_t, float*, float*, hipStream_t);
+template int launch_widen_inputs<double>(const double*, const double*, size_t, double*, double*, hipStream_t);
 
 template <typename T>
 int launch_tri_bounds(const T* d_tris9, size_t n, T* d_bb, T* d_cc, hipStream_t s) {

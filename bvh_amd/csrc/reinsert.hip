@@ -48,8 +48,9 @@ template <typename T> struct HeapCap { static constexpr uint32_t v = (1u << Heap
 struct Move { uint32_t from, to; };
 struct ReScalars { uint32_t n_moves, error, ambiguous, pad; };
 
-template <typename T> __device__ inline T ha6(const T* b) {                  // bounds = {minx,maxx,miny,maxy,minz,maxz}
+template <typename T> __device__ inline T ha6(const T* b, int dim) {         // bounds = {minx,maxx,miny,maxy,minz,maxz}
     const T d0 = b[1] - b[0], d1 = b[3] - b[2], d2 = b[5] - b[4];
+    if (dim == 2) return d0 + d1;                            // bbox.h:36 (2D nodes run three wide with z = 0, see build_common.h)
     return (d0 + d1) * d2 + d0 * d1;
 }
 template <typename T> __device__ inline bool is_leaf(const HostNode<T>& n) { return (n.index & kCountMask) != 0; }
@@ -59,11 +60,11 @@ __device__ inline uint32_t left_of(uint32_t id) { return (id & 1u) ? id : id - 1
 
 // compute_parents (:72-86) + half-area of every node
 template <typename T>
-__global__ void __launch_bounds__(256) k_parents_costs(const HostNode<T>* nodes, uint32_t n, uint32_t* parent, T* cost, int with_parents) {
+__global__ void __launch_bounds__(256) k_parents_costs(const HostNode<T>* nodes, uint32_t n, uint32_t* parent, T* cost, int with_parents, int dim) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const HostNode<T> nd = nodes[i];
-    cost[i] = ha6(nd.bounds);
+    cost[i] = ha6(nd.bounds, dim);
     if (with_parents) {
         if (i == 0) parent[0] = 0;
         if (!is_leaf(nd)) { parent[first_of(nd)] = i; parent[first_of(nd) + 1] = i; }
@@ -531,7 +532,7 @@ __global__ void __launch_bounds__(256) k_gain_keys(const T* neg_gain, uint32_t m
 // ---- find_reinsertion (:107-188), one lane per candidate ----------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(64) k_search(const HostNode<T>* nodes, const uint32_t* parent, const uint32_t* cand, uint32_t k,
-                                               Move* moves, T* gains, uint32_t* keep, ReScalars* sc) {
+                                               Move* moves, T* gains, uint32_t* keep, ReScalars* sc, int dim) {
     const uint32_t c = blockIdx.x * 64 + threadIdx.x;
     if (c >= k) return;
     const uint32_t id = cand[c];
@@ -541,9 +542,9 @@ __global__ void __launch_bounds__(64) k_search(const HostNode<T>* nodes, const u
     T self[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) self[q] = nodes[id].bounds[q];
-    const T self_area = ha6(self);
+    const T self_area = ha6(self, dim);
     const uint32_t first_parent = parent[id];
-    T gain_so_far = ha6(nodes[first_parent].bounds);
+    T gain_so_far = ha6(nodes[first_parent].bounds, dim);
     uint32_t sib = sibling_of(id);
     T pivot_box[6];
 #pragma unroll
@@ -563,10 +564,10 @@ __global__ void __launch_bounds__(64) k_search(const HostNode<T>* nodes, const u
                 merged[2 * q] = pick_min(dn.bounds[2 * q], self[2 * q]);
                 merged[2 * q + 1] = pick_max(dn.bounds[2 * q + 1], self[2 * q + 1]);
             }
-            const T gain = bound - ha6(merged);
+            const T gain = bound - ha6(merged, dim);
             if (gain > best_gain) { best_to = dst; best_gain = gain; }
             if (!is_leaf(dn)) {
-                const T child_bound = gain + ha6(dn.bounds);
+                const T child_bound = gain + ha6(dn.bounds, dim);
                 if (sp + 2 > kSearchStack) { overflow = true; break; }
                 s_bound[sp] = child_bound; s_node[sp] = first_of(dn); ++sp;
                 s_bound[sp] = child_bound; s_node[sp] = first_of(dn) + 1; ++sp;
@@ -580,7 +581,7 @@ __global__ void __launch_bounds__(64) k_search(const HostNode<T>* nodes, const u
                 pivot_box[2 * q] = pick_min(pivot_box[2 * q], sn.bounds[2 * q]);
                 pivot_box[2 * q + 1] = pick_max(pivot_box[2 * q + 1], sn.bounds[2 * q + 1]);
             }
-            gain_so_far += ha6(nodes[pivot].bounds) - ha6(pivot_box);
+            gain_so_far += ha6(nodes[pivot].bounds, dim) - ha6(pivot_box, dim);
         }
         sib = sibling_of(pivot);
         pivot = parent[pivot];
@@ -704,7 +705,7 @@ __global__ void __launch_bounds__(256) k_refit(HostNode<T>* nodes, const uint32_
 } // namespace
 
 template <typename T>
-int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) {
+int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) {   // (dimension-independent: z stays (+0, +0) in 2D)
     const uint32_t n = static_cast<uint32_t>(node_count);
     if (n < 3) return BVH_AMD_OK;
     DevBuf<uint32_t> parent, arrived;
@@ -714,7 +715,7 @@ int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) {
     if (e == hipSuccess) e = cost.alloc(n);
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("refit: hipMalloc: ") + hipGetErrorString(e));
     BVH_HIP_TRY(hipMemsetAsync(arrived.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
-    hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, 1);
+    hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, 1, 3);
     hipLaunchKernelGGL(k_refit<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, parent.p, arrived.p, n);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
@@ -729,7 +730,7 @@ void reinsertion_stats(unsigned out[2]) { out[0] = g_fast_iterations.load(); out
 
 // ReinsertionOptimizer::optimize on device-resident nodes (reference layout), in place.
 template <typename T>
-int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) {
+int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim) {
     using U = typename Ord<T>::U;
     const uint32_t n = static_cast<uint32_t>(node_count);
     if (n < 2) return BVH_AMD_OK;
@@ -778,7 +779,7 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
     for (size_t it = 0; it < iterations; ++it) {
         bool exact = always_exact;
         for (;;) {                                            // at most two rounds: fast, then (if the layout matters) exact
-            hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, parents_valid ? 0 : 1);
+            hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, parents_valid ? 0 : 1, dim);
             parents_valid = true;
             ReScalars hs;
             int rc;
@@ -804,7 +805,7 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
                 BVH_HIP_TRY(hipMemcpyAsync(cand.p, ids.p, size_t{k} * 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
             }
             BVH_HIP_TRY(hipMemsetAsync(touched.p, 0, n, stream), BVH_AMD_ERR_HIP);
-            hipLaunchKernelGGL(k_search<T>, dim3((k + 63) / 64), dim3(64), 0, stream, d_nodes, parent.p, cand.p, k, moves.p, gains.p, keep.p, scalars.p);
+            hipLaunchKernelGGL(k_search<T>, dim3((k + 63) / 64), dim3(64), 0, stream, d_nodes, parent.p, cand.p, k, moves.p, gains.p, keep.p, scalars.p, dim);
             BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
             uint32_t m = 0;
             rc = exclusive_scan_u32(keep.p, off.p, k, &m, stream);
@@ -853,7 +854,7 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
     return BVH_AMD_OK;
 }
 
-template int reinsertion_optimize_device<float>(HostNode<float>*, size_t, hipStream_t);
-template int reinsertion_optimize_device<double>(HostNode<double>*, size_t, hipStream_t);
+template int reinsertion_optimize_device<float>(HostNode<float>*, size_t, hipStream_t, int);
+template int reinsertion_optimize_device<double>(HostNode<double>*, size_t, hipStream_t, int);
 
 } // namespace bvh_amd

@@ -63,6 +63,7 @@ template <typename T> __device__ inline T pick_max(T a, T b) { return a > b ? a 
 template <typename T> __device__ inline T dot3(T a0, T a1, T a2, T b0, T b1, T b2) {   // vec.h:98-100
     return ((T(0) + a0 * b0) + a1 * b1) + a2 * b2;
 }
+template <typename T> __device__ inline T dot2(T a0, T a1, T b0, T b1) { return (T(0) + a0 * b0) + a1 * b1; }   // Vec<T, 2>
 
 template <typename T>
 struct TraceArgs {
@@ -127,6 +128,17 @@ __device__ inline void load_ray(const double* p, double (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
 }
+// Ray<T, 2>: {org[2], dir[2], tmin, tmax}
+__device__ inline void load_ray2(const float* p, float (&v)[6]) {
+    const float2* q = reinterpret_cast<const float2*>(p);
+    float2 a = q[0], b = q[1], c = q[2];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+}
+__device__ inline void load_ray2(const double* p, double (&v)[6]) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+}
 __device__ inline void store_hit(bvh_hit3f* out, uint32_t prim, float t, float u, float v) {
     *reinterpret_cast<float4*>(out) = make_float4(__uint_as_float(prim), t, u, v);
 }
@@ -148,7 +160,9 @@ __device__ inline void wave_sync() {
 // the four requests of a 64-byte pair record are the kernel's floor (4.9 G requests per 2^24-ray launch). A
 // quad-cooperative fetch (4 lanes x 16 B of one record per instruction + LDS transpose) was tried and is 3-4x SLOWER:
 // requests are charged per lane, not per line, and idle lanes then cost as much as active ones.
-template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
+// D = 2: Bvh<Node<T, 2>> with circles (Sphere<T, 2>, stride 3) and 6-value rays. The pair records stay three wide (their z
+// bounds are zero and never looked at): only the per-ray constants, the slab test and the leaf test run over D axes.
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3>
 __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
     constexpr int kDepth = kLdsDepth;
     constexpr int kSpill = 64 - kDepth;            // kDepth + kSpill = 64 = the reference's SmallStack capacity
@@ -196,9 +210,14 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
                 if (ticket < a.n) {
                     const unsigned long long my = a.order ? a.order[ticket] : ticket;
                     T r[8];
-                    load_ray(a.rays + 8 * my, r);
+                    if (D == 3) load_ray(a.rays + 8 * my, r);
+                    else {
+                        T q[6];
+                        load_ray2(a.rays + 6 * my, q);
+                        r[0] = q[0]; r[1] = q[1]; r[2] = T(0); r[3] = q[2]; r[4] = q[3]; r[5] = T(0); r[6] = q[4]; r[7] = q[5];
+                    }
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {                       // bvh.h:162-165, ray.h:29-48
+                    for (int k = 0; k < D; ++k) {                       // bvh.h:162-165, ray.h:29-48
                         org[k] = r[k]; dir[k] = r[3 + k];
                         T d = dir[k];
                         T iv = Robust ? T(1) / d
@@ -236,7 +255,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
                 if (Stats) ++n_pairs;
                 T l0 = tmin, l1 = tmax, r0 = tmin, r1 = tmax;               // node.h:105-117
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
+                for (int k = 0; k < D; ++k) {
                     const T ln = oct[k] ? lb[2 * k + 1] : lb[2 * k], lf = oct[k] ? lb[2 * k] : lb[2 * k + 1];
                     const T rn = oct[k] ? rb[2 * k + 1] : rb[2 * k], rf = oct[k] ? rb[2 * k] : rb[2 * k + 1];
                     T la, lz, ra, rz;
@@ -290,12 +309,21 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
                         if (t >= tmin && t <= tmax) { tmax = t; hit_t = t; hit_u = u; hit_v = v; hit_prim = i; }
                     }
                 } else {                                                // sphere.h:32-49
-                    T s[4];
-                    load_prim4(a.prims + 4ull * i, s);
-                    const T o0 = org[0] - s[0], o1 = org[1] - s[1], o2 = org[2] - s[2];
-                    const T qa = dot3(dir[0], dir[1], dir[2], dir[0], dir[1], dir[2]);
-                    const T qb = T(2) * dot3(dir[0], dir[1], dir[2], o0, o1, o2);
-                    const T qc = dot3(o0, o1, o2, o0, o1, o2) - s[3] * s[3];
+                    T qa, qb, qc;
+                    if (D == 3) {
+                        T s[4];
+                        load_prim4(a.prims + 4ull * i, s);
+                        const T o0 = org[0] - s[0], o1 = org[1] - s[1], o2 = org[2] - s[2];
+                        qa = dot3(dir[0], dir[1], dir[2], dir[0], dir[1], dir[2]);
+                        qb = T(2) * dot3(dir[0], dir[1], dir[2], o0, o1, o2);
+                        qc = dot3(o0, o1, o2, o0, o1, o2) - s[3] * s[3];
+                    } else {                                            // Sphere<T, 2>: {center[2], radius}
+                        const T* s = a.prims + 3ull * i;
+                        const T o0 = org[0] - s[0], o1 = org[1] - s[1];
+                        qa = dot2(dir[0], dir[1], dir[0], dir[1]);
+                        qb = T(2) * dot2(dir[0], dir[1], o0, o1);
+                        qc = dot2(o0, o1, o0, o1) - s[2] * s[2];
+                    }
                     const T delta = qb * qb - T(4) * qa * qc;
                     if (delta >= 0) {
                         const T iv = -T(0.5) / qa;
@@ -370,10 +398,10 @@ int persistent_grid(K kernel, int device, Grid& g) {
     return BVH_AMD_OK;
 }
 
-template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
 int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     static thread_local int cached_blocks[16] = {0};
-    auto kernel = trace_kernel<T, Any, Robust, Leaf, Stats>;
+    auto kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D>;
     int& blocks = cached_blocks[b.device & 15];
     if (blocks == 0) {
         Grid g;
@@ -391,9 +419,10 @@ int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t st
 }
 
 #define BVH_VARIANT(T, ANY, ROB, LEAF, STATS) \
-    launch_variant<T, ANY, ROB, LEAF, STATS>(b, args, stream, "trace_kernel<" #T "," #ANY "," #ROB "," #LEAF "," #STATS ">")
+    launch_variant<T, ANY, ROB, LEAF, STATS, D>(b, args, stream, D == 3 ? "trace_kernel<" #T "," #ANY "," #ROB "," #LEAF "," #STATS ">" \
+                                                                        : "trace_kernel<" #T "," #ANY "," #ROB "," #LEAF "," #STATS ",2>")
 
-template <typename T, int Leaf>
+template <typename T, int Leaf, int D = 3>
 int dispatch(const BvhImpl<T>& b, const TraceArgs<T>& args, unsigned flags, bool stats, hipStream_t stream) {
     const bool any = flags & BVH_AMD_RAY_ANY_HIT, rob = flags & BVH_AMD_RAY_ROBUST;
     if (stats) {
@@ -426,6 +455,10 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     static const int leaf_env = getenv("BVH_AMD_LEAF") ? atoi(getenv("BVH_AMD_LEAF")) : 0;
     args.refill_threshold = refill_env > 0 ? refill_env : kRefillThreshold;
     args.leaf_threshold = leaf_env > 0 ? leaf_env : kLeafThreshold;
+    if (b.dim == 2) {                                         // Node<T, 2>: circles only (tri.h has no 2D intersector)
+        if (leaf_kind != LEAF_SPHERE) return fail(BVH_AMD_ERR_ARG, "intersect_rays: a 2D BVH traces circles (Sphere<T, 2>) only");
+        return dispatch<T, LEAF_SPHERE, 2>(b, args, flags, d_counters != nullptr, stream);
+    }
     if ((flags & BVH_AMD_RAY_SORTED) && n > 4096 && n < (size_t{1} << 31)) {
         const uint32_t n32 = static_cast<uint32_t>(n);
         const size_t words = 4 * n + radix_sort_hist_words(n32, 1);

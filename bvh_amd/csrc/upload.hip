@@ -71,6 +71,32 @@ int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t st
     return BVH_AMD_OK;
 }
 
+template <typename T>
+int BvhImpl<T>::sync_host2() const {
+    const bool was_valid = host_valid;
+    int rc = sync_host();
+    if (rc) return rc;
+    if (!nodes2_valid || !was_valid) {
+        nodes2.resize(nodes.size());
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            for (int k = 0; k < 4; ++k) nodes2[i].bounds[k] = nodes[i].bounds[k];
+            nodes2[i].index = nodes[i].index;
+        }
+        nodes2_valid = true;
+    }
+    return BVH_AMD_OK;
+}
+
+template <typename T>
+void BvhImpl<T>::widen_host() const {
+    nodes.resize(nodes2.size());
+    for (size_t i = 0; i < nodes2.size(); ++i) {
+        for (int k = 0; k < 4; ++k) nodes[i].bounds[k] = nodes2[i].bounds[k];
+        nodes[i].bounds[4] = nodes[i].bounds[5] = T(0);
+        nodes[i].index = nodes2[i].index;
+    }
+}
+
 // Uploads the host mirror (b.nodes, b.prim_ids) to the current device.
 template <typename T>
 int upload_bvh(BvhImpl<T>& b, hipStream_t stream) {

@@ -41,6 +41,10 @@ struct bvh3f;
 struct bvh3d;
 struct bvh_node3f;
 struct bvh_node3d;
+struct bvh2f;                                   /* c_api/bvh.h:35-43: the 2D families (Node<T, 2>, 20/40-byte nodes) */
+struct bvh2d;
+struct bvh_node2f;
+struct bvh_node2d;
 struct bvh_thread_pool;
 
 enum bvh_build_quality { BVH_BUILD_QUALITY_LOW, BVH_BUILD_QUALITY_MEDIUM, BVH_BUILD_QUALITY_HIGH };
@@ -52,6 +56,12 @@ struct bvh_build_config {                    /* c_api/bvh.h:53-58 */
     size_t parallel_threshold;
 };
 
+struct bvh_vec2f { float x, y; };
+struct bvh_vec2d { double x, y; };
+struct bvh_bbox2f { struct bvh_vec2f min, max; };
+struct bvh_bbox2d { struct bvh_vec2d min, max; };
+struct bvh_ray2f { struct bvh_vec2f org, dir; float tmin, tmax; };
+struct bvh_ray2d { struct bvh_vec2d org, dir; double tmin, tmax; };
 struct bvh_vec3f { float x, y, z; };
 struct bvh_vec3d { double x, y, z; };
 struct bvh_bbox3f { struct bvh_vec3f min, max; };
@@ -247,6 +257,87 @@ BVH_AMD_API const char* bvh_amd_last_kernel_name(void);
  * exact replay of the reference's candidate heap + std::sort (taken when ties make their layout matter).
  * Both produce the reference's result bit for bit; BVH_AMD_REINSERT=exact in the environment forces the replay. */
 BVH_AMD_API void bvh_amd_reinsertion_stats(unsigned out[2]);
+
+
+/* ---- the 2D families `2f` / `2d` (c_api/bvh.cpp:7-10: Bvh<Node<T, 2>>) ---------------------------------------------------
+ * Same contracts as the 3D functions above with bvh_bbox2X / bvh_vec2X / bvh_ray2X and 20/40-byte nodes
+ * ({minx,maxx,miny,maxy}, index). Builders: serial DefaultBuilder (Low = binned SAH, Medium = sweep SAH, High = sweep +
+ * reinsertion), bit-identical with the reference; with a thread pool the reference runs the serial builder below
+ * parallel_threshold (default_builder.h:38-39) and so does this library, while AT OR ABOVE the threshold its mini-tree
+ * builder reads the third component of 2D points (mini_tree_builder.h:183: undefined behaviour), which is refused here
+ * (NULL + bvh_amd_last_error()). Leaf primitive of the batch traversal: circles = Sphere<T, 2> {center.x, center.y, radius}
+ * (sphere.h:15-50; tri.h has no 2D intersector). */
+BVH_AMD_API struct bvh2f* bvh2f_build(struct bvh_thread_pool*, const struct bvh_bbox2f* bboxes,
+    const struct bvh_vec2f* centers, size_t prim_count, const struct bvh_build_config* config);   /* c_api/bvh.h:99-125 */
+BVH_AMD_API struct bvh2f* bvh2f_build_device(const float* d_bboxes4, const float* d_centers2, size_t prim_count,
+    const struct bvh_build_config* config, enum bvh_amd_builder builder, void* stream);
+BVH_AMD_API struct bvh2f* bvh2f_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
+BVH_AMD_API struct bvh2f* bvh2f_extract(struct bvh2f* bvh, size_t root_id);
+BVH_AMD_API void bvh2f_destroy(struct bvh2f*);
+BVH_AMD_API void bvh2f_optimize(struct bvh_thread_pool*, struct bvh2f*);
+BVH_AMD_API void bvh2f_refit(struct bvh2f*);
+BVH_AMD_API int bvh2f_sync_device(struct bvh2f*);
+BVH_AMD_API void bvh2f_append_node(struct bvh2f*);
+BVH_AMD_API void bvh2f_remove_last_node(struct bvh2f*);
+BVH_AMD_API void bvh_node2f_set_prim_count(struct bvh_node2f*, size_t);
+BVH_AMD_API void bvh_node2f_set_first_id(struct bvh_node2f*, size_t);
+BVH_AMD_API void bvh_node2f_set_bbox(struct bvh_node2f*, const struct bvh_bbox2f*);
+BVH_AMD_API void bvh2f_save(const struct bvh2f*, FILE*);
+BVH_AMD_API struct bvh2f* bvh2f_load(FILE*);
+BVH_AMD_API size_t bvh2f_serialize(const struct bvh2f*, void* out, size_t capacity);
+BVH_AMD_API struct bvh2f* bvh2f_deserialize(const void* bytes, size_t size);
+BVH_AMD_API struct bvh_node2f* bvh2f_get_node(struct bvh2f*, size_t);
+BVH_AMD_API size_t bvh2f_get_prim_id(const struct bvh2f*, size_t);
+BVH_AMD_API size_t bvh2f_get_prim_count(const struct bvh2f*);
+BVH_AMD_API size_t bvh2f_get_node_count(const struct bvh2f*);
+BVH_AMD_API bool bvh_node2f_is_leaf(const struct bvh_node2f*);
+BVH_AMD_API size_t bvh_node2f_get_prim_count(const struct bvh_node2f*);
+BVH_AMD_API size_t bvh_node2f_get_first_id(const struct bvh_node2f*);
+BVH_AMD_API struct bvh_bbox2f bvh_node2f_get_bbox(const struct bvh_node2f*);
+BVH_AMD_API void bvh2f_copy_nodes(const struct bvh2f*, void* out);
+BVH_AMD_API void bvh2f_copy_prim_ids(const struct bvh2f*, size_t* out);
+BVH_AMD_API const uint32_t* bvh2f_device_prim_ids(const struct bvh2f*);
+/* circles3: n x {center.x, center.y, radius} -> bboxes n x {min.x,min.y,max.x,max.y}, centers n x 2 (sphere.h:24-27) */
+BVH_AMD_API int bvh_amd_sphere_bounds2f(const float* d_circles3, size_t n, float* d_bboxes4, float* d_centers2, void* stream);
+/* d_circles3 in BVH order; hit = {prim, t0, t1, 0} like the 3D sphere traversal */
+BVH_AMD_API int bvh2f_intersect_rays_sphere(const struct bvh2f* bvh, const float* d_circles3, const struct bvh_ray2f* d_rays,
+    size_t n, unsigned flags, struct bvh_hit3f* d_hits, struct bvh_amd_counters* d_counters, void* stream);
+
+BVH_AMD_API struct bvh2d* bvh2d_build(struct bvh_thread_pool*, const struct bvh_bbox2d* bboxes,
+    const struct bvh_vec2d* centers, size_t prim_count, const struct bvh_build_config* config);   /* c_api/bvh.h:99-125 */
+BVH_AMD_API struct bvh2d* bvh2d_build_device(const double* d_bboxes4, const double* d_centers2, size_t prim_count,
+    const struct bvh_build_config* config, enum bvh_amd_builder builder, void* stream);
+BVH_AMD_API struct bvh2d* bvh2d_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
+BVH_AMD_API struct bvh2d* bvh2d_extract(struct bvh2d* bvh, size_t root_id);
+BVH_AMD_API void bvh2d_destroy(struct bvh2d*);
+BVH_AMD_API void bvh2d_optimize(struct bvh_thread_pool*, struct bvh2d*);
+BVH_AMD_API void bvh2d_refit(struct bvh2d*);
+BVH_AMD_API int bvh2d_sync_device(struct bvh2d*);
+BVH_AMD_API void bvh2d_append_node(struct bvh2d*);
+BVH_AMD_API void bvh2d_remove_last_node(struct bvh2d*);
+BVH_AMD_API void bvh_node2d_set_prim_count(struct bvh_node2d*, size_t);
+BVH_AMD_API void bvh_node2d_set_first_id(struct bvh_node2d*, size_t);
+BVH_AMD_API void bvh_node2d_set_bbox(struct bvh_node2d*, const struct bvh_bbox2d*);
+BVH_AMD_API void bvh2d_save(const struct bvh2d*, FILE*);
+BVH_AMD_API struct bvh2d* bvh2d_load(FILE*);
+BVH_AMD_API size_t bvh2d_serialize(const struct bvh2d*, void* out, size_t capacity);
+BVH_AMD_API struct bvh2d* bvh2d_deserialize(const void* bytes, size_t size);
+BVH_AMD_API struct bvh_node2d* bvh2d_get_node(struct bvh2d*, size_t);
+BVH_AMD_API size_t bvh2d_get_prim_id(const struct bvh2d*, size_t);
+BVH_AMD_API size_t bvh2d_get_prim_count(const struct bvh2d*);
+BVH_AMD_API size_t bvh2d_get_node_count(const struct bvh2d*);
+BVH_AMD_API bool bvh_node2d_is_leaf(const struct bvh_node2d*);
+BVH_AMD_API size_t bvh_node2d_get_prim_count(const struct bvh_node2d*);
+BVH_AMD_API size_t bvh_node2d_get_first_id(const struct bvh_node2d*);
+BVH_AMD_API struct bvh_bbox2d bvh_node2d_get_bbox(const struct bvh_node2d*);
+BVH_AMD_API void bvh2d_copy_nodes(const struct bvh2d*, void* out);
+BVH_AMD_API void bvh2d_copy_prim_ids(const struct bvh2d*, size_t* out);
+BVH_AMD_API const uint32_t* bvh2d_device_prim_ids(const struct bvh2d*);
+/* circles3: n x {center.x, center.y, radius} -> bboxes n x {min.x,min.y,max.x,max.y}, centers n x 2 (sphere.h:24-27) */
+BVH_AMD_API int bvh_amd_sphere_bounds2d(const double* d_circles3, size_t n, double* d_bboxes4, double* d_centers2, void* stream);
+/* d_circles3 in BVH order; hit = {prim, t0, t1, 0} like the 3D sphere traversal */
+BVH_AMD_API int bvh2d_intersect_rays_sphere(const struct bvh2d* bvh, const double* d_circles3, const struct bvh_ray2d* d_rays,
+    size_t n, unsigned flags, struct bvh_hit3d* d_hits, struct bvh_amd_counters* d_counters, void* stream);
 
 #ifdef __cplusplus
 }
