@@ -156,6 +156,30 @@ def spheres(n: int, seed: int = 21, rmin: float = 0.002, rmax: float = 0.006, dt
     return np.concatenate([c, r], axis=1).astype(dtype)
 
 
+def circles(n: int, seed: int = 33, rmin: float = 0.0005, rmax: float = 0.004, dtype=np.float32) -> np.ndarray:
+    """2D families: n circles {center.x, center.y, radius} (Sphere<T, 2>), centre uniform in the unit square."""
+    c = uniform01(seed, 2 * n, 0).reshape(n, 2)
+    r = rmin + (rmax - rmin) * uniform01(seed, n, 1).reshape(n, 1)
+    return np.ascontiguousarray(np.concatenate([c, r], axis=1).astype(dtype))
+
+
+def rays_2d(n: int, lo=(0.0, 0.0), hi=(1.0, 1.0), seed: int = 1234, dtype=np.float32, scale: float = 1.1, segment: bool = False) -> np.ndarray:
+    """Ray<T, 2> {org[2], dir[2], tmin, tmax}: origin uniform in the box scaled about its centre, direction uniform on the
+    circle; with `segment` the shadow-ray form (unnormalised direction between two points, t in [1e-4, 1 - 1e-4])."""
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    out = np.empty((n, 6), dtype=dtype)
+    if segment:
+        a = lo + uniform01(seed, 2 * n, 0).reshape(n, 2) * (hi - lo)
+        b = lo + uniform01(seed, 2 * n, 1).reshape(n, 2) * (hi - lo)
+        out[:, 0:2], out[:, 2:4], out[:, 4], out[:, 5] = a, b - a, 1e-4, 1.0 - 1e-4
+        return out
+    ctr, half = 0.5 * (lo + hi), 0.5 * (hi - lo) * scale
+    org = ctr + (2.0 * uniform01(seed, 2 * n, 0).reshape(n, 2) - 1.0) * half
+    phi = 2.0 * np.pi * uniform01(seed, n, 1)
+    out[:, 0:2], out[:, 2], out[:, 3], out[:, 4], out[:, 5] = org, np.cos(phi), np.sin(phi), 0.0, np.finfo(dtype).max
+    return out
+
+
 def procedural_10m(n: int = 10_000_000, seed: int = 7, dtype=np.float32) -> np.ndarray:
     """Config 4's "10M-triangle procedural mesh" = the soup at 10M."""
     return soup(n, seed=seed, dtype=dtype)

@@ -10,7 +10,8 @@
 // and runs the build on the MI355X (hand-written HIP kernels behind the C-ABI of include/bvh_amd.h). What differs:
 // the reference's per-ray `Bvh::intersect(ray, ..., leaf_fn)` takes a host lambda per leaf and cannot run on a GPU;
 // its batched equivalent is `bvh::v2::amd::intersect_batch<IsAnyHit, IsRobust>(bvh, prims, rays, hits)` with the
-// reference's own leaf intersectors (PrecomputedTri / Sphere). Only Dim == 3 exists on the device (2D: next round).
+// reference's own leaf intersectors (PrecomputedTri / Sphere<T, 3> / Sphere<T, 2>). Node<T, 2> is served by the `2f` / `2d`
+// families of the C-ABI (serial builders; the reference's thread-pool build of 2D data is undefined above parallel_threshold).
 // Layouts are bit-compatible with the reference (Vec, BBox, Ray, Node: SURVEY.md §8 sizes), which is what lets the
 // C-ABI take these arrays as they are. Errors throw bvh::v2::amd::Error (the reference has no error channel).
 #ifndef BVH_V2_BVH_AMD_HPP
@@ -112,6 +113,8 @@ struct Node {
     void set_bbox(const BBox<T, Dim>& b) { for (size_t i = 0; i < Dim; ++i) { bounds[2 * i] = b.min[i]; bounds[2 * i + 1] = b.max[i]; } }
 };
 static_assert(sizeof(Node<float, 3>) == 28 && sizeof(Node<double, 3>) == 56, "layout must equal the reference's");
+static_assert(sizeof(Node<float, 2>) == 20 && sizeof(Node<double, 2>) == 40 && sizeof(BBox<float, 2>) == sizeof(bvh_bbox2f) &&
+              sizeof(Ray<double, 2>) == sizeof(bvh_ray2d), "2D layouts must equal the reference's");
 static_assert(sizeof(BBox<float, 3>) == sizeof(bvh_bbox3f) && sizeof(Vec<float, 3>) == sizeof(bvh_vec3f) && sizeof(Ray<float, 3>) == sizeof(bvh_ray3f));
 static_assert(sizeof(BBox<double, 3>) == sizeof(bvh_bbox3d) && sizeof(Ray<double, 3>) == sizeof(bvh_ray3d));
 
@@ -170,8 +173,8 @@ namespace amd {
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 inline void check(int rc, const char* what) { if (rc != 0) throw Error(std::string(what) + ": " + bvh_amd_last_error()); }
 
-template <typename T> struct Api;
-template <> struct Api<float> {
+template <typename T, size_t N = 3> struct Api;
+template <> struct Api<float, 3> {
     using Handle = bvh3f; using CHit = bvh_hit3f;
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3f_build(p, static_cast<const bvh_bbox3f*>(bb), static_cast<const bvh_vec3f*>(cc), n, c); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3f_from_nodes(nodes, nn, ids, np); }
@@ -188,7 +191,7 @@ template <> struct Api<float> {
     static int trace_tri(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3f_intersect_rays_tri(h, static_cast<const float*>(prims), static_cast<const bvh_ray3f*>(rays), n, f, static_cast<bvh_hit3f*>(hits), nullptr, nullptr); }
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3f_intersect_rays_sphere(h, static_cast<const float*>(prims), static_cast<const bvh_ray3f*>(rays), n, f, static_cast<bvh_hit3f*>(hits), nullptr, nullptr); }
 };
-template <> struct Api<double> {
+template <> struct Api<double, 3> {
     using Handle = bvh3d; using CHit = bvh_hit3d;
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3d_build(p, static_cast<const bvh_bbox3d*>(bb), static_cast<const bvh_vec3d*>(cc), n, c); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3d_from_nodes(nodes, nn, ids, np); }
@@ -205,6 +208,27 @@ template <> struct Api<double> {
     static int trace_tri(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3d_intersect_rays_tri(h, static_cast<const double*>(prims), static_cast<const bvh_ray3d*>(rays), n, f, static_cast<bvh_hit3d*>(hits), nullptr, nullptr); }
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3d_intersect_rays_sphere(h, static_cast<const double*>(prims), static_cast<const bvh_ray3d*>(rays), n, f, static_cast<bvh_hit3d*>(hits), nullptr, nullptr); }
 };
+
+
+#define BVH_AMD_API_2D(T, S)                                                                                                              \
+template <> struct Api<T, 2> {                                                                                                            \
+    using Handle = bvh##S; using CHit = std::conditional_t<std::is_same_v<T, float>, bvh_hit3f, bvh_hit3d>;                              \
+    static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh##S##_build(p, static_cast<const bvh_bbox##S*>(bb), static_cast<const bvh_vec##S*>(cc), n, c); } \
+    static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh##S##_from_nodes(nodes, nn, ids, np); } \
+    static void destroy(Handle* h) { bvh##S##_destroy(h); }                                                                               \
+    static size_t node_count(const Handle* h) { return bvh##S##_get_node_count(h); }                                                      \
+    static size_t prim_count(const Handle* h) { return bvh##S##_get_prim_count(h); }                                                      \
+    static void copy_nodes(const Handle* h, void* out) { bvh##S##_copy_nodes(h, out); }                                                   \
+    static void copy_prim_ids(const Handle* h, size_t* out) { bvh##S##_copy_prim_ids(h, out); }                                           \
+    static Handle* extract(Handle* h, size_t root_id) { return bvh##S##_extract(h, root_id); }                                            \
+    static void optimize(Handle* h) { bvh##S##_optimize(nullptr, h); }                                                                    \
+    static void refit(Handle* h) { bvh##S##_refit(h); }                                                                                   \
+    static const uint32_t* device_prim_ids(const Handle* h) { return bvh##S##_device_prim_ids(h); }                                       \
+    static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh##S##_intersect_rays_sphere(h, static_cast<const T*>(prims), static_cast<const bvh_ray##S*>(rays), n, f, static_cast<CHit*>(hits), nullptr, nullptr); } \
+};
+BVH_AMD_API_2D(float, 2f)
+BVH_AMD_API_2D(double, 2d)
+#undef BVH_AMD_API_2D
 
 // RAII device array (HBM of the current HIP device)
 template <typename T>
@@ -240,7 +264,7 @@ struct Bvh {
     using Index = typename Node::Index;
     using Scalar = typename Node::Scalar;
     using Ray = bvh::v2::Ray<Scalar, Node::dimension>;
-    static_assert(Node::dimension == 3, "bvh_amd: only 3D BVHs exist on the device in this round");
+    static_assert(Node::dimension == 2 || Node::dimension == 3, "bvh_amd: 2D and 3D BVHs");
 
     std::vector<Node> nodes;                                  // host mirror, reference layout (bvh.h:22-23)
     std::vector<size_t> prim_ids;
@@ -255,7 +279,7 @@ struct Bvh {
 
     // Bvh::extract_bvh (reference bvh.h:92-122) on the device
     [[nodiscard]] Bvh extract_bvh(size_t root_id) const {
-        auto* h = amd::Api<Scalar>::extract(device(), root_id);
+        auto* h = amd::Api<Scalar, Node::dimension>::extract(device(), root_id);
         if (!h) throw amd::Error(bvh_amd_last_error());
         Bvh out;
         out.adopt(h);
@@ -263,30 +287,30 @@ struct Bvh {
     }
 
     // Bvh::refit (reference bvh.h:211-218) on the device; `nodes` may have been edited by the caller.
-    void refit() { push(); amd::Api<Scalar>::refit(device_.get()); pull(); }
+    void refit() { push(); amd::Api<Scalar, Node::dimension>::refit(device_.get()); pull(); }
 
     // the device-resident twin (built by DefaultBuilder, or uploaded on demand)
-    typename amd::Api<Scalar>::Handle* device() const {
+    typename amd::Api<Scalar, Node::dimension>::Handle* device() const {
         if (!device_) const_cast<Bvh*>(this)->push();
         return device_.get();
     }
-    void adopt(typename amd::Api<Scalar>::Handle* h) {
-        device_ = std::shared_ptr<typename amd::Api<Scalar>::Handle>(h, [](auto* p) { amd::Api<Scalar>::destroy(p); });
+    void adopt(typename amd::Api<Scalar, Node::dimension>::Handle* h) {
+        device_ = std::shared_ptr<typename amd::Api<Scalar, Node::dimension>::Handle>(h, [](auto* p) { amd::Api<Scalar, Node::dimension>::destroy(p); });
         pull();
     }
 
 private:
-    std::shared_ptr<typename amd::Api<Scalar>::Handle> device_;
+    std::shared_ptr<typename amd::Api<Scalar, Node::dimension>::Handle> device_;
     void push() {                                             // host mirror -> device
-        auto* h = amd::Api<Scalar>::from_nodes(nodes.data(), nodes.size(), prim_ids.data(), prim_ids.size());
+        auto* h = amd::Api<Scalar, Node::dimension>::from_nodes(nodes.data(), nodes.size(), prim_ids.data(), prim_ids.size());
         if (!h) throw amd::Error(bvh_amd_last_error());
-        device_ = std::shared_ptr<typename amd::Api<Scalar>::Handle>(h, [](auto* p) { amd::Api<Scalar>::destroy(p); });
+        device_ = std::shared_ptr<typename amd::Api<Scalar, Node::dimension>::Handle>(h, [](auto* p) { amd::Api<Scalar, Node::dimension>::destroy(p); });
     }
     void pull() {                                             // device -> host mirror
-        nodes.resize(amd::Api<Scalar>::node_count(device_.get()));
-        prim_ids.resize(amd::Api<Scalar>::prim_count(device_.get()));
-        amd::Api<Scalar>::copy_nodes(device_.get(), nodes.data());
-        amd::Api<Scalar>::copy_prim_ids(device_.get(), prim_ids.data());
+        nodes.resize(amd::Api<Scalar, Node::dimension>::node_count(device_.get()));
+        prim_ids.resize(amd::Api<Scalar, Node::dimension>::prim_count(device_.get()));
+        amd::Api<Scalar, Node::dimension>::copy_nodes(device_.get(), nodes.data());
+        amd::Api<Scalar, Node::dimension>::copy_prim_ids(device_.get(), prim_ids.data());
     }
     template <typename N> friend class ReinsertionOptimizer;
 };
@@ -318,7 +342,7 @@ private:
         bvh_build_config c;
         c.quality = static_cast<bvh_build_quality>(config.quality);
         c.min_leaf_size = config.min_leaf_size; c.max_leaf_size = config.max_leaf_size; c.parallel_threshold = config.parallel_threshold;
-        auto* h = amd::Api<Scalar>::build(pool, bboxes.data(), centers.data(), bboxes.size(), &c);
+        auto* h = amd::Api<Scalar, Node::dimension>::build(pool, bboxes.data(), centers.data(), bboxes.size(), &c);
         if (!h) throw amd::Error(bvh_amd_last_error());
         Bvh<Node> bvh;
         bvh.adopt(h);
@@ -333,7 +357,7 @@ public:
     static void optimize(ThreadPool&, Bvh<Node>& bvh) { optimize(bvh); }
     static void optimize(Bvh<Node>& bvh) {
         bvh.push();
-        amd::Api<typename Node::Scalar>::optimize(bvh.device_.get());
+        amd::Api<typename Node::Scalar, Node::dimension>::optimize(bvh.device_.get());
         bvh.pull();
     }
 };
@@ -346,7 +370,7 @@ DeviceArray<PrecomputedTri<typename Node::Scalar>> permuted_triangles(const Bvh<
     using T = typename Node::Scalar;
     DeviceArray<Tri<T, 3>> d_tris(tris);
     DeviceArray<PrecomputedTri<T>> out(tris.size());
-    check(Api<T>::precompute(d_tris.data(), Api<T>::device_prim_ids(bvh.device()), tris.size(), out.data()), "precompute_tris");
+    check(Api<T, 3>::precompute(d_tris.data(), Api<T, 3>::device_prim_ids(bvh.device()), tris.size(), out.data()), "precompute_tris");
     check(bvh_amd_synchronize(nullptr), "synchronize");
     return out;
 }
@@ -358,7 +382,7 @@ void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<PrecomputedTri<type
                      const DeviceArray<Ray<typename Node::Scalar, 3>>& rays, DeviceArray<Hit<typename Node::Scalar>>& hits) {
     using T = typename Node::Scalar;
     const unsigned flags = (IsAnyHit ? unsigned(BVH_AMD_RAY_ANY_HIT) : 0u) | (IsRobust ? unsigned(BVH_AMD_RAY_ROBUST) : 0u);
-    check(Api<T>::trace_tri(bvh.device(), prims.data(), rays.data(), rays.size(), flags, hits.data()), "intersect_rays_tri");
+    check(Api<T, 3>::trace_tri(bvh.device(), prims.data(), rays.data(), rays.size(), flags, hits.data()), "intersect_rays_tri");
 }
 template <bool IsAnyHit, bool IsRobust, typename Node>
 void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<PrecomputedTri<typename Node::Scalar>>& prims,
@@ -371,13 +395,13 @@ void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<PrecomputedTri<type
 }
 // spheres: hit.t = t0, hit.u = t1 of Sphere::intersect (reference sphere.h:32-49); `spheres` in BVH order
 template <bool IsAnyHit, bool IsRobust, typename Node>
-void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<Sphere<typename Node::Scalar, 3>>& spheres,
-                     std::span<const Ray<typename Node::Scalar, 3>> rays, std::span<Hit<typename Node::Scalar>> hits) {
+void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<Sphere<typename Node::Scalar, Node::dimension>>& spheres,
+                     std::span<const Ray<typename Node::Scalar, Node::dimension>> rays, std::span<Hit<typename Node::Scalar>> hits) {
     using T = typename Node::Scalar;
     const unsigned flags = (IsAnyHit ? unsigned(BVH_AMD_RAY_ANY_HIT) : 0u) | (IsRobust ? unsigned(BVH_AMD_RAY_ROBUST) : 0u);
-    DeviceArray<Ray<T, 3>> d_rays(rays);
+    DeviceArray<Ray<T, Node::dimension>> d_rays(rays);
     DeviceArray<Hit<T>> d_hits(rays.size());
-    check(Api<T>::trace_sphere(bvh.device(), spheres.data(), d_rays.data(), rays.size(), flags, d_hits.data()), "intersect_rays_sphere");
+    check(Api<T, Node::dimension>::trace_sphere(bvh.device(), spheres.data(), d_rays.data(), rays.size(), flags, d_hits.data()), "intersect_rays_sphere");
     d_hits.download(hits);
 }
 

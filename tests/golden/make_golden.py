@@ -91,6 +91,26 @@ def main():
     scene_fixture(ref, "spheres2k_f64", synth.spheres(2048, rmin=0.01, rmax=0.04), 4096, np.float64, kind="sphere")
     scene_fixture(ref, "soup2k_f64", synth.soup(2048, seed=3, jitter=0.03, dtype=np.float64), 2048, np.float64)
 
+    # --- the 2D families (Node<T, 2>, circles): serial builders only (with a pool and n >= parallel_threshold the reference
+    # reads p[2] of 2D points, mini_tree_builder.h:183) ---------------------------------------------------------------------
+    for name, dt in (("circles2k_2f", np.float32), ("circles2k_2d", np.float64)):
+        circ = synth.circles(2048, dtype=dt, rmin=0.002, rmax=0.02)
+        fx = {"prims": circ}
+        fx["bboxes"], fx["centers"] = ref.sphere_bboxes(circ)
+        fx["rays_closest"], fx["rays_shadow"] = synth.rays_2d(4096, dtype=dt), synth.rays_2d(4096, dtype=dt, seed=4321, segment=True)
+        for mode, builder, quality in MODES[:5]:
+            bvh = ref.build(fx["bboxes"], fx["centers"], builder=builder, quality=quality)
+            fx[f"bvh_{mode}"] = np.frombuffer(bvh.serialize(), dtype=np.uint8)
+            if mode in ("serial_low", "serial_high"):
+                pp = circ[bvh.prim_ids().astype(np.int64)]
+                for any_hit in (0, 1):
+                    for robust in (0, 1):
+                        hits, cnt = bvh.intersect_sphere(pp, fx["rays_shadow"] if any_hit else fx["rays_closest"], any_hit, robust, counters=True)
+                        key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
+                        fx[f"hits_{key}"], fx[f"counters_{key}"] = hits, cnt
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fx)
+        print(name, {k: v.shape for k, v in fx.items() if k.startswith("bvh_")})
+
     # --- the reference's own known answers -------------------------------
     ka = {}
     # test/simple_example.cpp:25-35, :70-75: two triangles, one ray, parallel High build, fast traversal

@@ -10,11 +10,11 @@ from conftest import ROOT
 SRC = os.path.join(ROOT, "tests", "cpp", "simple_example_amd.cpp")
 
 
-def _compile(out):
+def _compile(out, src=SRC):
     from bvh_amd import build
     build.build()
     lib = os.path.join(ROOT, "bvh_amd", "lib")
-    cmd = ["g++", "-std=c++20", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), SRC,
+    cmd = ["g++", "-std=c++20", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src,
            "-L", lib, "-lbvh_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -22,6 +22,7 @@ def _compile(out):
 
 
 def test_cpp_mirror_compiles_with_gxx(tmp_path):
+    _compile(str(tmp_path / "circles_2d_amd"), os.path.join(ROOT, "tests", "cpp", "circles_2d_amd.cpp"))     # Node<T, 2>
     exe = _compile(str(tmp_path / "simple_example_amd"))
     import torch
     if not torch.cuda.is_available():                         # no GPU: the program must fail loudly, not fall back
@@ -37,3 +38,32 @@ def test_cpp_simple_example_known_answer(tmp_path):
     out = r.stdout
     assert "primitive: 1" in out and "distance: 1" in out and "barycentric coords.: -0, 0.5" in out
     assert "nodes: 1, prim_ids: 1 0" in out                   # serial-High stream of test/serialize.cpp: ids [1, 0]
+
+
+@pytest.mark.gpu
+def test_cpp_2d_circles_match_reference(tmp_path, orc):
+    """Bvh<Node<float, 2>> through the mirror: node count and every hit record equal the reference's."""
+    import numpy as np
+    exe = _compile(str(tmp_path / "circles_2d_amd"), os.path.join(ROOT, "tests", "cpp", "circles_2d_amd.cpp"))
+    n = 4096
+    r = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    s = np.uint64(12345)
+    vals = []
+    with np.errstate(over="ignore"):
+        for _ in range(3 * n):                                # the program's LCG
+            s = s * np.uint64(6364136223846793005) + np.uint64(1442695040888963407)
+            vals.append(np.float32(float(int(s) >> 40) * (1.0 / 16777216.0)))
+    v = np.array(vals, dtype=np.float32).reshape(n, 3)
+    circ = np.stack([v[:, 0], v[:, 1], np.float32(0.001) + np.float32(0.004) * v[:, 2]], axis=1).astype(np.float32)
+    bb, cc = orc.sphere_bboxes(circ)
+    ref = orc.build(bb, cc, quality=2)
+    rays = np.array([[-0.1, i / 1000, 1, 0, 0, 100] for i in range(1000)], dtype=np.float32)
+    rays[:, 1] = (np.arange(1000, dtype=np.float32) / np.float32(1000))
+    want = ref.intersect_sphere(circ[ref.prim_ids().astype(np.int64)], rays, 0, 1)
+    head = lines[0].split()
+    assert int(head[1]) == ref.node_count and int(head[3]) == int((want["prim"] != 0xFFFFFFFF).sum())
+    for line, w in zip(lines[1:], want):
+        p, t, u = line.split()
+        assert int(p) == int(w["prim"]) and np.float32(t) == w["t"] and np.float32(u) == w["u"]

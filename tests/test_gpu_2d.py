@@ -149,3 +149,30 @@ def test_2d_optimize_refit_extract_roundtrip(orc, dtype, tmp_path):
     bbx = getattr(lib, f"bvh_node{s}_get_bbox")(n0)
     root = loaded.nodes[0]["bounds"]
     assert list(bbx.v) == [root[0], root[2], root[1], root[3]]       # {min.x, min.y, max.x, max.y}
+
+
+@pytest.mark.parametrize("scene", ["circles2k_2f", "circles2k_2d"])
+def test_2d_matches_golden(scene):
+    """against the committed fixtures generated from the unmodified reference (tests/golden/make_golden.py)"""
+    import bvh_amd
+    from conftest import MODES, load_golden
+    g = load_golden(scene)
+    circ = g["prims"]
+    d_bb, d_cc = bvh_amd.sphere_bounds(circ)
+    assert d_bb.cpu().numpy().tobytes() == g["bboxes"].tobytes() and d_cc.cpu().numpy().tobytes() == g["centers"].tobytes()
+    builders = {"binned": lambda: bvh_amd.BinnedSahBuilder.build(d_bb, d_cc), "sweep": lambda: bvh_amd.SweepSahBuilder.build(d_bb, d_cc),
+                "serial_low": lambda: bvh_amd.DefaultBuilder.build(d_bb, d_cc, bvh_amd.Config(quality=bvh_amd.Quality.Low)),
+                "serial_med": lambda: bvh_amd.DefaultBuilder.build(d_bb, d_cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium)),
+                "serial_high": lambda: bvh_amd.DefaultBuilder.build(d_bb, d_cc, bvh_amd.Config(quality=bvh_amd.Quality.High))}
+    for mode, _, _ in MODES[:5]:
+        bvh = builders[mode]()
+        assert bvh.serialize() == g[f"bvh_{mode}"].tobytes(), mode
+        if mode in ("serial_low", "serial_high"):
+            pp = bvh_amd.gather(circ, bvh.device_prim_ids())
+            for any_hit in (0, 1):
+                for robust in (0, 1):
+                    key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
+                    hits, cnt = bvh_amd.intersect(bvh, pp, g["rays_shadow"] if any_hit else g["rays_closest"], any_hit=bool(any_hit),
+                                                  robust=bool(robust), counters=True)
+                    assert bvh_amd.hits_to_numpy(hits).tobytes() == g[f"hits_{key}"].tobytes(), key
+                    assert (cnt.cpu().numpy().astype(np.uint64) == g[f"counters_{key}"]).all()

@@ -83,3 +83,28 @@ def test_cornell_render_known_answer(orc):
         if q == 2:
             assert (cnt == ka["cornell_render_counters_high"]).all()
             assert cnt[0] == 7632318 and cnt[2] == 1445436
+
+
+# ---- the 2D families (Node<T, 2>): circles2k_2f / circles2k_2d were generated from the unmodified reference ----------------
+
+@pytest.mark.parametrize("scene", ["circles2k_2f", "circles2k_2d"])
+def test_2d_golden_builders_and_traversal(orc, scene):
+    g = load_golden(scene)
+    circ = g["prims"]
+    bb, cc = orc.sphere_bboxes(circ)
+    assert bb.tobytes() == g["bboxes"].tobytes() and cc.tobytes() == g["centers"].tobytes()
+    for mode, builder, quality in MODES[:5]:
+        bvh = orc.build(bb, cc, builder=builder, quality=quality)
+        assert bvh.serialize() == g[f"bvh_{mode}"].tobytes(), mode
+        if mode in ("serial_low", "serial_high"):
+            pp = circ[bvh.prim_ids().astype(np.int64)]
+            for any_hit in (0, 1):
+                for robust in (0, 1):
+                    key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
+                    hits, cnt = bvh.intersect_sphere(pp, g["rays_shadow"] if any_hit else g["rays_closest"], any_hit, robust, counters=True)
+                    assert hits.tobytes() == g[f"hits_{key}"].tobytes(), key
+                    assert (cnt == g[f"counters_{key}"]).all()
+    # with a thread pool below parallel_threshold the reference is the serial builder; at or above it is undefined: refused
+    assert orc.build(bb, cc, builder=1, quality=1, parallel_threshold=10**6).serialize() == g["bvh_serial_med"].tobytes()
+    with pytest.raises(RuntimeError):
+        orc.build(bb, cc, builder=1, quality=1)

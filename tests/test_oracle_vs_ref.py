@@ -73,3 +73,32 @@ def test_optimize_and_refit_match_reference(orc, ref):
     a.refit()
     b.refit()
     assert a.serialize() == b.serialize()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_2d_restatement_matches_reference(orc, ref, dtype):
+    """Node<T, 2>: every serial builder, optimize, extract_bvh, refit and the four traversal modes with circles."""
+    circ = synth.circles(12000, dtype=dtype, rmin=0.001, rmax=0.01)
+    bb, cc = ref.sphere_bboxes(circ)
+    bb2, cc2 = orc.sphere_bboxes(circ)
+    assert bb.tobytes() == bb2.tobytes() and cc.tobytes() == cc2.tobytes()
+    for builder in (oracle.BUILDER_DEFAULT_SERIAL, oracle.BUILDER_BINNED, oracle.BUILDER_SWEEP):
+        for quality in (0, 1, 2):
+            a = ref.build(bb, cc, builder=builder, quality=quality)
+            b = orc.build(bb, cc, builder=builder, quality=quality)
+            assert a.serialize() == b.serialize() and a.nodes().dtype.itemsize == (20 if dtype == np.float32 else 40)
+    a, b = ref.build(bb, cc, builder=oracle.BUILDER_BINNED), orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    for _ in range(2):
+        a.optimize(-1)
+        b.optimize(-1)
+        assert a.serialize() == b.serialize()
+    assert a.extract(5).serialize() == b.extract(5).serialize()
+    a.refit()
+    b.refit()
+    assert a.serialize() == b.serialize()
+    pp = circ[a.prim_ids().astype(np.int64)]
+    for any_hit, rays in ((0, synth.rays_2d(5000, dtype=dtype)), (1, synth.rays_2d(5000, dtype=dtype, segment=True))):
+        for robust in (0, 1):
+            ha, ca = a.intersect_sphere(pp, rays, any_hit, robust, counters=True)
+            hb, cb = b.intersect_sphere(pp, rays, any_hit, robust, counters=True)
+            assert ha.tobytes() == hb.tobytes() and (ca == cb).all()
