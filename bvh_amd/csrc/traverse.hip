@@ -27,8 +27,8 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kLdsDepth = 20;
-constexpr int kRefillThreshold = 32;          // refill when at least this many lanes of the wave are idle
-constexpr int kLeafThreshold = 32;            // run the leaf code when at least this many lanes wait at a leaf
+constexpr int kRefillThreshold = 54;          // refill when at least this many lanes of the wave are idle (swept: profiles/README.md)
+constexpr int kLeafThreshold = 8;             // run the leaf code when at least this many lanes wait at a leaf
 
 thread_local const char* g_last_kernel = "";
 
