@@ -107,6 +107,12 @@ struct BvhImpl {
     size_t pair_count = 0;
     uint32_t* d_prim_ids = nullptr;            // prim_count
     uint32_t root_index = 0;                   // nodes[0].index narrowed to 32 bits
+    // Deepest level of the tree (root = 0), computed lazily on the device by the first batch traversal after a (re)layout.
+    // The traversal stack never holds more entries than that: trees up to 64 levels use LDS + per-lane scratch (the
+    // reference's SmallStack<Index, 64>), deeper ones additionally spill to d_deep (its GrowingStack, stack.h:34-46).
+    mutable int max_depth = -1;
+    mutable uint32_t* d_deep = nullptr;
+    mutable size_t deep_words = 0;
     // per-object scratch for batch launches
     unsigned long long* d_work = nullptr;      // [0] ray counter, [1] status word
     // scratch of the optional ray-coherence sort (BVH_AMD_RAY_SORTED): keys, order, two temporaries, histograms
@@ -117,6 +123,7 @@ struct BvhImpl {
 
 // upload.hip
 template <typename T> int upload_bvh(BvhImpl<T>& b, hipStream_t stream);
+template <typename T> int tree_depth(const BvhImpl<T>& b, hipStream_t stream);   // fills b.max_depth (cached)
 
 // traverse.hip
 template <typename T>

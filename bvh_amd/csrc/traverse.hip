@@ -75,6 +75,8 @@ struct TraceArgs {
     unsigned long long* work;                  // [0] next ray ticket, [1] status (stack overflow)
     bvh_amd_counters* counters;
     const uint32_t* order;                     // optional: ticket -> ray index (coherence sort); results are unaffected
+    uint32_t* deep;                            // stack entries beyond 64, deep_cap per resident lane (trees deeper than 64 levels only)
+    uint32_t deep_cap;
     uint32_t root_index;
     int refill_threshold;                      // refill when at least this many lanes are idle
     int leaf_threshold;                        // leave the inner-node loop when this many lanes wait at a leaf
@@ -183,9 +185,12 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
     T hit_t = 0, hit_u = 0, hit_v = 0;
     unsigned long long n_pairs = 0, n_tests = 0, n_leaves = 0;
 
+    // (launch_traverse sizes `deep` from the depth of the tree, so `overflow` is a cannot-happen guard)
+    uint32_t* const deep = a.deep ? a.deep + (size_t{blockIdx.x} * kBlock + tid) * a.deep_cap : nullptr;
     auto push = [&](uint32_t v) {
         if (sp < kDepth) lds_stack[sp * kBlock + tid] = v;
         else if (sp < kDepth + kSpill) spill[sp - kDepth] = v;
+        else if (deep && sp - (kDepth + kSpill) < a.deep_cap) deep[sp - (kDepth + kSpill)] = v;
         else overflow = true;
         ++sp;
     };
@@ -193,6 +198,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
         --sp;
         if (sp < kDepth) return lds_stack[sp * kBlock + tid];
         if (sp < kDepth + kSpill) return spill[sp - kDepth];
+        if (deep && sp - (kDepth + kSpill) < a.deep_cap) return deep[sp - (kDepth + kSpill)];
         return 0u;
     };
 
@@ -451,6 +457,26 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
     args.n = n; args.work = b.d_work; args.counters = d_counters; args.root_index = b.root_index;
     args.order = nullptr;
+    args.deep = nullptr; args.deep_cap = 0;
+    {   // SmallStack<Index, 64> covers every tree of at most 64 levels; deeper trees get the GrowingStack equivalent
+        int rc = tree_depth<T>(b, stream);
+        if (rc) return rc;
+        if (b.max_depth > 64) {
+            int cus = 0;
+            BVH_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device), BVH_AMD_ERR_HIP);
+            const size_t lanes = size_t{8} * cus * kBlock;                   // persistent_grid launches at most 8 blocks per CU
+            const size_t cap = static_cast<size_t>(b.max_depth - 64 + 1);
+            if (lanes * cap > (size_t{1} << 32))
+                return fail(BVH_AMD_ERR_UNSUPPORTED, "intersect_rays: the tree is too deep for the traversal stack (" + std::to_string(b.max_depth) + " levels)");
+            if (b.deep_words < lanes * cap) {
+                if (b.d_deep) (void)hipFree(b.d_deep);
+                b.d_deep = nullptr; b.deep_words = 0;
+                BVH_HIP_TRY(hipMalloc(&b.d_deep, lanes * cap * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
+                b.deep_words = lanes * cap;
+            }
+            args.deep = b.d_deep; args.deep_cap = static_cast<uint32_t>(cap);
+        }
+    }
     static const int refill_env = getenv("BVH_AMD_REFILL") ? atoi(getenv("BVH_AMD_REFILL")) : 0;   // tuning knobs
     static const int leaf_env = getenv("BVH_AMD_LEAF") ? atoi(getenv("BVH_AMD_LEAF")) : 0;
     args.refill_threshold = refill_env > 0 ? refill_env : kRefillThreshold;

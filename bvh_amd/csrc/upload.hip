@@ -24,7 +24,56 @@ __global__ void __launch_bounds__(256) relayout_pairs(const HostNode<T>* nodes, 
     out[p] = rec;
 }
 
+// depth of every pair record by pointer jumping over the parent links: O(log depth) rounds, no host round trips
+template <typename T>
+__global__ void __launch_bounds__(256) k_depth_init(const PairNode<T>* pairs, uint32_t n_pairs, uint32_t* anc, uint32_t* dist) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs) return;
+    if (p == 0) { anc[0] = 0; dist[0] = 0; }                  // the root's children: level 1 (dist counts pairs above)
+    const uint32_t li = pairs[p].li, ri = pairs[p].ri;
+    if ((li & kCountMask) == 0) { anc[li >> (kCountBits + 1)] = p; dist[li >> (kCountBits + 1)] = 1; }
+    if ((ri & kCountMask) == 0) { anc[ri >> (kCountBits + 1)] = p; dist[ri >> (kCountBits + 1)] = 1; }
+}
+__global__ void __launch_bounds__(256) k_depth_jump(const uint32_t* anc, const uint32_t* dist, uint32_t n, uint32_t* anc_out, uint32_t* dist_out,
+                                                    uint32_t* max_out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = anc[i], d = dist[i] + dist[a];
+    anc_out[i] = anc[a];
+    dist_out[i] = d;
+    if (max_out) atomicMax(max_out, d);
+}
+
 } // namespace
+
+template <typename T>
+int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
+    if (b.max_depth >= 0) return BVH_AMD_OK;
+    if (b.pair_count == 0) { b.max_depth = 0; return BVH_AMD_OK; }
+    const uint32_t n = static_cast<uint32_t>(b.pair_count);
+    uint32_t* buf = nullptr;
+    BVH_HIP_TRY(hipMalloc(&buf, (size_t{4} * n + 1) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
+    uint32_t *anc = buf, *dist = buf + n, *anc2 = buf + 2 * size_t{n}, *dist2 = buf + 3 * size_t{n}, *d_max = buf + 4 * size_t{n};
+    hipError_t e = hipMemsetAsync(d_max, 0, 4, stream);
+    const unsigned grid = (n + 255) / 256;
+    hipLaunchKernelGGL(k_depth_init<T>, dim3(grid), dim3(256), 0, stream, b.d_pairs, n, anc, dist);
+    int rounds = 1;
+    while ((uint64_t{1} << rounds) < uint64_t{n} + 1) ++rounds;        // after r rounds every chain of length <= 2^r is resolved
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(k_depth_jump, dim3(grid), dim3(256), 0, stream, anc, dist, n, anc2, dist2, r == rounds - 1 ? d_max : nullptr);
+        std::swap(anc, anc2); std::swap(dist, dist2);
+    }
+    uint32_t deepest = 0;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&deepest, d_max, 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("tree_depth: ") + hipGetErrorString(e));
+    b.max_depth = static_cast<int>(deepest) + 1;              // pairs at distance d from the root pair hold nodes of level d + 1
+    return BVH_AMD_OK;
+}
+template int tree_depth<float>(const BvhImpl<float>&, hipStream_t);
+template int tree_depth<double>(const BvhImpl<double>&, hipStream_t);
 
 template <typename T>
 BvhImpl<T>::~BvhImpl() {
@@ -33,6 +82,7 @@ BvhImpl<T>::~BvhImpl() {
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
         if (d_pairs) (void)hipFree(d_pairs);
+        if (d_deep) (void)hipFree(d_deep);
         if (d_prim_ids) (void)hipFree(d_prim_ids);
         if (d_work) (void)hipFree(d_work);
         if (d_nodes) (void)hipFree(d_nodes);
@@ -61,6 +111,7 @@ int BvhImpl<T>::sync_host() const {
 template <typename T>
 int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream) {
     b.pair_count = (b.node_count - 1) / 2;
+    b.max_depth = -1;
     if (b.d_pairs) { (void)hipFree(b.d_pairs); b.d_pairs = nullptr; }
     if (b.pair_count) {
         BVH_HIP_TRY(hipMalloc(&b.d_pairs, b.pair_count * sizeof(PairNode<T>)), BVH_AMD_ERR_HIP);

@@ -800,7 +800,18 @@ void trace_one(const Tree<T>& tree, const T* prims, RayState<T>& ray, typename T
             t1 = pick_min(b, t1);
         }
     };
-    Index stack[64];                                         // SmallStack<Index, 64>, stack.h:11-30
+    // SmallStack<Index, 64> (stack.h:11-30) in the reference's examples and C API; this restatement grows instead
+    // (GrowingStack, stack.h:34-46: same push/pop order, no capacity) so that it can also check trees deeper than 64
+    Index small[64];
+    std::vector<Index> grown;
+    Index* stack = small;
+    size_t cap = 64;
+    auto reserve = [&](size_t need) {
+        if (need <= cap) return;
+        std::vector<Index> bigger(2 * need);
+        std::copy(stack, stack + cap, bigger.begin());
+        grown.swap(bigger); stack = grown.data(); cap = grown.size();
+    };
     unsigned sp = 0;
     stack[sp++] = tree.nodes[0].index;                       // traversal starts at root.index: the root box is never tested
     const Index count_mask = (Index(1) << kCountBits) - 1;
@@ -821,6 +832,7 @@ void trace_one(const Tree<T>& tree, const T* prims, RayState<T>& ray, typename T
                 if (hr) {
                     Index far_i = r.index;
                     if (!Any && l0 > r0) std::swap(near_i, far_i);
+                    reserve(sp + 1);
                     stack[sp++] = far_i;
                 }
                 top = near_i;

@@ -185,3 +185,50 @@ def test_cornell_render_ppm_md5(orc):
         d_hits = bvh_amd.intersect(bvh, prims, d_rays, any_hit=False, robust=False)
         d_img = bvh_amd.shade_eyelight(prims, d_rays, d_hits).cpu().numpy().reshape(H, W, 3)
         assert hashlib.md5(f"P6 {W} {H} 255\n".encode() + d_img[::-1].tobytes()).hexdigest() == "96f6bbdc03d7f750fdb833993e9f8538"
+
+
+@pytest.mark.parametrize("depth", [60, 64, 65, 300, 3000])
+def test_trees_deeper_than_the_small_stack(orc, depth):
+    """The reference's examples and C API trace with SmallStack<Index, 64>; its GrowingStack (stack.h:34-46) has no limit.
+    A chain-shaped tree whose inner child is always nearer than its leaf sibling fills the stack one entry per level: the
+    device traversal must give the growing-stack results (LDS + scratch up to 64 entries, HBM spill beyond)."""
+    import bvh_amd
+    n = depth + 1                                             # leaves; deepest level = depth
+    tris = np.zeros((n, 9), dtype=np.float32)
+    for k in range(n):
+        x = np.float32(4000 - k)
+        tris[k] = [x, -1, -1, x, 1, -1, x, 0, 1]
+    bb, _ = orc.prep_tris(tris)
+    nodes = np.zeros(2 * n - 1, dtype=oracle.NODEF)
+    suffix = bb.copy()                                        # suffix[k] = union of the boxes of leaves k..n-1
+    for k in range(n - 2, -1, -1):
+        suffix[k, :3] = np.minimum(bb[k, :3], suffix[k + 1, :3])
+        suffix[k, 3:] = np.maximum(bb[k, 3:], suffix[k + 1, 3:])
+    box = lambda b: [b[0], b[3], b[1], b[4], b[2], b[5]]
+    nodes[0]["bounds"], nodes[0]["index"] = box(suffix[0]), 1 << 4
+    for k in range(n - 1):
+        leaf, rest = 2 * k + 1, 2 * k + 2
+        nodes[leaf]["bounds"], nodes[leaf]["index"] = box(bb[k]), (k << 4) | 1
+        if k == n - 2:
+            nodes[rest]["bounds"], nodes[rest]["index"] = box(bb[n - 1]), ((n - 1) << 4) | 1
+        else:
+            nodes[rest]["bounds"], nodes[rest]["index"] = box(suffix[k + 1]), (2 * k + 3) << 4
+    ids = np.arange(n, dtype=np.uint64)
+    ref = orc.from_arrays(nodes, ids)
+    gpu = bvh_amd.Bvh.from_nodes(nodes, ids)
+    prims = orc.precompute_tris(tris)
+    rng = np.random.default_rng(depth)
+    rays = np.zeros((70_000, 8), dtype=np.float32)
+    rays[:, 0] = rng.random(len(rays)) * 100                   # origins in front of the stack of triangles
+    rays[:, 1:3] = (rng.random((len(rays), 2)) - 0.5) * 1.5
+    rays[:, 3] = 1
+    rays[:, 4:6] = (rng.random((len(rays), 2)) - 0.5) * 1e-4
+    rays[:, 7] = np.finfo(np.float32).max
+    rays[::7, 3] = -1                                          # some point away
+    for any_hit in (False, True):
+        for robust in (False, True):
+            want, cw = ref.intersect_tri(prims, rays, any_hit, robust, threads=8, counters=True)
+            got, cg = bvh_amd.intersect(gpu, prims, rays, any_hit=any_hit, robust=robust, counters=True)
+            assert bvh_amd.hits_to_numpy(got).tobytes() == want.tobytes(), (depth, any_hit, robust)
+            assert (cg.cpu().numpy().astype(np.uint64) == cw).all()
+    assert int((want["prim"] != oracle.INVALID).sum()) > 10_000
