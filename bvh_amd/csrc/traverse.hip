@@ -164,7 +164,8 @@ __device__ inline void wave_sync() {
 // requests are charged per lane, not per line, and idle lanes then cost as much as active ones.
 // D = 2: Bvh<Node<T, 2>> with circles (Sphere<T, 2>, stride 3) and 6-value rays. The pair records stay three wide (their z
 // bounds are zero and never looked at): only the per-ray constants, the slab test and the leaf test run over D axes.
-template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3>
+// Deep = true (trees of more than 64 levels only): stack entries beyond the 64 of SmallStack spill to HBM (GrowingStack).
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3, bool Deep = false>
 __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
     constexpr int kDepth = kLdsDepth;
     constexpr int kSpill = 64 - kDepth;            // kDepth + kSpill = 64 = the reference's SmallStack capacity
@@ -186,11 +187,12 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
     unsigned long long n_pairs = 0, n_tests = 0, n_leaves = 0;
 
     // (launch_traverse sizes `deep` from the depth of the tree, so `overflow` is a cannot-happen guard)
-    uint32_t* const deep = a.deep ? a.deep + (size_t{blockIdx.x} * kBlock + tid) * a.deep_cap : nullptr;
+    // (the address of the deep slot is formed inside the cold branch: nothing about it stays live in the hot loop)
+    auto deep_slot = [&](uint32_t i) { return a.deep + (size_t{blockIdx.x} * kBlock + tid) * a.deep_cap + i; };
     auto push = [&](uint32_t v) {
         if (sp < kDepth) lds_stack[sp * kBlock + tid] = v;
         else if (sp < kDepth + kSpill) spill[sp - kDepth] = v;
-        else if (deep && sp - (kDepth + kSpill) < a.deep_cap) deep[sp - (kDepth + kSpill)] = v;
+        else if (Deep && sp - (kDepth + kSpill) < a.deep_cap) *deep_slot(sp - (kDepth + kSpill)) = v;
         else overflow = true;
         ++sp;
     };
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
         --sp;
         if (sp < kDepth) return lds_stack[sp * kBlock + tid];
         if (sp < kDepth + kSpill) return spill[sp - kDepth];
-        if (deep && sp - (kDepth + kSpill) < a.deep_cap) return deep[sp - (kDepth + kSpill)];
+        if (Deep && sp - (kDepth + kSpill) < a.deep_cap) return *deep_slot(sp - (kDepth + kSpill));
         return 0u;
     };
 
@@ -404,10 +406,10 @@ int persistent_grid(K kernel, int device, Grid& g) {
     return BVH_AMD_OK;
 }
 
-template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
-int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D, bool Deep>
+int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     static thread_local int cached_blocks[16] = {0};
-    auto kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D>;
+    auto kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D, Deep>;
     int& blocks = cached_blocks[b.device & 15];
     if (blocks == 0) {
         Grid g;
@@ -422,6 +424,12 @@ int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t st
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
     return BVH_AMD_OK;
+}
+
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
+int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
+    if (args.deep) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, true>(b, args, stream, name);
+    return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false>(b, args, stream, name);
 }
 
 #define BVH_VARIANT(T, ANY, ROB, LEAF, STATS) \
