@@ -177,6 +177,7 @@ template <typename T, size_t N = 3> struct Api;
 template <> struct Api<float, 3> {
     using Handle = bvh3f; using CHit = bvh_hit3f;
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3f_build(p, static_cast<const bvh_bbox3f*>(bb), static_cast<const bvh_vec3f*>(cc), n, c); }
+    static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh3f_build_device(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, b, nullptr); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3f_from_nodes(nodes, nn, ids, np); }
     static void destroy(Handle* h) { bvh3f_destroy(h); }
     static size_t node_count(const Handle* h) { return bvh3f_get_node_count(h); }
@@ -194,6 +195,7 @@ template <> struct Api<float, 3> {
 template <> struct Api<double, 3> {
     using Handle = bvh3d; using CHit = bvh_hit3d;
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3d_build(p, static_cast<const bvh_bbox3d*>(bb), static_cast<const bvh_vec3d*>(cc), n, c); }
+    static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh3d_build_device(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, b, nullptr); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3d_from_nodes(nodes, nn, ids, np); }
     static void destroy(Handle* h) { bvh3d_destroy(h); }
     static size_t node_count(const Handle* h) { return bvh3d_get_node_count(h); }
@@ -214,6 +216,7 @@ template <> struct Api<double, 3> {
 template <> struct Api<T, 2> {                                                                                                            \
     using Handle = bvh##S; using CHit = std::conditional_t<std::is_same_v<T, float>, bvh_hit3f, bvh_hit3d>;                              \
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh##S##_build(p, static_cast<const bvh_bbox##S*>(bb), static_cast<const bvh_vec##S*>(cc), n, c); } \
+    static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh##S##_build_device(static_cast<const T*>(d_bb), static_cast<const T*>(d_cc), n, c, b, nullptr); } \
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh##S##_from_nodes(nodes, nn, ids, np); } \
     static void destroy(Handle* h) { bvh##S##_destroy(h); }                                                                               \
     static size_t node_count(const Handle* h) { return bvh##S##_get_node_count(h); }                                                      \
@@ -347,6 +350,63 @@ private:
         Bvh<Node> bvh;
         bvh.adopt(h);
         return bvh;
+    }
+};
+
+// ---- split_heuristic.h / top_down_sah_builder.h / binned_sah_builder.h / sweep_sah_builder.h -------------------------------------
+template <typename T>
+struct SplitHeuristic {                                       // reference split_heuristic.h:12-44 (the device builders implement the defaults)
+    size_t log_cluster_size = 0;
+    T cost_ratio = static_cast<T>(1.);
+    bool is_default() const { return log_cluster_size == 0 && cost_ratio == static_cast<T>(1.); }
+};
+
+template <typename Node>
+class TopDownSahBuilder {
+protected:
+    using Scalar = typename Node::Scalar;
+    using Vec = bvh::v2::Vec<Scalar, Node::dimension>;
+    using BBox = bvh::v2::BBox<Scalar, Node::dimension>;
+public:
+    struct Config {                                           // reference top_down_sah_builder.h:27-40
+        SplitHeuristic<Scalar> sah;
+        size_t min_leaf_size = 1;
+        size_t max_leaf_size = 8;
+    };
+protected:
+    static Bvh<Node> run(bvh_amd_builder which, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config) {
+        if (!config.sah.is_default()) throw amd::Error("bvh_amd: the device builders implement SplitHeuristic's default parameters only");
+        if (bboxes.size() != centers.size()) throw amd::Error("bvh_amd: bboxes and centers differ in length");
+        bvh_build_config c;
+        c.quality = BVH_BUILD_QUALITY_HIGH;                   // (unused by the explicit builders)
+        c.min_leaf_size = config.min_leaf_size; c.max_leaf_size = config.max_leaf_size; c.parallel_threshold = 1024;
+        amd::DeviceArray<BBox> d_bb(bboxes);
+        amd::DeviceArray<Vec> d_cc(centers);
+        auto* h = amd::Api<Scalar, Node::dimension>::build_device(d_bb.data(), d_cc.data(), bboxes.size(), &c, which);
+        if (!h) throw amd::Error(bvh_amd_last_error());
+        Bvh<Node> bvh;
+        bvh.adopt(h);
+        return bvh;
+    }
+};
+
+template <typename Node>
+class BinnedSahBuilder : public TopDownSahBuilder<Node> {     // reference binned_sah_builder.h:32-38 (BinCount = 8)
+    using Base = TopDownSahBuilder<Node>;
+public:
+    using typename Base::Config;
+    [[nodiscard]] static Bvh<Node> build(std::span<const typename Base::BBox> bboxes, std::span<const typename Base::Vec> centers, const Config& config = {}) {
+        return Base::run(BVH_AMD_BUILDER_BINNED, bboxes, centers, config);
+    }
+};
+
+template <typename Node>
+class SweepSahBuilder : public TopDownSahBuilder<Node> {      // reference sweep_sah_builder.h:30-36
+    using Base = TopDownSahBuilder<Node>;
+public:
+    using typename Base::Config;
+    [[nodiscard]] static Bvh<Node> build(std::span<const typename Base::BBox> bboxes, std::span<const typename Base::Vec> centers, const Config& config = {}) {
+        return Base::run(BVH_AMD_BUILDER_SWEEP, bboxes, centers, config);
     }
 };
 

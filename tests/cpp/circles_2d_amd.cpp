@@ -2,6 +2,8 @@
 // Prints "nodes <N> hits <H> first <prim> <t0>"; tests/test_cpp_mirror.py compares with the reference (oracle/_ref).
 #include <bvh/v2/bvh.h>
 #include <bvh/v2/default_builder.h>
+#include <bvh/v2/binned_sah_builder.h>
+#include <bvh/v2/sweep_sah_builder.h>
 #include <bvh/v2/sphere.h>
 #include <bvh/v2/ray.h>
 
@@ -44,6 +46,14 @@ int main(int argc, char** argv) {
     bvh::v2::amd::intersect_batch<false, true>(bvh, d_circles, std::span<const Ray>(rays), std::span(hits));
     size_t count = 0;
     for (auto& h : hits) count += h.prim != bvh::v2::amd::Hit<Scalar>::invalid;
+    // the explicit builders: Medium == SweepSahBuilder; BinnedSahBuilder == Quality::Low (default_builder.h:49-62)
+    typename bvh::v2::DefaultBuilder<Node>::Config low;
+    low.quality = bvh::v2::DefaultBuilder<Node>::Quality::Low;
+    const bool binned_ok = bvh::v2::BinnedSahBuilder<Node>::build(bboxes, centers) == bvh::v2::DefaultBuilder<Node>::build(bboxes, centers, low);
+    typename bvh::v2::DefaultBuilder<Node>::Config med;
+    med.quality = bvh::v2::DefaultBuilder<Node>::Quality::Medium;
+    const bool sweep_ok = bvh::v2::SweepSahBuilder<Node>::build(bboxes, centers) == bvh::v2::DefaultBuilder<Node>::build(bboxes, centers, med);
+    if (!binned_ok || !sweep_ok) { std::fprintf(stderr, "explicit builders differ from DefaultBuilder\n"); return 2; }
     std::printf("nodes %zu hits %zu first %u %.9g\n", bvh.nodes.size(), count, hits[500].prim, double(hits[500].t));
     for (auto& h : hits) std::printf("%u %.9g %.9g\n", h.prim, double(h.t), double(h.u));
     return 0;
