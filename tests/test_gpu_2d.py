@@ -176,3 +176,57 @@ def test_2d_matches_golden(scene):
                                                   robust=bool(robust), counters=True)
                     assert bvh_amd.hits_to_numpy(hits).tobytes() == g[f"hits_{key}"].tobytes(), key
                     assert (cnt.cpu().numpy().astype(np.uint64) == g[f"counters_{key}"]).all()
+
+
+@pytest.mark.parametrize("sfx,scene", [("2f", "circles2k_2f"), ("2d", "circles2k_2d")])
+def test_2d_raw_c_abi_host_pointers_and_editing(sfx, scene):
+    """bvh2X_build with host pointers exactly as a C program calls it (with and without a thread pool), then the node editing
+    API of c_api/bvh.h:170-218 on the 20/40-byte mirror: set_bbox + refit, append_node / remove_last_node + sync_device."""
+    from bvh_amd import _lib as L
+    from conftest import load_golden
+    dll = L.load()
+    g = load_golden(scene)
+    bb, cc = np.ascontiguousarray(g["bboxes"]), np.ascontiguousarray(g["centers"])
+    for quality, key in ((0, "serial_low"), (1, "serial_med"), (2, "serial_high")):
+        cfg = L.BuildConfig(quality, 1, 8, 1024)
+        h = getattr(dll, f"bvh{sfx}_build")(None, bb.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), len(bb), C.byref(cfg))
+        assert h, L.last_error()
+        n = getattr(dll, f"bvh{sfx}_serialize")(h, None, 0)
+        buf = C.create_string_buffer(n)
+        getattr(dll, f"bvh{sfx}_serialize")(h, buf, n)
+        assert buf.raw == g[f"bvh_{key}"].tobytes()
+        getattr(dll, f"bvh{sfx}_destroy")(h)
+    pool = dll.bvh_thread_pool_create(8)
+    cfg = L.BuildConfig(1, 1, 8, 1 << 20)                      # below parallel_threshold: the serial builder (default_builder.h:38-39)
+    h = getattr(dll, f"bvh{sfx}_build")(pool, bb.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), len(bb), C.byref(cfg))
+    assert h, L.last_error()
+    cfg = L.BuildConfig(1, 1, 8, 1024)                         # at/above it: undefined in the reference, refused
+    assert not getattr(dll, f"bvh{sfx}_build")(pool, bb.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), len(bb), C.byref(cfg))
+    assert "2D" in L.last_error()
+    dll.bvh_thread_pool_destroy(pool)
+    # NULL config = the defaults (Quality::High)
+    h2 = getattr(dll, f"bvh{sfx}_build")(None, bb.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), len(bb), None)
+    n2 = getattr(dll, f"bvh{sfx}_serialize")(h2, None, 0)
+    buf2 = C.create_string_buffer(n2)
+    getattr(dll, f"bvh{sfx}_serialize")(h2, buf2, n2)
+    assert buf2.raw == g["bvh_serial_high"].tobytes()
+    getattr(dll, f"bvh{sfx}_destroy")(h2)
+    # append a node, fill it through the setters, remove it again: the stream is unchanged after sync_device
+    nn = getattr(dll, f"bvh{sfx}_get_node_count")(h)
+    before = C.create_string_buffer(getattr(dll, f"bvh{sfx}_serialize")(h, None, 0))
+    getattr(dll, f"bvh{sfx}_serialize")(h, before, len(before))
+    getattr(dll, f"bvh{sfx}_append_node")(h)
+    assert getattr(dll, f"bvh{sfx}_get_node_count")(h) == nn + 1
+    node = getattr(dll, f"bvh{sfx}_get_node")(h, nn)
+    ct = C.c_float if sfx == "2f" else C.c_double
+    getattr(dll, f"bvh_node{sfx}_set_bbox")(node, (ct * 4)(0.25, 0.5, 0.75, 1.0))
+    getattr(dll, f"bvh_node{sfx}_set_first_id")(node, 7)
+    getattr(dll, f"bvh_node{sfx}_set_prim_count")(node, 3)
+    assert getattr(dll, f"bvh_node{sfx}_is_leaf")(node) and getattr(dll, f"bvh_node{sfx}_get_first_id")(node) == 7
+    assert list(getattr(dll, f"bvh_node{sfx}_get_bbox")(node).v) == [0.25, 0.5, 0.75, 1.0]
+    getattr(dll, f"bvh{sfx}_remove_last_node")(h)
+    assert getattr(dll, f"bvh{sfx}_sync_device")(h) == 0
+    after = C.create_string_buffer(len(before))
+    getattr(dll, f"bvh{sfx}_serialize")(h, after, len(after))
+    assert after.raw == before.raw
+    getattr(dll, f"bvh{sfx}_destroy")(h)
