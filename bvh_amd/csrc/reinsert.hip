@@ -286,11 +286,11 @@ __device__ bool top_adjust(WaveHeap<T>& h, uint32_t len, Ent<T> value, int lane,
 // children with one LDS instruction and chooses between them, all nodes at once; the path is then five dependent readlanes
 // ("pointer jumping" through the choices), and every path node itself stores its chosen child's entry (or the value,
 // at the first node whose chosen child is greater) into its own position, so no entry travels between lanes.
-// (the rounds are unrolled at compile time: 5 + 5 + 3 levels for float, 5 + 5 + 2 for double)
-template <typename T, int Level, typename Resolve>
+// (the rounds are unrolled at compile time: 5 + 5 + 3 levels for float, 5 + 5 + 2 for double when the heap extends below LDS;
+//  kCapLevel = the number of leading levels whose nodes all have two children, for heaps that end inside LDS)
+template <typename T, int Level, int kCapLevel, typename Resolve>
 __device__ inline bool fast_top_round(WaveHeap<T>& h, Ent<T> value, int lane, uint32_t cur, int d, uint32_t in_level,
                                       uint32_t& hand_pos, T& root_cost, Resolve& resolve_tasks) {
-    constexpr int kCapLevel = HeapLevels<T>::v - 1;
     constexpr int kSteps = kCapLevel - Level < 5 ? kCapLevel - Level : 5;
     const uint32_t node = ((cur + 1) << d) - 1 + in_level;                // heap position of BFS node `lane`
     const bool inner = lane < (1 << kSteps) - 1;
@@ -324,16 +324,27 @@ __device__ inline bool fast_top_round(WaveHeap<T>& h, Ent<T> value, int lane, ui
     heap_sync();
     const uint32_t below = lane_value(chosen_pos, r);
     if constexpr (Level + kSteps < kCapLevel)
-        return fast_top_round<T, Level + kSteps>(h, value, lane, below, d, in_level, hand_pos, root_cost, resolve_tasks);
+        return fast_top_round<T, Level + kSteps, kCapLevel>(h, value, lane, below, d, in_level, hand_pos, root_cost, resolve_tasks);
     hand_pos = below;
     return true;
 }
 
-template <typename T, typename Resolve>
-__device__ inline bool fast_top_adjust(WaveHeap<T>& h, Ent<T> value, int lane, uint32_t& hand_pos, T& root_cost, Resolve resolve_tasks) {
+// `full_levels` (wave-uniform, 1 .. HeapLevels - 1): every node above that level has both children inside the heap
+template <bool BelowLds, typename T, typename Resolve>
+__device__ inline bool fast_top_adjust(WaveHeap<T>& h, int full_levels, Ent<T> value, int lane, uint32_t& hand_pos, T& root_cost, Resolve resolve_tasks) {
     const int d = 31 - __clz(lane + 1);
     const uint32_t in_level = static_cast<uint32_t>(lane + 1) - (1u << d);
-    return fast_top_round<T, 0>(h, value, lane, 0u, d, in_level, hand_pos, root_cost, resolve_tasks);
+    if constexpr (BelowLds)                                   // the heap reaches below LDS (large scenes): one instantiation, no dispatch
+        return fast_top_round<T, 0, HeapLevels<T>::v - 1>(h, value, lane, 0u, d, in_level, hand_pos, root_cost, resolve_tasks);
+#define BVH_FAST_TOP(F) case F: if constexpr (F <= HeapLevels<T>::v - 1) return fast_top_round<T, 0, F>(h, value, lane, 0u, d, in_level, hand_pos, root_cost, resolve_tasks); break;
+    switch (full_levels) {
+        BVH_FAST_TOP(1) BVH_FAST_TOP(2) BVH_FAST_TOP(3) BVH_FAST_TOP(4) BVH_FAST_TOP(5) BVH_FAST_TOP(6) BVH_FAST_TOP(7)
+        BVH_FAST_TOP(8) BVH_FAST_TOP(9) BVH_FAST_TOP(10) BVH_FAST_TOP(11) BVH_FAST_TOP(12) BVH_FAST_TOP(13)
+        default: break;
+    }
+#undef BVH_FAST_TOP
+    hand_pos = 0;                                             // (unreachable for valid arguments)
+    return true;
 }
 
 // __push_heap(first, hole = k - 1, top = 0, w) on the chain: ancestors greater than w move down one place, w lands above them
@@ -424,7 +435,9 @@ __global__ void __launch_bounds__(64) k_make_heap_level(Ent<T>* glob, uint32_t k
 }
 
 // The replacement loop (:96-103). `glob` holds the finished make_heap; the top of the heap is staged into LDS.
-template <typename T>
+// BelowLds: the heap has more entries than fit in LDS (k - 1 >= HeapCap); the two cases are separate kernels so that the
+// large-scene loop carries exactly one instantiation of the top phase.
+template <typename T, bool BelowLds>
 __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_nodes, uint32_t target, Ent<T>* glob, uint32_t* out_ids) {
     extern __shared__ unsigned char heap_lds[];
     WaveHeap<T> h;
@@ -452,6 +465,10 @@ __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_no
         }
     };
     T root_cost = h.lds[0].cost;                              // cost of the heap minimum, tracked in a register
+    // pops work on positions [0, k - 1): every node above level `full_levels` has both children there
+    constexpr bool below_lds = BelowLds;
+    int full_levels = below_lds ? h.cap_level : 0;
+    if (!below_lds && k >= 4) { full_levels = (31 - __clz(static_cast<int>(k))) - 1; if (full_levels > h.cap_level) full_levels = h.cap_level; }
     const bool last_in_regs = k - 1 >= h.cap;                 // position k-1 (chain lane 0) is register-resident
     for (uint32_t chunk = head; chunk < n_nodes; chunk += kStreamChunk) {   // :96-103, kStreamChunk costs per HBM round trip
         bool any = false;
@@ -480,10 +497,12 @@ __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_no
                         else v = h.get_lds(k - 1);
                         uint32_t hand = 0;
                         bool handed;
-                        if (k - 1 >= h.cap) handed = fast_top_adjust(h, v, lane, hand, root_cost, resolve_tasks);
+                        if (full_levels >= 1) handed = fast_top_adjust<BelowLds>(h, full_levels, v, lane, hand, root_cost, resolve_tasks);
                         else { handed = top_adjust(h, k - 1, v, lane, hand, resolve_tasks); root_cost = h.lds[0].cost; }
                         if (handed) {
-                            if (chain.holds(hand, h.cap_level)) {     // the path follows the chain into HBM (rare): at once, by the wave
+                            if (!below_lds || chain.holds(hand, h.cap_level)) {
+                                // the rest of the path at once, by the wave: a heap that ends inside LDS (its last, incomplete
+                                // levels), or a path that follows the chain into HBM (rare)
                                 if (wave_adjust_heap(h, chain, hand, k - 1, v, lane)) chain.load(h);
                             } else {
                                 if (static_cast<uint32_t>(lane) == n_tasks) { task_pos = hand; task_value = v; }
@@ -764,7 +783,9 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
     if (!always_exact) BVH_HIP_TRY(hipMemsetAsync(group_mark.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
 
     const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>) + kStreamChunk * sizeof(T);
-    BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(heap_lds)),
+    const bool below_lds = k >= 1 && k - 1 >= HeapCap<T>::v;
+    auto heap_kernel = below_lds ? k_heap_select<T, true> : k_heap_select<T, false>;
+    BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(heap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(heap_lds)),
                 BVH_AMD_ERR_HIP);
     auto read_scalars = [&](ReScalars& hs) -> int {
         BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
@@ -795,7 +816,7 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
                         hipLaunchKernelGGL(k_make_heap_level<T>, dim3((count + 63) / 64), dim3(64), 0, stream, heap_g.p, k, first, count);
                     }
                 }
-                hipLaunchKernelGGL(k_heap_select<T>, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
+                hipLaunchKernelGGL(heap_kernel, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
             } else {
                 BVH_HIP_TRY(hipMemcpyAsync(backup.p, d_nodes, size_t{n} * sizeof(HostNode<T>), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
                 hipLaunchKernelGGL(k_cost_keys<T>, dim3((n + 255) / 256), dim3(256), 0, stream, cost.p, n, keys.p, ids.p);
