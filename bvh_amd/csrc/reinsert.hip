@@ -523,6 +523,219 @@ __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_no
     for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.get(j).id;
 }
 
+// ---- the replacement loop on TWO wavefronts (heaps that reach below LDS) -----------------------------------------------------
+// A lone wave is bound by its instruction count, so the work of one replacement is split in the order it happens:
+//   wave A  streams the node costs, does the first five heap levels of every pop and the whole push (the ancestor chain), i.e.
+//           everything the NEXT replacement depends on (the root and the value at k-1);
+//   wave B  continues each pop from level 5 down to the last LDS level and owns the deferred HBM tasks.
+// A hands (position at level 5, value) to B through a ring of tokens in LDS and sets that node's bit in a mask of open holes;
+// B clears it when the hole is filled. A samples the mask BEFORE it loads a round: if the two level-5 entries its path then
+// depends on were open at that moment, it waits for them and loads again (entries it does not use may be stale or torn). A pop
+// whose path follows the ancestor chain past level 5 (a few percent) could meet entries the push keeps in A's registers: A
+// walks that subtree alone (B never enters it) with its own list of deferred HBM tasks. Every wait is bounded (kSpinLimit)
+// and ends in an error, never a hang.
+constexpr uint32_t kQueueCap = 64;
+constexpr uint32_t kSpinLimit = 1u << 24;
+constexpr int kSplitLevel = 5;
+
+template <typename T> struct PipeToken { uint32_t pos; uint32_t id; T cost; };
+struct PipeCtrl { uint32_t head, tail, a_done, b_done, drain_req, drain_ack, error, open5; };   // open5: bit i = level-5 node i is an open hole
+
+// Control words in LDS with acquire / release at workgroup scope. (Relaxed accesses that rely on the LDS unit performing one
+// wave's DS instructions in issue order were tried for the saved s_waitcnt, ~6 %, and produced wrong heaps: not kept.)
+__device__ inline uint32_t ctrl_load(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void ctrl_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <typename T>
+__global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_t n_nodes, uint32_t target, Ent<T>* glob, uint32_t* out_ids,
+                                                          ReScalars* sc) {
+    extern __shared__ unsigned char heap_lds[];
+    WaveHeap<T> h;
+    h.lds = (typename WaveHeap<T>::LdsEnt*)heap_lds;
+    h.glob = (typename WaveHeap<T>::GlobEnt*)glob;
+    unsigned char* after_heap = heap_lds + size_t{HeapCap<T>::v} * sizeof(Ent<T>);
+    auto* stage = (__attribute__((address_space(3))) T*)after_heap;
+    auto* queue = reinterpret_cast<PipeToken<T>*>(after_heap + kStreamChunk * sizeof(T));
+    auto* ctrl = reinterpret_cast<PipeCtrl*>(after_heap + kStreamChunk * sizeof(T) + kQueueCap * sizeof(PipeToken<T>));
+    h.cap = HeapCap<T>::v;
+    h.cap_level = HeapLevels<T>::v - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t head = min(n_nodes, target + 1);
+    const uint32_t k = head - 1;                              // (k - 1 >= cap: checked by the host)
+    for (uint32_t j = threadIdx.x; j < h.cap; j += 128) h.set_lds(j, h.get_glob(j));
+    if (threadIdx.x < sizeof(PipeCtrl) / 4) reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;
+    __syncthreads();
+    const int d = 31 - __clz(lane + 1);
+    const uint32_t in_level = static_cast<uint32_t>(lane + 1) - (1u << d);
+    // bounded wait: returns false (and raises the error flag) instead of hanging
+    auto wait_until = [&](auto&& ready) -> bool {
+        for (uint32_t spin = 0; spin < kSpinLimit; ++spin) {
+            if (ready()) return true;
+            if (ctrl_load(&ctrl->error)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        ctrl_store(&ctrl->error, 1u);
+        return false;
+    };
+
+    if (wave == 1) {
+        // ---- wave B: levels 5 .. last LDS level of every handed-over pop, and the deferred HBM tasks -------------------------
+        Chain<T> no_chain;                                    // (B never touches the chain; wave_adjust_heap is not used here)
+        (void)no_chain;
+        uint32_t n_tasks = 0; uint32_t task_pos = 0; Ent<T> task_value{};
+        auto resolve_tasks = [&]() {
+            if (n_tasks) {
+                if (static_cast<uint32_t>(lane) < n_tasks) lane_adjust_heap(h, task_pos, k - 1, task_value);
+                heap_sync();
+                n_tasks = 0;
+            }
+        };
+        uint32_t done = 0;
+        T unused_root = T(0);
+        for (;;) {
+            bool stop = false;
+            const bool ok = wait_until([&]() {
+                if (ctrl_load(&ctrl->head) != done) return true;
+                if (ctrl_load(&ctrl->a_done) && ctrl_load(&ctrl->head) == done) { stop = true; return true; }
+                return false;
+            });
+            if (!ok || stop) break;
+            const PipeToken<T> tok = queue[done % kQueueCap];
+            Ent<T> v; v.cost = tok.cost; v.id = tok.id;
+            uint32_t hand = 0;
+            if (fast_top_round<T, kSplitLevel, HeapLevels<T>::v - 1>(h, v, lane, tok.pos, d, in_level, hand, unused_root, resolve_tasks)) {
+                if (static_cast<uint32_t>(lane) == n_tasks) { task_pos = hand; task_value = v; }
+                if (lane == 0) h.lds[hand].id = kOpenHole;
+                heap_sync();
+                if (++n_tasks == 64) resolve_tasks();
+            }
+            if (lane == 0) __hip_atomic_fetch_and(&ctrl->open5, ~(1u << (tok.pos - 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ++done;
+            ctrl_store(&ctrl->tail, done);
+        }
+        resolve_tasks();
+        __threadfence();
+        ctrl_store(&ctrl->b_done, 1u);
+        return;
+    }
+
+    // ---- wave A -------------------------------------------------------------------------------------------------------------
+    Chain<T> chain;
+    chain.init(h, k, lane);
+    chain.load(h);
+    T root_cost = h.lds[0].cost;
+    uint32_t sent = 0, tail_seen = 0;                         // tail_seen: B's progress as last read (only re-read when the ring looks full)
+    bool failed = false;
+    // A's own deferred HBM tasks: pops whose path stays on the chain at level 5 are walked by A alone (B never enters that
+    // subtree and A never shares an entry of it with B), their HBM parts collected and sifted like in the one-wave loop
+    uint32_t a_tasks = 0; uint32_t a_task_pos = 0; Ent<T> a_task_value{};
+    auto resolve_a = [&]() {
+        if (a_tasks) {
+            if (static_cast<uint32_t>(lane) < a_tasks) lane_adjust_heap(h, a_task_pos, k - 1, a_task_value);
+            heap_sync();
+            a_tasks = 0;
+        }
+    };
+    for (uint32_t chunk = head; chunk < n_nodes && !failed; chunk += kStreamChunk) {
+        bool any = false;
+#pragma unroll
+        for (uint32_t q = 0; q < kStreamChunk / 64; ++q) {
+            const uint32_t i = chunk + q * 64 + lane;
+            const T c_hbm = i < n_nodes ? cost[i] : T(0);
+            any = any || (i < n_nodes && root_cost < c_hbm);
+            stage[q * 64 + lane] = c_hbm;
+        }
+        if (!__ballot(any)) continue;
+        heap_sync();
+        for (uint32_t q = 0; q < kStreamChunk / 64 && !failed; ++q) {
+            const uint32_t base = chunk + q * 64;
+            if (base >= n_nodes) break;
+            const T c = stage[q * 64 + lane];
+            uint64_t mask = __ballot(base + lane < n_nodes && root_cost < c);
+            while (mask && !failed) {
+                const int j = __ffsll(static_cast<long long>(mask)) - 1;
+                mask &= mask - 1;
+                const T cj = lane_value(c, j);
+                if (!(root_cost < cj)) continue;
+                Ent<T> v; v.cost = lane_value(chain.reg.cost, 0); v.id = lane_value(chain.reg.id, 0);      // position k-1 lives in registers
+                // levels 0 .. 5 (the subtree under the root: heap position == BFS index == lane)
+                uint32_t hand = 0;
+                bool handed = false;
+                for (;;) {
+                    const uint32_t open = ctrl_load(&ctrl->open5);
+                    const bool inner = lane < 31;
+                    Ent<T> c1{}, c2{};
+                    if (inner) { c1 = h.get_lds(2 * lane + 1); c2 = h.get_lds(2 * lane + 2); }
+                    const bool left = c2.cost > c1.cost;
+                    const Ent<T> chosen = left ? c1 : c2;
+                    const int next = left ? 2 * lane + 1 : 2 * lane + 2;
+                    int r = 0;
+                    uint64_t path = 1;
+#pragma unroll
+                    for (int sidx = 1; sidx < kSplitLevel; ++sidx) { r = __builtin_amdgcn_readlane(next, r); path |= uint64_t{1} << r; }
+                    const uint32_t pair_bits = 3u << (2 * r + 1 - 31);            // the level-5 children of the level-4 path node
+                    if (open & pair_bits) {                   // one of them was an open hole when this round was loaded
+                        if (!wait_until([&]() { return (ctrl_load(&ctrl->open5) & pair_bits) == 0; })) { failed = true; break; }
+                        continue;
+                    }
+                    const bool on_path = (path >> lane) & 1u;
+                    const uint64_t greater = __ballot(on_path && chosen.cost > v.cost);
+                    root_cost = (greater & 1u) ? v.cost : lane_value(chosen.cost, 0);
+                    if (greater) {
+                        const int landing = __ffsll(static_cast<long long>(greater)) - 1;
+                        if (on_path && lane < landing) h.set_lds(lane, chosen);
+                        if (lane == landing) h.set_lds(lane, v);
+                    } else {
+                        if (on_path) h.set_lds(lane, chosen);
+                        hand = static_cast<uint32_t>(__builtin_amdgcn_readlane(next, r));
+                        handed = true;
+                    }
+                    heap_sync();
+                    break;
+                }
+                if (failed) break;
+                if (handed) {
+                    if (chain.holds(hand, kSplitLevel)) {
+                        uint32_t hand13 = 0;
+                        T unused_root = T(0);
+                        if (fast_top_round<T, kSplitLevel, HeapLevels<T>::v - 1>(h, v, lane, hand, d, in_level, hand13, unused_root, resolve_a)) {
+                            if (chain.holds(hand13, h.cap_level)) {          // along the chain into HBM (registers): at once
+                                if (wave_adjust_heap(h, chain, hand13, k - 1, v, lane)) chain.load(h);
+                            } else {
+                                if (static_cast<uint32_t>(lane) == a_tasks) { a_task_pos = hand13; a_task_value = v; }
+                                if (lane == 0) h.lds[hand13].id = kOpenHole;
+                                heap_sync();
+                                if (++a_tasks == 64) resolve_a();
+                            }
+                        }
+                    } else {
+                        if (sent - tail_seen >= kQueueCap &&
+                            !wait_until([&]() { tail_seen = ctrl_load(&ctrl->tail); return sent - tail_seen < kQueueCap; })) { failed = true; break; }
+                        if (lane == 0) {
+                            PipeToken<T> tok; tok.pos = hand; tok.id = v.id; tok.cost = v.cost;
+                            queue[sent % kQueueCap] = tok;
+                            __hip_atomic_fetch_or(&ctrl->open5, 1u << (hand - 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        heap_sync();
+                        ++sent;
+                        ctrl_store(&ctrl->head, sent);
+                    }
+                }
+                if (failed) break;
+                Ent<T> w; w.cost = cj; w.id = base + j;
+                if (wave_push_chain(h, chain, w, lane) == chain.top_level) root_cost = cj;
+            }
+        }
+    }
+    resolve_a();
+    ctrl_store(&ctrl->a_done, 1u);
+    if (!wait_until([&]() { return ctrl_load(&ctrl->b_done) != 0; })) failed = true;
+    if (failed || ctrl_load(&ctrl->error)) { if (lane == 0) atomicOr(&sc->error, 2u); return; }
+    __threadfence();
+    chain.flush(h);
+    for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.get(j).id;
+}
+
 // ---- fast path: top-k by cost without the heap (valid when no tie straddles the threshold) --------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) k_cost_keys(const T* cost, uint32_t n, typename Ord<T>::U* keys, uint32_t* ids) {
@@ -784,6 +997,12 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
 
     const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>) + kStreamChunk * sizeof(T);
     const bool below_lds = k >= 1 && k - 1 >= HeapCap<T>::v;
+    const char* pipe_knob = std::getenv("BVH_AMD_HEAP_PIPE");                      // 0: the one-wave replacement loop
+    const bool use_pipe = !(pipe_knob && std::atoi(pipe_knob) == 0);
+    const size_t pipe_lds = heap_lds + kQueueCap * sizeof(PipeToken<T>) + sizeof(PipeCtrl);
+    if (below_lds && use_pipe)
+        BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select_pipe<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pipe_lds)),
+                    BVH_AMD_ERR_HIP);
     auto heap_kernel = below_lds ? k_heap_select<T, true> : k_heap_select<T, false>;
     BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(heap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(heap_lds)),
                 BVH_AMD_ERR_HIP);
@@ -816,7 +1035,10 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
                         hipLaunchKernelGGL(k_make_heap_level<T>, dim3((count + 63) / 64), dim3(64), 0, stream, heap_g.p, k, first, count);
                     }
                 }
-                hipLaunchKernelGGL(heap_kernel, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
+                if (below_lds && use_pipe)
+                    hipLaunchKernelGGL(k_heap_select_pipe<T>, dim3(1), dim3(128), pipe_lds, stream, cost.p, n, batch, heap_g.p, cand.p, scalars.p);
+                else
+                    hipLaunchKernelGGL(heap_kernel, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
             } else {
                 BVH_HIP_TRY(hipMemcpyAsync(backup.p, d_nodes, size_t{n} * sizeof(HostNode<T>), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
                 hipLaunchKernelGGL(k_cost_keys<T>, dim3((n + 255) / 256), dim3(256), 0, stream, cost.p, n, keys.p, ids.p);
@@ -871,6 +1093,7 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
     ReScalars hs;
     BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    if (hs.error & 2u) return fail(BVH_AMD_ERR_HIP, "optimize: the two-wave candidate-heap replay timed out (internal error; BVH_AMD_HEAP_PIPE=0 selects the one-wave loop)");
     if (hs.error) return fail(BVH_AMD_ERR_OVERFLOW, "optimize: reinsertion search stack exceeded 96 entries");
     return BVH_AMD_OK;
 }

@@ -236,6 +236,17 @@ def test_high_quality_scenes(orc, scene, n, parallel):
     assert gpu.serialize() == ref.serialize()
 
 
+@pytest.mark.parametrize("parallel", [False, True])
+def test_high_quality_double_large(orc, parallel):
+    """double precision with a candidate heap that reaches below LDS (the two-wave replacement loop, 16-byte entries)"""
+    import bvh_amd
+    tris = synth.soup(250_000, jitter=0.01, dtype=np.float64)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL if parallel else oracle.BUILDER_DEFAULT_SERIAL, quality=oracle.QUALITY_HIGH)
+    gpu = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool() if parallel else None)
+    assert gpu.serialize() == ref.serialize()
+
+
 def _lattice(n_side, dtype=np.float32):
     """identical triangles on a power-of-two lattice: node costs and reinsertion gains tie massively"""
     g = np.arange(n_side, dtype=dtype)
