@@ -26,13 +26,20 @@ __global__ void __launch_bounds__(256) relayout_pairs(const HostNode<T>* nodes, 
 
 // depth of every pair record by pointer jumping over the parent links: O(log depth) rounds, no host round trips
 template <typename T>
-__global__ void __launch_bounds__(256) k_depth_init(const PairNode<T>* pairs, uint32_t n_pairs, uint32_t* anc, uint32_t* dist) {
+__global__ void __launch_bounds__(256) k_depth_init(const PairNode<T>* pairs, uint32_t n_pairs, uint32_t root_pair, uint32_t* anc, uint32_t* dist) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pairs) return;
-    if (p == 0) { anc[0] = 0; dist[0] = 0; }                  // the root's children: level 1 (dist counts pairs above)
+    // (the root's children, level 1, keep distance 0; they are not necessarily pair 0: reinsertion may move them)
     const uint32_t li = pairs[p].li, ri = pairs[p].ri;
-    if ((li & kCountMask) == 0) { anc[li >> (kCountBits + 1)] = p; dist[li >> (kCountBits + 1)] = 1; }
-    if ((ri & kCountMask) == 0) { anc[ri >> (kCountBits + 1)] = p; dist[ri >> (kCountBits + 1)] = 1; }
+    const uint32_t lp = li >> (kCountBits + 1), rp = ri >> (kCountBits + 1);
+    if ((li & kCountMask) == 0 && lp < n_pairs && lp != root_pair) { anc[lp] = p; dist[lp] = 1; }
+    if ((ri & kCountMask) == 0 && rp < n_pairs && rp != root_pair) { anc[rp] = p; dist[rp] = 1; }
+}
+// every pair starts as its own ancestor at distance 0, so that pairs no parent points to (only possible in a malformed tree
+// handed in through from_nodes / deserialize) never leave an uninitialised link behind
+__global__ void __launch_bounds__(256) k_depth_identity(uint32_t n, uint32_t* anc, uint32_t* dist) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { anc[i] = i; dist[i] = 0; }
 }
 __global__ void __launch_bounds__(256) k_depth_jump(const uint32_t* anc, const uint32_t* dist, uint32_t n, uint32_t* anc_out, uint32_t* dist_out,
                                                     uint32_t* max_out) {
@@ -56,7 +63,8 @@ int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
     uint32_t *anc = buf, *dist = buf + n, *anc2 = buf + 2 * size_t{n}, *dist2 = buf + 3 * size_t{n}, *d_max = buf + 4 * size_t{n};
     hipError_t e = hipMemsetAsync(d_max, 0, 4, stream);
     const unsigned grid = (n + 255) / 256;
-    hipLaunchKernelGGL(k_depth_init<T>, dim3(grid), dim3(256), 0, stream, b.d_pairs, n, anc, dist);
+    hipLaunchKernelGGL(k_depth_identity, dim3(grid), dim3(256), 0, stream, n, anc, dist);
+    hipLaunchKernelGGL(k_depth_init<T>, dim3(grid), dim3(256), 0, stream, b.d_pairs, n, b.root_index >> (kCountBits + 1), anc, dist);
     int rounds = 1;
     while ((uint64_t{1} << rounds) < uint64_t{n} + 1) ++rounds;        // after r rounds every chain of length <= 2^r is resolved
     for (int r = 0; r < rounds; ++r) {
