@@ -130,3 +130,68 @@ def test_fuzz_2d(orc, seed):
             same = (g["prim"] == want["prim"]) & ((g["t"].view(np.uint32 if dtype == np.float32 else np.uint64) == want["t"].view(np.uint32 if dtype == np.float32 else np.uint64)) | (np.isnan(g["t"]) & np.isnan(want["t"])))
             assert same.all(), (seed, any_hit, robust, int((~same).sum()))
             assert (cg.cpu().numpy().astype(np.uint64) == cw).all()
+
+
+@pytest.mark.parametrize("seed,kind,n", [(11, "lattice", 6000), (12, "dups", 9000), (13, "points", 5000), (14, "lattice", 30000),
+                                          (15, "flat", 20000), (16, "scales", 12000), (17, "dups", 40000)])
+def test_fuzz_3d_larger_ties(orc, seed, kind, n):
+    """enough primitives for the level-synchronous phases (chunked partitions, Hoare violator matching, the std::sort emulation)
+    on tie-saturated data, all builder modes incl. mini-trees + reinsertion"""
+    import bvh_amd
+    rng = np.random.default_rng(seed)
+    dtype = np.float32 if seed % 2 else np.float64
+    tris = _scene3(rng, n, kind, dtype)
+    bb, cc = orc.prep_tris(tris)
+    for builder, quality in ((2, 0), (3, 0), (0, 2), (1, 0), (1, 1), (1, 2)):
+        cfg = bvh_amd.Config(quality=bvh_amd.Quality(quality), min_leaf_size=1 + seed % 2, max_leaf_size=8 - seed % 5, parallel_threshold=[1024, 300][seed % 2])
+        if builder == 2:
+            gpu = bvh_amd.BinnedSahBuilder.build(bb, cc, cfg)
+        elif builder == 3:
+            gpu = bvh_amd.SweepSahBuilder.build(bb, cc, cfg)
+        else:
+            gpu = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=bvh_amd.ThreadPool() if builder == 1 else None)
+        ref = orc.build(bb, cc, builder=builder, quality=quality, min_leaf=cfg.min_leaf_size, max_leaf=cfg.max_leaf_size, parallel_threshold=cfg.parallel_threshold)
+        assert gpu.serialize() == ref.serialize(), (seed, kind, n, builder, quality)
+    # standalone ops on the last tree: optimize twice, extract a few subtrees, refit after shrinking nothing (identity)
+    for _ in range(2):
+        ref.optimize(-1)
+        gpu.optimize()
+        assert gpu.serialize() == ref.serialize()
+    nodes = ref.nodes()
+    inner = np.flatnonzero((nodes["index"] & 15) == 0)
+    for root in [int(x) for x in rng.choice(inner[inner > 0], size=3)] if (inner > 0).any() else []:
+        assert gpu.extract_bvh(root).serialize() == ref.extract(root).serialize()
+    again = bvh_amd.Bvh.deserialize(gpu.serialize(), dtype=dtype)
+    again.refit()
+    ref.refit()
+    assert again.serialize() == ref.serialize()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_3d_spheres(orc, seed):
+    import bvh_amd
+    rng = np.random.default_rng(500 + seed)
+    dtype = np.float32 if seed % 2 else np.float64
+    n = int(rng.choice([3, 100, 2500]))
+    ctr = rng.integers(0, 5, size=(n, 3)).astype(dtype) if seed == 0 else rng.random((n, 3)).astype(dtype)
+    rad = (rng.random((n, 1)) * 0.1).astype(dtype)
+    rad[rng.random(n) < 0.1] = 0                               # points
+    sph = np.ascontiguousarray(np.concatenate([ctr, rad], axis=1))
+    bb, cc = orc.sphere_bboxes(sph)
+    d_bb, d_cc = bvh_amd.sphere_bounds(sph)
+    assert d_bb.cpu().numpy().tobytes() == bb.tobytes()
+    ref = orc.build(bb, cc, builder=1, quality=2, parallel_threshold=128)
+    gpu = bvh_amd.DefaultBuilder.build(d_bb, d_cc, bvh_amd.Config(parallel_threshold=128), thread_pool=bvh_amd.ThreadPool())
+    assert gpu.serialize() == ref.serialize()
+    ordered = sph[ref.prim_ids().astype(np.int64)]
+    lo, hi = (ctr - rad).min(axis=0).astype(np.float64), (ctr + rad).max(axis=0).astype(np.float64)
+    rays = _rays3(rng, 3000, lo, hi, dtype)
+    for any_hit in (False, True):
+        for robust in (False, True):
+            want, cw = ref.intersect_sphere(ordered, rays, any_hit, robust, counters=True)
+            got, cg = bvh_amd.intersect(gpu, ordered, rays, any_hit=any_hit, robust=robust, leaf="sphere", counters=True)
+            g = bvh_amd.hits_to_numpy(got)
+            it = np.uint32 if dtype == np.float32 else np.uint64
+            same = (g["prim"] == want["prim"]) & ((g["t"].view(it) == want["t"].view(it)) | (np.isnan(g["t"]) & np.isnan(want["t"])))
+            assert same.all(), (seed, any_hit, robust, int((~same).sum()))
+            assert (cg.cpu().numpy().astype(np.uint64) == cw).all()
