@@ -254,8 +254,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
             const uint64_t inner_mask = __ballot(inner);
             if (!inner_mask) break;
             const int parked = __popcll(__ballot(have && !done && (top & kCountMask) != 0));
-            const int finished = __popcll(__ballot(!have || done));
-            if (parked >= a.leaf_threshold || (!drained && finished >= 2 * a.refill_threshold)) break;
+            if (parked >= a.leaf_threshold) break;        // (also leaving to refill when most lanes are idle was measured: no gain)
             T lb[6], rb[6];
             uint32_t li = 0, ri = 0;
             if (inner) {
