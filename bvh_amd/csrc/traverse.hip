@@ -187,20 +187,25 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
     unsigned long long n_pairs = 0, n_tests = 0, n_leaves = 0;
 
     // (launch_traverse sizes `deep` from the depth of the tree, so `overflow` is a cannot-happen guard)
-    // (the address of the deep slot is formed inside the cold branch: nothing about it stays live in the hot loop)
+    // launch_traverse knows the depth of the tree: the variant without Deep only ever runs on trees of at most 64 levels, whose
+    // stack cannot exceed the 64 entries of LDS + scratch, so its push/pop carry no overflow bookkeeping (the clamp only keeps
+    // a malformed, e.g. cyclic, user-supplied tree from writing outside the scratch array). Deep: entries beyond 64 live in HBM
+    // (the address of the deep slot is formed inside the cold branch: nothing about it stays live in the hot loop).
     auto deep_slot = [&](uint32_t i) { return a.deep + (size_t{blockIdx.x} * kBlock + tid) * a.deep_cap + i; };
     auto push = [&](uint32_t v) {
         if (sp < kDepth) lds_stack[sp * kBlock + tid] = v;
+        else if (!Deep) spill[min(sp - kDepth, static_cast<uint32_t>(kSpill - 1))] = v;
         else if (sp < kDepth + kSpill) spill[sp - kDepth] = v;
-        else if (Deep && sp - (kDepth + kSpill) < a.deep_cap) *deep_slot(sp - (kDepth + kSpill)) = v;
+        else if (sp - (kDepth + kSpill) < a.deep_cap) *deep_slot(sp - (kDepth + kSpill)) = v;
         else overflow = true;
         ++sp;
     };
     auto pop = [&]() -> uint32_t {
         --sp;
         if (sp < kDepth) return lds_stack[sp * kBlock + tid];
+        if (!Deep) return spill[min(sp - kDepth, static_cast<uint32_t>(kSpill - 1))];
         if (sp < kDepth + kSpill) return spill[sp - kDepth];
-        if (Deep && sp - (kDepth + kSpill) < a.deep_cap) return *deep_slot(sp - (kDepth + kSpill));
+        if (sp - (kDepth + kSpill) < a.deep_cap) return *deep_slot(sp - (kDepth + kSpill));
         return 0u;
     };
 
