@@ -424,7 +424,12 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     unsigned long long need = (args.n + kBlock - 1) / kBlock;
     int grid = static_cast<int>(need < static_cast<unsigned long long>(blocks) ? need : blocks);
     if (grid < 1) grid = 1;
-    g_last_kernel = name;
+    (void)name;
+    // the symbol as rocprofv3 prints it (profiles/*_kernel_stats.csv), for bench.py's roofline.kernel
+    static const std::string symbol = std::string("trace_kernel<") + (std::is_same_v<T, float> ? "float" : "double") + ", " + (Any ? "true" : "false") + ", " +
+                                      (Robust ? "true" : "false") + ", " + std::to_string(Leaf) + ", " + (Stats ? "true" : "false") + ", " + std::to_string(D) +
+                                      ", " + (Deep ? "true" : "false") + ">";
+    g_last_kernel = symbol.c_str();
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
     return BVH_AMD_OK;
