@@ -24,6 +24,11 @@ class Counters(C.Structure):
     _fields_ = [("node_pairs", C.c_ulonglong), ("prim_tests", C.c_ulonglong), ("leaves", C.c_ulonglong)]
 
 
+class MiniTreeConfig(C.Structure):                             # struct bvh_amd_minitree_config
+    _fields_ = [("min_leaf_size", C.c_size_t), ("max_leaf_size", C.c_size_t), ("enable_pruning", C.c_int),
+                ("pruning_area_ratio", C.c_double), ("parallel_threshold", C.c_size_t), ("log2_grid_dim", C.c_size_t)]
+
+
 class BBox3f(C.Structure):
     _fields_ = [("v", C.c_float * 6)]
 
@@ -68,6 +73,7 @@ _SIGS = {
 _SIGS_T = {
     "bvh{S}_build": (_P, [_P, _P, _P, _Z, _P]),
     "bvh{S}_build_device": (_P, [_P, _P, _Z, _P, _I, _P]),
+    "bvh{S}_build_minitree_device": (_P, [_P, _P, _Z, _P, _P]),
     "bvh{S}_from_nodes": (_P, [_P, _Z, _P, _Z]),
     "bvh{S}_extract": (_P, [_P, _Z]),
     "bvh{S}_destroy": (None, [_P]),
@@ -101,7 +107,8 @@ _SIGS_T = {
 }
 
 
-_ONLY_3D = ("bvh_amd_tri_bounds{S}", "bvh_amd_precompute_tris{S}", "bvh{S}_intersect_rays_tri")     # tri.h is 3D only
+_ONLY_3D = ("bvh_amd_tri_bounds{S}", "bvh_amd_precompute_tris{S}", "bvh{S}_intersect_rays_tri",     # tri.h is 3D only,
+            "bvh{S}_build_minitree_device")                                                           # and so is the mini-tree grid
 
 
 def exported_symbols():

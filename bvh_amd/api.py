@@ -247,6 +247,30 @@ class SweepSahBuilder:
         return _build(bboxes, centers, config or Config(), _Builder.SWEEP)
 
 
+class MiniTreeBuilder:
+    """bvh::v2::MiniTreeBuilder<Node>::build(thread_pool, bboxes, centers, config) (mini_tree_builder.h:29-58), 3D."""
+
+    @dataclass
+    class Config:
+        min_leaf_size: int = 1
+        max_leaf_size: int = 8
+        enable_pruning: bool = True
+        pruning_area_ratio: float = 0.01
+        parallel_threshold: int = 1024
+        log2_grid_dim: int = 4
+
+    @staticmethod
+    def build(bboxes, centers, config: "MiniTreeBuilder.Config | None" = None, thread_pool: ThreadPool | None = None) -> Bvh:
+        c = config or MiniTreeBuilder.Config()
+        bb, cc = _dev(bboxes, 6), _dev(centers, 3)
+        if bb.dtype != cc.dtype or bb.shape[0] != cc.shape[0]:
+            raise ValueError("bboxes (n,6) and centers (n,3) must agree in dtype and length")
+        s = _suffix(bb.dtype)
+        cfg = _lib.MiniTreeConfig(c.min_leaf_size, c.max_leaf_size, int(c.enable_pruning), float(c.pruning_area_ratio), c.parallel_threshold,
+                                  c.log2_grid_dim)
+        return Bvh(getattr(_lib.load(), f"bvh{s}_build_minitree_device")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), _stream()), s)
+
+
 def tri_bounds(tris9):
     """Tri::get_bbox / Tri::get_center (tri.h:24-25) for n triangles -> (bboxes (n,6), centers (n,3)) in HBM."""
     torch = _torch()

@@ -361,17 +361,18 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
 template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim);
 
 // DefaultBuilder::build(pool, ...): mini-trees, plus the reinsertion pass at Quality::High (default_builder.h:41-44, :65-73).
+// MiniTreeBuilder::build(pool, bboxes, centers, config) itself (mini_tree_builder.h:29-58) with its own knobs; DefaultBuilder's
+// three qualities are three settings of them (default_builder.h:65-73) plus the reinsertion pass at High.
 template <typename T>
-int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, hipStream_t stream) {
+int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T ratio,
+                            bool optimize, hipStream_t stream) {
     BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
     DevBuf<HostNode<T>> final_nodes;
     DevBuf<uint32_t> final_ids;
     size_t total_nodes = 0;
-    const bool prune = cfg.quality != BVH_BUILD_QUALITY_LOW;
-    const T ratio = cfg.quality == BVH_BUILD_QUALITY_HIGH ? T(0.01) : T(0.1);
     int rc = minitree_core<T>(d_bboxes, d_centers, n, cfg, prune, ratio, final_nodes, final_ids, total_nodes, stream);
     if (rc) return rc;
-    if (cfg.quality == BVH_BUILD_QUALITY_HIGH) {
+    if (optimize) {
         rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream, 3);
         if (rc) return rc;
     }
@@ -382,6 +383,14 @@ int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers
     return BVH_AMD_OK;
 }
 
+template <typename T>
+int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, hipStream_t stream) {
+    return build_minitree_explicit<T>(out, d_bboxes, d_centers, n, cfg, cfg.quality != BVH_BUILD_QUALITY_LOW,
+                                      cfg.quality == BVH_BUILD_QUALITY_HIGH ? T(0.01) : T(0.1), cfg.quality == BVH_BUILD_QUALITY_HIGH, stream);
+}
+
+template int build_minitree_explicit<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, bool, float, bool, hipStream_t);
+template int build_minitree_explicit<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, bool, double, bool, hipStream_t);
 template int build_minitree_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
 template int build_minitree_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
 

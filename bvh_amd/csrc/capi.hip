@@ -10,6 +10,9 @@ namespace bvh_amd {
 template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim);
 void reinsertion_stats(unsigned out[2]);
 template <typename T>
+int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T ratio,
+                            bool optimize, hipStream_t stream);
+template <typename T>
 int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_count, const uint32_t* d_ids, size_t root_id, hipStream_t stream);
 template <typename T> int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
 template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
@@ -54,6 +57,25 @@ typename CTypes<T>::Bvh* build_device(const T* d_bboxes, const T* d_centers, siz
     }
     auto b = std::make_unique<BvhImpl<T>>();
     if (build_on_device<T>(*b, d_bboxes, d_centers, n, cfg, builder, static_cast<hipStream_t>(stream)) != BVH_AMD_OK)
+        return nullptr;
+    return handle<T>(b.release());
+}
+
+template <typename T>
+typename CTypes<T>::Bvh* build_minitree(const T* d_bboxes, const T* d_centers, size_t n, const bvh_amd_minitree_config* config, void* stream) {
+    if (!d_bboxes || !d_centers || n == 0) { set_error("build: empty input"); return nullptr; }
+    bvh_amd_minitree_config c = config ? *config : bvh_amd_minitree_config{1, 8, 1, 0.01, 1024, 4};
+    if (c.min_leaf_size < 1 || c.min_leaf_size > c.max_leaf_size || c.max_leaf_size > 15) {
+        set_error("build: need 1 <= min_leaf_size <= max_leaf_size <= 15 (4-bit primitive count, index.h:38)");
+        return nullptr;
+    }
+    if (c.log2_grid_dim != 4) { set_error("build_minitree: only log2_grid_dim = 4 (the reference's default) is implemented"); return nullptr; }
+    if (c.parallel_threshold == 0) { set_error("build_minitree: parallel_threshold must be positive"); return nullptr; }
+    bvh_build_config cfg = default_config();
+    cfg.min_leaf_size = c.min_leaf_size; cfg.max_leaf_size = c.max_leaf_size; cfg.parallel_threshold = c.parallel_threshold;
+    auto b = std::make_unique<BvhImpl<T>>();
+    if (build_minitree_explicit<T>(*b, d_bboxes, d_centers, n, cfg, c.enable_pruning != 0, static_cast<T>(c.pruning_area_ratio), false,
+                                   static_cast<hipStream_t>(stream)) != BVH_AMD_OK)
         return nullptr;
     return handle<T>(b.release());
 }
@@ -415,6 +437,8 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_build_device(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,              \
                                   enum bvh_amd_builder builder, void* stream) {                                     \
         return build_device<T>(d_bb, d_cc, n, cfg, builder, stream); }                                              \
+    bvh##S* bvh##S##_build_minitree_device(const T* d_bb, const T* d_cc, size_t n, const bvh_amd_minitree_config* cfg, void* stream) { \
+        return build_minitree<T>(d_bb, d_cc, n, cfg, stream); }                                                     \
     bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return handle<T>(extract<T>(impl<T>(b), root_id)); }      \
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes<T>(nodes, nn, ids, np); }                                                                 \

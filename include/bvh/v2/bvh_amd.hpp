@@ -178,6 +178,7 @@ template <> struct Api<float, 3> {
     using Handle = bvh3f; using CHit = bvh_hit3f;
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3f_build(p, static_cast<const bvh_bbox3f*>(bb), static_cast<const bvh_vec3f*>(cc), n, c); }
     static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh3f_build_device(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, b, nullptr); }
+    static Handle* build_minitree(const void* d_bb, const void* d_cc, size_t n, const bvh_amd_minitree_config* c) { return bvh3f_build_minitree_device(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, nullptr); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3f_from_nodes(nodes, nn, ids, np); }
     static void destroy(Handle* h) { bvh3f_destroy(h); }
     static size_t node_count(const Handle* h) { return bvh3f_get_node_count(h); }
@@ -196,6 +197,7 @@ template <> struct Api<double, 3> {
     using Handle = bvh3d; using CHit = bvh_hit3d;
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3d_build(p, static_cast<const bvh_bbox3d*>(bb), static_cast<const bvh_vec3d*>(cc), n, c); }
     static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh3d_build_device(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, b, nullptr); }
+    static Handle* build_minitree(const void* d_bb, const void* d_cc, size_t n, const bvh_amd_minitree_config* c) { return bvh3d_build_minitree_device(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, nullptr); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3d_from_nodes(nodes, nn, ids, np); }
     static void destroy(Handle* h) { bvh3d_destroy(h); }
     static size_t node_count(const Handle* h) { return bvh3d_get_node_count(h); }
@@ -407,6 +409,37 @@ public:
     using typename Base::Config;
     [[nodiscard]] static Bvh<Node> build(std::span<const typename Base::BBox> bboxes, std::span<const typename Base::Vec> centers, const Config& config = {}) {
         return Base::run(BVH_AMD_BUILDER_SWEEP, bboxes, centers, config);
+    }
+};
+
+// ---- mini_tree_builder.h ------------------------------------------------------------------------------------------------------
+template <typename Node, typename MortonCode = uint32_t>
+class MiniTreeBuilder {                                       // reference mini_tree_builder.h:24-58 (3D; the grid reads three components)
+    using Scalar = typename Node::Scalar;
+    using Vec = bvh::v2::Vec<Scalar, Node::dimension>;
+    using BBox = bvh::v2::BBox<Scalar, Node::dimension>;
+    static_assert(Node::dimension == 3, "MiniTreeBuilder: 3D only (the reference's own 2D instantiation reads out of bounds)");
+public:
+    struct Config : TopDownSahBuilder<Node>::Config {
+        bool enable_pruning = true;
+        Scalar pruning_area_ratio = static_cast<Scalar>(0.01);
+        size_t parallel_threshold = 1024;
+        size_t log2_grid_dim = 4;
+    };
+    [[nodiscard]] static Bvh<Node> build(ThreadPool&, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config = {}) {
+        if (!config.sah.is_default()) throw amd::Error("bvh_amd: the device builders implement SplitHeuristic's default parameters only");
+        if (bboxes.size() != centers.size()) throw amd::Error("bvh_amd: bboxes and centers differ in length");
+        bvh_amd_minitree_config c;
+        c.min_leaf_size = config.min_leaf_size; c.max_leaf_size = config.max_leaf_size; c.enable_pruning = config.enable_pruning ? 1 : 0;
+        c.pruning_area_ratio = static_cast<double>(config.pruning_area_ratio); c.parallel_threshold = config.parallel_threshold;
+        c.log2_grid_dim = config.log2_grid_dim;
+        amd::DeviceArray<BBox> d_bb(bboxes);
+        amd::DeviceArray<Vec> d_cc(centers);
+        auto* h = amd::Api<Scalar, 3>::build_minitree(d_bb.data(), d_cc.data(), bboxes.size(), &c);
+        if (!h) throw amd::Error(bvh_amd_last_error());
+        Bvh<Node> bvh;
+        bvh.adopt(h);
+        return bvh;
     }
 };
 

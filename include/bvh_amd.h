@@ -129,6 +129,21 @@ BVH_AMD_API struct bvh3f* bvh3f_build_device(const float* d_bboxes, const float*
 BVH_AMD_API struct bvh3d* bvh3d_build_device(const double* d_bboxes, const double* d_centers, size_t prim_count,
     const struct bvh_build_config* config, enum bvh_amd_builder builder, void* stream);
 
+/* Additive: MiniTreeBuilder::build(pool, bboxes, centers, config) itself (src/bvh/v2/mini_tree_builder.h:29-58) with its own
+ * configuration; DefaultBuilder(pool)'s three qualities are three settings of it (default_builder.h:65-73). log2_grid_dim
+ * must be 4 (the reference's default; the device kernels are specialised for the 16^3 grid). */
+struct bvh_amd_minitree_config {
+    size_t min_leaf_size, max_leaf_size;       /* TopDownSahBuilder::Config (top_down_sah_builder.h:27-40), defaults 1 / 8 */
+    int enable_pruning;                        /* default 1 */
+    double pruning_area_ratio;                 /* default 0.01 */
+    size_t parallel_threshold;                 /* default 1024 */
+    size_t log2_grid_dim;                      /* default 4 */
+};
+BVH_AMD_API struct bvh3f* bvh3f_build_minitree_device(const float* d_bboxes, const float* d_centers, size_t prim_count,
+    const struct bvh_amd_minitree_config* config, void* stream);
+BVH_AMD_API struct bvh3d* bvh3d_build_minitree_device(const double* d_bboxes, const double* d_centers, size_t prim_count,
+    const struct bvh_amd_minitree_config* config, void* stream);
+
 /* Additive: wrap an existing reference-layout BVH (28/56-byte nodes, node.h:31-37) and upload it. */
 BVH_AMD_API struct bvh3f* bvh3f_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
 BVH_AMD_API struct bvh3d* bvh3d_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);

@@ -112,6 +112,7 @@ class CpuLib:
     _SIG = {
         "build": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                C.c_size_t, C.c_int]),
+        "build_minitree": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_double, C.c_size_t, C.c_int]),
         "destroy": (None, [C.c_void_p]),
         "node_count": (C.c_size_t, [C.c_void_p]),
         "prim_count": (C.c_size_t, [C.c_void_p]),
@@ -157,6 +158,19 @@ class CpuLib:
         assert len(bboxes) == len(centers) and len(bboxes) > 0
         h = self._fn("build", s)(_ptr(bboxes), _ptr(centers), len(bboxes), builder, quality, min_leaf, max_leaf,
                                  parallel_threshold, threads)
+        if not h:
+            raise RuntimeError("oracle build failed")
+        return CpuBvh(self, h, s)
+
+    def build_minitree(self, bboxes, centers, min_leaf=1, max_leaf=8, enable_pruning=True, pruning_area_ratio=0.01,
+                       parallel_threshold=1024, threads=0) -> CpuBvh:
+        """MiniTreeBuilder::build(pool, bboxes, centers, config) (mini_tree_builder.h:29-58), 3D."""
+        dt = bboxes.dtype
+        s = self._sfx(dt)
+        bboxes = np.ascontiguousarray(bboxes, dtype=dt).reshape(-1, 6)
+        centers = np.ascontiguousarray(centers, dtype=dt).reshape(-1, 3)
+        h = self._fn("build_minitree", s)(_ptr(bboxes), _ptr(centers), len(bboxes), min_leaf, max_leaf, int(enable_pruning),
+                                          float(pruning_area_ratio), parallel_threshold, threads)
         if not h:
             raise RuntimeError("oracle build failed")
         return CpuBvh(self, h, s)

@@ -7,6 +7,8 @@
 #include <bvh/v2/ray.h>
 #include <bvh/v2/node.h>
 #include <bvh/v2/default_builder.h>
+#include <bvh/v2/mini_tree_builder.h>
+#include <bvh/v2/reinsertion_optimizer.h>
 #include <bvh/v2/thread_pool.h>
 #include <bvh/v2/executor.h>
 #include <bvh/v2/stack.h>
@@ -49,6 +51,16 @@ int main() {
     std::vector<Ray> rays{ Ray(Vec3(0., 0., 0.), Vec3(0., 0., 1.), 0., 100.) };
     std::vector<Hit> hits(rays.size());
     bvh::v2::amd::intersect_batch<false, false>(bvh, precomputed_tris, std::span<const Ray>(rays), std::span<Hit>(hits));
+
+    // DefaultBuilder(pool, High) == MiniTreeBuilder with pruning at 0.01 + ReinsertionOptimizer (default_builder.h:41-44, :65-73);
+    // parallel_threshold = 1 keeps the two triangles on the mini-tree path instead of DefaultBuilder's serial fallback
+    typename bvh::v2::DefaultBuilder<Node>::Config forced = config;
+    forced.parallel_threshold = 1;
+    typename bvh::v2::MiniTreeBuilder<Node>::Config mini;
+    mini.parallel_threshold = 1;
+    auto by_hand = bvh::v2::MiniTreeBuilder<Node>::build(thread_pool, bboxes, centers, mini);
+    bvh::v2::ReinsertionOptimizer<Node>::optimize(thread_pool, by_hand);
+    if (!(by_hand == bvh::v2::DefaultBuilder<Node>::build(thread_pool, bboxes, centers, forced))) { std::cout << "MiniTreeBuilder mismatch" << std::endl; return 2; }
 
     std::cout << "nodes: " << bvh.nodes.size() << ", prim_ids: " << bvh.prim_ids[0] << " " << bvh.prim_ids[1] << "\n";
     if (hits[0].prim != Hit::invalid) {

@@ -196,6 +196,27 @@ def test_minitree_scenes(orc, scene, n, q):
     assert gpu.serialize() == ref.serialize()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_minitree_builder_direct(orc, dtype):
+    """MiniTreeBuilder::build(pool, ...) with its own Config (pruning on/off, area ratio, parallel_threshold, leaf limits),
+    which DefaultBuilder only reaches in three settings."""
+    import bvh_amd
+    tris = synth.sponza_proxy(50_000).astype(dtype)
+    bb, cc = orc.prep_tris(tris)
+    for kw in (dict(), dict(enable_pruning=False), dict(pruning_area_ratio=0.3), dict(pruning_area_ratio=1.5, max_leaf_size=4),
+               dict(parallel_threshold=200, pruning_area_ratio=0.05), dict(min_leaf_size=2, max_leaf_size=15, pruning_area_ratio=0.0)):
+        okw = {{"max_leaf_size": "max_leaf", "min_leaf_size": "min_leaf"}.get(k, k): v for k, v in kw.items()}
+        ref = orc.build_minitree(bb, cc, **okw)
+        gpu = bvh_amd.MiniTreeBuilder.build(bb, cc, bvh_amd.MiniTreeBuilder.Config(**kw), thread_pool=bvh_amd.ThreadPool())
+        assert gpu.serialize() == ref.serialize(), kw
+    for n in (1, 2, 9, 300):                                  # no serial fallback here: tiny inputs go through the grid too
+        t = synth.soup(n, jitter=0.05).astype(dtype)
+        b2, c2 = orc.prep_tris(t)
+        assert bvh_amd.MiniTreeBuilder.build(b2, c2).serialize() == orc.build_minitree(b2, c2).serialize(), n
+    with pytest.raises(bvh_amd.BvhAmdError, match="log2_grid_dim"):
+        bvh_amd.MiniTreeBuilder.build(bb, cc, bvh_amd.MiniTreeBuilder.Config(log2_grid_dim=5))
+
+
 def test_minitree_threshold_and_clustered_input(orc):
     """A dense cluster puts most primitives into one grid cell (one big mini-tree) and parallel_threshold changes
     the merge; both must follow the reference."""

@@ -102,3 +102,15 @@ def test_2d_restatement_matches_reference(orc, ref, dtype):
             ha, ca = a.intersect_sphere(pp, rays, any_hit, robust, counters=True)
             hb, cb = b.intersect_sphere(pp, rays, any_hit, robust, counters=True)
             assert ha.tobytes() == hb.tobytes() and (ca == cb).all()
+
+
+def test_minitree_builder_direct_matches_reference(orc, ref):
+    tris = synth.sponza_proxy(30000)
+    bb, cc = ref.prep_tris(tris)
+    for kw in (dict(), dict(enable_pruning=False), dict(pruning_area_ratio=0.3), dict(pruning_area_ratio=1.5, max_leaf=4),
+               dict(parallel_threshold=200, pruning_area_ratio=0.05)):
+        assert ref.build_minitree(bb, cc, threads=3, **kw).serialize() == orc.build_minitree(bb, cc, **kw).serialize(), kw
+    for n in (1, 2, 9, 300):
+        t = synth.soup(n, jitter=0.05)
+        b2, c2 = ref.prep_tris(t)
+        assert ref.build_minitree(b2, c2, threads=2).serialize() == orc.build_minitree(b2, c2).serialize(), n
