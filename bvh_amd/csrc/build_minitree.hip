@@ -1,9 +1,9 @@
 // K1-K4, K7-K9 — MiniTreeBuilder (mini_tree_builder.h:47-310) on gfx950, bit-exact with the reference:
 //
-//   build_mini_trees (:160-205): centroid bounds -> 16^3 Morton grid cell per primitive -> greedy merge of adjacent
+//   build_mini_trees (:160-205): centroid bounds -> (2^log2_grid_dim)^3 Morton grid cell per primitive (16^3 by default) -> greedy merge of adjacent
 //       cells up to parallel_threshold (when pruning is on) -> one BinnedSahBuilder tree per group over the group's
 //       ids in ascending order (:124). The reference's per-thread bin vectors + std::sort become one histogram,
-//       a one-lane merge over the 4096 cells and ONE stable radix sort by group id; all groups are then built
+//       a one-wavefront merge over the cells and ONE stable radix sort by group id; all groups are then built
 //       simultaneously by the forest variant of the binned builder (build_binned.hip).
 //   prune_mini_trees (:207-247): area threshold from the serially summed root areas; per tree, the reference's
 //       explicit-stack DFS (second child first) cuts at nodes with half_area < threshold or leaves; each cut subtree
@@ -31,7 +31,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
 
 namespace {
 
-constexpr uint32_t kGridDim = 16, kCells = 4096;             // log2_grid_dim = 4 (:42)
+constexpr uint32_t kDefaultLog2Grid = 4;                     // Config::log2_grid_dim (:42); at most 10: MortonCode has 32 bits (:169)
 constexpr int kWalkStack = 160;
 
 template <typename T> struct Eps;
@@ -45,9 +45,8 @@ template <typename T> __device__ inline T guarded_inverse(T x) {            // u
 struct MtScalars { uint32_t n_groups, n_cuts, error, pad; };
 
 template <typename T>
-__global__ void k_mt_prepare(typename Ord<T>::U* keybox, uint32_t* hist, MtScalars* sc) {
+__global__ void k_mt_prepare(typename Ord<T>::U* keybox, MtScalars* sc) {
     for (int k = threadIdx.x; k < 3; k += blockDim.x) { keybox[k] = Ord<T>::enc(Ord<T>::kMax); keybox[3 + k] = Ord<T>::enc(-Ord<T>::kMax); }
-    for (uint32_t i = threadIdx.x; i < kCells; i += blockDim.x) hist[i] = 0;
     if (threadIdx.x == 0) { MtScalars z = {}; *sc = z; }
 }
 
@@ -67,46 +66,80 @@ __global__ void __launch_bounds__(256) k_center_bounds(const T* centers, uint32_
     if (threadIdx.x < 3) { atomicMin(&keybox[threadIdx.x], slo[threadIdx.x]); atomicMax(&keybox[3 + threadIdx.x], shi[threadIdx.x]); }
 }
 
-__device__ inline uint32_t spread3(uint32_t v) {             // utils.h:104-115 for 4-bit inputs: bit k -> bit 3k
-    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+__device__ inline uint32_t spread3(uint32_t v) {             // utils.h:104-115 for inputs below 2^10: bit k -> bit 3k
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
 }
 
 // grid cell of every primitive (:170-185) + cell histogram
 template <typename T>
-__global__ void __launch_bounds__(256) k_cells(const T* centers, uint32_t n, const typename Ord<T>::U* keybox, uint32_t* codes, uint32_t* hist) {
+__global__ void __launch_bounds__(256) k_cells(const T* centers, uint32_t n, const typename Ord<T>::U* keybox, uint32_t grid_dim, uint32_t cells,
+                                               uint32_t* codes, uint32_t* hist) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     uint32_t g[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const T lo = Ord<T>::dec(keybox[k]), hi = Ord<T>::dec(keybox[3 + k]);
-        const T scale = static_cast<T>(kGridDim) * guarded_inverse(hi - lo);
+        const T scale = static_cast<T>(grid_dim) * guarded_inverse(hi - lo);
         const T shift = (-lo) * scale;
         const T p = pick_max(Ord<T>::fma_(centers[3ull * i + k], scale, shift), T(0));
-        g[k] = p >= T(kGridDim - 1) ? kGridDim - 1 : static_cast<uint32_t>(p);
+        g[k] = p >= static_cast<T>(grid_dim - 1) ? grid_dim - 1 : static_cast<uint32_t>(p);
     }
-    const uint32_t code = (spread3(g[0]) | (spread3(g[1]) << 1) | (spread3(g[2]) << 2)) & (kCells - 1);
+    const uint32_t code = (spread3(g[0]) | (spread3(g[1]) << 1) | (spread3(g[2]) << 2)) & (cells - 1);
     codes[i] = code;
     atomicAdd(&hist[code], 1u);
 }
 
-// merge_small_bins (:84-91) + remove_empty_bins (:93-96), one lane over the 4096 cells
-__global__ void k_merge_cells(const uint32_t* hist, int merge, uint32_t threshold, uint32_t* group_of, uint32_t* group_begin, MtScalars* sc) {
-    uint32_t groups = 0, run = 0;
-    for (uint32_t i = 0; i < kCells;) {
-        uint32_t acc = hist[i], j = i + 1;
-        if (merge)
-            for (; j < kCells && hist[j] + acc <= threshold; ++j) acc += hist[j];
-        if (acc) {
-            for (uint32_t q = i; q < j; ++q) group_of[q] = groups;
-            group_begin[groups] = run;
-            run += acc;
-            ++groups;
+// merge_small_bins (:84-91) + remove_empty_bins (:93-96) by one wavefront, 64 cells per step. The reference's loop starts a bin
+// at cell i and absorbs the following cells while the running size stays <= threshold; empty cells never change the outcome
+// (they join anything, or start a bin that the next non-empty cell either joins or replaces), so the greedy runs over the
+// non-empty cells only: `acc` = size of the open bin (0 = none). Steps = cells / 64 + bins closed.
+__global__ void __launch_bounds__(64) k_merge_cells(const uint32_t* hist, uint32_t cells, int merge, uint32_t threshold, uint32_t* group_of,
+                                                    uint32_t* group_begin, MtScalars* sc) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t groups = 0, run = 0, acc = 0;                   // wave-uniform: bins opened, primitives in closed bins, open bin's size
+    for (uint32_t base = 0; base < cells; base += 64) {
+        const uint32_t cell = base + lane;
+        const uint32_t c = cell < cells ? hist[cell] : 0;
+        uint64_t todo = __ballot(c != 0);
+        if (!todo) continue;
+        uint32_t incl = c;                                    // inclusive prefix sum of the 64 counts
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= static_cast<uint32_t>(d)) incl += o; }
+        uint32_t consumed = 0;                                // counts of this step already placed in closed bins / before the open bin's part
+        uint32_t mine = 0;
+        while (todo) {
+            if (acc == 0) {                                   // open a bin at the first unplaced non-empty cell
+                const int first = __builtin_ctzll(todo);
+                if (lane == 0) group_begin[groups] = run;
+                if (lane == static_cast<uint32_t>(first)) mine = groups;
+                ++groups;
+                acc = __shfl(c, first);
+                consumed = __shfl(incl, first);
+                todo &= todo - 1;
+                continue;
+            }
+            const bool joins = merge && acc + (incl - consumed) <= threshold;     // monotone over the unplaced lanes
+            const uint64_t rest = todo & ~__ballot(joins);
+            const uint64_t joined = todo & ~rest;
+            if ((joined >> lane) & 1) mine = groups - 1;
+            if (!rest) { acc += __shfl(incl, 63) - consumed; todo = 0; break; }
+            const int stop = __builtin_ctzll(rest);           // this cell does not fit: close the bin in front of it
+            const uint32_t before = __shfl(incl, stop) - __shfl(c, stop);
+            run += acc + (before - consumed);
+            acc = 0;
+            consumed = before;
+            todo = rest;
         }
-        i = j;
+        if (c != 0) group_of[cell] = mine;
     }
-    group_begin[groups] = run;
-    sc->n_groups = groups;
+    run += acc;
+    if (lane == 0) { group_begin[groups] = run; sc->n_groups = groups; }
 }
 
 __global__ void __launch_bounds__(256) k_group_keys(const uint32_t* codes, const uint32_t* group_of, uint32_t n, uint32_t* keys, uint32_t* vals) {
@@ -256,30 +289,38 @@ __global__ void __launch_bounds__(256) k_splice_top(const HostNode<T>* top, cons
 
 // MiniTreeBuilder::build on the device: final nodes (reference layout) + prim ids, both resident.
 template <typename T>
-int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T prune_ratio,
+int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T prune_ratio, uint32_t log2_grid,
                   DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& final_ids, size_t& total_nodes, hipStream_t stream)
 {
     if (n >= (size_t{1} << 28)) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: more than 2^28 primitives");
+    if (log2_grid < 1 || log2_grid > 10) return fail(BVH_AMD_ERR_ARG, "build: log2_grid_dim must be in [1, 10] (three coordinates in a 32-bit Morton code)");
     const uint32_t n32 = static_cast<uint32_t>(n);
+    const uint32_t grid_dim = 1u << log2_grid, cells = 1u << (3 * log2_grid);
+    const size_t max_groups = std::min<size_t>(cells, n);
     using U = typename Ord<T>::U;
     DevBuf<U> keybox;
     DevBuf<uint32_t> hist, codes, group_of, group_begin, keys, ids, keys_tmp, vals_tmp;
     DevBuf<MtScalars> scalars;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    A(keybox.alloc(6)); A(hist.alloc(kCells)); A(codes.alloc(n)); A(group_of.alloc(kCells)); A(group_begin.alloc(kCells + 1));
+    A(keybox.alloc(6)); A(hist.alloc(cells)); A(codes.alloc(n)); A(group_of.alloc(cells)); A(group_begin.alloc(max_groups + 1));
     A(keys.alloc(n)); A(ids.alloc(n)); A(keys_tmp.alloc(n)); A(vals_tmp.alloc(n)); A(scalars.alloc(1));
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
 
     // ---- build_mini_trees
-    hipLaunchKernelGGL(k_mt_prepare<T>, dim3(1), dim3(256), 0, stream, keybox.p, hist.p, scalars.p);
+    BVH_HIP_TRY(hipMemsetAsync(hist.p, 0, size_t{cells} * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
+    hipLaunchKernelGGL(k_mt_prepare<T>, dim3(1), dim3(64), 0, stream, keybox.p, scalars.p);
     const unsigned red_grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 2048));
     hipLaunchKernelGGL(k_center_bounds<T>, dim3(red_grid), dim3(256), 0, stream, d_centers, n32, keybox.p);
-    hipLaunchKernelGGL(k_cells<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_centers, n32, keybox.p, codes.p, hist.p);
-    hipLaunchKernelGGL(k_merge_cells, dim3(1), dim3(1), 0, stream, hist.p, prune ? 1 : 0, static_cast<uint32_t>(cfg.parallel_threshold),
-                       group_of.p, group_begin.p, scalars.p);
+    hipLaunchKernelGGL(k_cells<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_centers, n32, keybox.p, grid_dim, cells, codes.p,
+                       hist.p);
+    const uint32_t merge_threshold = static_cast<uint32_t>(std::min<size_t>(cfg.parallel_threshold, 0x7fffffffu));   // counts stay below 2^28
+    hipLaunchKernelGGL(k_merge_cells, dim3(1), dim3(64), 0, stream, hist.p, cells, prune ? 1 : 0, merge_threshold, group_of.p, group_begin.p,
+                       scalars.p);
     hipLaunchKernelGGL(k_group_keys, dim3((n32 + 255) / 256), dim3(256), 0, stream, codes.p, group_of.p, n32, keys.p, ids.p);
-    int rc = radix_sort_pairs<uint32_t>(keys.p, ids.p, keys_tmp.p, vals_tmp.p, n32, 1, 12, stream);   // stable: ids ascending per group (:124)
+    int key_bits = 1;                                         // group ids are below min(cells, n)
+    while (key_bits < 32 && (size_t{1} << key_bits) < max_groups) ++key_bits;
+    int rc = radix_sort_pairs<uint32_t>(keys.p, ids.p, keys_tmp.p, vals_tmp.p, n32, 1, key_bits, stream);   // stable: ids ascending per group (:124)
     if (rc) return rc;
     MtScalars hs;
     BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
@@ -365,12 +406,12 @@ template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size
 // three qualities are three settings of them (default_builder.h:65-73) plus the reinsertion pass at High.
 template <typename T>
 int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T ratio,
-                            bool optimize, hipStream_t stream) {
+                            bool optimize, uint32_t log2_grid, hipStream_t stream) {
     BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
     DevBuf<HostNode<T>> final_nodes;
     DevBuf<uint32_t> final_ids;
     size_t total_nodes = 0;
-    int rc = minitree_core<T>(d_bboxes, d_centers, n, cfg, prune, ratio, final_nodes, final_ids, total_nodes, stream);
+    int rc = minitree_core<T>(d_bboxes, d_centers, n, cfg, prune, ratio, log2_grid, final_nodes, final_ids, total_nodes, stream);
     if (rc) return rc;
     if (optimize) {
         rc = reinsertion_optimize_device<T>(final_nodes.p, total_nodes, stream, 3);
@@ -386,11 +427,12 @@ int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_cente
 template <typename T>
 int build_minitree_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, hipStream_t stream) {
     return build_minitree_explicit<T>(out, d_bboxes, d_centers, n, cfg, cfg.quality != BVH_BUILD_QUALITY_LOW,
-                                      cfg.quality == BVH_BUILD_QUALITY_HIGH ? T(0.01) : T(0.1), cfg.quality == BVH_BUILD_QUALITY_HIGH, stream);
+                                      cfg.quality == BVH_BUILD_QUALITY_HIGH ? T(0.01) : T(0.1), cfg.quality == BVH_BUILD_QUALITY_HIGH, kDefaultLog2Grid,
+                                      stream);
 }
 
-template int build_minitree_explicit<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, bool, float, bool, hipStream_t);
-template int build_minitree_explicit<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, bool, double, bool, hipStream_t);
+template int build_minitree_explicit<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, bool, float, bool, uint32_t, hipStream_t);
+template int build_minitree_explicit<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, bool, double, bool, uint32_t, hipStream_t);
 template int build_minitree_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
 template int build_minitree_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
 

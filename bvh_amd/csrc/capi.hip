@@ -11,7 +11,7 @@ template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size
 void reinsertion_stats(unsigned out[2]);
 template <typename T>
 int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T ratio,
-                            bool optimize, hipStream_t stream);
+                            bool optimize, uint32_t log2_grid, hipStream_t stream);
 template <typename T>
 int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_count, const uint32_t* d_ids, size_t root_id, hipStream_t stream);
 template <typename T> int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
@@ -69,13 +69,15 @@ typename CTypes<T>::Bvh* build_minitree(const T* d_bboxes, const T* d_centers, s
         set_error("build: need 1 <= min_leaf_size <= max_leaf_size <= 15 (4-bit primitive count, index.h:38)");
         return nullptr;
     }
-    if (c.log2_grid_dim != 4) { set_error("build_minitree: only log2_grid_dim = 4 (the reference's default) is implemented"); return nullptr; }
-    if (c.parallel_threshold == 0) { set_error("build_minitree: parallel_threshold must be positive"); return nullptr; }
+    if (c.log2_grid_dim < 1 || c.log2_grid_dim > 10) {       // mini_tree_builder.h:169 asserts <= digits(MortonCode) / 3; 0 would be one cell
+        set_error("build_minitree: log2_grid_dim must be in [1, 10] (three coordinates in a 32-bit Morton code, mini_tree_builder.h:169)");
+        return nullptr;
+    }
     bvh_build_config cfg = default_config();
     cfg.min_leaf_size = c.min_leaf_size; cfg.max_leaf_size = c.max_leaf_size; cfg.parallel_threshold = c.parallel_threshold;
     auto b = std::make_unique<BvhImpl<T>>();
     if (build_minitree_explicit<T>(*b, d_bboxes, d_centers, n, cfg, c.enable_pruning != 0, static_cast<T>(c.pruning_area_ratio), false,
-                                   static_cast<hipStream_t>(stream)) != BVH_AMD_OK)
+                                   static_cast<uint32_t>(c.log2_grid_dim), static_cast<hipStream_t>(stream)) != BVH_AMD_OK)
         return nullptr;
     return handle<T>(b.release());
 }

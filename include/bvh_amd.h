@@ -131,7 +131,8 @@ BVH_AMD_API struct bvh3d* bvh3d_build_device(const double* d_bboxes, const doubl
 
 /* Additive: MiniTreeBuilder::build(pool, bboxes, centers, config) itself (src/bvh/v2/mini_tree_builder.h:29-58) with its own
  * configuration; DefaultBuilder(pool)'s three qualities are three settings of it (default_builder.h:65-73). log2_grid_dim
- * must be 4 (the reference's default; the device kernels are specialised for the 16^3 grid). */
+ * may be 1..10 (three coordinates in the reference's 32-bit Morton code, mini_tree_builder.h:169); the cell histogram takes
+ * 8^log2_grid_dim x 8 bytes of HBM. */
 struct bvh_amd_minitree_config {
     size_t min_leaf_size, max_leaf_size;       /* TopDownSahBuilder::Config (top_down_sah_builder.h:27-40), defaults 1 / 8 */
     int enable_pruning;                        /* default 1 */

@@ -112,7 +112,7 @@ class CpuLib:
     _SIG = {
         "build": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                C.c_size_t, C.c_int]),
-        "build_minitree": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_double, C.c_size_t, C.c_int]),
+        "build_minitree": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_double, C.c_size_t, C.c_int, C.c_size_t]),
         "destroy": (None, [C.c_void_p]),
         "node_count": (C.c_size_t, [C.c_void_p]),
         "prim_count": (C.c_size_t, [C.c_void_p]),
@@ -149,7 +149,7 @@ class CpuLib:
         return int(getattr(self.dll, f"{self.prefix}_hardware_threads")())
 
     def build(self, bboxes, centers, builder=BUILDER_DEFAULT_SERIAL, quality=QUALITY_HIGH, min_leaf=1,
-              max_leaf=8, parallel_threshold=1024, threads=0) -> CpuBvh:
+              max_leaf=8, parallel_threshold=1024, threads=0, log2_grid_dim=4) -> CpuBvh:
         dt = bboxes.dtype
         dim = np.asarray(centers).shape[-1]                   # (n, 3) centers + (n, 6) boxes, or (n, 2) + (n, 4) {min, max}
         s = self._sfx(dt, dim)
@@ -163,14 +163,14 @@ class CpuLib:
         return CpuBvh(self, h, s)
 
     def build_minitree(self, bboxes, centers, min_leaf=1, max_leaf=8, enable_pruning=True, pruning_area_ratio=0.01,
-                       parallel_threshold=1024, threads=0) -> CpuBvh:
+                       parallel_threshold=1024, threads=0, log2_grid_dim=4) -> CpuBvh:
         """MiniTreeBuilder::build(pool, bboxes, centers, config) (mini_tree_builder.h:29-58), 3D."""
         dt = bboxes.dtype
         s = self._sfx(dt)
         bboxes = np.ascontiguousarray(bboxes, dtype=dt).reshape(-1, 6)
         centers = np.ascontiguousarray(centers, dtype=dt).reshape(-1, 3)
         h = self._fn("build_minitree", s)(_ptr(bboxes), _ptr(centers), len(bboxes), min_leaf, max_leaf, int(enable_pruning),
-                                          float(pruning_area_ratio), parallel_threshold, threads)
+                                          float(pruning_area_ratio), parallel_threshold, threads, log2_grid_dim)
         if not h:
             raise RuntimeError("oracle build failed")
         return CpuBvh(self, h, s)

@@ -927,13 +927,14 @@ extern "C" {
         size_t min_leaf, size_t max_leaf, size_t par_threshold, int /*threads*/) {                      \
         if (!n) return nullptr;                                                                          \
         return new Tree<T>(build_dispatch<T>(bboxes, centers, n, builder, quality, LeafLimits{min_leaf, max_leaf}, par_threshold)); } \
-    /* MiniTreeBuilder::build(pool, bboxes, centers, config) itself (mini_tree_builder.h:29-58), log2_grid_dim = 4 */  \
+    /* MiniTreeBuilder::build(pool, bboxes, centers, config) itself (mini_tree_builder.h:29-58) */                      \
     ORC_EXPORT void* orc_build_minitree##S(const T* bboxes, const T* centers, size_t n, size_t min_leaf, size_t max_leaf, \
-        int enable_pruning, double pruning_area_ratio, size_t par_threshold, int /*threads*/) {           \
+        int enable_pruning, double pruning_area_ratio, size_t par_threshold, int /*threads*/, size_t log2_grid_dim) { \
         if (!n) return nullptr;                                                                          \
         std::vector<Box<T>> boxes(n);                                                                    \
         for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { boxes[i].lo[k] = bboxes[6 * i + k]; boxes[i].hi[k] = bboxes[6 * i + 3 + k]; } \
         MiniTreeParams<T> mp; mp.prune = enable_pruning != 0; mp.prune_ratio = static_cast<T>(pruning_area_ratio); mp.par_threshold = par_threshold; \
+        mp.log2_grid = static_cast<unsigned>(log2_grid_dim);                                             \
         return new Tree<T>(build_mini_trees<T>(boxes.data(), centers, n, LeafLimits{min_leaf, max_leaf}, mp)); } \
     ORC_EXPORT void orc_destroy##S(void* h) { delete static_cast<Tree<T>*>(h); }                        \
     ORC_EXPORT size_t orc_node_count##S(const void* h) { return static_cast<const Tree<T>*>(h)->nodes.size(); } \

@@ -316,13 +316,14 @@ extern "C" {
 /* triangles exist in 3D only (tri.h:30-74); MiniTreeBuilder::build itself too (its grid reads three components) */
 #define REF_IMPL_TRI(T, S)                                                                              \
     ORC_EXPORT void* ref_build_minitree##S(const T* bboxes, const T* centers, size_t n, size_t min_leaf, size_t max_leaf, \
-        int enable_pruning, double pruning_area_ratio, size_t par_threshold, int threads) {             \
+        int enable_pruning, double pruning_area_ratio, size_t par_threshold, int threads, size_t log2_grid_dim) { \
         std::vector<BBox<T, 3>> bb(n); std::vector<Vec<T, 3>> cc(n);                                    \
         for (size_t i = 0; i < n; ++i) for (size_t k = 0; k < 3; ++k) {                                  \
             bb[i].min[k] = bboxes[6 * i + k]; bb[i].max[k] = bboxes[6 * i + 3 + k]; cc[i][k] = centers[3 * i + k]; } \
         typename MiniTreeBuilder<Node3<T>>::Config cfg;                                                 \
         cfg.min_leaf_size = min_leaf; cfg.max_leaf_size = max_leaf; cfg.enable_pruning = enable_pruning != 0; \
         cfg.pruning_area_ratio = static_cast<T>(pruning_area_ratio); cfg.parallel_threshold = par_threshold; \
+        cfg.log2_grid_dim = log2_grid_dim;                                                              \
         ThreadPool pool(static_cast<size_t>(threads));                                                  \
         return new Bvh3<T>(MiniTreeBuilder<Node3<T>>::build(pool, bb, cc, cfg)); }                      \
     ORC_EXPORT void ref_prep_tris##S(const T* t9, size_t n, T* bb, T* cc) { prep_tris<T>(t9, n, bb, cc); } \

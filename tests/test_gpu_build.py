@@ -213,8 +213,14 @@ def test_minitree_builder_direct(orc, dtype):
         t = synth.soup(n, jitter=0.05).astype(dtype)
         b2, c2 = orc.prep_tris(t)
         assert bvh_amd.MiniTreeBuilder.build(b2, c2).serialize() == orc.build_minitree(b2, c2).serialize(), n
-    with pytest.raises(bvh_amd.BvhAmdError, match="log2_grid_dim"):
-        bvh_amd.MiniTreeBuilder.build(bb, cc, bvh_amd.MiniTreeBuilder.Config(log2_grid_dim=5))
+    for L in (1, 2, 3, 5, 6, 7):                              # other grids than the default 16^3
+        for kw in (dict(), dict(enable_pruning=False), dict(parallel_threshold=64, pruning_area_ratio=0.2), dict(parallel_threshold=0)):
+            okw = dict(kw, log2_grid_dim=L)
+            gpu = bvh_amd.MiniTreeBuilder.build(bb, cc, bvh_amd.MiniTreeBuilder.Config(**okw))
+            assert gpu.serialize() == orc.build_minitree(bb, cc, **okw).serialize(), okw
+    for L in (0, 11):
+        with pytest.raises(bvh_amd.BvhAmdError, match="log2_grid_dim"):
+            bvh_amd.MiniTreeBuilder.build(bb, cc, bvh_amd.MiniTreeBuilder.Config(log2_grid_dim=L))
 
 
 def test_minitree_threshold_and_clustered_input(orc):

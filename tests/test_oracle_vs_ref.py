@@ -110,6 +110,9 @@ def test_minitree_builder_direct_matches_reference(orc, ref):
     for kw in (dict(), dict(enable_pruning=False), dict(pruning_area_ratio=0.3), dict(pruning_area_ratio=1.5, max_leaf=4),
                dict(parallel_threshold=200, pruning_area_ratio=0.05)):
         assert ref.build_minitree(bb, cc, threads=3, **kw).serialize() == orc.build_minitree(bb, cc, **kw).serialize(), kw
+    for L in (1, 3, 6):
+        for kw in (dict(), dict(enable_pruning=False), dict(parallel_threshold=0)):
+            assert ref.build_minitree(bb, cc, threads=2, log2_grid_dim=L, **kw).serialize() == orc.build_minitree(bb, cc, log2_grid_dim=L, **kw).serialize(), (L, kw)
     for n in (1, 2, 9, 300):
         t = synth.soup(n, jitter=0.05)
         b2, c2 = ref.prep_tris(t)
