@@ -104,7 +104,24 @@ _SIGS_T = {
     "bvh_amd_sphere_bounds{S}": (_I, [_P, _Z, _P, _P, _P]),
     "bvh{S}_intersect_rays_tri": (_I, [_P, _P, _P, _Z, _U, _P, _P, _P]),
     "bvh{S}_intersect_rays_sphere": (_I, [_P, _P, _P, _Z, _U, _P, _P, _P]),
+    # one ray, host leaf callback (c_api/bvh.h:277-295): (bvh, ray, callback struct)
+    "bvh{S}_intersect_ray": (None, [_P, _P, _P]),
+    "bvh{S}_intersect_ray_any": (None, [_P, _P, _P]),
+    "bvh{S}_intersect_ray_robust": (None, [_P, _P, _P]),
+    "bvh{S}_intersect_ray_any_robust": (None, [_P, _P, _P]),
+    "bvh{S}_intersect_ray_visit": (_I, [_P, _P, _Z, _U, _P]),
 }
+
+
+def ray_visitor_types(suffix: str):
+    """(struct bvh_amd_ray_visitor{f,d}, leaf CFUNCTYPE, inner CFUNCTYPE) for a family suffix like '3f'."""
+    scalar = C.c_float if suffix[1] == "f" else C.c_double
+    leaf_t = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.POINTER(scalar), C.c_size_t, C.c_size_t)
+    inner_t = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t)
+
+    class Visitor(C.Structure):
+        _fields_ = [("user_data", C.c_void_p), ("leaf_fn", leaf_t), ("inner_fn", inner_t)]
+    return Visitor, leaf_t, inner_t
 
 
 _ONLY_3D = ("bvh_amd_tri_bounds{S}", "bvh_amd_precompute_tris{S}", "bvh{S}_intersect_rays_tri",     # tri.h is 3D only,

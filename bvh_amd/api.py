@@ -190,6 +190,43 @@ class Bvh:
         _torch()
         return Bvh(getattr(lib, f"bvh{s}_deserialize")(data, len(data)), s)
 
+    def intersect_ray(self, ray, leaf_fn, any_hit: bool = False, robust: bool = False, inner_fn=None, start=None):
+        """Bvh::intersect<IsAnyHit, IsRobust>(ray, start, stack, leaf_fn, inner_fn) (bvh.h:72-73) for ONE ray with host
+        callbacks, over bvhXX_intersect_ray_visit: leaf_fn(tmax, begin, end) -> (was_hit, new_tmax) receives a BVH-order
+        primitive range and the ray's current tmax and returns the possibly shortened tmax; inner_fn(first_child_id), if
+        given, is called per visited pair. `ray` = {org, dir, tmin, tmax}; `start` = packed index word (default: the root's).
+        The walk runs on the device (several kernel launches per ray): for throughput use bvh_amd.intersect."""
+        lib = _lib.load()
+        dt = np.float32 if self._s[1] == "f" else np.float64
+        r = np.ascontiguousarray(ray, dtype=dt).reshape(2 * self.dim + 2)
+        Visitor, leaf_t, inner_t = _lib.ray_visitor_types(self._s)
+        failure = []
+
+        def on_leaf(_user, t, begin, end):
+            try:
+                hit, new_t = leaf_fn(dt(t[0]), int(begin), int(end))
+                t[0] = new_t
+                return bool(hit)
+            except BaseException as exc:                      # an exception cannot cross the C frames: end the walk, re-raise after
+                failure.append(exc)
+                t[0] = float("-inf")
+                return True
+
+        def on_inner(_user, first):
+            try:
+                if not failure:
+                    inner_fn(int(first))
+            except BaseException as exc:
+                failure.append(exc)
+
+        v = Visitor(None, leaf_t(on_leaf), inner_t(on_inner) if inner_fn is not None else inner_t())
+        if start is None:
+            start = (1 << 64) - 1                             # BVH_AMD_START_AT_ROOT
+        rc = getattr(lib, f"bvh{self._s}_intersect_ray_visit")(self._h, r.ctypes.data, int(start), (RayFlags.ANY_HIT if any_hit else 0) | (RayFlags.ROBUST if robust else 0), C.byref(v))
+        if failure:
+            raise failure[0]
+        _lib.check(rc, "intersect_ray_visit")
+
     def extract_bvh(self, root_id: int) -> "Bvh":
         """Bvh::extract_bvh (bvh.h:92-122): the subtree under node `root_id` as its own BVH (device op)."""
         h = getattr(_lib.load(), f"bvh{self._s}_extract")(self._h, int(root_id))

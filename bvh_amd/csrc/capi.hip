@@ -391,6 +391,43 @@ int intersect(const typename CTypes<T>::Bvh* bvh, int leaf, const T* d_prims, co
                               static_cast<hipStream_t>(stream));
 }
 
+// bvhXX_intersect_ray{,_any}{,_robust} (c_api/bvh.h:277-295 over bvh_impl.h:235-250): one ray, the leaves go to the caller's
+// function. The walk runs on the device (traverse.hip, ray_step_kernel); `ray` is the family's own struct.
+template <typename T, int D>
+int intersect_ray_visit(const BvhImpl<T>* b, const void* ray, size_t start, unsigned flags, bool (*leaf_fn)(void*, T*, size_t, size_t),
+                        void (*inner_fn)(void*, size_t), void* user) {
+    if (!b || !ray) return fail(BVH_AMD_ERR_ARG, "intersect_ray: null bvh or ray");
+    if (b->dim != D) return fail(BVH_AMD_ERR_ARG, "intersect_ray: dimension mismatch");
+    int cur = -1;
+    BVH_HIP_TRY(hipGetDevice(&cur), BVH_AMD_ERR_HIP);
+    if (cur != b->device) return fail(BVH_AMD_ERR_ARG, "intersect_ray: BVH lives on another device than the current one");
+    if (start == BVH_AMD_START_AT_ROOT) start = b->root_index;
+    const T* r = static_cast<const T*>(ray);
+    T ray8[8];
+    if (D == 3) { for (int k = 0; k < 8; ++k) ray8[k] = r[k]; }
+    else { ray8[0] = r[0]; ray8[1] = r[1]; ray8[2] = T(0); ray8[3] = r[2]; ray8[4] = r[3]; ray8[5] = T(0); ray8[6] = r[4]; ray8[7] = r[5]; }
+    return trace_ray_callbacks<T>(*b, ray8, static_cast<uint32_t>(start), (flags & BVH_AMD_RAY_ANY_HIT) != 0, (flags & BVH_AMD_RAY_ROBUST) != 0,
+                                  leaf_fn, inner_fn, user);
+}
+
+// The reference's bvhXX_build never returns NULL and its callers do not check (test/c_api_example.c:114-120): say why before they trip.
+template <typename P> P* loud(P* result, const char* what) {
+    if (!result) std::fprintf(stderr, "bvh_amd: %s failed: %s\n", what, g_error.c_str());
+    return result;
+}
+
+// The reference's functions return void and cannot fail; a failure here would otherwise read as "no intersection".
+template <typename T, int D, typename Callback>
+void intersect_ray_legacy(const BvhImpl<T>* b, const void* ray, const Callback* callback, unsigned flags) {
+    int rc = callback && callback->user_fn && b
+                 ? intersect_ray_visit<T, D>(b, ray, b->root_index, flags, callback->user_fn, nullptr, callback->user_data)
+                 : fail(BVH_AMD_ERR_ARG, "intersect_ray: null bvh or callback");
+    if (rc != BVH_AMD_OK) {
+        std::fprintf(stderr, "bvh_amd: bvh_intersect_ray failed: %s\n", g_error.c_str());
+        std::abort();
+    }
+}
+
 } // namespace
 } // namespace bvh_amd
 
@@ -435,7 +472,7 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
 
 #define BVH_AMD_IMPL(T, S)                                                                                          \
     bvh##S* bvh##S##_build(bvh_thread_pool* pool, const bvh_bbox##S* bb, const bvh_vec##S* cc, size_t n,            \
-                           const bvh_build_config* cfg) { return build_host<T>(pool, bb, cc, n, cfg); }             \
+                           const bvh_build_config* cfg) { return loud(build_host<T>(pool, bb, cc, n, cfg), "bvh" #S "_build"); } \
     bvh##S* bvh##S##_build_device(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,              \
                                   enum bvh_amd_builder builder, void* stream) {                                     \
         return build_device<T>(d_bb, d_cc, n, cfg, builder, stream); }                                              \
@@ -506,9 +543,24 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
 BVH_AMD_IMPL(float, 3f)
 BVH_AMD_IMPL(double, 3d)
 
+#define BVH_AMD_IMPL_RAY(T, S, CB, VIS, D, IMPL)                                                                         \
+    void bvh##S##_intersect_ray(const bvh##S* b, const bvh_ray##S* r, const CB* cb) { intersect_ray_legacy<T, D>(IMPL<T>(b), r, cb, 0u); } \
+    void bvh##S##_intersect_ray_any(const bvh##S* b, const bvh_ray##S* r, const CB* cb) {                           \
+        intersect_ray_legacy<T, D>(IMPL<T>(b), r, cb, BVH_AMD_RAY_ANY_HIT); }                                        \
+    void bvh##S##_intersect_ray_robust(const bvh##S* b, const bvh_ray##S* r, const CB* cb) {                        \
+        intersect_ray_legacy<T, D>(IMPL<T>(b), r, cb, BVH_AMD_RAY_ROBUST); }                                         \
+    void bvh##S##_intersect_ray_any_robust(const bvh##S* b, const bvh_ray##S* r, const CB* cb) {                    \
+        intersect_ray_legacy<T, D>(IMPL<T>(b), r, cb, BVH_AMD_RAY_ANY_HIT | BVH_AMD_RAY_ROBUST); }                   \
+    int bvh##S##_intersect_ray_visit(const bvh##S* b, const bvh_ray##S* r, size_t start, unsigned flags, const VIS* v) { \
+        if (!v || !v->leaf_fn) return fail(BVH_AMD_ERR_ARG, "intersect_ray_visit: null visitor");                   \
+        return intersect_ray_visit<T, D>(IMPL<T>(b), r, start, flags, v->leaf_fn, v->inner_fn, v->user_data); }
+
+BVH_AMD_IMPL_RAY(float, 3f, bvh_intersect_callbackf, bvh_amd_ray_visitorf, 3, impl)
+BVH_AMD_IMPL_RAY(double, 3d, bvh_intersect_callbackd, bvh_amd_ray_visitord, 3, impl)
+
 #define BVH_AMD_IMPL2(T, S)                                                                                         \
     bvh##S* bvh##S##_build(bvh_thread_pool* pool, const bvh_bbox##S* bb, const bvh_vec##S* cc, size_t n,            \
-                           const bvh_build_config* cfg) { return build2_host<T>(pool, bb, cc, n, cfg); }            \
+                           const bvh_build_config* cfg) { return loud(build2_host<T>(pool, bb, cc, n, cfg), "bvh" #S "_build"); } \
     bvh##S* bvh##S##_build_device(const T* d_bb4, const T* d_cc2, size_t n, const bvh_build_config* cfg,            \
                                   enum bvh_amd_builder builder, void* stream) {                                     \
         return build2_device<T>(d_bb4, d_cc2, n, cfg, builder, stream); }                                           \
@@ -571,6 +623,8 @@ BVH_AMD_IMPL(double, 3d)
 
 BVH_AMD_IMPL2(float, 2f)
 BVH_AMD_IMPL2(double, 2d)
+BVH_AMD_IMPL_RAY(float, 2f, bvh_intersect_callbackf, bvh_amd_ray_visitorf, 2, impl2)
+BVH_AMD_IMPL_RAY(double, 2d, bvh_intersect_callbackd, bvh_amd_ray_visitord, 2, impl2)
 
 int bvh_amd_std_sort_ids3f(const float* d_keys, size_t n, uint32_t* d_ids_out, void* stream) {
     return std_sort_ids<float>(d_ids_out, d_keys, static_cast<uint32_t>(n), 1, 0, 1, static_cast<hipStream_t>(stream));

@@ -130,6 +130,9 @@ template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
                     typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream);
 const char* last_kernel_name();
+template <typename T>
+int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bool any, bool robust,
+                        bool (*leaf_fn)(void*, T*, size_t, size_t), void (*inner_fn)(void*, size_t), void* user);
 
 // prep.hip
 template <typename T> int launch_tri_bounds(const T* d_tris9, size_t n, T* d_bb, T* d_cc, hipStream_t s);

@@ -18,7 +18,10 @@
 
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <type_traits>
 
 namespace bvh_amd {
@@ -456,6 +459,164 @@ int dispatch(const BvhImpl<T>& b, const TraceArgs<T>& args, unsigned flags, bool
     return rob ? BVH_VARIANT(T, false, true, Leaf, false) : BVH_VARIANT(T, false, false, Leaf, false);
 }
 
+
+// ---- one ray, leaves handed to a HOST callback (c_api/bvh.h:277-295 over bvh_impl.h:235-250; Bvh::intersect with a
+// leaf lambda, bvh.h:160-182) ------------------------------------------------------------------------------------------------
+// The callback may shorten the ray (it gets &ray.tmax), and the traversal culls with the current tmax, so the device cannot run
+// ahead of the host unconditionally. It runs ahead SPECULATIVELY: one launch walks the tree with the tmax it was given and
+// logs, in order, every leaf it reaches (and every pair it visits, when an inner callback wants them) together with the
+// traversal stack at that moment. The host replays the log through the callbacks; as long as a callback leaves tmax alone the
+// next logged event is exactly what the reference would do next. When a callback changes tmax, the rest of the log is
+// discarded and the walk restarts from that leaf's stack snapshot with the new tmax. Typical cost: 1 + (number of accepted
+// hits) launches per ray. One lane walks; the wavefront's other lanes only move stacks around.
+constexpr uint32_t kStepLds = 1024;            // stack entries held in LDS (deeper ones live in the context's HBM scratch)
+constexpr uint32_t kStepContinue = 0xFFFFFFFFu;
+constexpr uint32_t kStepEvents = 2048;
+constexpr uint32_t kStepHeader = 4;            // out[0] events, out[1] traversal finished, out[2] error, out[3] unused
+
+template <typename T>
+struct StepArgs {
+    const PairNode<T>* pairs;
+    T ray[8];                                  // org, dir (z = 0 in 2D), tmin, tmax
+    const uint32_t* in;                        // pinned: [0] = number of stack entries (bottom first) or kStepContinue
+    uint32_t* out;                             // pinned: header | kStepEvents x {index word, snapshot offset, snapshot length} | snapshots
+    uint32_t* scratch;                         // device: [0] = size of the stack left by the previous launch, [1..] its entries
+    uint32_t stack_cap;                        // entries the stack may hold
+    uint32_t snap_words;
+    uint32_t max_events;                       // <= kStepEvents
+    uint32_t max_steps;                        // pairs in the tree: no walk visits a pair twice, a cyclic (malformed) tree would
+    uint32_t any, record_pairs;
+};
+
+template <typename T, bool Robust, int D>
+__global__ void __launch_bounds__(kWave) ray_step_kernel(StepArgs<T> a) {
+    __shared__ uint32_t s_stack[kStepLds];
+    __shared__ uint32_t s_sp;
+    const uint32_t lane = threadIdx.x;
+    uint32_t sp = a.in[0];
+    if (sp == kStepContinue) {
+        sp = a.scratch[0];
+        for (uint32_t i = lane; i < sp && i < kStepLds; i += kWave) s_stack[i] = a.scratch[1 + i];
+    } else {
+        for (uint32_t i = lane; i < sp; i += kWave) {
+            const uint32_t v = a.in[1 + i];
+            if (i < kStepLds) s_stack[i] = v; else a.scratch[1 + i] = v;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t* events = a.out + kStepHeader;
+        uint32_t* snaps = events + 3 * kStepEvents;
+        uint32_t n_events = 0, snap_used = 0, finished = 0, error = 0, steps = 0;
+        T org[3] = {0, 0, 0}, inv[3] = {0, 0, 0}, aux[3] = {0, 0, 0};
+        uint32_t oct[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < D; ++k) {                                   // bvh.h:162-165, ray.h:29-48 (as in trace_kernel)
+            org[k] = a.ray[k];
+            const T d = a.ray[3 + k];
+            const T iv = Robust ? T(1) / d : (Num<T>::abs_(d) <= Num<T>::kEps ? Num<T>::copysign_(Num<T>::kMax, d) : T(1) / d);
+            inv[k] = iv;
+            aux[k] = Robust ? (Num<T>::finite(iv) ? Num<T>::bump2(iv) : iv) : (-iv) * org[k];
+            oct[k] = Num<T>::sign(d) ? 1u : 0u;
+        }
+        const T tmin = a.ray[6], tmax = a.ray[7];
+        auto put = [&](uint32_t i, uint32_t v) { if (i < kStepLds) s_stack[i] = v; else a.scratch[1 + i] = v; };
+        auto get = [&](uint32_t i) { return i < kStepLds ? s_stack[i] : a.scratch[1 + i]; };
+        for (;;) {                                                      // bvh.h:128-156
+            if (sp == 0) { finished = 1; break; }
+            uint32_t top = get(--sp);
+            bool dead = false, stop = false;
+            while ((top & kCountMask) == 0) {
+                if (++steps > a.max_steps) { error = 2; stop = true; break; }
+                if (a.record_pairs) {
+                    if (n_events == a.max_events) { stop = true; break; }
+                    events[3 * n_events] = top; events[3 * n_events + 1] = 0; events[3 * n_events + 2] = 0;
+                    ++n_events;
+                }
+                T lb[6], rb[6];
+                uint32_t li = 0, ri = 0;
+                load_pair(a.pairs + (top >> (kCountBits + 1)), lb, rb, li, ri);
+                T l0 = tmin, l1 = tmax, r0 = tmin, r1 = tmax;           // node.h:105-117
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const T ln = oct[k] ? lb[2 * k + 1] : lb[2 * k], lf = oct[k] ? lb[2 * k] : lb[2 * k + 1];
+                    const T rn = oct[k] ? rb[2 * k + 1] : rb[2 * k], rf = oct[k] ? rb[2 * k] : rb[2 * k + 1];
+                    T la, lz, ra, rz;
+                    if (Robust) {                                       // node.h:74-75
+                        la = (ln - org[k]) * inv[k]; lz = (lf - org[k]) * aux[k];
+                        ra = (rn - org[k]) * inv[k]; rz = (rf - org[k]) * aux[k];
+                    } else {                                            // node.h:85-86
+                        la = Num<T>::fma_(ln, inv[k], aux[k]); lz = Num<T>::fma_(lf, inv[k], aux[k]);
+                        ra = Num<T>::fma_(rn, inv[k], aux[k]); rz = Num<T>::fma_(rf, inv[k], aux[k]);
+                    }
+                    l0 = pick_max(la, l0); l1 = pick_min(lz, l1);
+                    r0 = pick_max(ra, r0); r1 = pick_min(rz, r1);
+                }
+                const bool hl = l0 <= l1, hr = r0 <= r1;                // bvh.h:177-180
+                if (hl) {
+                    uint32_t near_i = li;
+                    if (hr) {
+                        uint32_t far_i = ri;
+                        if (!a.any && l0 > r0) { near_i = ri; far_i = li; }
+                        if (sp >= a.stack_cap) { error = 1; stop = true; break; }
+                        put(sp++, far_i);
+                    }
+                    top = near_i;
+                } else if (hr) {
+                    top = ri;
+                } else {
+                    dead = true;                                        // bvh.h:147-148: back to the stack
+                    break;
+                }
+            }
+            if (!stop && !dead && (n_events == a.max_events || snap_used + sp > a.snap_words)) stop = true;   // no room to log this leaf
+            if (stop) {                                                 // resume here next time: the unprocessed node goes back on top
+                if (!error) { if (sp >= a.stack_cap) error = 1; else put(sp++, top); }
+                break;
+            }
+            if (dead) continue;
+            events[3 * n_events] = top; events[3 * n_events + 1] = snap_used; events[3 * n_events + 2] = sp;
+            for (uint32_t i = 0; i < sp; ++i) snaps[snap_used + i] = get(i);
+            snap_used += sp;
+            ++n_events;
+        }
+        a.out[0] = n_events; a.out[1] = finished; a.out[2] = error; a.out[3] = 0;
+        s_sp = sp;
+    }
+    __syncthreads();
+    sp = s_sp;
+    for (uint32_t i = lane; i < sp && i < kStepLds; i += kWave) a.scratch[1 + i] = s_stack[i];
+    if (lane == 0) a.scratch[0] = sp;
+}
+
+struct StepContext {                           // one per calling thread: the per-ray entry points are re-entrant
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint32_t* pinned = nullptr;
+    uint32_t* scratch = nullptr;
+    uint32_t stack_cap = 0, snap_words = 0;
+    void release() {
+        if (pinned) (void)hipHostFree(pinned);
+        if (scratch) (void)hipFree(scratch);
+        if (stream) (void)hipStreamDestroy(stream);
+        pinned = nullptr; scratch = nullptr; stream = nullptr; stack_cap = 0; device = -1;
+    }
+    ~StepContext() { release(); }
+    int ensure(int dev, uint32_t cap) {
+        if (device == dev && stack_cap >= cap) return BVH_AMD_OK;
+        release();
+        BVH_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), BVH_AMD_ERR_HIP);
+        snap_words = std::max<uint32_t>(16384u, 4 * cap);
+        const size_t words = size_t{1} + cap + kStepHeader + 3 * size_t{kStepEvents} + snap_words;
+        BVH_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pinned), words * sizeof(uint32_t), hipHostMallocDefault), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), (size_t{1} + cap) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
+        device = dev; stack_cap = cap;
+        return BVH_AMD_OK;
+    }
+};
+thread_local StepContext t_step;
+std::mutex g_depth_mutex;
+
 } // namespace
 
 const char* last_kernel_name() { return g_last_kernel; }
@@ -527,6 +688,87 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     if (leaf_kind == LEAF_TRIANGLE) return dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream);
     return dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream);
 }
+
+
+// Bvh::intersect<IsAnyHit, IsRobust>(ray, start, stack, leaf_fn, inner_fn) for ONE ray with host callbacks; see ray_step_kernel.
+// ray8 = {org[3], dir[3], tmin, tmax} (z = 0 for a 2D BVH); `start` is the packed Index word the walk starts from.
+template <typename T>
+int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bool any, bool robust,
+                        bool (*leaf_fn)(void*, T*, size_t, size_t), void (*inner_fn)(void*, size_t), void* user)
+{
+    if (!leaf_fn) return fail(BVH_AMD_ERR_ARG, "intersect_ray: null leaf callback");
+    if (b.node_count == 0 || (b.pair_count && !b.d_pairs)) return fail(BVH_AMD_ERR_ARG, "intersect_ray: BVH has no device copy");
+    if (b.max_depth < 0) {                                    // first traversal of this layout: depth of the tree, once
+        std::lock_guard<std::mutex> lock(g_depth_mutex);
+        if (b.max_depth < 0) {
+            // the walk runs on this thread's own stream: whatever built or re-laid the tree on another stream must be done
+            BVH_HIP_TRY(hipDeviceSynchronize(), BVH_AMD_ERR_HIP);
+            int rc = tree_depth<T>(b, nullptr);
+            if (rc) return rc;
+        }
+    }
+    // SmallStack<Index, 64> of bvh_impl.h:244 for every tree it can hold, as deep as the tree needs otherwise
+    const uint32_t cap = static_cast<uint32_t>(std::max(64, b.max_depth + 2));
+    StepContext& c = t_step;
+    int rc = c.ensure(b.device, cap);
+    if (rc) return rc;
+    uint32_t* in = c.pinned;
+    uint32_t* out = in + 1 + c.stack_cap;
+    const uint32_t* events = out + kStepHeader;
+    const uint32_t* snaps = events + 3 * kStepEvents;
+    StepArgs<T> a;
+    a.pairs = b.d_pairs; a.in = in; a.out = out; a.scratch = c.scratch; a.stack_cap = c.stack_cap; a.snap_words = c.snap_words;
+    a.any = any ? 1u : 0u; a.record_pairs = inner_fn ? 1u : 0u;
+    a.max_events = kStepEvents;
+    a.max_steps = static_cast<uint32_t>(std::min<size_t>(b.pair_count + 1, 0xFFFFFFFFu));
+    if (const char* cap = getenv("BVH_AMD_STEP_EVENTS")) {    // test knob: a short log exercises the continue-from-device path
+        const long v = atol(cap);
+        if (v >= 1 && v < static_cast<long>(kStepEvents)) a.max_events = static_cast<uint32_t>(v);
+    }
+    for (int k = 0; k < 8; ++k) a.ray[k] = ray8[k];
+    T tmax = ray8[7];
+    in[0] = 1; in[1] = start;
+    for (;;) {
+        a.ray[7] = tmax;
+        if (b.dim == 2) {
+            if (robust) hipLaunchKernelGGL((ray_step_kernel<T, true, 2>), dim3(1), dim3(kWave), 0, c.stream, a);
+            else hipLaunchKernelGGL((ray_step_kernel<T, false, 2>), dim3(1), dim3(kWave), 0, c.stream, a);
+        } else {
+            if (robust) hipLaunchKernelGGL((ray_step_kernel<T, true, 3>), dim3(1), dim3(kWave), 0, c.stream, a);
+            else hipLaunchKernelGGL((ray_step_kernel<T, false, 3>), dim3(1), dim3(kWave), 0, c.stream, a);
+        }
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(c.stream), BVH_AMD_ERR_HIP);
+        if (out[2]) return fail(BVH_AMD_ERR_OVERFLOW, out[2] == 2 ? "intersect_ray: the walk visited more pairs than the tree has (cyclic tree?)"
+                                                                   : "intersect_ray: traversal stack overflow (malformed tree?)");
+        const uint32_t n_events = out[0];
+        bool restarted = false;
+        for (uint32_t e = 0; e < n_events; ++e) {
+            const uint32_t word = events[3 * e];
+            if ((word & kCountMask) == 0) { inner_fn(user, word >> kCountBits); continue; }
+            const T before = tmax;
+            const size_t begin = word >> kCountBits;
+            const bool was_hit = leaf_fn(user, &tmax, begin, begin + (word & kCountMask));     // bvh.h:152-155
+            if (any && was_hit) return BVH_AMD_OK;
+            if (std::memcmp(&before, &tmax, sizeof(T)) != 0) {          // the ray changed: what was logged after this leaf is void
+                const uint32_t off = events[3 * e + 1], len = events[3 * e + 2];
+                if (len == 0) return BVH_AMD_OK;                        // nothing was left to visit
+                in[0] = len;
+                std::memcpy(in + 1, snaps + off, len * sizeof(uint32_t));
+                restarted = true;
+                break;
+            }
+        }
+        if (restarted) continue;
+        if (out[1]) return BVH_AMD_OK;
+        in[0] = kStepContinue;                                         // log full: carry on from the stack the device kept
+    }
+}
+
+template int trace_ray_callbacks<float>(const BvhImpl<float>&, const float*, uint32_t, bool, bool, bool (*)(void*, float*, size_t, size_t),
+                                        void (*)(void*, size_t), void*);
+template int trace_ray_callbacks<double>(const BvhImpl<double>&, const double*, uint32_t, bool, bool, bool (*)(void*, double*, size_t, size_t),
+                                         void (*)(void*, size_t), void*);
 
 template int launch_traverse<float>(const BvhImpl<float>&, int, const float*, const float*, size_t, unsigned,
                                     bvh_hit3f*, bvh_amd_counters*, hipStream_t);

@@ -17,22 +17,69 @@
 #ifndef BVH_V2_BVH_AMD_HPP
 #define BVH_V2_BVH_AMD_HPP
 
+#include <algorithm>
 #include <array>
+#include <cassert>
 #include <climits>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <istream>
 #include <limits>
 #include <memory>
+#include <optional>
+#include <ostream>
 #include <span>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../bvh_amd.h"
 
 namespace bvh::v2 {
+
+// ---- stream.h: the byte-stream interface Bvh::serialize / deserialize are written against (reference stream.h:9-66) --------
+class OutputStream {
+public:
+    virtual ~OutputStream() = default;
+    template <typename T> bool write(const T& value) { return write_raw(&value, sizeof(T)); }
+protected:
+    virtual bool write_raw(const void* bytes, size_t size) = 0;
+};
+class InputStream {
+public:
+    virtual ~InputStream() = default;
+    template <typename T> T read(T&& fallback = {}) {          // a short read yields the fallback, like the reference
+        T value;
+        return read_raw(&value, sizeof(T)) == sizeof(T) ? value : std::move(fallback);
+    }
+protected:
+    virtual size_t read_raw(void* bytes, size_t size) = 0;
+};
+class StdOutputStream : public OutputStream {
+public:
+    explicit StdOutputStream(std::ostream& os) : os_(os) {}
+protected:
+    std::ostream& os_;
+    bool write_raw(const void* bytes, size_t size) override {
+        os_.write(static_cast<const char*>(bytes), static_cast<std::streamsize>(size));
+        return os_.good();
+    }
+};
+class StdInputStream : public InputStream {
+public:
+    explicit StdInputStream(std::istream& is) : is_(is) {}
+protected:
+    std::istream& is_;
+    size_t read_raw(void* bytes, size_t size) override {
+        is_.read(static_cast<char*>(bytes), static_cast<std::streamsize>(size));
+        return static_cast<size_t>(is_.gcount());
+    }
+};
 
 // ---- vec.h / bbox.h / ray.h ---------------------------------------------------------------------------------------
 template <typename T, size_t N>
@@ -47,6 +94,15 @@ struct Vec {
 template <typename T, size_t N> Vec<T, N> operator+(const Vec<T, N>& a, const Vec<T, N>& b) { Vec<T, N> r; for (size_t i = 0; i < N; ++i) r[i] = a[i] + b[i]; return r; }
 template <typename T, size_t N> Vec<T, N> operator-(const Vec<T, N>& a, const Vec<T, N>& b) { Vec<T, N> r; for (size_t i = 0; i < N; ++i) r[i] = a[i] - b[i]; return r; }
 template <typename T, size_t N> Vec<T, N> operator*(const Vec<T, N>& a, T s) { Vec<T, N> r; for (size_t i = 0; i < N; ++i) r[i] = a[i] * s; return r; }
+template <typename T, size_t N> Vec<T, N> operator-(const Vec<T, N>& a) { Vec<T, N> r; for (size_t i = 0; i < N; ++i) r[i] = -a[i]; return r; }
+template <typename T, size_t N> Vec<T, N> operator*(T s, const Vec<T, N>& a) { return a * s; }
+template <typename T, size_t N> T dot(const Vec<T, N>& a, const Vec<T, N>& b) {   // reference vec.h:98-100: ((0 + a0 b0) + a1 b1) + ...
+    T sum = T(0);
+    for (size_t i = 0; i < N; ++i) sum = sum + a[i] * b[i];
+    return sum;
+}
+template <typename T, size_t N> T length(const Vec<T, N>& v) { return std::sqrt(dot(v, v)); }
+template <typename T, size_t N> Vec<T, N> normalize(const Vec<T, N>& v) { return v * (static_cast<T>(1.) / length(v)); }
 template <typename T> Vec<T, 3> cross(const Vec<T, 3>& a, const Vec<T, 3>& b) {
     return Vec<T, 3>(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
 }
@@ -111,6 +167,16 @@ struct Node {
         return b;
     }
     void set_bbox(const BBox<T, Dim>& b) { for (size_t i = 0; i < Dim; ++i) { bounds[2 * i] = b.min[i]; bounds[2 * i + 1] = b.max[i]; } }
+    void serialize(OutputStream& out) const {                 // reference node.h:90-94: the bounds, then the packed index word
+        for (const T& b : bounds) out.write(b);
+        out.write(index.value);
+    }
+    [[nodiscard]] static Node deserialize(InputStream& in) {   // reference node.h:96-102
+        Node node;
+        for (T& b : node.bounds) b = in.template read<T>();
+        node.index = Index(in.template read<typename Index::Type>());
+        return node;
+    }
 };
 static_assert(sizeof(Node<float, 3>) == 28 && sizeof(Node<double, 3>) == 56, "layout must equal the reference's");
 static_assert(sizeof(Node<float, 2>) == 20 && sizeof(Node<double, 2>) == 40 && sizeof(BBox<float, 2>) == sizeof(bvh_bbox2f) &&
@@ -133,6 +199,23 @@ struct PrecomputedTri {
     PrecomputedTri() = default;
     PrecomputedTri(const Vec<T, 3>& a, const Vec<T, 3>& b, const Vec<T, 3>& c) : p0(a), e1(a - b), e2(c - a), n(cross(e1, e2)) {}
     PrecomputedTri(const Tri<T, 3>& t) : PrecomputedTri(t.p0, t.p1, t.p2) {}
+    Tri<T, 3> convert_to_tri() const { return Tri<T, 3>(p0, p0 - e1, e2 + p0); }
+    BBox<T, 3> get_bbox() const { return convert_to_tri().get_bbox(); }
+    Vec<T, 3> get_center() const { return convert_to_tri().get_center(); }
+    // The leaf test a host callback of Bvh::intersect runs (reference tri.h:56-74); the batch kernels carry the same
+    // sequence of operations (traverse.hip). Returns (t, u, v).
+    std::optional<std::tuple<T, T, T>> intersect(const Ray<T, 3>& ray) const {
+        const auto c = p0 - ray.org;
+        const auto r = cross(ray.dir, c);
+        const T inv_det = static_cast<T>(1.) / dot(n, ray.dir);
+        const T u = dot(r, e2) * inv_det, v = dot(r, e1) * inv_det, w = static_cast<T>(1.) - u - v;
+        const T tolerance = -std::numeric_limits<T>::epsilon();
+        if (u >= tolerance && v >= tolerance && w >= tolerance) {
+            const T t = dot(n, c) * inv_det;
+            if (t >= ray.tmin && t <= ray.tmax) return std::make_optional(std::tuple<T, T, T>{ t, u, v });
+        }
+        return std::nullopt;
+    }
 };
 template <typename T, size_t N>
 struct Sphere {
@@ -140,6 +223,22 @@ struct Sphere {
     T radius;
     Vec<T, N> get_center() const { return center; }
     BBox<T, N> get_bbox() const { return BBox<T, N>(center - Vec<T, N>(radius), center + Vec<T, N>(radius)); }
+    // reference sphere.h:32-49: the two roots clipped to [tmin, tmax]
+    template <bool AssumeNormalized = false>
+    std::optional<std::pair<T, T>> intersect(const Ray<T, N>& ray) const {
+        const auto oc = ray.org - center;
+        const T a = AssumeNormalized ? static_cast<T>(1.) : dot(ray.dir, ray.dir);
+        const T b = static_cast<T>(2.) * dot(ray.dir, oc);
+        const T c = dot(oc, oc) - radius * radius;
+        const T delta = b * b - static_cast<T>(4.) * a * c;
+        if (delta >= 0) {
+            const T inv = -static_cast<T>(0.5) / a, root = std::sqrt(delta);
+            const T x0 = (b + root) * inv, x1 = (b - root) * inv;
+            const T t0 = x0 > ray.tmin ? x0 : ray.tmin, t1 = x1 < ray.tmax ? x1 : ray.tmax;
+            if (t0 <= t1) return std::make_optional(std::make_pair(t0, t1));
+        }
+        return std::nullopt;
+    }
 };
 
 // ---- thread_pool.h / executor.h / stack.h: kept for source compatibility; the GPU grid replaces the pool ----------------
@@ -167,6 +266,14 @@ struct SmallStack {                                           // reference stack
     void push(const T& t) { elems[size++] = t; }
     T pop() { return elems[--size]; }
 };
+template <typename T>
+struct GrowingStack {                                         // reference stack.h:33-48
+    std::vector<T> elems;
+    bool is_empty() const { return elems.empty(); }
+    void push(const T& t) { elems.push_back(t); }
+    T pop() { T top = std::move(elems.back()); elems.pop_back(); return top; }
+    void clear() { elems.clear(); }
+};
 
 namespace amd {
 
@@ -192,6 +299,10 @@ template <> struct Api<float, 3> {
     static int precompute(const void* t9, const uint32_t* perm, size_t n, void* out) { return bvh_amd_precompute_tris3f(static_cast<const float*>(t9), perm, n, static_cast<float*>(out), nullptr); }
     static int trace_tri(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3f_intersect_rays_tri(h, static_cast<const float*>(prims), static_cast<const bvh_ray3f*>(rays), n, f, static_cast<bvh_hit3f*>(hits), nullptr, nullptr); }
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3f_intersect_rays_sphere(h, static_cast<const float*>(prims), static_cast<const bvh_ray3f*>(rays), n, f, static_cast<bvh_hit3f*>(hits), nullptr, nullptr); }
+    static int visit(const Handle* h, const void* ray, size_t start, unsigned f, void* user, bool (*leaf)(void*, float*, size_t, size_t), void (*inner)(void*, size_t)) {
+        const bvh_amd_ray_visitorf v{ user, leaf, inner };
+        return bvh3f_intersect_ray_visit(h, static_cast<const bvh_ray3f*>(ray), start, f, &v);
+    }
 };
 template <> struct Api<double, 3> {
     using Handle = bvh3d; using CHit = bvh_hit3d;
@@ -211,6 +322,10 @@ template <> struct Api<double, 3> {
     static int precompute(const void* t9, const uint32_t* perm, size_t n, void* out) { return bvh_amd_precompute_tris3d(static_cast<const double*>(t9), perm, n, static_cast<double*>(out), nullptr); }
     static int trace_tri(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3d_intersect_rays_tri(h, static_cast<const double*>(prims), static_cast<const bvh_ray3d*>(rays), n, f, static_cast<bvh_hit3d*>(hits), nullptr, nullptr); }
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3d_intersect_rays_sphere(h, static_cast<const double*>(prims), static_cast<const bvh_ray3d*>(rays), n, f, static_cast<bvh_hit3d*>(hits), nullptr, nullptr); }
+    static int visit(const Handle* h, const void* ray, size_t start, unsigned f, void* user, bool (*leaf)(void*, double*, size_t, size_t), void (*inner)(void*, size_t)) {
+        const bvh_amd_ray_visitord v{ user, leaf, inner };
+        return bvh3d_intersect_ray_visit(h, static_cast<const bvh_ray3d*>(ray), start, f, &v);
+    }
 };
 
 
@@ -230,6 +345,9 @@ template <> struct Api<T, 2> {                                                  
     static void refit(Handle* h) { bvh##S##_refit(h); }                                                                                   \
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh##S##_device_prim_ids(h); }                                       \
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh##S##_intersect_rays_sphere(h, static_cast<const T*>(prims), static_cast<const bvh_ray##S*>(rays), n, f, static_cast<CHit*>(hits), nullptr, nullptr); } \
+    static int visit(const Handle* h, const void* ray, size_t start, unsigned f, void* user, bool (*leaf)(void*, T*, size_t, size_t), void (*inner)(void*, size_t)) { \
+        const std::conditional_t<std::is_same_v<T, float>, bvh_amd_ray_visitorf, bvh_amd_ray_visitord> v{ user, leaf, inner };           \
+        return bvh##S##_intersect_ray_visit(h, static_cast<const bvh_ray##S*>(ray), start, f, &v); }                                      \
 };
 BVH_AMD_API_2D(float, 2f)
 BVH_AMD_API_2D(double, 2d)
@@ -281,6 +399,8 @@ struct Bvh {
     const Node& get_root() const { return nodes[0]; }
     static bool is_left_sibling(size_t id) { return id % 2 == 1; }
     static size_t get_sibling_id(size_t id) { return is_left_sibling(id) ? id + 1 : id - 1; }
+    static size_t get_left_sibling_id(size_t id) { return is_left_sibling(id) ? id : id - 1; }
+    static size_t get_right_sibling_id(size_t id) { return is_left_sibling(id) ? id + 1 : id; }
 
     // Bvh::extract_bvh (reference bvh.h:92-122) on the device
     [[nodiscard]] Bvh extract_bvh(size_t root_id) const {
@@ -293,6 +413,59 @@ struct Bvh {
 
     // Bvh::refit (reference bvh.h:211-218) on the device; `nodes` may have been edited by the caller.
     void refit() { push(); amd::Api<Scalar, Node::dimension>::refit(device_.get()); pull(); }
+    // with the reference's leaf callback (bvh.h:211-218 via traverse_bottom_up, :186-208): leaf_fn recomputes each leaf's
+    // box on the host, in the reference's order (leaves by descending node index); the inner nodes are refitted on the device
+    template <typename LeafFn>
+    void refit(LeafFn&& leaf_fn) {
+        for (size_t i = nodes.size(); i-- > 0;)
+            if (nodes[i].is_leaf()) leaf_fn(nodes[i]);
+        refit();
+    }
+
+    // Bvh::intersect (reference bvh.h:72-73, :160-182) for one ray with host callbacks: leaf_fn(begin, end) -> bool over
+    // BVH-order primitive ranges, optional inner_fn(left, right) per visited pair. The walk runs on the device
+    // (bvhXX_intersect_ray_visit); leaf_fn shortens the ray by writing ray.tmax, exactly as with the reference, which is why
+    // the ray is re-read after every leaf. The caller's stack object is not used (the device keeps the stack).
+    struct IgnoreArgs { template <typename... Args> void operator()(Args&&...) const {} };
+    template <bool IsAnyHit, bool IsRobust, typename Stack, typename LeafFn, typename InnerFn = IgnoreArgs>
+    void intersect(const Ray& ray, Index start, Stack&, LeafFn&& leaf_fn, InnerFn&& inner_fn = {}) const {
+        struct Visit {
+            const Bvh* bvh; const Ray* ray; std::remove_reference_t<LeafFn>* leaf; std::remove_reference_t<InnerFn>* inner;
+            static bool on_leaf(void* self, Scalar* t, size_t begin, size_t end) {
+                auto* v = static_cast<Visit*>(self);
+                const bool hit = static_cast<bool>((*v->leaf)(begin, end));
+                *t = v->ray->tmax;                            // the reference's traversal reads ray.tmax live (node.h:105-117)
+                return hit;
+            }
+            static void on_inner(void* self, size_t first) {
+                auto* v = static_cast<Visit*>(self);
+                (*v->inner)(v->bvh->nodes[first], v->bvh->nodes[first + 1]);
+            }
+        } visit{ this, &ray, &leaf_fn, &inner_fn };
+        const unsigned flags = (IsAnyHit ? unsigned(BVH_AMD_RAY_ANY_HIT) : 0u) | (IsRobust ? unsigned(BVH_AMD_RAY_ROBUST) : 0u);
+        constexpr bool wants_inner = !std::is_same_v<std::remove_cvref_t<InnerFn>, IgnoreArgs>;
+        amd::check(amd::Api<Scalar, Node::dimension>::visit(device(), &ray, static_cast<size_t>(start.value), flags, &visit, &Visit::on_leaf,
+                                                            wants_inner ? &Visit::on_inner : nullptr), "intersect_ray_visit");
+    }
+
+    // Bvh::serialize / deserialize (reference bvh.h:221-243): counts, nodes, primitive ids, all as IndexType; the same byte
+    // stream bvhXX_save / bvhXX_serialize of the C-ABI produce
+    template <typename IndexType = typename Index::Type>
+    void serialize(OutputStream& out) const {
+        out.write(static_cast<IndexType>(nodes.size()));
+        out.write(static_cast<IndexType>(prim_ids.size()));
+        for (const Node& node : nodes) node.serialize(out);
+        for (size_t id : prim_ids) out.write(static_cast<IndexType>(id));
+    }
+    template <typename IndexType = typename Index::Type>
+    [[nodiscard]] static Bvh deserialize(InputStream& in) {
+        Bvh bvh;
+        bvh.nodes.resize(in.template read<IndexType>());
+        bvh.prim_ids.resize(in.template read<IndexType>());
+        for (Node& node : bvh.nodes) node = Node::deserialize(in);
+        for (size_t& id : bvh.prim_ids) id = in.template read<IndexType>();
+        return bvh;
+    }
 
     // the device-resident twin (built by DefaultBuilder, or uploaded on demand)
     typename amd::Api<Scalar, Node::dimension>::Handle* device() const {

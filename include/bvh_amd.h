@@ -9,8 +9,9 @@
  *
  *  (2) additive, callback-free batch entry points (`*_device`, `*_rays_*`). The reference's
  *      per-ray `bvhXX_intersect_ray(bvh, ray, callback)` (c_api/bvh.h:277-295) takes a host function
- *      pointer per leaf and therefore cannot run on a GPU; the batch family is what a maintainer binds
- *      for the hot path (INTEGRATION.md shows the binding). Buffers named d_* are DEVICE pointers
+ *      pointer per leaf: it is served (the walk runs on the device, the leaves come back to the host
+ *      callback in the reference's order), but it costs kernel launches per ray; the batch family is what
+ *      a maintainer binds for the hot path (INTEGRATION.md shows the binding). Buffers named d_* are DEVICE pointers
  *      (HBM of the current HIP device); all others are host pointers. `stream` is a hipStream_t
  *      passed as void* (NULL = the default stream); batch calls are asynchronous on it.
  *
@@ -68,6 +69,30 @@ struct bvh_bbox3f { struct bvh_vec3f min, max; };
 struct bvh_bbox3d { struct bvh_vec3d min, max; };
 struct bvh_ray3f { struct bvh_vec3f org, dir; float tmin, tmax; };
 struct bvh_ray3d { struct bvh_vec3d org, dir; double tmin, tmax; };
+
+/* c_api/bvh.h:75-83: leaf callback of the per-ray entry points. user_fn(user_data, &tmax, begin, end) intersects the
+ * primitives [begin, end) (BVH order), returns true on a hit and may shorten the ray through the pointer. */
+struct bvh_intersect_callbackf {
+    void* user_data;
+    bool (*user_fn)(void*, float*, size_t begin, size_t end);
+};
+struct bvh_intersect_callbackd {
+    void* user_data;
+    bool (*user_fn)(void*, double*, size_t begin, size_t end);
+};
+
+/* Additive: the same with the reference's optional InnerFn (bvh.h:72-73): inner_fn(user_data, first_child_id) is called for
+ * every visited pair of siblings (nodes first_child_id and first_child_id + 1) before its boxes are tested; may be NULL. */
+struct bvh_amd_ray_visitorf {
+    void* user_data;
+    bool (*leaf_fn)(void*, float*, size_t begin, size_t end);
+    void (*inner_fn)(void*, size_t first_child_id);
+};
+struct bvh_amd_ray_visitord {
+    void* user_data;
+    bool (*leaf_fn)(void*, double*, size_t begin, size_t end);
+    void (*inner_fn)(void*, size_t first_child_id);
+};
 
 /* ---- additive types --------------------------------------------------------------------------- */
 
@@ -275,6 +300,28 @@ BVH_AMD_API const char* bvh_amd_last_kernel_name(void);
 BVH_AMD_API void bvh_amd_reinsertion_stats(unsigned out[2]);
 
 
+/* ---- one ray, leaves intersected by a HOST callback (c_api/bvh.h:277-295; bvh_impl.h:235-250) --------------------------------
+ * Bvh::intersect<IsAnyHit, IsRobust>(ray, root, SmallStack<Index, 64>, leaf_fn): the walk runs on the device and logs the
+ * leaves it reaches; the callback is invoked on the calling thread, in the reference's order, with &ray.tmax. Whenever
+ * the callback changes tmax the walk restarts from that leaf with the shortened ray, so culling is the reference's.
+ * Re-entrant (per-thread stream and buffers). Cost: one or more kernel launches per ray; use the *_intersect_rays_* family for
+ * throughput. These return void like the reference's; a device failure aborts with a message instead of reporting "no hit". */
+BVH_AMD_API void bvh3f_intersect_ray(const struct bvh3f*, const struct bvh_ray3f*, const struct bvh_intersect_callbackf*);
+BVH_AMD_API void bvh3d_intersect_ray(const struct bvh3d*, const struct bvh_ray3d*, const struct bvh_intersect_callbackd*);
+BVH_AMD_API void bvh3f_intersect_ray_any(const struct bvh3f*, const struct bvh_ray3f*, const struct bvh_intersect_callbackf*);
+BVH_AMD_API void bvh3d_intersect_ray_any(const struct bvh3d*, const struct bvh_ray3d*, const struct bvh_intersect_callbackd*);
+BVH_AMD_API void bvh3f_intersect_ray_robust(const struct bvh3f*, const struct bvh_ray3f*, const struct bvh_intersect_callbackf*);
+BVH_AMD_API void bvh3d_intersect_ray_robust(const struct bvh3d*, const struct bvh_ray3d*, const struct bvh_intersect_callbackd*);
+BVH_AMD_API void bvh3f_intersect_ray_any_robust(const struct bvh3f*, const struct bvh_ray3f*, const struct bvh_intersect_callbackf*);
+BVH_AMD_API void bvh3d_intersect_ray_any_robust(const struct bvh3d*, const struct bvh_ray3d*, const struct bvh_intersect_callbackd*);
+/* Additive: start at any node (`start_index` = the packed index word of Bvh::intersect's `start`, i.e. first_id << 4 |
+ * prim_count; BVH_AMD_START_AT_ROOT = the root's), optional inner callback, error code instead of abort. */
+#define BVH_AMD_START_AT_ROOT SIZE_MAX
+BVH_AMD_API int bvh3f_intersect_ray_visit(const struct bvh3f*, const struct bvh_ray3f*, size_t start_index, unsigned flags,
+    const struct bvh_amd_ray_visitorf*);
+BVH_AMD_API int bvh3d_intersect_ray_visit(const struct bvh3d*, const struct bvh_ray3d*, size_t start_index, unsigned flags,
+    const struct bvh_amd_ray_visitord*);
+
 /* ---- the 2D families `2f` / `2d` (c_api/bvh.cpp:7-10: Bvh<Node<T, 2>>) ---------------------------------------------------
  * Same contracts as the 3D functions above with bvh_bbox2X / bvh_vec2X / bvh_ray2X and 20/40-byte nodes
  * ({minx,maxx,miny,maxy}, index). Builders: serial DefaultBuilder (Low = binned SAH, Medium = sweep SAH, High = sweep +
@@ -354,6 +401,20 @@ BVH_AMD_API int bvh_amd_sphere_bounds2d(const double* d_circles3, size_t n, doub
 /* d_circles3 in BVH order; hit = {prim, t0, t1, 0} like the 3D sphere traversal */
 BVH_AMD_API int bvh2d_intersect_rays_sphere(const struct bvh2d* bvh, const double* d_circles3, const struct bvh_ray2d* d_rays,
     size_t n, unsigned flags, struct bvh_hit3d* d_hits, struct bvh_amd_counters* d_counters, void* stream);
+
+/* c_api/bvh.h:277-295, 2D */
+BVH_AMD_API void bvh2f_intersect_ray(const struct bvh2f*, const struct bvh_ray2f*, const struct bvh_intersect_callbackf*);
+BVH_AMD_API void bvh2d_intersect_ray(const struct bvh2d*, const struct bvh_ray2d*, const struct bvh_intersect_callbackd*);
+BVH_AMD_API void bvh2f_intersect_ray_any(const struct bvh2f*, const struct bvh_ray2f*, const struct bvh_intersect_callbackf*);
+BVH_AMD_API void bvh2d_intersect_ray_any(const struct bvh2d*, const struct bvh_ray2d*, const struct bvh_intersect_callbackd*);
+BVH_AMD_API void bvh2f_intersect_ray_robust(const struct bvh2f*, const struct bvh_ray2f*, const struct bvh_intersect_callbackf*);
+BVH_AMD_API void bvh2d_intersect_ray_robust(const struct bvh2d*, const struct bvh_ray2d*, const struct bvh_intersect_callbackd*);
+BVH_AMD_API void bvh2f_intersect_ray_any_robust(const struct bvh2f*, const struct bvh_ray2f*, const struct bvh_intersect_callbackf*);
+BVH_AMD_API void bvh2d_intersect_ray_any_robust(const struct bvh2d*, const struct bvh_ray2d*, const struct bvh_intersect_callbackd*);
+BVH_AMD_API int bvh2f_intersect_ray_visit(const struct bvh2f*, const struct bvh_ray2f*, size_t start_index, unsigned flags,
+    const struct bvh_amd_ray_visitorf*);
+BVH_AMD_API int bvh2d_intersect_ray_visit(const struct bvh2d*, const struct bvh_ray2d*, size_t start_index, unsigned flags,
+    const struct bvh_amd_ray_visitord*);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ def _compile(out, src=SRC):
 
 def test_cpp_mirror_compiles_with_gxx(tmp_path):
     _compile(str(tmp_path / "circles_2d_amd"), os.path.join(ROOT, "tests", "cpp", "circles_2d_amd.cpp"))     # Node<T, 2>
+    _compile(str(tmp_path / "serialize_amd"), os.path.join(ROOT, "tests", "cpp", "serialize_amd.cpp"))       # streams
     exe = _compile(str(tmp_path / "simple_example_amd"))
     import torch
     if not torch.cuda.is_available():                         # no GPU: the program must fail loudly, not fall back
@@ -38,6 +39,24 @@ def test_cpp_simple_example_known_answer(tmp_path):
     out = r.stdout
     assert "primitive: 1" in out and "distance: 1" in out and "barycentric coords.: -0, 0.5" in out
     assert "nodes: 1, prim_ids: 1 0" in out                   # serial-High stream of test/serialize.cpp: ids [1, 0]
+
+
+@pytest.mark.gpu
+def test_cpp_serialize_round_trip(tmp_path, orc):
+    """test/serialize.cpp's flow through the mirror; the file it writes is the reference's stream for the same build."""
+    import numpy as np
+    exe = _compile(str(tmp_path / "serialize_amd"), os.path.join(ROOT, "tests", "cpp", "serialize_amd.cpp"))
+    path = str(tmp_path / "bvh.bin")
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "The deserialized BVH is the same as the original one" in r.stdout
+    tris = []
+    for i in range(40):
+        x = float(i)
+        tris.append([x + 1, -1, 1, x + 1, 1, 1, x, 1, 1])
+        tris.append([x + 1, -1, 1, x, -1, 1, x, 1, 1])
+    bb, cc = orc.prep_tris(np.array(tris, dtype=np.float32))
+    assert open(path, "rb").read() == orc.build(bb, cc, quality=2).serialize()
 
 
 @pytest.mark.gpu
