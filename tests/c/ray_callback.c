@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <tgmath.h>
+#include <time.h>
+
+static double now_s(void) { struct timespec ts; timespec_get(&ts, TIME_UTC); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 #define FAMILY3(T, S, CB, EPS)                                                                                       \
     struct user##S { struct bvh##S* bvh; const T* prims; struct bvh_ray##S ray; int64_t prim; uint64_t calls; };      \
@@ -64,6 +67,7 @@
         if (!bvh) return 1;                                                                                          \
         struct user##S u = { .bvh = bvh, .prims = prims };                                                            \
         const struct CB callback = { .user_data = &u, .user_fn = leaf##S };                                           \
+        const double t_begin = now_s();                                                                              \
         for (size_t j = 0; j < m; ++j) {                                                                             \
             const T* r = rays + 8 * j;                                                                               \
             u.ray = (struct bvh_ray##S) { { r[0], r[1], r[2] }, { r[3], r[4], r[5] }, r[6], r[7] };                   \
@@ -74,7 +78,8 @@
             fwrite(&u.prim, sizeof u.prim, 1, out); fwrite(&t, sizeof t, 1, out);                                     \
         }                                                                                                            \
         fwrite(&u.calls, sizeof u.calls, 1, out);                                                                    \
-        printf("%zu nodes, %" PRIu64 " leaf callbacks\n", bvh##S##_get_node_count(bvh), u.calls);                     \
+        printf("%zu nodes, %zu rays, %" PRIu64 " leaf callbacks, %.1f us per ray\n", bvh##S##_get_node_count(bvh), m, u.calls,       \
+               1e6 * (now_s() - t_begin) / (double)(m ? m : 1));                     \
         bvh##S##_destroy(bvh); free(bb); free(cc);                                                                    \
         return 0;                                                                                                    \
     }
@@ -115,6 +120,7 @@
         if (!bvh) return 1;                                                                                          \
         struct user##S u = { .bvh = bvh, .prims = prims };                                                            \
         const struct CB callback = { .user_data = &u, .user_fn = leaf##S };                                           \
+        const double t_begin = now_s();                                                                              \
         for (size_t j = 0; j < m; ++j) {                                                                             \
             const T* r = rays + 6 * j;                                                                               \
             u.ray = (struct bvh_ray##S) { { r[0], r[1] }, { r[2], r[3] }, r[4], r[5] };                               \
@@ -125,7 +131,8 @@
             fwrite(&u.prim, sizeof u.prim, 1, out); fwrite(&t, sizeof t, 1, out);                                     \
         }                                                                                                            \
         fwrite(&u.calls, sizeof u.calls, 1, out);                                                                    \
-        printf("%zu nodes, %" PRIu64 " leaf callbacks\n", bvh##S##_get_node_count(bvh), u.calls);                     \
+        printf("%zu nodes, %zu rays, %" PRIu64 " leaf callbacks, %.1f us per ray\n", bvh##S##_get_node_count(bvh), m, u.calls,       \
+               1e6 * (now_s() - t_begin) / (double)(m ? m : 1));                     \
         bvh##S##_destroy(bvh); free(bb); free(cc);                                                                    \
         return 0;                                                                                                    \
     }

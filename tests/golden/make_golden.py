@@ -145,5 +145,19 @@ def main():
           ka["cornell_render_counters_high"])
 
 
+def c_api_symbol_list():
+    """The 94 function names the reference's C header declares (src/bvh/v2/c_api/bvh.h) -> tests/golden/c_api_symbols.txt:
+    the drop-in library must export every one of them."""
+    import re
+    header = open("/root/reference/src/bvh/v2/c_api/bvh.h").read()
+    names = sorted(set(re.findall(r"BVH_API[^;]*?\b(bvh\w+)\s*\(", header)))
+    assert len(names) == 94
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_api_symbols.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+
+
 if __name__ == "__main__":
-    main()
+    if "--symbols" in sys.argv:
+        c_api_symbol_list()
+    else:
+        main()

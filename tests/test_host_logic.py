@@ -25,6 +25,20 @@ def test_library_exports_every_declared_symbol():
     assert dll.bvh_amd_version().startswith(b"bvh_amd")
 
 
+def test_every_function_of_the_reference_c_header_is_exported():
+    """tests/golden/c_api_symbols.txt = the 94 names of src/bvh/v2/c_api/bvh.h (make_golden.py --symbols)."""
+    from bvh_amd import _lib, build
+    build.build()
+    dll = _lib.load()
+    names = open(os.path.join(ROOT, "tests", "golden", "c_api_symbols.txt")).read().split()
+    assert len(names) == 94
+    header = open(os.path.join(ROOT, "include", "bvh_amd.h")).read()
+    for name in names:
+        assert hasattr(dll, name), f"{name}: in the reference's C API, not exported by libbvh_amd.so"
+        assert re.search(r"\b" + name + r"\s*\(", header), f"{name}: not declared in include/bvh_amd.h"
+    assert os.path.exists(os.path.join(ROOT, "include", "bvh", "v2", "c_api", "bvh.h"))
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
