@@ -78,6 +78,7 @@ _SIGS_T = {
     "bvh{S}_extract": (_P, [_P, _Z]),
     "bvh{S}_destroy": (None, [_P]),
     "bvh{S}_optimize": (None, [_P, _P]),
+    "bvh{S}_optimize_config": (_I, [_P, _P]),
     "bvh{S}_refit": (None, [_P]),
     "bvh{S}_sync_device": (_I, [_P]),
     "bvh{S}_append_node": (None, [_P]),
@@ -111,6 +112,10 @@ _SIGS_T = {
     "bvh{S}_intersect_ray_any_robust": (None, [_P, _P, _P]),
     "bvh{S}_intersect_ray_visit": (_I, [_P, _P, _Z, _U, _P]),
 }
+
+
+class OptimizeConfig(C.Structure):            # struct bvh_amd_optimize_config
+    _fields_ = [("batch_size_ratio", C.c_double), ("max_iter_count", C.c_size_t)]
 
 
 def ray_visitor_types(suffix: str):

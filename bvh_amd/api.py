@@ -149,9 +149,15 @@ class Bvh:
         t._bvh_keepalive = self
         return t
 
-    def optimize(self, thread_pool=None):
-        """ReinsertionOptimizer::optimize (reinsertion_optimizer.h:27-35), in place on the device."""
+    def optimize(self, thread_pool=None, batch_size_ratio=None, max_iter_count=None):
+        """ReinsertionOptimizer::optimize (reinsertion_optimizer.h:27-35), in place on the device; the two keyword arguments are
+        its Config (:18-24, defaults 0.05 and 3)."""
         _torch()
+        if batch_size_ratio is not None or max_iter_count is not None:
+            cfg = _lib.OptimizeConfig(0.05 if batch_size_ratio is None else float(batch_size_ratio),
+                                      3 if max_iter_count is None else int(max_iter_count))
+            _lib.check(self._f("bvh{S}_optimize_config")(self._h, C.byref(cfg)), "optimize")
+            return
         _lib.load().bvh_amd_last_error()
         before = self._lib.bvh_amd_last_error()
         self._f("bvh{S}_optimize")(None, self._h)

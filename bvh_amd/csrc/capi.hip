@@ -8,6 +8,8 @@
 namespace bvh_amd {
 
 template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim);
+template <typename T>
+int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim, double batch_size_ratio, size_t iterations);
 void reinsertion_stats(unsigned out[2]);
 template <typename T>
 int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T ratio,
@@ -230,6 +232,13 @@ template <typename T> BvhImpl<T>* extract(BvhImpl<T>* pb, size_t root_id) {
 template <typename T> int optimize(BvhImpl<T>* b) {
     const int dim = b ? b->dim : 3;
     return on_resident_nodes<T>(b, [dim](HostNode<T>* d, size_t n) { return reinsertion_optimize_device<T>(d, n, nullptr, dim); });
+}
+template <typename T> int optimize_config(BvhImpl<T>* b, const bvh_amd_optimize_config* config) {
+    const int dim = b ? b->dim : 3;
+    const bvh_amd_optimize_config c = config ? *config : bvh_amd_optimize_config{0.05, 3};
+    return on_resident_nodes<T>(b, [dim, c](HostNode<T>* d, size_t n) {
+        return reinsertion_optimize_config_device<T>(d, n, nullptr, dim, c.batch_size_ratio, c.max_iter_count);
+    });
 }
 template <typename T> int refit(BvhImpl<T>* b) {
     return on_resident_nodes<T>(b, [](HostNode<T>* d, size_t n) { return refit_device<T>(d, n, nullptr); });
@@ -483,6 +492,7 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
         return from_nodes<T>(nodes, nn, ids, np); }                                                                 \
     void bvh##S##_destroy(bvh##S* b) { delete impl<T>(b); }                                                         \
     void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(impl<T>(b)); }                         \
+    int bvh##S##_optimize_config(bvh##S* b, const bvh_amd_optimize_config* c) { return optimize_config<T>(impl<T>(b), c); } \
     void bvh##S##_refit(bvh##S* b) { (void)refit<T>(impl<T>(b)); }                                                  \
     int bvh##S##_sync_device(bvh##S* b) { return sync_device<T>(impl<T>(b)); }                                       \
     void bvh##S##_append_node(bvh##S* b) {                                                                          \
@@ -569,6 +579,7 @@ BVH_AMD_IMPL_RAY(double, 3d, bvh_intersect_callbackd, bvh_amd_ray_visitord, 3, i
         return from_nodes2<T>(nodes, nn, ids, np); }                                                                \
     void bvh##S##_destroy(bvh##S* b) { delete impl2<T>(b); }                                                        \
     void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(impl2<T>(b)); }                        \
+    int bvh##S##_optimize_config(bvh##S* b, const bvh_amd_optimize_config* c) { return optimize_config<T>(impl2<T>(b), c); } \
     void bvh##S##_refit(bvh##S* b) { (void)refit<T>(impl2<T>(b)); }                                                 \
     int bvh##S##_sync_device(bvh##S* b) { return sync_device<T>(impl2<T>(b)); }                                      \
     void bvh##S##_append_node(bvh##S* b) {                                                                          \

@@ -962,13 +962,17 @@ void reinsertion_stats(unsigned out[2]) { out[0] = g_fast_iterations.load(); out
 
 // ReinsertionOptimizer::optimize on device-resident nodes (reference layout), in place.
 template <typename T>
-int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim) {
+int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim, double batch_size_ratio,
+                                        size_t iterations) {
     using U = typename Ord<T>::U;
     const uint32_t n = static_cast<uint32_t>(node_count);
-    if (n < 2) return BVH_AMD_OK;
-    const T ratio = static_cast<T>(0.05);                     // Config (:19-25)
-    const size_t iterations = 3;
-    const uint32_t batch = static_cast<uint32_t>(std::max<size_t>(1, static_cast<size_t>(static_cast<T>(node_count) * ratio)));   // :238-239
+    if (n < 2 || iterations == 0) return BVH_AMD_OK;
+    if (!(batch_size_ratio >= 0.0)) return fail(BVH_AMD_ERR_ARG, "optimize: batch_size_ratio must be >= 0");
+    const T ratio = static_cast<T>(batch_size_ratio);         // Config (:19-25)
+    if (static_cast<double>(static_cast<T>(node_count) * ratio) >= 1.8e19)        // the reference casts this product to size_t (:238-239)
+        return fail(BVH_AMD_ERR_ARG, "optimize: batch_size_ratio * node count does not fit size_t");
+    // :238-239; anything beyond the node count selects every node but the root (find_candidates, :91)
+    const uint32_t batch = static_cast<uint32_t>(std::min<size_t>(n, std::max<size_t>(1, static_cast<size_t>(static_cast<T>(node_count) * ratio))));
     const uint32_t head = std::min<uint32_t>(n, batch + 1), k = head - 1;
     if (k == 0) return BVH_AMD_OK;
     const char* mode = std::getenv("BVH_AMD_REINSERT");
@@ -1016,7 +1020,12 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
         return BVH_AMD_OK;
     };
     bool parents_valid = false;
-    for (size_t it = 0; it < iterations; ++it) {
+    uint64_t gid_base = 0;                                    // k_apply numbers its tie groups gid_base + 1 .. gid_base + k at most
+    for (size_t it = 0; it < iterations; ++it, gid_base += uint64_t{k} + 1) {
+        if (!always_exact && gid_base + k + 1 > 0xFFFFFFFFull) {      // many iterations: start the group numbers over
+            BVH_HIP_TRY(hipMemsetAsync(group_mark.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
+            gid_base = 0;
+        }
         bool exact = always_exact;
         for (;;) {                                            // at most two rounds: fast, then (if the layout matters) exact
             hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, parents_valid ? 0 : 1, dim);
@@ -1072,7 +1081,7 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
                 }
                 if (rc) return rc;
                 hipLaunchKernelGGL(k_apply<T>, dim3(1), dim3(1), 0, stream, d_nodes, parent.p, touched.p, kept.p, order.p, neg_gain.p, m,
-                                   exact ? 0 : 1, group_mark.p, static_cast<uint32_t>(it) * (k + 1), scalars.p);
+                                   exact ? 0 : 1, group_mark.p, static_cast<uint32_t>(gid_base), scalars.p);
                 BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
                 if (!exact) {
                     if ((rc = read_scalars(hs))) return rc;
@@ -1098,7 +1107,15 @@ int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStre
     return BVH_AMD_OK;
 }
 
+// ReinsertionOptimizer::optimize with its default Config {0.05, 3}
+template <typename T>
+int reinsertion_optimize_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim) {
+    return reinsertion_optimize_config_device<T>(d_nodes, node_count, stream, dim, 0.05, 3);
+}
+
 template int reinsertion_optimize_device<float>(HostNode<float>*, size_t, hipStream_t, int);
 template int reinsertion_optimize_device<double>(HostNode<double>*, size_t, hipStream_t, int);
+template int reinsertion_optimize_config_device<float>(HostNode<float>*, size_t, hipStream_t, int, double, size_t);
+template int reinsertion_optimize_config_device<double>(HostNode<double>*, size_t, hipStream_t, int, double, size_t);
 
 } // namespace bvh_amd

@@ -294,6 +294,7 @@ template <> struct Api<float, 3> {
     static void copy_prim_ids(const Handle* h, size_t* out) { bvh3f_copy_prim_ids(h, out); }
     static Handle* extract(Handle* h, size_t root_id) { return bvh3f_extract(h, root_id); }
     static void optimize(Handle* h) { bvh3f_optimize(nullptr, h); }
+    static int optimize_config(Handle* h, const bvh_amd_optimize_config* c) { return bvh3f_optimize_config(h, c); }
     static void refit(Handle* h) { bvh3f_refit(h); }
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh3f_device_prim_ids(h); }
     static int precompute(const void* t9, const uint32_t* perm, size_t n, void* out) { return bvh_amd_precompute_tris3f(static_cast<const float*>(t9), perm, n, static_cast<float*>(out), nullptr); }
@@ -317,6 +318,7 @@ template <> struct Api<double, 3> {
     static void copy_prim_ids(const Handle* h, size_t* out) { bvh3d_copy_prim_ids(h, out); }
     static Handle* extract(Handle* h, size_t root_id) { return bvh3d_extract(h, root_id); }
     static void optimize(Handle* h) { bvh3d_optimize(nullptr, h); }
+    static int optimize_config(Handle* h, const bvh_amd_optimize_config* c) { return bvh3d_optimize_config(h, c); }
     static void refit(Handle* h) { bvh3d_refit(h); }
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh3d_device_prim_ids(h); }
     static int precompute(const void* t9, const uint32_t* perm, size_t n, void* out) { return bvh_amd_precompute_tris3d(static_cast<const double*>(t9), perm, n, static_cast<double*>(out), nullptr); }
@@ -342,6 +344,7 @@ template <> struct Api<T, 2> {                                                  
     static void copy_prim_ids(const Handle* h, size_t* out) { bvh##S##_copy_prim_ids(h, out); }                                           \
     static Handle* extract(Handle* h, size_t root_id) { return bvh##S##_extract(h, root_id); }                                            \
     static void optimize(Handle* h) { bvh##S##_optimize(nullptr, h); }                                                                    \
+    static int optimize_config(Handle* h, const bvh_amd_optimize_config* c) { return bvh##S##_optimize_config(h, c); }                    \
     static void refit(Handle* h) { bvh##S##_refit(h); }                                                                                   \
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh##S##_device_prim_ids(h); }                                       \
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh##S##_intersect_rays_sphere(h, static_cast<const T*>(prims), static_cast<const bvh_ray##S*>(rays), n, f, static_cast<CHit*>(hits), nullptr, nullptr); } \
@@ -619,11 +622,17 @@ public:
 // ---- reinsertion_optimizer.h ------------------------------------------------------------------------------------------------
 template <typename Node>
 class ReinsertionOptimizer {
+    using Scalar = typename Node::Scalar;
 public:
-    static void optimize(ThreadPool&, Bvh<Node>& bvh) { optimize(bvh); }
-    static void optimize(Bvh<Node>& bvh) {
+    struct Config {                                           // reference reinsertion_optimizer.h:18-24
+        Scalar batch_size_ratio = static_cast<Scalar>(0.05);  // fraction of the nodes re-inserted per iteration
+        size_t max_iter_count = 3;
+    };
+    static void optimize(ThreadPool&, Bvh<Node>& bvh, const Config& config = {}) { optimize(bvh, config); }
+    static void optimize(Bvh<Node>& bvh, const Config& config = {}) {
         bvh.push();
-        amd::Api<typename Node::Scalar, Node::dimension>::optimize(bvh.device_.get());
+        const bvh_amd_optimize_config c{ static_cast<double>(config.batch_size_ratio), config.max_iter_count };
+        amd::check(amd::Api<Scalar, Node::dimension>::optimize_config(bvh.device_.get(), &c), "optimize");
         bvh.pull();
     }
 };

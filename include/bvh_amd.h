@@ -187,6 +187,14 @@ BVH_AMD_API void bvh3d_destroy(struct bvh3d*);                                  
  * On failure the BVH is left unchanged and bvh_amd_last_error() is set. */
 BVH_AMD_API void bvh3f_optimize(struct bvh_thread_pool*, struct bvh3f*);
 BVH_AMD_API void bvh3d_optimize(struct bvh_thread_pool*, struct bvh3d*);
+/* Additive: ReinsertionOptimizer::Config (src/bvh/v2/reinsertion_optimizer.h:18-24), which the reference's C API does not
+ * expose; NULL = its defaults {0.05, 3}. Returns an error code (the void functions above only set bvh_amd_last_error). */
+struct bvh_amd_optimize_config {
+    double batch_size_ratio;                   /* fraction of the nodes re-inserted per iteration, default 0.05 */
+    size_t max_iter_count;                     /* default 3 */
+};
+BVH_AMD_API int bvh3f_optimize_config(struct bvh3f*, const struct bvh_amd_optimize_config*);
+BVH_AMD_API int bvh3d_optimize_config(struct bvh3d*, const struct bvh_amd_optimize_config*);
 
 /* ---- refit and node editing (c_api/bvh.h:170-229). The setters, append and remove act on the host mirror exactly
  * like the reference (node pointers alias the mirror and are invalidated by append). `bvhXX_refit` pushes the mirror
@@ -338,6 +346,7 @@ BVH_AMD_API struct bvh2f* bvh2f_from_nodes(const void* nodes, size_t node_count,
 BVH_AMD_API struct bvh2f* bvh2f_extract(struct bvh2f* bvh, size_t root_id);
 BVH_AMD_API void bvh2f_destroy(struct bvh2f*);
 BVH_AMD_API void bvh2f_optimize(struct bvh_thread_pool*, struct bvh2f*);
+BVH_AMD_API int bvh2f_optimize_config(struct bvh2f*, const struct bvh_amd_optimize_config*);
 BVH_AMD_API void bvh2f_refit(struct bvh2f*);
 BVH_AMD_API int bvh2f_sync_device(struct bvh2f*);
 BVH_AMD_API void bvh2f_append_node(struct bvh2f*);
@@ -374,6 +383,7 @@ BVH_AMD_API struct bvh2d* bvh2d_from_nodes(const void* nodes, size_t node_count,
 BVH_AMD_API struct bvh2d* bvh2d_extract(struct bvh2d* bvh, size_t root_id);
 BVH_AMD_API void bvh2d_destroy(struct bvh2d*);
 BVH_AMD_API void bvh2d_optimize(struct bvh_thread_pool*, struct bvh2d*);
+BVH_AMD_API int bvh2d_optimize_config(struct bvh2d*, const struct bvh_amd_optimize_config*);
 BVH_AMD_API void bvh2d_refit(struct bvh2d*);
 BVH_AMD_API int bvh2d_sync_device(struct bvh2d*);
 BVH_AMD_API void bvh2d_append_node(struct bvh2d*);

@@ -78,9 +78,13 @@ class CpuBvh:
         """Bvh::extract_bvh(root_id) (bvh.h:92-122)."""
         return CpuBvh(self.lib, self.lib._fn("extract", self.s)(self.h, root_id), self.s)
 
-    def optimize(self, threads: int = -1):
-        """ReinsertionOptimizer::optimize; threads < 0 = SequentialExecutor overload."""
-        self.lib._fn("optimize", self.s)(self.h, threads)
+    def optimize(self, threads: int = -1, batch_size_ratio=None, max_iter_count=None):
+        """ReinsertionOptimizer::optimize; threads < 0 = SequentialExecutor overload; Config (reinsertion_optimizer.h:18-24)."""
+        if batch_size_ratio is None and max_iter_count is None:
+            self.lib._fn("optimize", self.s)(self.h, threads)
+        else:
+            self.lib._fn("optimize_config", self.s)(self.h, threads, 0.05 if batch_size_ratio is None else float(batch_size_ratio),
+                                                    3 if max_iter_count is None else int(max_iter_count))
 
     def refit(self):
         self.lib._fn("refit", self.s)(self.h)
@@ -112,6 +116,7 @@ class CpuLib:
     _SIG = {
         "build": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                C.c_size_t, C.c_int]),
+        "optimize_config": (None, [C.c_void_p, C.c_int, C.c_double, C.c_size_t]),
         "build_minitree": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_double, C.c_size_t, C.c_int, C.c_size_t]),
         "destroy": (None, [C.c_void_p]),
         "node_count": (C.c_size_t, [C.c_void_p]),

@@ -611,6 +611,8 @@ struct Reinserter {
 
 template <typename T>
 void optimize_tree(Tree<T>& t) { Reinserter<T>(t).run(); }
+template <typename T>
+void optimize_tree(Tree<T>& t, double batch_ratio, size_t iterations) { Reinserter<T>(t).run(static_cast<T>(batch_ratio), iterations); }
 
 // ---------------------------------------------------------------------------------------------
 // DefaultBuilder dispatch (default_builder.h:33-73)
@@ -949,6 +951,8 @@ extern "C" {
     ORC_EXPORT size_t orc_serialize##S(const void* h, uint8_t* out, size_t cap) {                       \
         return serialize_tree<T>(*static_cast<const Tree<T>*>(h), out, cap); }                          \
     ORC_EXPORT void orc_optimize##S(void* h, int /*threads*/) { optimize_tree<T>(*static_cast<Tree<T>*>(h)); } \
+    ORC_EXPORT void orc_optimize_config##S(void* h, int /*threads*/, double ratio, size_t iterations) {  \
+        optimize_tree<T>(*static_cast<Tree<T>*>(h), ratio, iterations); }                                  \
     ORC_EXPORT void* orc_extract##S(const void* h, size_t root) {                                        \
         return new Tree<T>(extract_subtree<T>(*static_cast<const Tree<T>*>(h), root)); }                 \
     ORC_EXPORT void orc_refit##S(void* h) { refit_tree<T>(*static_cast<Tree<T>*>(h)); }                 \
@@ -1052,6 +1056,8 @@ extern "C" {
     ORC_EXPORT size_t orc_serialize##S(const void* h, uint8_t* out, size_t cap) {                       \
         return serialize2<T>(*static_cast<const Tree<T>*>(h), out, cap); }                              \
     ORC_EXPORT void orc_optimize##S(void* h, int /*threads*/) { DimScope dim(2); optimize_tree<T>(*static_cast<Tree<T>*>(h)); } \
+    ORC_EXPORT void orc_optimize_config##S(void* h, int /*threads*/, double ratio, size_t iterations) {  \
+        DimScope dim(2); optimize_tree<T>(*static_cast<Tree<T>*>(h), ratio, iterations); }                 \
     ORC_EXPORT void* orc_extract##S(const void* h, size_t root) {                                        \
         DimScope dim(2); return new Tree<T>(extract_subtree<T>(*static_cast<const Tree<T>*>(h), root)); } \
     ORC_EXPORT void orc_refit##S(void* h) { DimScope dim(2); refit_tree<T>(*static_cast<Tree<T>*>(h)); } \

@@ -135,6 +135,19 @@ void optimize(BvhN<T, D>* b, int threads) {
     }
 }
 
+template <typename T, size_t D>
+void optimize_config(BvhN<T, D>* b, int threads, double ratio, size_t iterations) {
+    typename ReinsertionOptimizer<Node<T, D>>::Config config;
+    config.batch_size_ratio = static_cast<T>(ratio);
+    config.max_iter_count = iterations;
+    if (threads < 0) {
+        ReinsertionOptimizer<Node<T, D>>::optimize(*b, config);
+    } else {
+        ThreadPool pool(static_cast<size_t>(threads));
+        ReinsertionOptimizer<Node<T, D>>::optimize(pool, *b, config);
+    }
+}
+
 template <typename T>
 void prep_tris(const T* t9, size_t n, T* bboxes, T* centers) {
     for (size_t i = 0; i < n; ++i) {
@@ -304,6 +317,8 @@ extern "C" {
     ORC_EXPORT size_t ref_serialize##S(const void* h, uint8_t* out, size_t cap) {                       \
         return serialize<T, D>(static_cast<const BvhN<T, D>*>(h), out, cap); }                          \
     ORC_EXPORT void ref_optimize##S(void* h, int threads) { optimize<T, D>(static_cast<BvhN<T, D>*>(h), threads); } \
+    ORC_EXPORT void ref_optimize_config##S(void* h, int threads, double ratio, size_t iterations) {       \
+        optimize_config<T, D>(static_cast<BvhN<T, D>*>(h), threads, ratio, iterations); }                  \
     ORC_EXPORT void* ref_extract##S(const void* h, size_t root) {                                       \
         return new BvhN<T, D>(static_cast<const BvhN<T, D>*>(h)->extract_bvh(root)); }                  \
     ORC_EXPORT void ref_refit##S(void* h) { static_cast<BvhN<T, D>*>(h)->refit(); }                     \

@@ -59,7 +59,10 @@ int main() {
     typename bvh::v2::MiniTreeBuilder<Node>::Config mini;
     mini.parallel_threshold = 1;
     auto by_hand = bvh::v2::MiniTreeBuilder<Node>::build(thread_pool, bboxes, centers, mini);
-    bvh::v2::ReinsertionOptimizer<Node>::optimize(thread_pool, by_hand);
+    typename bvh::v2::ReinsertionOptimizer<Node>::Config reinsertion;       // reinsertion_optimizer.h:18-24, the defaults spelled out
+    reinsertion.batch_size_ratio = 0.05f;
+    reinsertion.max_iter_count = 3;
+    bvh::v2::ReinsertionOptimizer<Node>::optimize(thread_pool, by_hand, reinsertion);
     if (!(by_hand == bvh::v2::DefaultBuilder<Node>::build(thread_pool, bboxes, centers, forced))) { std::cout << "MiniTreeBuilder mismatch" << std::endl; return 2; }
 
     std::cout << "nodes: " << bvh.nodes.size() << ", prim_ids: " << bvh.prim_ids[0] << " " << bvh.prim_ids[1] << "\n";

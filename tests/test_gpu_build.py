@@ -223,6 +223,33 @@ def test_minitree_builder_direct(orc, dtype):
             bvh_amd.MiniTreeBuilder.build(bb, cc, bvh_amd.MiniTreeBuilder.Config(log2_grid_dim=L))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_reinsertion_optimizer_config(orc, dtype):
+    """ReinsertionOptimizer::Config {batch_size_ratio, max_iter_count} (reinsertion_optimizer.h:18-24): small and large batches
+    (a ratio >= 1 selects every node but the root: the candidate heap is never replaced into), zero iterations, many."""
+    import bvh_amd
+    for scene, tris in (("sponza", synth.sponza_proxy(30_000)), ("terrain", synth.terrain(20_000))):
+        bb, cc = orc.prep_tris(tris.astype(dtype))
+        for ratio, iters in ((0.05, 3), (0.01, 1), (0.2, 2), (1.0, 1), (3.0, 2), (0.0, 4), (0.5, 0), (1e-9, 5), (0.3, 7)):
+            ref = orc.build(bb, cc, quality=1)
+            ref.optimize(batch_size_ratio=ratio, max_iter_count=iters)
+            gpu = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium))
+            gpu.optimize(batch_size_ratio=ratio, max_iter_count=iters)
+            assert gpu.serialize() == ref.serialize(), (scene, ratio, iters)
+    with pytest.raises(bvh_amd.BvhAmdError, match="batch_size_ratio"):
+        gpu.optimize(batch_size_ratio=-0.1)
+    with pytest.raises(bvh_amd.BvhAmdError, match="batch_size_ratio"):
+        gpu.optimize(batch_size_ratio=float("nan"))
+    # 2D
+    circ = synth.circles(6000, dtype=dtype)
+    b2, c2 = orc.sphere_bboxes(circ)
+    ref = orc.build(b2, c2, quality=1)
+    ref.optimize(batch_size_ratio=0.5, max_iter_count=2)
+    gpu = bvh_amd.DefaultBuilder.build(b2, c2, bvh_amd.Config(quality=bvh_amd.Quality.Medium))
+    gpu.optimize(batch_size_ratio=0.5, max_iter_count=2)
+    assert gpu.serialize() == ref.serialize()
+
+
 def test_minitree_threshold_and_clustered_input(orc):
     """A dense cluster puts most primitives into one grid cell (one big mini-tree) and parallel_threshold changes
     the merge; both must follow the reference."""
