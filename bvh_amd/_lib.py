@@ -26,7 +26,8 @@ class Counters(C.Structure):
 
 class MiniTreeConfig(C.Structure):                             # struct bvh_amd_minitree_config
     _fields_ = [("min_leaf_size", C.c_size_t), ("max_leaf_size", C.c_size_t), ("enable_pruning", C.c_int),
-                ("pruning_area_ratio", C.c_double), ("parallel_threshold", C.c_size_t), ("log2_grid_dim", C.c_size_t)]
+                ("pruning_area_ratio", C.c_double), ("parallel_threshold", C.c_size_t), ("log2_grid_dim", C.c_size_t),
+                ("log_cluster_size", C.c_size_t), ("cost_ratio", C.c_double)]
 
 
 class BBox3f(C.Structure):
@@ -73,6 +74,8 @@ _SIGS = {
 _SIGS_T = {
     "bvh{S}_build": (_P, [_P, _P, _P, _Z, _P]),
     "bvh{S}_build_device": (_P, [_P, _P, _Z, _P, _I, _P]),
+    "bvh{S}_build_sah": (_P, [_P, _P, _P, _Z, _P, _P]),
+    "bvh{S}_build_device_sah": (_P, [_P, _P, _Z, _P, _I, _P, _P]),
     "bvh{S}_build_minitree_device": (_P, [_P, _P, _Z, _P, _P]),
     "bvh{S}_from_nodes": (_P, [_P, _Z, _P, _Z]),
     "bvh{S}_extract": (_P, [_P, _Z]),
@@ -112,6 +115,10 @@ _SIGS_T = {
     "bvh{S}_intersect_ray_any_robust": (None, [_P, _P, _P]),
     "bvh{S}_intersect_ray_visit": (_I, [_P, _P, _Z, _U, _P]),
 }
+
+
+class SahConfig(C.Structure):                 # struct bvh_amd_sah_config
+    _fields_ = [("log_cluster_size", C.c_size_t), ("cost_ratio", C.c_double)]
 
 
 class OptimizeConfig(C.Structure):            # struct bvh_amd_optimize_config

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 
@@ -39,11 +39,21 @@ class _Builder(enum.IntEnum):
 
 
 @dataclass
+class SplitHeuristic:                 # split_heuristic.h:17-23: SplitHeuristic(log_cluster_size = 0, cost_ratio = 1)
+    log_cluster_size: int = 0
+    cost_ratio: float = 1.0
+
+    def _c(self):
+        return _lib.SahConfig(int(self.log_cluster_size), float(self.cost_ratio))
+
+
+@dataclass
 class Config:                         # default_builder.h:23-30 + top_down_sah_builder.h:27-40
     quality: Quality = Quality.High
     min_leaf_size: int = 1
     max_leaf_size: int = 8
     parallel_threshold: int = 1024
+    sah: SplitHeuristic = field(default_factory=SplitHeuristic)
 
     def _c(self):
         return _lib.BuildConfig(int(self.quality), self.min_leaf_size, self.max_leaf_size, self.parallel_threshold)
@@ -258,7 +268,8 @@ def _build(bboxes, centers, config: Config, builder: _Builder) -> Bvh:
         raise ValueError("bboxes (n, 2 dim) and centers (n, dim) must agree in dtype and length")
     s = _suffix(bb.dtype, dim)
     cfg = config._c()
-    h = getattr(lib, f"bvh{s}_build_device")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), int(builder), _stream())
+    sah = config.sah._c()
+    h = getattr(lib, f"bvh{s}_build_device_sah")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), int(builder), C.byref(sah), _stream())
     return Bvh(h, s)
 
 
@@ -301,6 +312,7 @@ class MiniTreeBuilder:
         pruning_area_ratio: float = 0.01
         parallel_threshold: int = 1024
         log2_grid_dim: int = 4
+        sah: SplitHeuristic = field(default_factory=SplitHeuristic)
 
     @staticmethod
     def build(bboxes, centers, config: "MiniTreeBuilder.Config | None" = None, thread_pool: ThreadPool | None = None) -> Bvh:
@@ -310,7 +322,7 @@ class MiniTreeBuilder:
             raise ValueError("bboxes (n,6) and centers (n,3) must agree in dtype and length")
         s = _suffix(bb.dtype)
         cfg = _lib.MiniTreeConfig(c.min_leaf_size, c.max_leaf_size, int(c.enable_pruning), float(c.pruning_area_ratio), c.parallel_threshold,
-                                  c.log2_grid_dim)
+                                  c.log2_grid_dim, int(c.sah.log_cluster_size), float(c.sah.cost_ratio))
         return Bvh(getattr(_lib.load(), f"bvh{s}_build_minitree_device")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), _stream()), s)
 
 

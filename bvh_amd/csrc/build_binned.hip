@@ -92,11 +92,11 @@ __global__ void __launch_bounds__(64) k_decide(BuildCtx<T> c, uint32_t n_active)
         sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
             for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(b.lo[k][i][j]); hi[j] = Ord<T>::dec(b.hi[k][i][j]); }
             n = b.cnt[k][i];
-        }, cost, bin, c.dim);
+        }, cost, bin, c.dim, c.sah_log);
         if (cost < best_cost) { best_cost = cost; best_bin = bin; best_axis = k; }
     }
     const uint32_t size = nd.end - nd.begin;
-    const T stay = half_area(nd.lo, nd.hi, c.dim) * (static_cast<T>(size) - T(1));       // split_heuristic.h:36-38
+    const T stay = half_area(nd.lo, nd.hi, c.dim) * (sah_prims<T>(size, c.sah_log) - c.sah_ratio);   // split_heuristic.h:35-37
     st.wide = wide;
     st.axis = best_axis;
     if (best_cost >= stay) {
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) 
                 sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
                     for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(L.lo[k][i][j]); hi[j] = Ord<T>::dec(L.hi[k][i][j]); }
                     n = L.cnt[k][i];
-                }, cost, bin, c.dim);
+                }, cost, bin, c.dim, c.sah_log);
                 L.axis_cost[k] = cost;
                 L.axis_bin[k] = bin;
             }
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) 
                 const T cst = L.axis_cost[k];
                 if (cst < best_cost) { best_cost = cst; best_bin = L.axis_bin[k]; best_axis = k; }
             }
-            const T stay = half_area(nlo, nhi, c.dim) * (static_cast<T>(cnt) - T(1));
+            const T stay = half_area(nlo, nhi, c.dim) * (sah_prims<T>(cnt, c.sah_log) - c.sah_ratio);
             bool fallback = false;
             if (best_cost >= stay) {
                 if (cnt > c.max_leaf) fallback = true;        // else: leaf
@@ -538,6 +538,7 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
         c.bboxes = d_bboxes; c.centers = d_centers;
         c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
         c.dim = out.dim;
+        c.sah_log = ambient_sah().log_cluster; c.sah_ratio = static_cast<T>(ambient_sah().cost_ratio);
         int rc = ws.alloc(c, static_cast<uint32_t>(n), 1, attempt, true);
         if (rc) return rc;
         hipLaunchKernelGGL(k_prepare_root<T>, dim3(1), dim3(1), 0, stream, c);
@@ -582,6 +583,7 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
         BuildCtx<T> c;
         c.bboxes = d_bboxes; c.centers = d_centers; c.ids = d_ids;
         c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
+        c.sah_log = ambient_sah().log_cluster; c.sah_ratio = static_cast<T>(ambient_sah().cost_ratio);
         int rc = ws.alloc(c, n, n_groups, attempt, false);
         if (rc) return rc;
         hipLaunchKernelGGL(k_forest_prepare<T>, dim3(1), dim3(1), 0, stream, c, n_groups);

@@ -56,6 +56,12 @@ template <typename T> __device__ inline T pick_max(T a, T b) { return a > b ? a 
 // 2D builds (`2f` / `2d` families, Node<T, 2>) run the same kernels on three-wide data with z = 0 everywhere: the z lanes of
 // every box stay (+0, +0) and are inert; only the DECISIONS know the dimension: the half area (bbox.h:32-38: d0 + d1 in
 // 2D), the widest axis, and which axes are candidates for a split.
+// SplitHeuristic (split_heuristic.h:17-38): a range of `size` primitives counts as ceil(size / 2^log_cluster) clusters
+// (get_prim_count, :25-27), as the scalar the costs are computed in; the defaults {0, 1} make it the plain count.
+template <typename T> __device__ inline T sah_prims(uint32_t size, uint32_t log_cluster) {
+    return static_cast<T>((static_cast<unsigned long long>(size) + ((1ull << log_cluster) - 1ull)) >> log_cluster);
+}
+
 template <typename T> __device__ inline T half_area(const T* lo, const T* hi, int dim = 3) {   // bbox.h:32-38
     T d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
     if (dim == 2) return d0 + d1;
@@ -123,6 +129,8 @@ struct BuildCtx {
     uint32_t n;
     uint32_t min_leaf, max_leaf;
     int dim = 3;                         // 2: Node<T, 2> semantics on z = 0 data (see half_area)
+    uint32_t sah_log = 0;                // SplitHeuristic: log2 of the cluster size ...
+    T sah_ratio = T(1);                  // ... and the node / primitive cost ratio (split_heuristic.h:17-23)
     ANode<T>* nodes;
     uint32_t node_cap;
     SlotBins<T>* bins;
@@ -203,7 +211,7 @@ __device__ void partial_sort_replay(uint32_t* a, long middle, long last, KeyFn k
 // Starts from (FLT_MAX, -) and reports the first strict minimum; combining axes 0,1,2 with strict `<`
 // afterwards equals the reference's carried `best_split`.
 template <typename T, typename LoadBin>
-__device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin, int dim) {
+__device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin, int dim, uint32_t sah_log) {
     T right_cost[kBins];
     {
         T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
@@ -215,7 +223,7 @@ __device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin
 #pragma unroll
             for (int k = 0; k < 3; ++k) { lo[k] = pick_min(lo[k], blo[k]); hi[k] = pick_max(hi[k], bhi[k]); }
             cnt += bc;
-            right_cost[i] = half_area(lo, hi, dim) * static_cast<T>(cnt);
+            right_cost[i] = half_area(lo, hi, dim) * sah_prims<T>(cnt, sah_log);
         }
     }
     best_cost = Ord<T>::kMax;
@@ -229,7 +237,7 @@ __device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin
 #pragma unroll
         for (int k = 0; k < 3; ++k) { lo[k] = pick_min(lo[k], blo[k]); hi[k] = pick_max(hi[k], bhi[k]); }
         cnt += bc;
-        T cost = half_area(lo, hi, dim) * static_cast<T>(cnt) + right_cost[i + 1];
+        T cost = half_area(lo, hi, dim) * sah_prims<T>(cnt, sah_log) + right_cost[i + 1];
         if (cost < best_cost) { best_cost = cost; best_bin = i + 1; }
     }
 }

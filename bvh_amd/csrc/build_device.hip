@@ -3,6 +3,11 @@
 
 namespace bvh_amd {
 
+SahParams& ambient_sah() {
+    static thread_local SahParams params;
+    return params;
+}
+
 template <typename T>
 int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg,
                         hipStream_t stream);

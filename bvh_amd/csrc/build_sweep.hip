@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kScanThreads) k_sweep_axis(SweepCtx<T> c) {
         const uint32_t pos = e - 1 - (in ? r : 0);
         Box6<T> v = in ? load_box(c.b.bboxes, ord[pos]) : empty_box<T>();
         v = block_scan_boxes(v, carry, wtot);
-        if (in && pos > b) cost_r[pos] = half_area(v.lo, v.hi, c.b.dim) * static_cast<T>(e - pos);
+        if (in && pos > b) cost_r[pos] = half_area(v.lo, v.hi, c.b.dim) * sah_prims<T>(e - pos, c.b.sah_log);
     }
     __syncthreads();
     // left-to-right: cost(i) = half_area(box[b, i]) * (i + 1 - b) + cost_r[i + 1], split position i + 1
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(kScanThreads) k_sweep_axis(SweepCtx<T> c) {
         Box6<T> v = in ? load_box(c.b.bboxes, ord[pos]) : empty_box<T>();
         v = block_scan_boxes(v, carry, wtot);
         if (in && pos + 1 < e) {
-            const T cost = half_area(v.lo, v.hi, c.b.dim) * static_cast<T>(pos + 1 - b) + cost_r[pos + 1];
+            const T cost = half_area(v.lo, v.hi, c.b.dim) * sah_prims<T>(pos + 1 - b, c.b.sah_log) + cost_r[pos + 1];
             if (cost < best) { best = cost; best_pos = pos + 1; }          // earlier positions win ties (strict <)
         }
     }
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64) k_sweep_decide(SweepCtx<T> c, uint32_t n_a
     SlotState<T>& st = c.b.state[slot];
     const ANode<T>& nd = c.b.nodes[st.node];
     const uint32_t size = nd.end - nd.begin;
-    const T stay = half_area(nd.lo, nd.hi, c.b.dim) * (static_cast<T>(size) - T(1));
+    const T stay = half_area(nd.lo, nd.hi, c.b.dim) * (sah_prims<T>(size, c.b.sah_log) - c.b.sah_ratio);
     uint32_t pos = (nd.begin + nd.end + 1) / 2; T cost = stay; uint32_t axis = 0;     // :111
     for (int k = 0; k < c.b.dim; ++k) {
         const AxisBest<T> ab = c.axis_best[3 * slot + k];
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
         uint32_t cut = 0;
 
         if (cnt > c.b.min_leaf) {
-            const T stay = half_area(nlo, nhi, c.b.dim) * (static_cast<T>(cnt) - T(1));
+            const T stay = half_area(nlo, nhi, c.b.dim) * (sah_prims<T>(cnt, c.b.sah_log) - c.b.sah_ratio);
             uint32_t best_pos = (B + lb + B + le + 1) / 2 - B; T best_cost = stay; uint32_t best_axis = 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -325,12 +325,12 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
                     for (int q = 0; q < 3; ++q) { o.lo[q] = __shfl_up(pre.lo[q], off); o.hi[q] = __shfl_up(pre.hi[q], off); }
                     if (lane >= off) pre = join(o, pre);
                 }
-                const T cr = half_area(suf.lo, suf.hi, c.b.dim) * static_cast<T>(le - uint32_t(lane));    // cost of [lane, le)
+                const T cr = half_area(suf.lo, suf.hi, c.b.dim) * sah_prims<T>(le - uint32_t(lane), c.b.sah_log);    // cost of [lane, le)
                 const T cr_next = __shfl_down(cr, 1);
                 T cost = __builtin_inff();
                 uint32_t pos = 0xFFFFFFFFu;
                 if (in && uint32_t(lane) + 1 < le) {
-                    const T cl = half_area(pre.lo, pre.hi, c.b.dim) * static_cast<T>(uint32_t(lane) + 1 - lb);
+                    const T cl = half_area(pre.lo, pre.hi, c.b.dim) * sah_prims<T>(uint32_t(lane) + 1 - lb, c.b.sah_log);
                     const T tot = cl + cr_next;
                     if (tot < cost) { cost = tot; pos = lane + 1; }
                 }
@@ -472,6 +472,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         c.bboxes = d_bboxes; c.centers = d_centers; c.ids = ord.p; c.n = n32;
         c.min_leaf = min_leaf; c.max_leaf = max_leaf;
         c.dim = dim;
+        c.sah_log = ambient_sah().log_cluster; c.sah_ratio = static_cast<T>(ambient_sah().cost_ratio);
         c.nodes = nodes.p; c.node_cap = node_cap; c.bins = nullptr; c.state = st_a.p; c.state_next = st_b.p; c.slot_cap = slot_cap;
         c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = nullptr;
         c.ltab = nullptr; c.rtab = nullptr; c.small_list = small_list.p; c.stage = stage.p; c.counters = counters.p;

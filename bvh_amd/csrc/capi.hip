@@ -47,6 +47,19 @@ bvh_build_config default_config() {               // default_builder.h:23-30, to
     return c;
 }
 
+// Runs `build` with the caller's SplitHeuristic in force (NULL = the reference's default {0, 1}).
+template <typename Build>
+auto with_sah(const bvh_amd_sah_config* sah, Build&& build) -> decltype(build()) {
+    SahParams p;
+    if (sah) {
+        if (sah->log_cluster_size >= 64) { set_error("build: sah.log_cluster_size must be below 64 (split_heuristic.h:21, make_bitmask<size_t>)"); return nullptr; }
+        p.log_cluster = static_cast<uint32_t>(sah->log_cluster_size);
+        p.cost_ratio = sah->cost_ratio;
+    }
+    SahScope scope(p);
+    return build();
+}
+
 template <typename T>
 typename CTypes<T>::Bvh* build_device(const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config* config,
                                       bvh_amd_builder builder, void* stream)
@@ -66,7 +79,7 @@ typename CTypes<T>::Bvh* build_device(const T* d_bboxes, const T* d_centers, siz
 template <typename T>
 typename CTypes<T>::Bvh* build_minitree(const T* d_bboxes, const T* d_centers, size_t n, const bvh_amd_minitree_config* config, void* stream) {
     if (!d_bboxes || !d_centers || n == 0) { set_error("build: empty input"); return nullptr; }
-    bvh_amd_minitree_config c = config ? *config : bvh_amd_minitree_config{1, 8, 1, 0.01, 1024, 4};
+    bvh_amd_minitree_config c = config ? *config : bvh_amd_minitree_config{1, 8, 1, 0.01, 1024, 4, 0, 1.0};
     if (c.min_leaf_size < 1 || c.min_leaf_size > c.max_leaf_size || c.max_leaf_size > 15) {
         set_error("build: need 1 <= min_leaf_size <= max_leaf_size <= 15 (4-bit primitive count, index.h:38)");
         return nullptr;
@@ -77,6 +90,10 @@ typename CTypes<T>::Bvh* build_minitree(const T* d_bboxes, const T* d_centers, s
     }
     bvh_build_config cfg = default_config();
     cfg.min_leaf_size = c.min_leaf_size; cfg.max_leaf_size = c.max_leaf_size; cfg.parallel_threshold = c.parallel_threshold;
+    if (c.log_cluster_size >= 64) { set_error("build: log_cluster_size must be below 64 (split_heuristic.h:21)"); return nullptr; }
+    SahParams sah;
+    sah.log_cluster = static_cast<uint32_t>(c.log_cluster_size); sah.cost_ratio = c.cost_ratio;
+    SahScope scope(sah);
     auto b = std::make_unique<BvhImpl<T>>();
     if (build_minitree_explicit<T>(*b, d_bboxes, d_centers, n, cfg, c.enable_pruning != 0, static_cast<T>(c.pruning_area_ratio), false,
                                    static_cast<uint32_t>(c.log2_grid_dim), static_cast<hipStream_t>(stream)) != BVH_AMD_OK)
@@ -485,6 +502,12 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_build_device(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,              \
                                   enum bvh_amd_builder builder, void* stream) {                                     \
         return build_device<T>(d_bb, d_cc, n, cfg, builder, stream); }                                              \
+    bvh##S* bvh##S##_build_sah(bvh_thread_pool* pool, const bvh_bbox##S* bb, const bvh_vec##S* cc, size_t n,        \
+                               const bvh_build_config* cfg, const bvh_amd_sah_config* sah) {                       \
+        return with_sah(sah, [&] { return build_host<T>(pool, bb, cc, n, cfg); }); }                                \
+    bvh##S* bvh##S##_build_device_sah(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,          \
+                                      enum bvh_amd_builder builder, const bvh_amd_sah_config* sah, void* stream) {  \
+        return with_sah(sah, [&] { return build_device<T>(d_bb, d_cc, n, cfg, builder, stream); }); }               \
     bvh##S* bvh##S##_build_minitree_device(const T* d_bb, const T* d_cc, size_t n, const bvh_amd_minitree_config* cfg, void* stream) { \
         return build_minitree<T>(d_bb, d_cc, n, cfg, stream); }                                                     \
     bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return handle<T>(extract<T>(impl<T>(b), root_id)); }      \
@@ -574,6 +597,12 @@ BVH_AMD_IMPL_RAY(double, 3d, bvh_intersect_callbackd, bvh_amd_ray_visitord, 3, i
     bvh##S* bvh##S##_build_device(const T* d_bb4, const T* d_cc2, size_t n, const bvh_build_config* cfg,            \
                                   enum bvh_amd_builder builder, void* stream) {                                     \
         return build2_device<T>(d_bb4, d_cc2, n, cfg, builder, stream); }                                           \
+    bvh##S* bvh##S##_build_sah(bvh_thread_pool* pool, const bvh_bbox##S* bb, const bvh_vec##S* cc, size_t n,        \
+                               const bvh_build_config* cfg, const bvh_amd_sah_config* sah) {                       \
+        return with_sah(sah, [&] { return build2_host<T>(pool, bb, cc, n, cfg); }); }                               \
+    bvh##S* bvh##S##_build_device_sah(const T* d_bb4, const T* d_cc2, size_t n, const bvh_build_config* cfg,        \
+                                      enum bvh_amd_builder builder, const bvh_amd_sah_config* sah, void* stream) {  \
+        return with_sah(sah, [&] { return build2_device<T>(d_bb4, d_cc2, n, cfg, builder, stream); }); }            \
     bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return handle2<T>(extract<T>(impl2<T>(b), root_id)); }    \
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes2<T>(nodes, nn, ids, np); }                                                                \

@@ -121,6 +121,19 @@ struct BvhImpl {
     ~BvhImpl();
 };
 
+// The SplitHeuristic (reference split_heuristic.h:17-23) of the build in progress on the calling thread. The reference's C
+// struct bvh_build_config has no room for it, so the C-ABI entry points that accept one (bvh_amd_sah_config) set it for the
+// duration of the call and the builders read it where they fill their kernel arguments; the default is the reference's {0, 1}.
+struct SahParams { uint32_t log_cluster = 0; double cost_ratio = 1.0; };
+SahParams& ambient_sah();                     // build_device.hip
+struct SahScope {
+    SahParams saved;
+    explicit SahScope(const SahParams& p) : saved(ambient_sah()) { ambient_sah() = p; }
+    ~SahScope() { ambient_sah() = saved; }
+    SahScope(const SahScope&) = delete;
+    SahScope& operator=(const SahScope&) = delete;
+};
+
 // upload.hip
 template <typename T> int upload_bvh(BvhImpl<T>& b, hipStream_t stream);
 template <typename T> int tree_depth(const BvhImpl<T>& b, hipStream_t stream);   // fills b.max_depth (cached)

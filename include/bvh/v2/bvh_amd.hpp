@@ -285,6 +285,8 @@ template <> struct Api<float, 3> {
     using Handle = bvh3f; using CHit = bvh_hit3f;
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3f_build(p, static_cast<const bvh_bbox3f*>(bb), static_cast<const bvh_vec3f*>(cc), n, c); }
     static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh3f_build_device(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, b, nullptr); }
+    static Handle* build_sah(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h) { return bvh3f_build_sah(p, static_cast<const bvh_bbox3f*>(bb), static_cast<const bvh_vec3f*>(cc), n, c, h); }
+    static Handle* build_device_sah(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b, const bvh_amd_sah_config* h) { return bvh3f_build_device_sah(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, b, h, nullptr); }
     static Handle* build_minitree(const void* d_bb, const void* d_cc, size_t n, const bvh_amd_minitree_config* c) { return bvh3f_build_minitree_device(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, nullptr); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3f_from_nodes(nodes, nn, ids, np); }
     static void destroy(Handle* h) { bvh3f_destroy(h); }
@@ -309,6 +311,8 @@ template <> struct Api<double, 3> {
     using Handle = bvh3d; using CHit = bvh_hit3d;
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh3d_build(p, static_cast<const bvh_bbox3d*>(bb), static_cast<const bvh_vec3d*>(cc), n, c); }
     static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh3d_build_device(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, b, nullptr); }
+    static Handle* build_sah(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h) { return bvh3d_build_sah(p, static_cast<const bvh_bbox3d*>(bb), static_cast<const bvh_vec3d*>(cc), n, c, h); }
+    static Handle* build_device_sah(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b, const bvh_amd_sah_config* h) { return bvh3d_build_device_sah(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, b, h, nullptr); }
     static Handle* build_minitree(const void* d_bb, const void* d_cc, size_t n, const bvh_amd_minitree_config* c) { return bvh3d_build_minitree_device(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, nullptr); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3d_from_nodes(nodes, nn, ids, np); }
     static void destroy(Handle* h) { bvh3d_destroy(h); }
@@ -336,6 +340,8 @@ template <> struct Api<T, 2> {                                                  
     using Handle = bvh##S; using CHit = std::conditional_t<std::is_same_v<T, float>, bvh_hit3f, bvh_hit3d>;                              \
     static Handle* build(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c) { return bvh##S##_build(p, static_cast<const bvh_bbox##S*>(bb), static_cast<const bvh_vec##S*>(cc), n, c); } \
     static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh##S##_build_device(static_cast<const T*>(d_bb), static_cast<const T*>(d_cc), n, c, b, nullptr); } \
+    static Handle* build_sah(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h) { return bvh##S##_build_sah(p, static_cast<const bvh_bbox##S*>(bb), static_cast<const bvh_vec##S*>(cc), n, c, h); } \
+    static Handle* build_device_sah(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b, const bvh_amd_sah_config* h) { return bvh##S##_build_device_sah(static_cast<const T*>(d_bb), static_cast<const T*>(d_cc), n, c, b, h, nullptr); } \
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh##S##_from_nodes(nodes, nn, ids, np); } \
     static void destroy(Handle* h) { bvh##S##_destroy(h); }                                                                               \
     static size_t node_count(const Handle* h) { return bvh##S##_get_node_count(h); }                                                      \
@@ -496,49 +502,23 @@ private:
     template <typename N> friend class ReinsertionOptimizer;
 };
 
-// ---- default_builder.h ----------------------------------------------------------------------------------------------------
-template <typename Node>
-class DefaultBuilder {
-    using Scalar = typename Node::Scalar;
-    using Vec = bvh::v2::Vec<Scalar, Node::dimension>;
-    using BBox = bvh::v2::BBox<Scalar, Node::dimension>;
-public:
-    enum class Quality { Low, Medium, High };
-    struct Config {
-        size_t min_leaf_size = 1;
-        size_t max_leaf_size = 8;
-        Quality quality = Quality::High;
-        size_t parallel_threshold = 1024;
-    };
-    // with a thread pool: the reference's mini-tree builder semantics (default_builder.h:33-46)
-    [[nodiscard]] static Bvh<Node> build(ThreadPool& pool, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config = {}) {
-        return run(reinterpret_cast<bvh_thread_pool*>(&pool), bboxes, centers, config);
-    }
-    // without: the serial builders' semantics (default_builder.h:49-62)
-    [[nodiscard]] static Bvh<Node> build(std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config = {}) {
-        return run(nullptr, bboxes, centers, config);
-    }
-private:
-    static Bvh<Node> run(bvh_thread_pool* pool, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config) {
-        bvh_build_config c;
-        c.quality = static_cast<bvh_build_quality>(config.quality);
-        c.min_leaf_size = config.min_leaf_size; c.max_leaf_size = config.max_leaf_size; c.parallel_threshold = config.parallel_threshold;
-        auto* h = amd::Api<Scalar, Node::dimension>::build(pool, bboxes.data(), centers.data(), bboxes.size(), &c);
-        if (!h) throw amd::Error(bvh_amd_last_error());
-        Bvh<Node> bvh;
-        bvh.adopt(h);
-        return bvh;
-    }
-};
-
-// ---- split_heuristic.h / top_down_sah_builder.h / binned_sah_builder.h / sweep_sah_builder.h -------------------------------------
+// ---- split_heuristic.h ----------------------------------------------------------------------------------------------------------
 template <typename T>
-struct SplitHeuristic {                                       // reference split_heuristic.h:12-44 (the device builders implement the defaults)
-    size_t log_cluster_size = 0;
-    T cost_ratio = static_cast<T>(1.);
-    bool is_default() const { return log_cluster_size == 0 && cost_ratio == static_cast<T>(1.); }
+class SplitHeuristic {                                        // reference split_heuristic.h:11-43; the device builders evaluate it
+public:
+    SplitHeuristic(size_t log_cluster_size = 0, T cost_ratio = static_cast<T>(1.)) : log_cluster_size_(log_cluster_size), cost_ratio_(cost_ratio) {}
+    size_t get_prim_count(size_t size) const { return (size + ((size_t{1} << log_cluster_size_) - 1)) >> log_cluster_size_; }
+    template <size_t N> T get_leaf_cost(size_t begin, size_t end, const BBox<T, N>& bbox) const { return bbox.get_half_area() * static_cast<T>(get_prim_count(end - begin)); }
+    template <size_t N> T get_non_split_cost(size_t begin, size_t end, const BBox<T, N>& bbox) const {
+        return bbox.get_half_area() * (static_cast<T>(get_prim_count(end - begin)) - cost_ratio_);
+    }
+    bvh_amd_sah_config c_config() const { return bvh_amd_sah_config{ log_cluster_size_, static_cast<double>(cost_ratio_) }; }
+private:
+    size_t log_cluster_size_;
+    T cost_ratio_;
 };
 
+// ---- top_down_sah_builder.h / binned_sah_builder.h / sweep_sah_builder.h -------------------------------------
 template <typename Node>
 class TopDownSahBuilder {
 protected:
@@ -553,14 +533,14 @@ public:
     };
 protected:
     static Bvh<Node> run(bvh_amd_builder which, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config) {
-        if (!config.sah.is_default()) throw amd::Error("bvh_amd: the device builders implement SplitHeuristic's default parameters only");
         if (bboxes.size() != centers.size()) throw amd::Error("bvh_amd: bboxes and centers differ in length");
         bvh_build_config c;
         c.quality = BVH_BUILD_QUALITY_HIGH;                   // (unused by the explicit builders)
         c.min_leaf_size = config.min_leaf_size; c.max_leaf_size = config.max_leaf_size; c.parallel_threshold = 1024;
+        const bvh_amd_sah_config sah = config.sah.c_config();
         amd::DeviceArray<BBox> d_bb(bboxes);
         amd::DeviceArray<Vec> d_cc(centers);
-        auto* h = amd::Api<Scalar, Node::dimension>::build_device(d_bb.data(), d_cc.data(), bboxes.size(), &c, which);
+        auto* h = amd::Api<Scalar, Node::dimension>::build_device_sah(d_bb.data(), d_cc.data(), bboxes.size(), &c, which, &sah);
         if (!h) throw amd::Error(bvh_amd_last_error());
         Bvh<Node> bvh;
         bvh.adopt(h);
@@ -588,6 +568,40 @@ public:
     }
 };
 
+// ---- default_builder.h ----------------------------------------------------------------------------------------------------
+template <typename Node>
+class DefaultBuilder {
+    using Scalar = typename Node::Scalar;
+    using Vec = bvh::v2::Vec<Scalar, Node::dimension>;
+    using BBox = bvh::v2::BBox<Scalar, Node::dimension>;
+public:
+    enum class Quality { Low, Medium, High };
+    struct Config : TopDownSahBuilder<Node>::Config {         // default_builder.h:23-30: sah, min_leaf_size, max_leaf_size, and
+        Quality quality = Quality::High;
+        size_t parallel_threshold = 1024;
+    };
+    // with a thread pool: the reference's mini-tree builder semantics (default_builder.h:33-46)
+    [[nodiscard]] static Bvh<Node> build(ThreadPool& pool, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config = {}) {
+        return run(reinterpret_cast<bvh_thread_pool*>(&pool), bboxes, centers, config);
+    }
+    // without: the serial builders' semantics (default_builder.h:49-62)
+    [[nodiscard]] static Bvh<Node> build(std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config = {}) {
+        return run(nullptr, bboxes, centers, config);
+    }
+private:
+    static Bvh<Node> run(bvh_thread_pool* pool, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config) {
+        bvh_build_config c;
+        c.quality = static_cast<bvh_build_quality>(config.quality);
+        c.min_leaf_size = config.min_leaf_size; c.max_leaf_size = config.max_leaf_size; c.parallel_threshold = config.parallel_threshold;
+        const bvh_amd_sah_config sah = config.sah.c_config();
+        auto* h = amd::Api<Scalar, Node::dimension>::build_sah(pool, bboxes.data(), centers.data(), bboxes.size(), &c, &sah);
+        if (!h) throw amd::Error(bvh_amd_last_error());
+        Bvh<Node> bvh;
+        bvh.adopt(h);
+        return bvh;
+    }
+};
+
 // ---- mini_tree_builder.h ------------------------------------------------------------------------------------------------------
 template <typename Node, typename MortonCode = uint32_t>
 class MiniTreeBuilder {                                       // reference mini_tree_builder.h:24-58 (3D; the grid reads three components)
@@ -603,12 +617,12 @@ public:
         size_t log2_grid_dim = 4;
     };
     [[nodiscard]] static Bvh<Node> build(ThreadPool&, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config = {}) {
-        if (!config.sah.is_default()) throw amd::Error("bvh_amd: the device builders implement SplitHeuristic's default parameters only");
         if (bboxes.size() != centers.size()) throw amd::Error("bvh_amd: bboxes and centers differ in length");
         bvh_amd_minitree_config c;
         c.min_leaf_size = config.min_leaf_size; c.max_leaf_size = config.max_leaf_size; c.enable_pruning = config.enable_pruning ? 1 : 0;
         c.pruning_area_ratio = static_cast<double>(config.pruning_area_ratio); c.parallel_threshold = config.parallel_threshold;
         c.log2_grid_dim = config.log2_grid_dim;
+        c.log_cluster_size = config.sah.c_config().log_cluster_size; c.cost_ratio = config.sah.c_config().cost_ratio;
         amd::DeviceArray<BBox> d_bb(bboxes);
         amd::DeviceArray<Vec> d_cc(centers);
         auto* h = amd::Api<Scalar, 3>::build_minitree(d_bb.data(), d_cc.data(), bboxes.size(), &c);

@@ -154,6 +154,24 @@ BVH_AMD_API struct bvh3f* bvh3f_build_device(const float* d_bboxes, const float*
 BVH_AMD_API struct bvh3d* bvh3d_build_device(const double* d_bboxes, const double* d_centers, size_t prim_count,
     const struct bvh_build_config* config, enum bvh_amd_builder builder, void* stream);
 
+/* Additive: TopDownSahBuilder::Config::sah, the SplitHeuristic every builder's Config carries (src/bvh/v2/split_heuristic.h:17-38,
+ * top_down_sah_builder.h:27-30) and the reference's C struct bvh_build_config has no field for: a range of `size` primitives
+ * costs ceil(size / 2^log_cluster_size) primitive intersections, and a node that is not split saves `cost_ratio` (ratio of the
+ * cost of a ray-box test over a ray-primitive test). NULL = the reference's defaults {0, 1}. bvhXX_build_sah is bvhXX_build
+ * (DefaultBuilder, pool or not) with it; bvhXX_build_device_sah is bvhXX_build_device with it. */
+struct bvh_amd_sah_config {
+    size_t log_cluster_size;                   /* default 0 */
+    double cost_ratio;                         /* default 1 */
+};
+BVH_AMD_API struct bvh3f* bvh3f_build_sah(struct bvh_thread_pool*, const struct bvh_bbox3f* bboxes, const struct bvh_vec3f* centers,
+    size_t prim_count, const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah);
+BVH_AMD_API struct bvh3d* bvh3d_build_sah(struct bvh_thread_pool*, const struct bvh_bbox3d* bboxes, const struct bvh_vec3d* centers,
+    size_t prim_count, const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah);
+BVH_AMD_API struct bvh3f* bvh3f_build_device_sah(const float* d_bboxes, const float* d_centers, size_t prim_count,
+    const struct bvh_build_config* config, enum bvh_amd_builder builder, const struct bvh_amd_sah_config* sah, void* stream);
+BVH_AMD_API struct bvh3d* bvh3d_build_device_sah(const double* d_bboxes, const double* d_centers, size_t prim_count,
+    const struct bvh_build_config* config, enum bvh_amd_builder builder, const struct bvh_amd_sah_config* sah, void* stream);
+
 /* Additive: MiniTreeBuilder::build(pool, bboxes, centers, config) itself (src/bvh/v2/mini_tree_builder.h:29-58) with its own
  * configuration; DefaultBuilder(pool)'s three qualities are three settings of it (default_builder.h:65-73). log2_grid_dim
  * may be 1..10 (three coordinates in the reference's 32-bit Morton code, mini_tree_builder.h:169); the cell histogram takes
@@ -164,6 +182,8 @@ struct bvh_amd_minitree_config {
     double pruning_area_ratio;                 /* default 0.01 */
     size_t parallel_threshold;                 /* default 1024 */
     size_t log2_grid_dim;                      /* default 4 */
+    size_t log_cluster_size;                   /* SplitHeuristic (split_heuristic.h:17-23), defaults 0 ... */
+    double cost_ratio;                         /* ... and 1 */
 };
 BVH_AMD_API struct bvh3f* bvh3f_build_minitree_device(const float* d_bboxes, const float* d_centers, size_t prim_count,
     const struct bvh_amd_minitree_config* config, void* stream);
@@ -342,6 +362,10 @@ BVH_AMD_API struct bvh2f* bvh2f_build(struct bvh_thread_pool*, const struct bvh_
     const struct bvh_vec2f* centers, size_t prim_count, const struct bvh_build_config* config);   /* c_api/bvh.h:99-125 */
 BVH_AMD_API struct bvh2f* bvh2f_build_device(const float* d_bboxes4, const float* d_centers2, size_t prim_count,
     const struct bvh_build_config* config, enum bvh_amd_builder builder, void* stream);
+BVH_AMD_API struct bvh2f* bvh2f_build_sah(struct bvh_thread_pool*, const struct bvh_bbox2f* bboxes, const struct bvh_vec2f* centers,
+    size_t prim_count, const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah);
+BVH_AMD_API struct bvh2f* bvh2f_build_device_sah(const float* d_bboxes4, const float* d_centers2, size_t prim_count,
+    const struct bvh_build_config* config, enum bvh_amd_builder builder, const struct bvh_amd_sah_config* sah, void* stream);
 BVH_AMD_API struct bvh2f* bvh2f_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
 BVH_AMD_API struct bvh2f* bvh2f_extract(struct bvh2f* bvh, size_t root_id);
 BVH_AMD_API void bvh2f_destroy(struct bvh2f*);
@@ -379,6 +403,10 @@ BVH_AMD_API struct bvh2d* bvh2d_build(struct bvh_thread_pool*, const struct bvh_
     const struct bvh_vec2d* centers, size_t prim_count, const struct bvh_build_config* config);   /* c_api/bvh.h:99-125 */
 BVH_AMD_API struct bvh2d* bvh2d_build_device(const double* d_bboxes4, const double* d_centers2, size_t prim_count,
     const struct bvh_build_config* config, enum bvh_amd_builder builder, void* stream);
+BVH_AMD_API struct bvh2d* bvh2d_build_sah(struct bvh_thread_pool*, const struct bvh_bbox2d* bboxes, const struct bvh_vec2d* centers,
+    size_t prim_count, const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah);
+BVH_AMD_API struct bvh2d* bvh2d_build_device_sah(const double* d_bboxes4, const double* d_centers2, size_t prim_count,
+    const struct bvh_build_config* config, enum bvh_amd_builder builder, const struct bvh_amd_sah_config* sah, void* stream);
 BVH_AMD_API struct bvh2d* bvh2d_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
 BVH_AMD_API struct bvh2d* bvh2d_extract(struct bvh2d* bvh, size_t root_id);
 BVH_AMD_API void bvh2d_destroy(struct bvh2d*);

@@ -150,6 +150,12 @@ class CpuLib:
     def _sfx(dtype, dim=3):
         return f"{dim}f" if np.dtype(dtype) == np.float32 else f"{dim}d"
 
+    def set_sah(self, log_cluster_size: int = 0, cost_ratio: float = 1.0):
+        """SplitHeuristic(log_cluster_size, cost_ratio) (split_heuristic.h:17-23) for the builds that follow; () restores the default."""
+        f = getattr(self.dll, f"{self.prefix}_set_sah")
+        f.restype, f.argtypes = None, [C.c_size_t, C.c_double]
+        f(log_cluster_size, cost_ratio)
+
     def hardware_threads(self) -> int:
         return int(getattr(self.dll, f"{self.prefix}_hardware_threads")())
 

@@ -122,7 +122,19 @@ struct Tree {                                                // bvh.h:17-23
     std::vector<size_t> prim_ids;
 };
 
-struct LeafLimits { size_t min_leaf = 1, max_leaf = 8; };   // top_down_sah_builder.h:27-40 (sah = {0, 1})
+// TopDownSahBuilder::Config (top_down_sah_builder.h:27-40) with its SplitHeuristic (split_heuristic.h:17-38): a range of
+// `size` primitives counts as ceil(size / 2^log_cluster) clusters, and a node that stays a leaf saves `cost_ratio`.
+inline size_t g_sah_log_cluster = 0;      // set by orc_set_sah(): the SplitHeuristic the following builds use (default {0, 1})
+inline double g_sah_cost_ratio = 1.;
+struct LeafLimits {
+    size_t min_leaf = 1, max_leaf = 8;
+    size_t log_cluster = g_sah_log_cluster;
+    double cost_ratio = g_sah_cost_ratio;
+    template <typename T> T prims(size_t size) const {                      // get_prim_count (:25-27) as the Scalar the costs use
+        return static_cast<T>((size + ((size_t{1} << log_cluster) - 1)) >> log_cluster);
+    }
+    template <typename T> T stay(size_t size) const { return prims<T>(size) - static_cast<T>(cost_ratio); }   // get_non_split_cost (:35-37)
+};
 
 // ---------------------------------------------------------------------------------------------
 // Top-down driver shared by the binned and sweep builders (top_down_sah_builder.h:74-139)
@@ -220,16 +232,16 @@ struct BinnedSplitter {
             T right_cost[kBins];
             for (size_t i = kBins - 1; i > 0; --i) {
                 acc.box.grow(slots[k][i].box); acc.count += slots[k][i].count;
-                right_cost[i] = acc.box.half_area() * static_cast<T>(acc.count);
+                right_cost[i] = acc.box.half_area() * lim.template prims<T>(acc.count);
             }
             Slot left;
             for (size_t i = 0; i + 1 < kBins; ++i) {
                 left.box.grow(slots[k][i].box); left.count += slots[k][i].count;
-                T cost = left.box.half_area() * static_cast<T>(left.count) + right_cost[i + 1];
+                T cost = left.box.half_area() * lim.template prims<T>(left.count) + right_cost[i + 1];
                 if (cost < best_cost) { best_bin = i + 1; best_cost = cost; best_axis = k; }
             }
         }
-        T stay_cost = nb.half_area() * (static_cast<T>(e - b) - T(1));     // split_heuristic.h:36-38
+        T stay_cost = nb.half_area() * lim.template stay<T>(e - b);          // split_heuristic.h:35-37
         if (best_cost >= stay_cost) {                        // :138-143
             if (e - b <= lim.max_leaf) return false;
             cut = median_fallback(wide, b, e);
@@ -284,7 +296,7 @@ struct SweepSplitter {
             T cost = T(0);
             for (; i > stop; --i) {
                 right.grow(boxes[ord[i]]);
-                suffix_cost[i] = cost = right.half_area() * static_cast<T>(e - i);
+                suffix_cost[i] = cost = right.half_area() * lim.template prims<T>(e - i);
             }
             if (cost > best_cost) { resume = i; break; }     // :82-85 chunked early-out
         }
@@ -292,7 +304,7 @@ struct SweepSplitter {
         for (size_t i = b; i < resume; ++i) left.grow(boxes[ord[i]]);
         for (size_t i = resume; i + 1 < e; ++i) {
             left.grow(boxes[ord[i]]);
-            T lcost = left.half_area() * static_cast<T>(i + 1 - b);
+            T lcost = left.half_area() * lim.template prims<T>(i + 1 - b);
             T cost = lcost + suffix_cost[i + 1];
             if (cost < best_cost) { best_pos = i + 1; best_cost = cost; best_axis = k; }
             else if (lcost > best_cost) break;
@@ -300,7 +312,7 @@ struct SweepSplitter {
     }
 
     bool try_split(const Box<T>& nb, size_t b, size_t e, size_t& cut) {    // :108-139
-        T stay_cost = nb.half_area() * (static_cast<T>(e - b) - T(1));
+        T stay_cost = nb.half_area() * lim.template stay<T>(e - b);
         size_t best_pos = (b + e + 1) / 2; T best_cost = stay_cost; int best_axis = 0;
         for (int k = 0; k < g_dim; ++k) scan_axis(k, b, e, best_pos, best_cost, best_axis);
         if (best_cost >= stay_cost) {
@@ -452,7 +464,7 @@ Tree<T> build_mini_trees(const Box<T>* boxes, const T* centers, size_t n, LeafLi
         tb[i] = trees[i].nodes[0].box();
         for (int k = 0; k < 3; ++k) tc[3 * i + k] = (tb[i].hi[k] + tb[i].lo[k]) * T(0.5);   // bbox.h:30
     }
-    Tree<T> top = build_sweep<T>(tb.data(), tc.data(), m, LeafLimits{1, 1});   // :258-260
+    Tree<T> top = build_sweep<T>(tb.data(), tc.data(), m, LeafLimits{1, 1, lim.log_cluster, lim.cost_ratio});   // :258-260 (the rest of the config is kept)
 
     std::vector<size_t> node_off(m), prim_off(m);
     size_t node_total = top.nodes.size(), prim_total = 0;
@@ -923,6 +935,10 @@ size_t serialize_tree(const Tree<T>& t, uint8_t* out, size_t cap) {
 } // namespace
 
 extern "C" {
+
+ORC_EXPORT void orc_set_sah(size_t log_cluster_size, double cost_ratio) {
+    g_sah_log_cluster = log_cluster_size; g_sah_cost_ratio = cost_ratio;
+}
 
 #define ORC_IMPL(T, S)                                                                                  \
     ORC_EXPORT void* orc_build##S(const T* bboxes, const T* centers, size_t n, int builder, int quality, \

@@ -46,6 +46,10 @@ using namespace bvh::v2;
 
 template <typename T> using Node3 = Node<T, 3>;
 template <typename T> using Bvh3 = Bvh<Node3<T>>;
+// the SplitHeuristic (split_heuristic.h:17-23) the following builds use; ref_set_sah() changes it (default {0, 1})
+static size_t g_sah_log_cluster = 0;
+static double g_sah_cost_ratio = 1.;
+
 template <typename T, size_t D> using BvhN = Bvh<Node<T, D>>;   // D = 2: the `2f` / `2d` families of the C API (c_api/bvh.cpp:7-10)
 
 template <typename T, size_t D>
@@ -63,6 +67,7 @@ BvhN<T, D>* build(const T* bboxes, const T* centers, size_t n, int builder, int 
         }
     }
     typename DefaultBuilder<N>::Config cfg;
+    cfg.sah = SplitHeuristic<T>(g_sah_log_cluster, static_cast<T>(g_sah_cost_ratio));
     cfg.quality = static_cast<typename DefaultBuilder<N>::Quality>(quality);
     cfg.min_leaf_size = min_leaf;
     cfg.max_leaf_size = max_leaf;
@@ -301,6 +306,8 @@ extern "C" {
     } while (0)
 
 /* everything that exists for every dimension (D = 2: bboxes n x 4, centers n x 2, nodes 20/40 bytes, spheres n x 3, rays n x 6) */
+ORC_EXPORT void ref_set_sah(size_t log_cluster_size, double cost_ratio) { g_sah_log_cluster = log_cluster_size; g_sah_cost_ratio = cost_ratio; }
+
 #define REF_IMPL(T, D, S)                                                                               \
     ORC_EXPORT void* ref_build##S(const T* bboxes, const T* centers, size_t n, int builder,            \
         int quality, size_t min_leaf, size_t max_leaf, size_t par_threshold, int threads) {            \
@@ -336,6 +343,7 @@ extern "C" {
         for (size_t i = 0; i < n; ++i) for (size_t k = 0; k < 3; ++k) {                                  \
             bb[i].min[k] = bboxes[6 * i + k]; bb[i].max[k] = bboxes[6 * i + 3 + k]; cc[i][k] = centers[3 * i + k]; } \
         typename MiniTreeBuilder<Node3<T>>::Config cfg;                                                 \
+        cfg.sah = SplitHeuristic<T>(g_sah_log_cluster, static_cast<T>(g_sah_cost_ratio));               \
         cfg.min_leaf_size = min_leaf; cfg.max_leaf_size = max_leaf; cfg.enable_pruning = enable_pruning != 0; \
         cfg.pruning_area_ratio = static_cast<T>(pruning_area_ratio); cfg.parallel_threshold = par_threshold; \
         cfg.log2_grid_dim = log2_grid_dim;                                                              \

@@ -55,6 +55,7 @@ int main() {
     // DefaultBuilder(pool, High) == MiniTreeBuilder with pruning at 0.01 + ReinsertionOptimizer (default_builder.h:41-44, :65-73);
     // parallel_threshold = 1 keeps the two triangles on the mini-tree path instead of DefaultBuilder's serial fallback
     typename bvh::v2::DefaultBuilder<Node>::Config forced = config;
+    forced.sah = bvh::v2::SplitHeuristic<Scalar>(0, 1.f);                   // top_down_sah_builder.h:29, the default spelled out
     forced.parallel_threshold = 1;
     typename bvh::v2::MiniTreeBuilder<Node>::Config mini;
     mini.parallel_threshold = 1;

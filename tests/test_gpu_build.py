@@ -250,6 +250,47 @@ def test_reinsertion_optimizer_config(orc, dtype):
     assert gpu.serialize() == ref.serialize()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_split_heuristic_parameters(orc, dtype):
+    """TopDownSahBuilder::Config::sah = SplitHeuristic(log_cluster_size, cost_ratio) (split_heuristic.h:17-38) through every
+    builder: clusters of 2 / 4 / 8 primitives, cheap and expensive nodes, a negative ratio."""
+    import bvh_amd
+    from bvh_amd import SplitHeuristic as SH
+    tris = synth.sponza_proxy(20_000).astype(dtype)
+    bb, cc = orc.prep_tris(tris)
+    circ = synth.circles(5000, dtype=dtype)
+    b2, c2 = orc.sphere_bboxes(circ)
+    default = bvh_amd.SweepSahBuilder.build(bb, cc).serialize()
+    for log, ratio in ((1, 1.0), (2, 1.0), (3, 0.5), (0, 2.0), (0, 0.25), (2, 3.0), (0, -1.0)):
+        sah = SH(log, ratio)
+        orc.set_sah(log, ratio)
+        try:
+            for name, builder, quality in conftest_modes():
+                cfg = bvh_amd.Config(quality=bvh_amd.Quality(quality), sah=sah)
+                if builder == 2:
+                    gpu = bvh_amd.BinnedSahBuilder.build(bb, cc, cfg)
+                elif builder == 3:
+                    gpu = bvh_amd.SweepSahBuilder.build(bb, cc, cfg)
+                else:
+                    gpu = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=bvh_amd.ThreadPool() if builder == 1 else None)
+                assert gpu.serialize() == orc.build(bb, cc, builder=builder, quality=quality).serialize(), (name, log, ratio)
+                if builder == 3:
+                    assert gpu.serialize() != default           # the parameters do change the tree
+            gpu = bvh_amd.MiniTreeBuilder.build(bb, cc, bvh_amd.MiniTreeBuilder.Config(pruning_area_ratio=0.2, parallel_threshold=300, sah=sah))
+            assert gpu.serialize() == orc.build_minitree(bb, cc, pruning_area_ratio=0.2, parallel_threshold=300).serialize(), (log, ratio)
+            gpu = bvh_amd.DefaultBuilder.build(b2, c2, bvh_amd.Config(sah=sah))                         # 2D, serial High
+            assert gpu.serialize() == orc.build(b2, c2, quality=2).serialize(), ("2d", log, ratio)
+        finally:
+            orc.set_sah()
+    with pytest.raises(bvh_amd.BvhAmdError, match="log_cluster_size"):
+        bvh_amd.SweepSahBuilder.build(bb, cc, bvh_amd.Config(sah=SH(64, 1.0)))
+
+
+def conftest_modes():
+    from conftest import MODES
+    return MODES
+
+
 def test_minitree_threshold_and_clustered_input(orc):
     """A dense cluster puts most primitives into one grid cell (one big mini-tree) and parallel_threshold changes
     the merge; both must follow the reference."""
