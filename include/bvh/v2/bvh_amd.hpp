@@ -548,8 +548,9 @@ protected:
     }
 };
 
-template <typename Node>
-class BinnedSahBuilder : public TopDownSahBuilder<Node> {     // reference binned_sah_builder.h:32-38 (BinCount = 8)
+template <typename Node, size_t BinCount = 8>
+class BinnedSahBuilder : public TopDownSahBuilder<Node> {     // reference binned_sah_builder.h:18-38
+    static_assert(BinCount == 8, "bvh_amd: the device binned builder is written for the reference's default of 8 bins per axis");
     using Base = TopDownSahBuilder<Node>;
 public:
     using typename Base::Config;
