@@ -195,3 +195,46 @@ def test_fuzz_3d_spheres(orc, seed):
             same = (g["prim"] == want["prim"]) & ((g["t"].view(it) == want["t"].view(it)) | (np.isnan(g["t"]) & np.isnan(want["t"])))
             assert same.all(), (seed, any_hit, robust, int((~same).sum()))
             assert (cg.cpu().numpy().astype(np.uint64) == cw).all()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_configs(orc, seed):
+    """Every Config knob at once on adversarial scenes: SplitHeuristic, leaf limits, MiniTreeBuilder grid / pruning / threshold,
+    ReinsertionOptimizer batch ratio / iterations; float and double."""
+    import bvh_amd
+    rng = np.random.default_rng(9000 + seed)
+    dtype = np.float32 if seed % 2 else np.float64
+    kind = ("lattice", "dups", "flat", "points", "scales", "uniform")[seed % 6]
+    n = int(rng.choice([1, 2, 9, 64, 65, 300, 1500, 6000]))
+    tris = _scene3(rng, n, kind, dtype)
+    bb, cc = orc.prep_tris(tris)
+    log, ratio = int(rng.integers(0, 4)), float(rng.choice([1.0, 0.5, 2.0, 0.0, -0.5, 3.5]))
+    lim = [(1, 8), (1, 1), (2, 4), (3, 15), (1, 2)][int(rng.integers(0, 5))]
+    sah = bvh_amd.SplitHeuristic(log, ratio)
+    orc.set_sah(log, ratio)
+    try:
+        for builder, quality in ((2, 0), (3, 0), (0, 2), (1, 1), (1, 2)):
+            thr = int(rng.choice([1024, 64, 7]))
+            cfg = bvh_amd.Config(quality=bvh_amd.Quality(quality), min_leaf_size=lim[0], max_leaf_size=lim[1], parallel_threshold=thr, sah=sah)
+            if builder == 2:
+                gpu = bvh_amd.BinnedSahBuilder.build(bb, cc, cfg)
+            elif builder == 3:
+                gpu = bvh_amd.SweepSahBuilder.build(bb, cc, cfg)
+            else:
+                gpu = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=bvh_amd.ThreadPool() if builder == 1 else None)
+            ref = orc.build(bb, cc, builder=builder, quality=quality, min_leaf=lim[0], max_leaf=lim[1], parallel_threshold=thr)
+            assert gpu.serialize() == ref.serialize(), (seed, kind, n, builder, quality, lim, log, ratio, thr)
+        for _ in range(3):
+            mt = dict(min_leaf_size=lim[0], max_leaf_size=lim[1], enable_pruning=bool(rng.integers(0, 2)),
+                      pruning_area_ratio=float(rng.choice([0.01, 0.1, 0.5, 1.5, 0.0])), parallel_threshold=int(rng.choice([1024, 100, 8, 1, 0])),
+                      log2_grid_dim=int(rng.integers(1, 7)))
+            gpu = bvh_amd.MiniTreeBuilder.build(bb, cc, bvh_amd.MiniTreeBuilder.Config(sah=sah, **mt))
+            okw = {{"max_leaf_size": "max_leaf", "min_leaf_size": "min_leaf"}.get(k, k): v for k, v in mt.items()}
+            ref = orc.build_minitree(bb, cc, **okw)
+            assert gpu.serialize() == ref.serialize(), (seed, kind, n, mt, log, ratio)
+            br, it = float(rng.choice([0.05, 0.01, 0.3, 1.0, 2.5, 0.0])), int(rng.integers(0, 5))
+            gpu.optimize(batch_size_ratio=br, max_iter_count=it)
+            ref.optimize(batch_size_ratio=br, max_iter_count=it)
+            assert gpu.serialize() == ref.serialize(), (seed, kind, n, mt, "optimize", br, it)
+    finally:
+        orc.set_sah()

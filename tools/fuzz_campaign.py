@@ -17,7 +17,7 @@ for seed in range(lo, hi):
         except AssertionError as e:
             bad.append(("3d", seed, kind, str(e)[:200])); print("FAIL", bad[-1], flush=True)
     if time.time() - t0 > budget: break
-    for fn, name in ((F.test_fuzz_2d, "2d"), (F.test_fuzz_3d_spheres, "spheres")):
+    for fn, name in ((F.test_fuzz_2d, "2d"), (F.test_fuzz_3d_spheres, "spheres"), (F.test_fuzz_configs, "configs")):
         try:
             fn(orc, seed); ran += 1
         except AssertionError as e:
