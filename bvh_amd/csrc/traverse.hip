@@ -19,6 +19,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -472,7 +473,7 @@ int dispatch(const BvhImpl<T>& b, const TraceArgs<T>& args, unsigned flags, bool
 constexpr uint32_t kStepLds = 1024;            // stack entries held in LDS (deeper ones live in the context's HBM scratch)
 constexpr uint32_t kStepContinue = 0xFFFFFFFFu;
 constexpr uint32_t kStepEvents = 2048;
-constexpr uint32_t kStepHeader = 4;            // out[0] events, out[1] traversal finished, out[2] error, out[3] unused
+constexpr uint32_t kStepHeader = 4;            // out[0] events, out[1] traversal finished, out[2] error, out[3] launch number (written last)
 
 template <typename T>
 struct StepArgs {
@@ -485,6 +486,7 @@ struct StepArgs {
     uint32_t snap_words;
     uint32_t max_events;                       // <= kStepEvents
     uint32_t max_steps;                        // pairs in the tree: no walk visits a pair twice, a cyclic (malformed) tree would
+    uint32_t seq;                              // launch number, stored to out[3] once the log is complete (the host polls it)
     uint32_t any, record_pairs;
 };
 
@@ -580,7 +582,9 @@ __global__ void __launch_bounds__(kWave) ray_step_kernel(StepArgs<T> a) {
             snap_used += sp;
             ++n_events;
         }
-        a.out[0] = n_events; a.out[1] = finished; a.out[2] = error; a.out[3] = 0;
+        a.out[0] = n_events; a.out[1] = finished; a.out[2] = error;
+        // the log lives in fine-grained host memory: release it to the polling host without waiting for the kernel to retire
+        __hip_atomic_store(&a.out[3], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         s_sp = sp;
     }
     __syncthreads();
@@ -595,7 +599,9 @@ struct StepContext {                           // one per calling thread: the pe
     uint32_t* pinned = nullptr;
     uint32_t* scratch = nullptr;
     uint32_t stack_cap = 0, snap_words = 0;
+    uint32_t seq = 0;
     void release() {
+        if (stream) (void)hipStreamSynchronize(stream);
         if (pinned) (void)hipHostFree(pinned);
         if (scratch) (void)hipFree(scratch);
         if (stream) (void)hipStreamDestroy(stream);
@@ -608,7 +614,8 @@ struct StepContext {                           // one per calling thread: the pe
         BVH_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), BVH_AMD_ERR_HIP);
         snap_words = std::max<uint32_t>(16384u, 4 * cap);
         const size_t words = size_t{1} + cap + kStepHeader + 3 * size_t{kStepEvents} + snap_words;
-        BVH_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pinned), words * sizeof(uint32_t), hipHostMallocDefault), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pinned), words * sizeof(uint32_t), hipHostMallocCoherent), BVH_AMD_ERR_HIP);
+        std::memset(pinned, 0, words * sizeof(uint32_t));
         BVH_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), (size_t{1} + cap) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
         device = dev; stack_cap = cap;
         return BVH_AMD_OK;
@@ -726,10 +733,12 @@ int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bo
         if (v >= 1 && v < static_cast<long>(kStepEvents)) a.max_events = static_cast<uint32_t>(v);
     }
     for (int k = 0; k < 8; ++k) a.ray[k] = ray8[k];
+    static const bool poll = !(getenv("BVH_AMD_STEP_POLL") && atoi(getenv("BVH_AMD_STEP_POLL")) == 0);
     T tmax = ray8[7];
     in[0] = 1; in[1] = start;
     for (;;) {
         a.ray[7] = tmax;
+        a.seq = ++c.seq;
         if (b.dim == 2) {
             if (robust) hipLaunchKernelGGL((ray_step_kernel<T, true, 2>), dim3(1), dim3(kWave), 0, c.stream, a);
             else hipLaunchKernelGGL((ray_step_kernel<T, false, 2>), dim3(1), dim3(kWave), 0, c.stream, a);
@@ -738,7 +747,18 @@ int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bo
             else hipLaunchKernelGGL((ray_step_kernel<T, false, 3>), dim3(1), dim3(kWave), 0, c.stream, a);
         }
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(c.stream), BVH_AMD_ERR_HIP);
+        // Wait for the log: poll its launch number for a short while (a stream synchronisation costs more than a short walk),
+        // then fall back to blocking. The kernel may still be saving its stack when the number appears; the next launch is
+        // ordered behind it by the stream.
+        bool arrived = false;
+        if (poll) {
+            const auto give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(60);
+            for (uint32_t spin = 0; !arrived; ++spin) {
+                arrived = __atomic_load_n(&out[3], __ATOMIC_ACQUIRE) == a.seq;
+                if (!arrived && (spin & 31u) == 31u && std::chrono::steady_clock::now() > give_up) break;
+            }
+        }
+        if (!arrived) BVH_HIP_TRY(hipStreamSynchronize(c.stream), BVH_AMD_ERR_HIP);
         if (out[2]) return fail(BVH_AMD_ERR_OVERFLOW, out[2] == 2 ? "intersect_ray: the walk visited more pairs than the tree has (cyclic tree?)"
                                                                    : "intersect_ray: traversal stack overflow (malformed tree?)");
         const uint32_t n_events = out[0];
