@@ -559,7 +559,7 @@ int finish_build(BvhImpl<T>& out, DevBuf<HostNode<T>>& final_nodes, uint32_t* d_
     out.host_valid = false;
     int rc = relayout_on_device(out, final_nodes.p, stream);
     if (rc) return rc;
-    if (!out.d_work) BVH_HIP_TRY(hipMalloc(&out.d_work, 2 * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
+    if (!out.d_work) BVH_HIP_TRY(hipMalloc(&out.d_work, size_t{BvhImpl<T>::kWorkSlots} * BvhImpl<T>::kWorkStride * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
     if (out.d_prim_ids) { (void)hipFree(out.d_prim_ids); out.d_prim_ids = nullptr; }
     if (take_ids) out.d_prim_ids = d_ids;
     else {

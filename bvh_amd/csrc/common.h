@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/bvh_amd.h"
@@ -110,14 +111,14 @@ struct BvhImpl {
     // Deepest level of the tree (root = 0), computed lazily on the device by the first batch traversal after a (re)layout.
     // The traversal stack never holds more entries than that: trees up to 64 levels use LDS + per-lane scratch (the
     // reference's SmallStack<Index, 64>), deeper ones additionally spill to d_deep (its GrowingStack, stack.h:34-46).
-    mutable int max_depth = -1;
-    mutable uint32_t* d_deep = nullptr;
-    mutable size_t deep_words = 0;
-    // per-object scratch for batch launches
-    unsigned long long* d_work = nullptr;      // [0] ray counter, [1] status word
-    // scratch of the optional ray-coherence sort (BVH_AMD_RAY_SORTED): keys, order, two temporaries, histograms
-    mutable uint32_t* d_sort = nullptr;
-    mutable size_t sort_cap = 0;
+    // (the spill buffer and the scratch of the optional ray-coherence sort are stream-ordered allocations of each launch)
+    mutable std::atomic<int> max_depth{-1};
+    // Batch launches are re-entrant like the reference's Bvh::intersect on a const Bvh: every launch takes the next of
+    // kWorkSlots {ray ticket counter, status word} slots, so launches of one BVH issued from several threads / on several streams
+    // do not share a counter (up to kWorkSlots of them in flight at a time).
+    static constexpr uint32_t kWorkSlots = 64, kWorkStride = 8;        // slots of 64 bytes
+    unsigned long long* d_work = nullptr;      // kWorkSlots x kWorkStride words: [0] ray counter, [1] status word
+    mutable std::atomic<uint32_t> work_next{0};
     ~BvhImpl();
 };
 

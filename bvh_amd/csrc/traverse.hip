@@ -622,7 +622,6 @@ struct StepContext {                           // one per calling thread: the pe
     }
 };
 thread_local StepContext t_step;
-std::mutex g_depth_mutex;
 
 } // namespace
 
@@ -636,30 +635,36 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     if (!d_prims || !d_rays || !d_hits) return fail(BVH_AMD_ERR_ARG, "intersect_rays: null device pointer");
     if (b.node_count == 0 || !b.d_work) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device copy");
     if (b.pair_count && !b.d_pairs) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device nodes");
-    BVH_HIP_TRY(hipMemsetAsync(b.d_work, 0, 2 * sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
+    unsigned long long* work = b.d_work + size_t{b.work_next.fetch_add(1) % BvhImpl<T>::kWorkSlots} * BvhImpl<T>::kWorkStride;
+    BVH_HIP_TRY(hipMemsetAsync(work, 0, 2 * sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
     if (d_counters) BVH_HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream), BVH_AMD_ERR_HIP);
     TraceArgs<T> args;
     args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
-    args.n = n; args.work = b.d_work; args.counters = d_counters; args.root_index = b.root_index;
+    args.n = n; args.work = work; args.counters = d_counters; args.root_index = b.root_index;
     args.order = nullptr;
     args.deep = nullptr; args.deep_cap = 0;
+    // Scratch that only some launches need is allocated and freed in stream order (hipMallocAsync / hipFreeAsync), so that
+    // concurrent launches of one BVH never share it.
+    void* deep_mem = nullptr;
+    void* sort_mem = nullptr;
+    auto release = [&](int rc) {
+        if (deep_mem) (void)hipFreeAsync(deep_mem, stream);
+        if (sort_mem) (void)hipFreeAsync(sort_mem, stream);
+        return rc;
+    };
     {   // SmallStack<Index, 64> covers every tree of at most 64 levels; deeper trees get the GrowingStack equivalent
         int rc = tree_depth<T>(b, stream);
         if (rc) return rc;
-        if (b.max_depth > 64) {
+        const int max_depth = b.max_depth.load();
+        if (max_depth > 64) {
             int cus = 0;
             BVH_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device), BVH_AMD_ERR_HIP);
             const size_t lanes = size_t{8} * cus * kBlock;                   // persistent_grid launches at most 8 blocks per CU
-            const size_t cap = static_cast<size_t>(b.max_depth - 64 + 1);
+            const size_t cap = static_cast<size_t>(max_depth - 64 + 1);
             if (lanes * cap > (size_t{1} << 32))
-                return fail(BVH_AMD_ERR_UNSUPPORTED, "intersect_rays: the tree is too deep for the traversal stack (" + std::to_string(b.max_depth) + " levels)");
-            if (b.deep_words < lanes * cap) {
-                if (b.d_deep) (void)hipFree(b.d_deep);
-                b.d_deep = nullptr; b.deep_words = 0;
-                BVH_HIP_TRY(hipMalloc(&b.d_deep, lanes * cap * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
-                b.deep_words = lanes * cap;
-            }
-            args.deep = b.d_deep; args.deep_cap = static_cast<uint32_t>(cap);
+                return fail(BVH_AMD_ERR_UNSUPPORTED, "intersect_rays: the tree is too deep for the traversal stack (" + std::to_string(max_depth) + " levels)");
+            BVH_HIP_TRY(hipMallocAsync(&deep_mem, lanes * cap * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
+            args.deep = static_cast<uint32_t*>(deep_mem); args.deep_cap = static_cast<uint32_t>(cap);
         }
     }
     static const int refill_env = getenv("BVH_AMD_REFILL") ? atoi(getenv("BVH_AMD_REFILL")) : 0;   // tuning knobs
@@ -667,19 +672,15 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     args.refill_threshold = refill_env > 0 ? refill_env : kRefillThreshold;
     args.leaf_threshold = leaf_env > 0 ? leaf_env : kLeafThreshold;
     if (b.dim == 2) {                                         // Node<T, 2>: circles only (tri.h has no 2D intersector)
-        if (leaf_kind != LEAF_SPHERE) return fail(BVH_AMD_ERR_ARG, "intersect_rays: a 2D BVH traces circles (Sphere<T, 2>) only");
-        return dispatch<T, LEAF_SPHERE, 2>(b, args, flags, d_counters != nullptr, stream);
+        if (leaf_kind != LEAF_SPHERE) return release(fail(BVH_AMD_ERR_ARG, "intersect_rays: a 2D BVH traces circles (Sphere<T, 2>) only"));
+        return release(dispatch<T, LEAF_SPHERE, 2>(b, args, flags, d_counters != nullptr, stream));
     }
     if ((flags & BVH_AMD_RAY_SORTED) && n > 4096 && n < (size_t{1} << 31)) {
         const uint32_t n32 = static_cast<uint32_t>(n);
         const size_t words = 4 * n + radix_sort_hist_words(n32, 1);
-        if (b.sort_cap < words) {
-            if (b.d_sort) (void)hipFree(b.d_sort);
-            b.d_sort = nullptr; b.sort_cap = 0;
-            BVH_HIP_TRY(hipMalloc(&b.d_sort, words * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
-            b.sort_cap = words;
-        }
-        uint32_t *keys = b.d_sort, *vals = keys + n, *kt = vals + n, *vt = kt + n, *hist = vt + n;
+        hipError_t e = hipMallocAsync(&sort_mem, words * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return release(fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: hipMallocAsync: ") + hipGetErrorString(e)));
+        uint32_t *keys = static_cast<uint32_t*>(sort_mem), *vals = keys + n, *kt = vals + n, *vt = kt + n, *hist = vt + n;
         T lo[3], sc[3];
         for (int k = 0; k < 3; ++k) {
             const T ext = b.root_bounds[2 * k + 1] - b.root_bounds[2 * k];
@@ -689,11 +690,11 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2],
                            keys, vals);
         int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, 18, stream, hist);
-        if (rc) return rc;
+        if (rc) return release(rc);
         args.order = vals;
     }
-    if (leaf_kind == LEAF_TRIANGLE) return dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream);
-    return dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream);
+    if (leaf_kind == LEAF_TRIANGLE) return release(dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream));
+    return release(dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream));
 }
 
 
@@ -705,17 +706,14 @@ int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bo
 {
     if (!leaf_fn) return fail(BVH_AMD_ERR_ARG, "intersect_ray: null leaf callback");
     if (b.node_count == 0 || (b.pair_count && !b.d_pairs)) return fail(BVH_AMD_ERR_ARG, "intersect_ray: BVH has no device copy");
-    if (b.max_depth < 0) {                                    // first traversal of this layout: depth of the tree, once
-        std::lock_guard<std::mutex> lock(g_depth_mutex);
-        if (b.max_depth < 0) {
-            // the walk runs on this thread's own stream: whatever built or re-laid the tree on another stream must be done
-            BVH_HIP_TRY(hipDeviceSynchronize(), BVH_AMD_ERR_HIP);
-            int rc = tree_depth<T>(b, nullptr);
-            if (rc) return rc;
-        }
+    if (b.max_depth.load() < 0) {                             // first traversal of this layout: depth of the tree, once
+        // the walk runs on this thread's own stream: whatever built or re-laid the tree on another stream must be done
+        BVH_HIP_TRY(hipDeviceSynchronize(), BVH_AMD_ERR_HIP);
+        int rc = tree_depth<T>(b, nullptr);
+        if (rc) return rc;
     }
     // SmallStack<Index, 64> of bvh_impl.h:244 for every tree it can hold, as deep as the tree needs otherwise
-    const uint32_t cap = static_cast<uint32_t>(std::max(64, b.max_depth + 2));
+    const uint32_t cap = static_cast<uint32_t>(std::max(64, b.max_depth.load() + 2));
     StepContext& c = t_step;
     int rc = c.ensure(b.device, cap);
     if (rc) return rc;

@@ -1,6 +1,8 @@
 // Device copy of a reference-layout BVH: sibling pairs re-laid out as aligned PairNode records.
 #include "common.h"
 
+#include <mutex>
+
 namespace bvh_amd {
 
 namespace {
@@ -55,7 +57,10 @@ __global__ void __launch_bounds__(256) k_depth_jump(const uint32_t* anc, const u
 
 template <typename T>
 int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
-    if (b.max_depth >= 0) return BVH_AMD_OK;
+    if (b.max_depth.load() >= 0) return BVH_AMD_OK;
+    static std::mutex once;                                   // concurrent first traversals compute it once
+    std::lock_guard<std::mutex> lock(once);
+    if (b.max_depth.load() >= 0) return BVH_AMD_OK;
     if (b.pair_count == 0) { b.max_depth = 0; return BVH_AMD_OK; }
     const uint32_t n = static_cast<uint32_t>(b.pair_count);
     uint32_t* buf = nullptr;
@@ -90,11 +95,9 @@ BvhImpl<T>::~BvhImpl() {
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
         if (d_pairs) (void)hipFree(d_pairs);
-        if (d_deep) (void)hipFree(d_deep);
         if (d_prim_ids) (void)hipFree(d_prim_ids);
         if (d_work) (void)hipFree(d_work);
         if (d_nodes) (void)hipFree(d_nodes);
-        if (d_sort) (void)hipFree(d_sort);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
 }
@@ -166,7 +169,7 @@ int upload_bvh(BvhImpl<T>& b, hipStream_t stream) {
     if (b.nodes.size() >= (size_t{1} << 28) || b.prim_ids.size() >= (size_t{1} << 28))
         return fail(BVH_AMD_ERR_UNSUPPORTED, "upload: more than 2^28 nodes/primitives (32-bit device indices)");
     BVH_HIP_TRY(hipGetDevice(&b.device), BVH_AMD_ERR_HIP);
-    if (!b.d_work) BVH_HIP_TRY(hipMalloc(&b.d_work, 2 * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
+    if (!b.d_work) BVH_HIP_TRY(hipMalloc(&b.d_work, size_t{BvhImpl<T>::kWorkSlots} * BvhImpl<T>::kWorkStride * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
     b.root_index = static_cast<uint32_t>(b.nodes[0].index);
 
     HostNode<T>* d_nodes = nullptr;

@@ -302,7 +302,8 @@ BVH_AMD_API int bvh_amd_shade_eyelight3d(const double* d_tris12, const struct bv
 
 /* ---- batched traversal: Bvh::intersect<IsAnyHit, IsRobust> (bvh.h:160-182) for n rays ---------- */
 /* d_prims are in BVH order (prims[i] belongs to prim_ids[i]), like the reference's permuted
- * primitives (test/simple_example.cpp:57-65). d_counters may be NULL. */
+ * primitives (test/simple_example.cpp:57-65). d_counters may be NULL. Re-entrant like Bvh::intersect on a const Bvh: launches
+ * of one BVH may be issued concurrently from several host threads and on several streams (up to 64 in flight per BVH). */
 BVH_AMD_API int bvh3f_intersect_rays_tri(const struct bvh3f*, const float* d_tris12, const struct bvh_ray3f* d_rays,
     size_t n, unsigned flags, struct bvh_hit3f* d_hits, struct bvh_amd_counters* d_counters, void* stream);
 BVH_AMD_API int bvh3d_intersect_rays_tri(const struct bvh3d*, const double* d_tris12, const struct bvh_ray3d* d_rays,

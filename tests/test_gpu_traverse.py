@@ -232,3 +232,43 @@ def test_trees_deeper_than_the_small_stack(orc, depth):
             assert bvh_amd.hits_to_numpy(got).tobytes() == want.tobytes(), (depth, any_hit, robust)
             assert (cg.cpu().numpy().astype(np.uint64) == cw).all()
     assert int((want["prim"] != oracle.INVALID).sum()) > 10_000
+
+
+def test_concurrent_batches_on_one_bvh(orc):
+    """Bvh::intersect on a const Bvh is re-entrant in the reference (SURVEY.md 8b): batch launches of ONE device BVH issued from
+    several host threads on several streams must not share a ray counter or scratch (work-slot ring, stream-ordered scratch)."""
+    import threading
+    import torch
+    import bvh_amd
+    tris = synth.sponza_proxy(30_000)
+    bb, cc = bvh_amd.tri_bounds(tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+    prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+    obb, occ = orc.prep_tris(tris)
+    ob = orc.build(obb, occ, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_MEDIUM)
+    oprims = orc.precompute_tris(tris, ob.prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    n_threads, rounds = 6, 8
+    rays = [synth.rays_closest(200_000, lo, hi, seed=100 + k) for k in range(n_threads)]
+    want = [ob.intersect_tri(oprims, r, 0, 1, threads=8) for r in rays]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                d_rays = torch.from_numpy(rays[k]).cuda()
+                for i in range(rounds):
+                    hits = bvh_amd.intersect(bvh, prims, d_rays, any_hit=False, robust=True, sort_rays=(i % 2 == 1))
+                    stream.synchronize()
+                    if bvh_amd.hits_to_numpy(hits).tobytes() != want[k].tobytes():
+                        errors.append((k, i))
+        except Exception as exc:                              # noqa: BLE001
+            errors.append((k, repr(exc)))
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
