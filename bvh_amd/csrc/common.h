@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <string>
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "../../include/bvh_amd.h"
@@ -88,14 +89,15 @@ struct BvhImpl {
     // lazily from d_nodes / d_prim_ids by sync_host(): GPU-resident workflows never pay the device-to-host copy.
     mutable std::vector<HostNode<T>> nodes;
     mutable std::vector<size_t> prim_ids;
-    mutable bool host_valid = true;
+    mutable std::atomic<bool> host_valid{true};
+    mutable std::mutex host_mutex;             // the lazy fill below may be triggered by concurrent const accessors (bvhXX_get_prim_id in callbacks)
     size_t node_count = 0, prim_count = 0;
     // 3, or 2 for the `2f` / `2d` families (Node<T, 2>): everything on the device stays three wide with z = 0 (inert), only the
     // decisions (half area, widest axis, split candidates, slab test, circle test) know the dimension. The host mirror of
     // a 2D BVH is `nodes2` in the reference's 20/40-byte layout; `nodes` then only stages transfers.
     int dim = 3;
     mutable std::vector<HostNode2<T>> nodes2;
-    mutable bool nodes2_valid = false;         // nodes2 mirrors `nodes` (it goes stale whenever `nodes` is refreshed from the device)
+    mutable std::atomic<bool> nodes2_valid{false};         // nodes2 mirrors `nodes` (it goes stale whenever `nodes` is refreshed from the device)
     int sync_host2() const;                    // sync_host() + nodes -> nodes2
     void widen_host() const;                   // nodes2 -> nodes (z = 0): the caller may have edited nodes2 through bvh_node2X pointers
     HostNode<T>* d_nodes = nullptr;            // reference-layout nodes resident in HBM (device builds)

@@ -104,7 +104,9 @@ BvhImpl<T>::~BvhImpl() {
 
 template <typename T>
 int BvhImpl<T>::sync_host() const {
-    if (host_valid) return BVH_AMD_OK;
+    if (host_valid.load(std::memory_order_acquire)) return BVH_AMD_OK;
+    std::lock_guard<std::mutex> lock(host_mutex);
+    if (host_valid.load(std::memory_order_acquire)) return BVH_AMD_OK;
     int cur = -1;
     BVH_HIP_TRY(hipGetDevice(&cur), BVH_AMD_ERR_HIP);
     if (cur != device) BVH_HIP_TRY(hipSetDevice(device), BVH_AMD_ERR_HIP);
@@ -115,7 +117,8 @@ int BvhImpl<T>::sync_host() const {
     if (cur != device) (void)hipSetDevice(cur);
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("sync_host: ") + hipGetErrorString(e));
     prim_ids.assign(ids.begin(), ids.end());
-    host_valid = true;
+    nodes2_valid.store(false);                                // a 2D mirror, if any, is stale now
+    host_valid.store(true, std::memory_order_release);
     return BVH_AMD_OK;
 }
 
@@ -135,16 +138,17 @@ int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t st
 
 template <typename T>
 int BvhImpl<T>::sync_host2() const {
-    const bool was_valid = host_valid;
     int rc = sync_host();
     if (rc) return rc;
-    if (!nodes2_valid || !was_valid) {
+    if (nodes2_valid.load(std::memory_order_acquire)) return BVH_AMD_OK;
+    std::lock_guard<std::mutex> lock(host_mutex);
+    if (!nodes2_valid.load(std::memory_order_acquire)) {
         nodes2.resize(nodes.size());
         for (size_t i = 0; i < nodes.size(); ++i) {
             for (int k = 0; k < 4; ++k) nodes2[i].bounds[k] = nodes[i].bounds[k];
             nodes2[i].index = nodes[i].index;
         }
-        nodes2_valid = true;
+        nodes2_valid.store(true, std::memory_order_release);
     }
     return BVH_AMD_OK;
 }

@@ -24,7 +24,7 @@ def _compile_c(out):
     lib = os.path.join(ROOT, "bvh_amd", "lib")
     cmd = ["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "c", "ray_callback.c"), "-L", lib, "-lbvh_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib",
-           "-lm", "-o", out]
+           "-lm", "-lpthread", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out
@@ -68,13 +68,14 @@ def test_callback_programs_compile_and_fail_loudly_without_a_gpu(tmp_path):
         assert r.returncode != 0 and "no ROCm-capable device" in r.stderr
 
 
-CASES = [("3f", "closest", 0), ("3f", "closest", 1), ("3f", "any", 0), ("3d", "closest", 1), ("3d", "any", 1),
-         ("2f", "closest", 0), ("2f", "any", 1), ("2d", "closest", 1)]
+CASES = [("3f", "closest", 0, 1), ("3f", "closest", 1, 1), ("3f", "any", 0, 1), ("3d", "closest", 1, 1), ("3d", "any", 1, 1),
+         ("2f", "closest", 0, 1), ("2f", "any", 1, 1), ("2d", "closest", 1, 1),
+         ("3f", "closest", 1, 8), ("2d", "any", 0, 5)]          # several host threads through one bvh
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("family,mode,robust", CASES)
-def test_c_callback_api_matches_oracle(tmp_path, orc, family, mode, robust):
+@pytest.mark.parametrize("family,mode,robust,threads", CASES)
+def test_c_callback_api_matches_oracle(tmp_path, orc, family, mode, robust, threads):
     import oracle
     exe = _compile_c(str(tmp_path / "ray_callback"))
     dt = np.float32 if family[1] == "f" else np.float64
@@ -95,7 +96,7 @@ def test_c_callback_api_matches_oracle(tmp_path, orc, family, mode, robust):
         want, cnt = ob.intersect_sphere(prims[ob.prim_ids().astype(np.int64)], rays, any_hit, robust, counters=True)
     inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
     inp.write_bytes(np.array([len(prims), m], dtype=np.uint64).tobytes() + prims.tobytes() + rays.tobytes())
-    r = subprocess.run([exe, family, mode, str(robust), str(inp), str(outp)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, family, mode, str(robust), str(inp), str(outp), str(threads)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = outp.read_bytes()
     got = np.frombuffer(raw[:16 * m], dtype=[("prim", "<i8"), ("t", "<f8")])

@@ -24,8 +24,8 @@ for scene, tris in (("sponza_proxy 262144", synth.sponza_proxy(262144)), ("soup 
     inp = os.path.join(tmp, "in.bin")
     with open(inp, "wb") as f:
         f.write(np.array([len(tris), m], dtype=np.uint64).tobytes() + tris.tobytes() + rays.tobytes())
-    for mode in ("closest", "any"):
-        r = subprocess.run([exe, "3f", mode, "0", inp, os.path.join(tmp, "out.bin")], capture_output=True, text=True)
+    for mode, threads in (("closest", 1), ("any", 1), ("closest", 8), ("closest", 32)):
+        r = subprocess.run([exe, "3f", mode, "0", inp, os.path.join(tmp, "out.bin"), str(threads)], capture_output=True, text=True)
         print(f"{scene:22s} {mode:8s} per-ray callback API: {r.stdout.strip()} {r.stderr.strip()}", flush=True)
     bb, cc = bvh_amd.tri_bounds(tris)
     bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(), thread_pool=bvh_amd.ThreadPool())
