@@ -117,3 +117,27 @@ def test_minitree_builder_direct_matches_reference(orc, ref):
         t = synth.soup(n, jitter=0.05)
         b2, c2 = ref.prep_tris(t)
         assert ref.build_minitree(b2, c2, threads=2).serialize() == orc.build_minitree(b2, c2).serialize(), n
+
+
+def test_split_heuristic_and_optimizer_config_match_reference(orc, ref):
+    """TopDownSahBuilder::Config::sah (split_heuristic.h:17-38) through every builder, and ReinsertionOptimizer::Config
+    (reinsertion_optimizer.h:18-24): the restatement against the compiled reference."""
+    tris = synth.sponza_proxy(20000)
+    bb, cc = ref.prep_tris(tris)
+    for log, ratio in ((1, 1.0), (3, 0.5), (0, 2.0), (2, 3.0), (0, -1.0)):
+        orc.set_sah(log, ratio)
+        ref.set_sah(log, ratio)
+        try:
+            for builder, quality in ((2, 0), (3, 0), (0, 2), (1, 0), (1, 2)):
+                assert ref.build(bb, cc, builder=builder, quality=quality, threads=2).serialize() == \
+                    orc.build(bb, cc, builder=builder, quality=quality).serialize(), (log, ratio, builder, quality)
+            assert ref.build_minitree(bb, cc, threads=2, pruning_area_ratio=0.2, parallel_threshold=300).serialize() == \
+                orc.build_minitree(bb, cc, pruning_area_ratio=0.2, parallel_threshold=300).serialize(), (log, ratio)
+        finally:
+            orc.set_sah()
+            ref.set_sah()
+    for ratio, iters in ((0.01, 1), (0.2, 2), (1.0, 1), (3.0, 2), (0.0, 4), (0.5, 0), (0.3, 7)):
+        a, b = ref.build(bb, cc, quality=1), orc.build(bb, cc, quality=1)
+        a.optimize(threads=2, batch_size_ratio=ratio, max_iter_count=iters)
+        b.optimize(batch_size_ratio=ratio, max_iter_count=iters)
+        assert a.serialize() == b.serialize(), (ratio, iters)
