@@ -457,6 +457,31 @@ struct Bvh {
                                                             wants_inner ? &Visit::on_inner : nullptr), "intersect_ray_visit");
     }
 
+    // Bvh::traverse_bottom_up (reference bvh.h:76-78, :185-208) with arbitrary host functors: a host-side utility over the
+    // mirror's nodes (user code runs per node, so there is nothing to offload; the library's own bottom-up pass, refit, is a
+    // device kernel). Leaves are visited by descending node index; an inner node right after its second child.
+    template <typename LeafFn = IgnoreArgs, typename InnerFn = IgnoreArgs>
+    void traverse_bottom_up(LeafFn&& leaf_fn = {}, InnerFn&& inner_fn = {}) {
+        std::vector<size_t> parent_of(nodes.size(), 0);
+        std::vector<unsigned char> pending(nodes.size(), 0);   // children of an inner node not visited yet
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            if (nodes[i].is_leaf()) continue;
+            const size_t first = nodes[i].index.first_id();
+            parent_of[first] = parent_of[first + 1] = i;
+            pending[i] = 2;
+        }
+        for (size_t i = nodes.size(); i-- > 0;) {
+            if (!nodes[i].is_leaf()) continue;
+            leaf_fn(nodes[i]);
+            for (size_t up = i; up != 0;) {
+                up = parent_of[up];
+                if (--pending[up] != 0) break;
+                inner_fn(nodes[up]);
+            }
+        }
+        device_.reset();                                      // the functors may have edited the nodes
+    }
+
     // Bvh::serialize / deserialize (reference bvh.h:221-243): counts, nodes, primitive ids, all as IndexType; the same byte
     // stream bvhXX_save / bvhXX_serialize of the C-ABI produce
     template <typename IndexType = typename Index::Type>

@@ -13,6 +13,7 @@
 #include <fstream>
 #include <iostream>
 #include <optional>
+#include <cstdlib>
 #include <sstream>
 
 using Scalar = float;
@@ -83,6 +84,27 @@ int main(int argc, char** argv) {
     if (!(*other == bvh) || leaves == 0) { std::cerr << "refit(leaf_fn) changed a consistent tree" << std::endl; return 1; }
     other->refit([](Node& leaf) { auto b = leaf.get_bbox(); b.min[2] -= 1; leaf.set_bbox(b); });
     if (other->get_root().get_bbox().min[2] != 0) { std::cerr << "refit(leaf_fn) did not propagate" << std::endl; return 1; }
+
+    // traverse_bottom_up: every node once, children before parents; a refit written with it equals Bvh::refit
+    {
+        std::vector<int> order(bvh.nodes.size(), -1);
+        int clock = 0;
+        size_t n_leaves = 0, n_inner = 0;
+        std::istringstream again(mine);
+        bvh::v2::StdInputStream again_in(again);
+        Bvh copy = Bvh::deserialize(again_in);
+        copy.traverse_bottom_up(
+            [&](Node& leaf) { order[static_cast<size_t>(&leaf - copy.nodes.data())] = clock++; ++n_leaves; },
+            [&](Node& inner) {
+                const size_t id = static_cast<size_t>(&inner - copy.nodes.data()), first = inner.index.first_id();
+                if (order[first] < 0 || order[first + 1] < 0) { std::cerr << "parent before child" << std::endl; std::exit(1); }
+                order[id] = clock++; ++n_inner;
+                inner.set_bbox(copy.nodes[first].get_bbox().extend(copy.nodes[first + 1].get_bbox()));
+            });
+        if (n_leaves + n_inner != copy.nodes.size() || order[0] != clock - 1 || !(copy == bvh)) {
+            std::cerr << "traverse_bottom_up did not visit the tree bottom-up" << std::endl; return 1;
+        }
+    }
 
     bvh::v2::GrowingStack<Node::Index> stack;
     stack.push(bvh.get_root().index);
