@@ -127,3 +127,41 @@ def test_two_rank_broadcast_and_sharding_gloo(tmp_path):
             break
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()      # (stdout of two ranks can interleave)
+
+
+def test_ctypes_structures_match_the_c_header(tmp_path):
+    """Every struct the Python binding passes by pointer has the size and field offsets gcc gives the header's declaration
+    (the C-ABI is plain C: compiled here as C11, no HIP)."""
+    import ctypes as C
+    from bvh_amd import _lib, api
+    Visitor, _, _ = _lib.ray_visitor_types("3f")
+    pairs = [("bvh_build_config", _lib.BuildConfig, ["quality", "min_leaf_size", "max_leaf_size", "parallel_threshold"]),
+             ("bvh_amd_counters", _lib.Counters, ["node_pairs", "prim_tests", "leaves"]),
+             ("bvh_amd_minitree_config", _lib.MiniTreeConfig, ["min_leaf_size", "max_leaf_size", "enable_pruning", "pruning_area_ratio",
+                                                               "parallel_threshold", "log2_grid_dim", "log_cluster_size", "cost_ratio"]),
+             ("bvh_amd_sah_config", _lib.SahConfig, ["log_cluster_size", "cost_ratio"]),
+             ("bvh_amd_optimize_config", _lib.OptimizeConfig, ["batch_size_ratio", "max_iter_count"]),
+             ("bvh_amd_ray_visitorf", Visitor, ["user_data", "leaf_fn", "inner_fn"])]
+    src = ["#include <bvh/v2/c_api/bvh.h>", "#include <stddef.h>", "#include <stdio.h>", "int main(void) {"]
+    for name, _, fields in pairs:
+        src.append(f'    printf("{name} %zu", sizeof(struct {name}));')
+        for f in fields:
+            src.append(f'    printf(" %zu", offsetof(struct {name}, {f}));')
+        src.append('    printf("\\n");')
+    for name, size in (("bvh_bbox3f", 24), ("bvh_bbox3d", 48), ("bvh_bbox2f", 16), ("bvh_bbox2d", 32), ("bvh_ray3f", 32), ("bvh_ray3d", 64),
+                       ("bvh_ray2f", 24), ("bvh_ray2d", 48), ("bvh_hit3f", 16), ("bvh_hit3d", 32)):
+        src.append(f'    _Static_assert(sizeof(struct {name}) == {size}, "{name}");')
+    src += ["    return 0;", "}"]
+    c_file = tmp_path / "layout.c"
+    c_file.write_text("\n".join(src) + "\n")
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c_file), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(lines) == len(pairs)
+    for line, (name, cls, fields) in zip(lines, pairs):
+        got = line.split()
+        assert got[0] == name and int(got[1]) == C.sizeof(cls), (name, got[1], C.sizeof(cls))
+        assert [int(x) for x in got[2:]] == [getattr(cls, f).offset for f in fields], name
+    assert api.HITF.itemsize == 16 and api.HITD.itemsize == 32 and api.NODEF.itemsize == 28 and api.NODED.itemsize == 56
+    assert api.NODE2F.itemsize == 20 and api.NODE2D.itemsize == 40
