@@ -7,10 +7,12 @@
 //     auto bvh = bvh::v2::DefaultBuilder<Node>::build(pool, bboxes, centers, config);     // reference default_builder.h:33
 //     bvh.nodes, bvh.prim_ids, bvh.get_root().index ...                                     // reference bvh.h:17-89
 //
-// and runs the build on the MI355X (hand-written HIP kernels behind the C-ABI of include/bvh_amd.h). What differs:
-// the reference's per-ray `Bvh::intersect(ray, ..., leaf_fn)` takes a host lambda per leaf and cannot run on a GPU;
-// its batched equivalent is `bvh::v2::amd::intersect_batch<IsAnyHit, IsRobust>(bvh, prims, rays, hits)` with the
-// reference's own leaf intersectors (PrecomputedTri / Sphere<T, 3> / Sphere<T, 2>). Node<T, 2> is served by the `2f` / `2d`
+// and runs the build on the MI355X (hand-written HIP kernels behind the C-ABI of include/bvh_amd.h). The reference's per-ray
+// `Bvh::intersect(ray, start, stack, leaf_fn, inner_fn)` keeps working (the walk runs on the device, the lambdas on the calling
+// thread, in the reference's order), at kernel launches per ray; what to adopt for throughput is its batched equivalent
+// `bvh::v2::amd::intersect_batch<IsAnyHit, IsRobust>(bvh, prims, rays, hits)` with the reference's own leaf intersectors
+// (PrecomputedTri / Sphere<T, 3> / Sphere<T, 2>). The reference's example programs compile against these headers unchanged
+// (oracle/Makefile `refprogs`). Node<T, 2> is served by the `2f` / `2d`
 // families of the C-ABI (serial builders; the reference's thread-pool build of 2D data is undefined above parallel_threshold).
 // Layouts are bit-compatible with the reference (Vec, BBox, Ray, Node: SURVEY.md §8 sizes), which is what lets the
 // C-ABI take these arrays as they are. Errors throw bvh::v2::amd::Error (the reference has no error channel).
