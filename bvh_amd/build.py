@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "bvh_amd.h")]
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))) + [os.path.join(os.path.dirname(HERE), "include", "bvh_amd.h")]
     jobs = []
     for s in srcs:
         o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")

@@ -17,6 +17,7 @@
 // Compiled with -ffp-contract=off; division and sqrt are the correctly rounded forms.
 
 #include "common.h"
+#include "compact_pair.h"
 
 #include <algorithm>
 #include <chrono>
@@ -171,211 +172,25 @@ __device__ inline void wave_sync() {
 // Deep = true (trees of more than 64 levels only): stack entries beyond the 64 of SmallStack spill to HBM (GrowingStack).
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3, bool Deep = false>
 __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
-    constexpr int kDepth = kLdsDepth;
-    constexpr int kSpill = 64 - kDepth;            // kDepth + kSpill = 64 = the reference's SmallStack capacity
-    __shared__ uint32_t lds_stack[kDepth * kBlock];
-    uint32_t spill[kSpill];
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const uint64_t lanes_below = (uint64_t{1} << lane) - 1;
+#define BVH_TRACE_COMPACT 0
+#include "trace_body.inc"
+#undef BVH_TRACE_COMPACT
+}
 
-    // per-slot ray state
-    bool have = false, done = false, drained = false, overflow = false;
-    unsigned long long ray_id = 0;
-    T org[3], dir[3], inv[3], aux[3];            // aux = inv_dir_pad (robust) or inv_org (fast)
-    T tmin = 0, tmax = 0;
-    uint32_t oct[3] = {0, 0, 0};
-    uint32_t top = 0, sp = 0;
-    uint32_t hit_prim = BVH_AMD_INVALID;
-    T hit_t = 0, hit_u = 0, hit_v = 0;
-    unsigned long long n_pairs = 0, n_tests = 0, n_leaves = 0;
-
-    // (launch_traverse sizes `deep` from the depth of the tree, so `overflow` is a cannot-happen guard)
-    // launch_traverse knows the depth of the tree: the variant without Deep only ever runs on trees of at most 64 levels, whose
-    // stack cannot exceed the 64 entries of LDS + scratch, so its push/pop carry no overflow bookkeeping (the clamp only keeps
-    // a malformed, e.g. cyclic, user-supplied tree from writing outside the scratch array). Deep: entries beyond 64 live in HBM
-    // (the address of the deep slot is formed inside the cold branch: nothing about it stays live in the hot loop).
-    auto deep_slot = [&](uint32_t i) { return a.deep + (size_t{blockIdx.x} * kBlock + tid) * a.deep_cap + i; };
-    auto push = [&](uint32_t v) {
-        if (sp < kDepth) lds_stack[sp * kBlock + tid] = v;
-        else if (!Deep) spill[min(sp - kDepth, static_cast<uint32_t>(kSpill - 1))] = v;
-        else if (sp < kDepth + kSpill) spill[sp - kDepth] = v;
-        else if (sp - (kDepth + kSpill) < a.deep_cap) *deep_slot(sp - (kDepth + kSpill)) = v;
-        else overflow = true;
-        ++sp;
-    };
-    auto pop = [&]() -> uint32_t {
-        --sp;
-        if (sp < kDepth) return lds_stack[sp * kBlock + tid];
-        if (!Deep) return spill[min(sp - kDepth, static_cast<uint32_t>(kSpill - 1))];
-        if (sp < kDepth + kSpill) return spill[sp - kDepth];
-        if (sp - (kDepth + kSpill) < a.deep_cap) return *deep_slot(sp - (kDepth + kSpill));
-        return 0u;
-    };
-
-    for (;;) {
-        // ---- refill idle slots with new rays (one atomic per wave) --------------------------------
-        const uint64_t idle = __ballot(!have);
-        const int n_idle = __popcll(idle);
-        if (!drained && (n_idle >= a.refill_threshold || n_idle == kWave)) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(a.work, static_cast<unsigned long long>(n_idle));
-            base = __shfl(base, 0);
-            if (base + n_idle >= a.n) drained = true;
-            if (!have) {
-                const unsigned long long ticket = base + __popcll(idle & lanes_below);
-                if (ticket < a.n) {
-                    const unsigned long long my = a.order ? a.order[ticket] : ticket;
-                    T r[8];
-                    if (D == 3) load_ray(a.rays + 8 * my, r);
-                    else {
-                        T q[6];
-                        load_ray2(a.rays + 6 * my, q);
-                        r[0] = q[0]; r[1] = q[1]; r[2] = T(0); r[3] = q[2]; r[4] = q[3]; r[5] = T(0); r[6] = q[4]; r[7] = q[5];
-                    }
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {                       // bvh.h:162-165, ray.h:29-48
-                        org[k] = r[k]; dir[k] = r[3 + k];
-                        T d = dir[k];
-                        T iv = Robust ? T(1) / d
-                                      : (Num<T>::abs_(d) <= Num<T>::kEps ? Num<T>::copysign_(Num<T>::kMax, d) : T(1) / d);
-                        inv[k] = iv;
-                        aux[k] = Robust ? (Num<T>::finite(iv) ? Num<T>::bump2(iv) : iv) : (-iv) * org[k];
-                        oct[k] = Num<T>::sign(d) ? 1u : 0u;
-                    }
-                    tmin = r[6]; tmax = r[7];
-                    ray_id = my;
-                    have = true; done = false;
-                    sp = 0;
-                    top = a.root_index;                                 // bvh.h:128-131: push(start); pop()
-                    hit_prim = BVH_AMD_INVALID; hit_t = tmax; hit_u = 0; hit_v = 0;
-                }
-            }
-        }
-        if (__ballot(have) == 0) break;
-
-        // ---- inner nodes (bvh.h:132-150) ------------------------------------------------------------
-        // All lanes step together; a lane that reaches a leaf (or finishes) parks. The loop is left as soon as
-        // enough lanes are parked at leaves, so the leaf code runs for many lanes at once without anyone waiting
-        // for the slowest descent (the order of operations of each ray is unchanged).
-        for (;;) {
-            const bool inner = have && !done && (top & kCountMask) == 0;
-            const uint64_t inner_mask = __ballot(inner);
-            if (!inner_mask) break;
-            const int parked = __popcll(__ballot(have && !done && (top & kCountMask) != 0));
-            if (parked >= a.leaf_threshold) break;        // (also leaving to refill when most lanes are idle was measured: no gain)
-            T lb[6], rb[6];
-            uint32_t li = 0, ri = 0;
-            if (inner) {
-                load_pair(a.pairs + (top >> (kCountBits + 1)), lb, rb, li, ri);
-                if (Stats) ++n_pairs;
-                T l0 = tmin, l1 = tmax, r0 = tmin, r1 = tmax;               // node.h:105-117
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const T ln = oct[k] ? lb[2 * k + 1] : lb[2 * k], lf = oct[k] ? lb[2 * k] : lb[2 * k + 1];
-                    const T rn = oct[k] ? rb[2 * k + 1] : rb[2 * k], rf = oct[k] ? rb[2 * k] : rb[2 * k + 1];
-                    T la, lz, ra, rz;
-                    if (Robust) {                                           // node.h:74-75
-                        la = (ln - org[k]) * inv[k]; lz = (lf - org[k]) * aux[k];
-                        ra = (rn - org[k]) * inv[k]; rz = (rf - org[k]) * aux[k];
-                    } else {                                                // node.h:85-86
-                        la = Num<T>::fma_(ln, inv[k], aux[k]); lz = Num<T>::fma_(lf, inv[k], aux[k]);
-                        ra = Num<T>::fma_(rn, inv[k], aux[k]); rz = Num<T>::fma_(rf, inv[k], aux[k]);
-                    }
-                    l0 = pick_max(la, l0); l1 = pick_min(lz, l1);
-                    r0 = pick_max(ra, r0); r1 = pick_min(rz, r1);
-                }
-                const bool hl = l0 <= l1, hr = r0 <= r1;                    // bvh.h:177-180
-                if (hl) {
-                    uint32_t near_i = li;
-                    if (hr) {
-                        uint32_t far_i = ri;
-                        if (!Any && l0 > r0) { near_i = ri; far_i = li; }
-                        push(far_i);
-                    }
-                    top = near_i;
-                } else if (hr) {
-                    top = ri;
-                } else if (sp == 0) {
-                    done = true;
-                } else {
-                    top = pop();
-                }
-            }
-        }
-
-        // ---- leaf (bvh.h:152-155 + test/benchmark.cpp:281-291) ------------------------------------------
-        if (have && !done && (top & kCountMask) != 0) {
-            const uint32_t first = top >> kCountBits, count = top & kCountMask;
-            if (Stats) ++n_leaves;
-            for (uint32_t i = first; i < first + count; ++i) {
-                if (Stats) ++n_tests;
-                if (Leaf == LEAF_TRIANGLE) {                            // tri.h:56-74
-                    T p[12];
-                    load_prim12(a.prims + 12ull * i, p);
-                    const T c0 = p[0] - org[0], c1 = p[1] - org[1], c2 = p[2] - org[2];
-                    const T rx = dir[1] * c2 - dir[2] * c1, ry = dir[2] * c0 - dir[0] * c2, rz = dir[0] * c1 - dir[1] * c0;
-                    const T inv_det = T(1) / dot3(p[9], p[10], p[11], dir[0], dir[1], dir[2]);
-                    const T u = dot3(rx, ry, rz, p[6], p[7], p[8]) * inv_det;
-                    const T v = dot3(rx, ry, rz, p[3], p[4], p[5]) * inv_det;
-                    const T w = T(1) - u - v;
-                    const T tol = -Num<T>::kEps;
-                    if (u >= tol && v >= tol && w >= tol) {
-                        const T t = dot3(p[9], p[10], p[11], c0, c1, c2) * inv_det;
-                        if (t >= tmin && t <= tmax) { tmax = t; hit_t = t; hit_u = u; hit_v = v; hit_prim = i; }
-                    }
-                } else {                                                // sphere.h:32-49
-                    T qa, qb, qc;
-                    if (D == 3) {
-                        T s[4];
-                        load_prim4(a.prims + 4ull * i, s);
-                        const T o0 = org[0] - s[0], o1 = org[1] - s[1], o2 = org[2] - s[2];
-                        qa = dot3(dir[0], dir[1], dir[2], dir[0], dir[1], dir[2]);
-                        qb = T(2) * dot3(dir[0], dir[1], dir[2], o0, o1, o2);
-                        qc = dot3(o0, o1, o2, o0, o1, o2) - s[3] * s[3];
-                    } else {                                            // Sphere<T, 2>: {center[2], radius}
-                        const T* s = a.prims + 3ull * i;
-                        const T o0 = org[0] - s[0], o1 = org[1] - s[1];
-                        qa = dot2(dir[0], dir[1], dir[0], dir[1]);
-                        qb = T(2) * dot2(dir[0], dir[1], o0, o1);
-                        qc = dot2(o0, o1, o0, o1) - s[2] * s[2];
-                    }
-                    const T delta = qb * qb - T(4) * qa * qc;
-                    if (delta >= 0) {
-                        const T iv = -T(0.5) / qa;
-                        const T root = Num<T>::sqrt_(delta);
-                        const T t0 = pick_max((qb + root) * iv, tmin);
-                        const T t1 = pick_min((qb - root) * iv, tmax);
-                        if (t0 <= t1) { tmax = t0; hit_t = t0; hit_u = t1; hit_v = 0; hit_prim = i; }
-                    }
-                }
-            }
-            if (Any && hit_prim != BVH_AMD_INVALID) done = true;
-            else if (sp == 0) done = true;
-            else top = pop();
-        }
-
-        // ---- retire finished rays --------------------------------------------------------------------
-        if (have && done) {
-            store_hit(a.hits + ray_id, hit_prim, hit_t, hit_u, hit_v);
-            have = false;
-        }
-    }
-
-    if (overflow) atomicOr(a.work + 1, 1ull);
-    if (Stats) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            n_pairs += __shfl_down(n_pairs, off);
-            n_tests += __shfl_down(n_tests, off);
-            n_leaves += __shfl_down(n_leaves, off);
-        }
-        if (lane == 0) {
-            atomicAdd(&a.counters->node_pairs, n_pairs);
-            atomicAdd(&a.counters->prim_tests, n_tests);
-            atomicAdd(&a.counters->leaves, n_leaves);
-        }
-    }
+// EXPERIMENTAL, opt-in (BVH_AMD_PAIRS=compact; compact_pair.h): the same walk, but a lane that has just descended into a node
+// holds that node's box and fetches the 32-byte CompactPair of its children (two requests); after a stack pop it has no box
+// and fetches the 64-byte PairNode (four). Float, 3D, trees of at most 64 levels.
+struct CompactTraceArgs : TraceArgs<float> {
+    const CompactPair* cpairs;
+};
+template <bool Any, bool Robust, int Leaf, bool Stats>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) trace_kernel_compact(CompactTraceArgs a) {
+    using T = float;
+    constexpr int D = 3;
+    constexpr bool Deep = false;
+#define BVH_TRACE_COMPACT 1
+#include "trace_body.inc"
+#undef BVH_TRACE_COMPACT
 }
 
 // Coherence key of a ray: Morton code of its origin cell (32^3 grid over the root box) above the direction octant.
@@ -439,9 +254,40 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     return BVH_AMD_OK;
 }
 
+// EXPERIMENTAL: the compact-record kernel (float, 3D, trees of at most 64 levels; launch_traverse decides)
+template <bool Any, bool Robust, int Leaf, bool Stats>
+int launch_variant_compact(const BvhImpl<float>& b, const TraceArgs<float>& args, const CompactPair* cpairs, hipStream_t stream) {
+    static thread_local int cached_blocks[16] = {0};
+    auto kernel = trace_kernel_compact<Any, Robust, Leaf, Stats>;
+    int& blocks = cached_blocks[b.device & 15];
+    if (blocks == 0) {
+        Grid g;
+        int rc = persistent_grid(kernel, b.device, g);
+        if (rc) return rc;
+        blocks = g.blocks;
+    }
+    unsigned long long need = (args.n + kBlock - 1) / kBlock;
+    int grid = static_cast<int>(need < static_cast<unsigned long long>(blocks) ? need : blocks);
+    if (grid < 1) grid = 1;
+    static const std::string symbol = std::string("trace_kernel_compact<") + (Any ? "true" : "false") + ", " + (Robust ? "true" : "false") + ", " +
+                                      std::to_string(Leaf) + ", " + (Stats ? "true" : "false") + ">";
+    g_last_kernel = symbol.c_str();
+    CompactTraceArgs cargs;
+    static_cast<TraceArgs<float>&>(cargs) = args;
+    cargs.cpairs = cpairs;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, cargs);
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
+}
+
+thread_local const CompactPair* t_cpairs = nullptr;       // set by launch_traverse for the launch it is about to make
+
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
 int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     if (args.deep) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, true>(b, args, stream, name);
+    if constexpr (std::is_same_v<T, float> && D == 3) {
+        if (t_cpairs) return launch_variant_compact<Any, Robust, Leaf, Stats>(b, args, t_cpairs, stream);
+    }
     return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false>(b, args, stream, name);
 }
 
@@ -665,6 +511,17 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
                 return fail(BVH_AMD_ERR_UNSUPPORTED, "intersect_rays: the tree is too deep for the traversal stack (" + std::to_string(max_depth) + " levels)");
             BVH_HIP_TRY(hipMallocAsync(&deep_mem, lanes * cap * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
             args.deep = static_cast<uint32_t*>(deep_mem); args.deep_cap = static_cast<uint32_t>(cap);
+        }
+    }
+    // EXPERIMENTAL, off by default: BVH_AMD_PAIRS=compact fetches 32-byte records where it can (compact_pair.h). Float 3D trees of
+    // at most 64 levels whose pairs are all representable; anything else silently keeps the PairNode kernel.
+    static const bool want_compact = getenv("BVH_AMD_PAIRS") && std::strcmp(getenv("BVH_AMD_PAIRS"), "compact") == 0;
+    t_cpairs = nullptr;
+    if constexpr (std::is_same_v<T, float>) {
+        if (want_compact && b.dim == 3 && !args.deep && b.pair_count) {
+            int rc = ensure_compact_pairs(b, stream);
+            if (rc) return release(rc);
+            if (b.compact_state.load() == 1) t_cpairs = b.d_cpairs;
         }
     }
     static const int refill_env = getenv("BVH_AMD_REFILL") ? atoi(getenv("BVH_AMD_REFILL")) : 0;   // tuning knobs

@@ -1,0 +1,119 @@
+"""CPU: the compact traversal records (bvh_amd/csrc/compact_pair.h, EXPERIMENTAL / opt-in on the device) are lossless for the walk.
+
+tests/cpp/compact_pair_walk.cpp compiles the very header the device code compiles and walks rays with one scalar lane that
+follows trace_body.inc's state machine (32-byte record while the lane holds the parent's box, 64-byte record after a pop).
+Hits and visit counters must equal the oracle's traversal of the same tree, for trees of every builder mode (the reinsertion
+optimizer rewires and refits nodes: the "every parent plane is a child's plane" property must survive it)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from bvh_amd import synth
+from conftest import ROOT, load_golden, parse_stream
+
+
+@pytest.fixture(scope="module")
+def walker(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("compact") / "libcompact_walk.so")
+    src = os.path.join(ROOT, "tests", "cpp", "compact_pair_walk.cpp")
+    cmd = ["g++", "-std=c++20", "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", src, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dll = C.CDLL(out)
+    dll.compact_encode_tree.restype = C.c_int
+    dll.compact_encode_tree.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    dll.compact_walk.restype = None
+    dll.compact_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return dll
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _encode(walker, nodes):
+    nodes = np.ascontiguousarray(nodes)
+    n_pairs = (len(nodes) - 1) // 2
+    pairs = np.zeros((max(n_pairs, 1), 16), dtype=np.uint32)
+    recs = np.zeros((max(n_pairs, 1), 8), dtype=np.uint32)
+    rc = walker.compact_encode_tree(_ptr(nodes), len(nodes), _ptr(pairs), _ptr(recs))
+    return rc, pairs, recs
+
+
+def _walk(walker, nodes, pairs, recs, prims, rays, any_hit, robust):
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    prims = np.ascontiguousarray(prims, dtype=np.float32)
+    hits = np.empty(len(rays), dtype=oracle.HITF)
+    cnt = np.zeros(4, dtype=np.uint64)
+    walker.compact_walk(_ptr(pairs), _ptr(recs), int(nodes["index"][0]), _ptr(prims), _ptr(rays), len(rays), int(any_hit), int(robust),
+                        _ptr(hits), _ptr(cnt))
+    return hits, cnt
+
+
+@pytest.mark.parametrize("scene", ["cornell", "soup2k", "terrain2k"])
+@pytest.mark.parametrize("mode", ["serial_low", "serial_high", "parallel_med", "parallel_high"])
+def test_compact_walk_equals_golden(walker, scene, mode):
+    g = load_golden(scene)
+    nodes, ids = parse_stream(g[f"bvh_{mode}"].tobytes())
+    rc, pairs, recs = _encode(walker, nodes)
+    assert rc == 0
+    prims = np.zeros((len(ids), 12), dtype=np.float32)
+    lib = oracle.load_oracle()
+    prims = lib.precompute_tris(g["prims"], ids)
+    for any_hit in (False, True):
+        for robust in (False, True):
+            key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
+            if f"hits_{key}" not in g.files:
+                continue
+            rays = g["rays_shadow"] if any_hit else g["rays_closest"]
+            hits, cnt = _walk(walker, nodes, pairs, recs, prims, rays, any_hit, robust)
+            assert hits.tobytes() == g[f"hits_{key}"].tobytes(), key
+            assert (cnt[:2] == g[f"counters_{key}"][:2]).all(), key
+            assert cnt[2] + cnt[3] == cnt[0]
+
+
+@pytest.mark.parametrize("gen,n", [("soup", 30000), ("terrain", 20000), ("sponza_proxy", 16384)])
+def test_compact_walk_equals_oracle(walker, orc, gen, n):
+    tris = getattr(synth, gen)(n)
+    bb, cc = orc.prep_tris(tris)
+    lo, hi = synth.scene_bounds(tris)
+    rays_c = synth.rays_closest(4000, lo, hi, seed=11)
+    rays_s = synth.rays_shadow(4000, lo, hi, seed=12)
+    for builder, quality in ((oracle.BUILDER_DEFAULT_SERIAL, oracle.QUALITY_HIGH), (oracle.BUILDER_DEFAULT_PARALLEL, oracle.QUALITY_HIGH),
+                             (oracle.BUILDER_DEFAULT_PARALLEL, oracle.QUALITY_LOW)):
+        bvh = orc.build(bb, cc, builder=builder, quality=quality, threads=4)
+        nodes, ids = bvh.nodes(), bvh.prim_ids()
+        rc, pairs, recs = _encode(walker, nodes)
+        assert rc == 0, "a pair of a builder-made tree is not representable"
+        prims = orc.precompute_tris(tris, ids)
+        for any_hit, rays in ((False, rays_c), (True, rays_s)):
+            for robust in (False, True):
+                ref_hits, ref_cnt = bvh.intersect_tri(prims, rays, any_hit, robust, counters=True)
+                hits, cnt = _walk(walker, nodes, pairs, recs, prims, rays, any_hit, robust)
+                assert hits.tobytes() == ref_hits.tobytes()
+                assert (cnt[:2] == ref_cnt[:2]).all()
+        # what the experiment is about: 16-byte requests per visited pair, 4 with PairNode
+        _, cnt = _walk(walker, nodes, pairs, recs, prims, rays_c, False, True)
+        assert (2 * cnt[2] + 4 * cnt[3]) / (4.0 * cnt[0]) < 0.85
+
+
+def test_compact_encode_rejects_foreign_boxes(walker):
+    g = load_golden("soup2k")
+    nodes, _ = parse_stream(g["bvh_serial_high"].tobytes())
+    nodes = nodes.copy()
+    victim = int(np.flatnonzero((nodes["index"] & 15) == 0)[5])       # an inner node below the root
+    assert victim != 0
+    b = nodes["bounds"][victim].copy()
+    b[0] -= 1.0; b[1] += 1.0                                           # a hand-edited box: no child shares its x planes any more
+    nodes["bounds"][victim] = b
+    rc, _, _ = _encode(walker, nodes)
+    assert rc & 1
+    # signed zeros are fine: planes are compared numerically
+    nodes2, _ = parse_stream(g["bvh_serial_high"].tobytes())
+    nodes2 = nodes2.copy()
+    nodes2["bounds"][nodes2["bounds"] == 0.0] = -0.0
+    assert _encode(walker, nodes2)[0] == 0
