@@ -190,6 +190,12 @@ class Bvh:
     def sync_device(self):
         _lib.check(self._f("bvh{S}_sync_device")(self._h), "sync_device")
 
+    def sync_host(self):
+        """Fills the host mirror (reference-layout nodes + prim ids) from the device now instead of at the first accessor: the
+        device-to-host copy that turns a device-resident build into the reference's host `Bvh` (what bvhXX_get_node does first)."""
+        if not self._f("bvh{S}_get_node")(self._h, 0):
+            raise _lib.BvhAmdError(_lib.last_error())
+
     def get_root(self):
         return self.nodes[0]
 
