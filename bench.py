@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s closest-hit on a ~1M-triangle scene, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload soup_1m|sponza_262k|terrain_1m]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload soup_1m|sponza_262k|terrain_1m|soup_10m]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch of synthetic rays: `rays_per_gpu` uniform-random
@@ -33,6 +33,7 @@ WORKLOADS = {
     "soup_1m": ("soup", 1_000_000, "1,000,000-triangle random soup (M3), worst-case incoherent"),
     "terrain_1m": ("terrain", 1_000_000, "~1M-triangle height field (M2), tie-heavy"),
     "sponza_262k": ("sponza_proxy", 262_144, "262,144-triangle Sponza proxy (M1) — BASELINE configs[1]"),
+    "soup_10m": ("soup", 10_000_000, "10,000,000-triangle random soup (M3-10M) — BASELINE configs[3]; use --rays 12500000 for its 100M / 8 shards"),
 }
 
 
