@@ -105,6 +105,7 @@ def pmc_traffic_gbs(args, robust, kernel_ms):
 
 def main():
     args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs across processes on this driver
     import torch
     import torch.distributed as dist
 
