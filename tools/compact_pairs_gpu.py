@@ -79,7 +79,7 @@ def main():
         if mode == "compact":
             env["BVH_AMD_PAIRS"] = "compact"
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", scene, str(n), str(nr)], env=env, capture_output=True,
-                           text=True, timeout=1200)
+                           text=True, timeout=400)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         if r.returncode != 0 or not line:
             print(f"[{mode}] FAILED rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
