@@ -117,3 +117,36 @@ def test_compact_encode_rejects_foreign_boxes(walker):
     nodes2 = nodes2.copy()
     nodes2["bounds"][nodes2["bounds"] == 0.0] = -0.0
     assert _encode(walker, nodes2)[0] == 0
+
+
+ADVERSARIAL = [(seed, kind) for seed in range(8) for kind in ("lattice", "dups", "flat", "points", "scales", "uniform")]
+
+
+@pytest.mark.parametrize("seed,kind", ADVERSARIAL)
+def test_compact_walk_adversarial(walker, orc, seed, kind):
+    """The generators of tests/test_gpu_fuzz.py: ties everywhere, duplicated primitives, planes at +-0 with origins snapped onto them,
+    zero direction components of both signs, zero-area triangles, mixed magnitudes. This is where "a decoded plane may differ from
+    the child's in the sign of a zero, and that cannot change a comparison" has to hold."""
+    import test_gpu_fuzz as F
+    rng = np.random.default_rng(7000 + 10 * seed + len(kind))
+    n = int(rng.choice([2, 5, 17, 64, 65, 200, 1500, 4000]))
+    tris = F._scene3(rng, n, kind, np.float32)
+    bb, cc = orc.prep_tris(tris)
+    lo = tris.reshape(-1, 3).min(axis=0).astype(np.float64)
+    hi = tris.reshape(-1, 3).max(axis=0).astype(np.float64)
+    rays = F._rays3(rng, 3000, lo, hi, np.float32)
+    lim = [(1, 8), (1, 1), (2, 4), (3, 15)][seed % 4]
+    for builder, quality in ((0, 0), (0, 2), (1, 2), (3, 0)):
+        bvh = orc.build(bb, cc, builder=builder, quality=quality, min_leaf=lim[0], max_leaf=lim[1], parallel_threshold=[1024, 64][seed % 2])
+        nodes, ids = bvh.nodes(), bvh.prim_ids()
+        if len(nodes) < 3:
+            continue
+        rc, pairs, recs = _encode(walker, nodes)
+        assert rc == 0
+        prims = orc.precompute_tris(tris, ids)
+        for any_hit in (False, True):
+            for robust in (False, True):
+                ref_hits, ref_cnt = bvh.intersect_tri(prims, rays, any_hit, robust, counters=True)
+                hits, cnt = _walk(walker, nodes, pairs, recs, prims, rays, any_hit, robust)
+                assert hits.tobytes() == ref_hits.tobytes(), (builder, quality, any_hit, robust)
+                assert (cnt[:2] == ref_cnt[:2]).all()
