@@ -61,6 +61,11 @@ int compact_encode_tree(const void* nodes28, size_t node_count, void* out_pairs,
 
 // One lane of trace_body.inc with BVH_TRACE_COMPACT 1. counters: [0] pairs visited, [1] primitive tests, [2] pair fetches made
 // with a box (two requests), [3] without (four requests).
+// far_cache != 0: additionally model a one-entry register cache holding the box of the most recently pushed far child (the variant
+// considered in DESIGN.md §8): a pop that takes exactly that entry keeps its box.
+static int g_far_cache = 0;
+void compact_walk_set_far_cache(int on) { g_far_cache = on; }
+
 void compact_walk(const void* pairs64, const void* compact32, uint32_t root_index, const float* tris12, const float* rays8, size_t n_rays,
                   int any, int robust, float* hits4, uint64_t* counters) {
     const Pair64* pairs = static_cast<const Pair64*>(pairs64);
@@ -86,6 +91,13 @@ void compact_walk(const void* pairs64, const void* compact32, uint32_t root_inde
         uint32_t top = root_index;
         float box[6] = {0, 0, 0, 0, 0, 0};
         bool have_box = false, done = false;
+        float fbox[6] = {0, 0, 0, 0, 0, 0};            // far-box cache: the box of stack entry number fsp - 1
+        size_t fsp = 0;                                // 0 = empty
+        auto pop_box = [&]() {                         // called right after stack.pop_back(): stack.size() is the popped entry's number
+            have_box = false;
+            if (g_far_cache && fsp == stack.size() + 1) { for (int k = 0; k < 6; ++k) box[k] = fbox[k]; have_box = true; }
+            fsp = 0;
+        };
         while (!done) {
             if ((top & kCountMask) == 0) {
                 const uint32_t p = top >> (kCountBits + 1);
@@ -118,11 +130,13 @@ void compact_walk(const void* pairs64, const void* compact32, uint32_t root_inde
                     have_box = true;
                     if (hr) {
                         uint32_t far_i = ri;
+                        for (int k = 0; k < 6; ++k) fbox[k] = rb[k];
                         if (!any && l0 > r0) {
                             near_i = ri; far_i = li;
-                            for (int k = 0; k < 6; ++k) box[k] = rb[k];
+                            for (int k = 0; k < 6; ++k) { box[k] = rb[k]; fbox[k] = lb[k]; }
                         }
                         stack.push_back(far_i);
+                        fsp = stack.size();
                     }
                     top = near_i;
                 } else if (hr) {
@@ -133,7 +147,7 @@ void compact_walk(const void* pairs64, const void* compact32, uint32_t root_inde
                     done = true;
                 } else {
                     top = stack.back(); stack.pop_back();
-                    have_box = false;
+                    pop_box();
                 }
             } else {
                 const uint32_t first = top >> kCountBits, count = top & kCountMask;
@@ -154,7 +168,7 @@ void compact_walk(const void* pairs64, const void* compact32, uint32_t root_inde
                 }
                 if (any && hit_prim != kInvalid) done = true;
                 else if (stack.empty()) done = true;
-                else { top = stack.back(); stack.pop_back(); have_box = false; }
+                else { top = stack.back(); stack.pop_back(); pop_box(); }
             }
         }
         float* out = hits4 + 4 * r;
