@@ -1,0 +1,115 @@
+// TEST INFRASTRUCTURE (CPU, no GPU): compiles the text of the batch traversal kernels — bvh_amd/csrc/trace_body.inc with the device
+// helpers of bvh_amd/csrc/trace_device.h — for the HOST and runs it with ONE emulated lane (refill and leaf thresholds 1, the
+// wave intrinsics reduced to their single-lane meaning). What it can show: the per-ray logic of the very source the device runs —
+// record addressing, the box bookkeeping of the compact variant, push / pop, the leaf loop — gives the oracle's hits and counters.
+// What it cannot show: anything that needs 64 lanes or the hardware (divergence, LDS layout across lanes, occupancy, speed).
+// tests/test_compact_pairs.py drives it. Nothing here is shipped; the product runs this body on the device only.
+//
+// Built by the test with: g++ -std=c++20 -O1 -mavx2 -mfma -ffp-contract=off -fno-strict-aliasing -shared -fPIC.
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+
+#include "../../include/bvh_amd.h"                               // bvh_hit3f / bvh_hit3d, bvh_amd_counters, BVH_AMD_INVALID
+
+// ---- single-lane stand-ins for what hip_runtime.h provides ------------------------------------------------------------
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(x)
+#define __shared__ static
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline double2 make_double2(double x, double y) { return {x, y}; }
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return {x, y}; }
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return {x, y, z, w}; }
+inline uint32_t __float_as_uint(float x) { return __builtin_bit_cast(uint32_t, x); }
+inline float __uint_as_float(uint32_t x) { return __builtin_bit_cast(float, x); }
+inline long long __double_as_longlong(double x) { return __builtin_bit_cast(long long, x); }
+inline double __longlong_as_double(long long x) { return __builtin_bit_cast(double, x); }
+inline uint64_t __ballot(bool p) { return p ? 1ull : 0ull; }     // one lane: lane 0
+inline int __popcll(uint64_t m) { return __builtin_popcountll(m); }
+template <typename V> inline V __shfl(V v, int) { return v; }
+template <typename V> inline V __shfl_down(V, int) { return V(0); }        // the other 63 lanes hold nothing
+template <typename V> inline V atomicAdd(V* p, V v) { V old = *p; *p = old + v; return old; }
+template <typename V> inline V atomicOr(V* p, V v) { V old = *p; *p = old | v; return old; }
+static const struct { unsigned x; } threadIdx = {0}, blockIdx = {0};
+using std::min;
+
+// ---- stand-ins for bvh_amd/csrc/common.h (which needs the HIP headers) ------------------------------------------------------
+namespace bvh_amd {
+constexpr unsigned kCountBits = 4;
+constexpr uint32_t kCountMask = 15u;
+constexpr int kWave = 64;
+template <typename T> struct PairNode;
+template <> struct PairNode<float> { float lb[6], rb[6]; uint32_t li, ri; uint32_t pad[2]; };
+template <> struct PairNode<double> { double lb[6], rb[6]; uint32_t li, ri; uint32_t pad[6]; };
+template <typename T> struct HitOf;
+template <> struct HitOf<float> { using Type = bvh_hit3f; };
+template <> struct HitOf<double> { using Type = bvh_hit3d; };
+enum { LEAF_TRIANGLE = 0, LEAF_SPHERE = 1 };
+} // namespace bvh_amd
+
+#include "../../bvh_amd/csrc/trace_device.h"
+
+namespace bvh_amd {
+namespace {
+
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D, bool Deep>
+void host_trace(TraceArgs<T> a) {
+#define BVH_TRACE_COMPACT 0
+#include "../../bvh_amd/csrc/trace_body.inc"
+#undef BVH_TRACE_COMPACT
+}
+
+template <bool Any, bool Robust, int Leaf, bool Stats>
+void host_trace_compact(CompactTraceArgs a) {
+    using T = float;
+    constexpr int D = 3;
+    constexpr bool Deep = false;
+#define BVH_TRACE_COMPACT 1
+#include "../../bvh_amd/csrc/trace_body.inc"
+#undef BVH_TRACE_COMPACT
+}
+
+} // namespace
+} // namespace bvh_amd
+
+extern "C" {
+
+// compact32 == NULL: the PairNode body; otherwise the compact body. Triangles, counters on. Returns the status word (overflow flag).
+int trace_body_host(const void* pairs64, const void* compact32, uint32_t root_index, const float* tris12, const float* rays8, size_t n_rays,
+                    int any, int robust, void* hits16, unsigned long long* counters3) {
+    using namespace bvh_amd;
+    unsigned long long work[2] = {0, 0};
+    bvh_amd_counters cnt = {0, 0, 0};
+    CompactTraceArgs a;
+    a.pairs = static_cast<const PairNode<float>*>(pairs64);
+    a.prims = tris12; a.rays = rays8; a.hits = static_cast<bvh_hit3f*>(hits16);
+    a.n = n_rays; a.work = work; a.counters = &cnt; a.order = nullptr; a.deep = nullptr; a.deep_cap = 0;
+    a.root_index = root_index;
+    a.refill_threshold = 1;                                      // one lane: refill as soon as it is idle,
+    a.leaf_threshold = 1;                                        // run the leaf code as soon as it waits at a leaf
+    a.cpairs = static_cast<const CompactPair*>(compact32);
+    const TraceArgs<float>& base = a;
+    if (compact32) {
+        if (any) { if (robust) host_trace_compact<true, true, LEAF_TRIANGLE, true>(a); else host_trace_compact<true, false, LEAF_TRIANGLE, true>(a); }
+        else { if (robust) host_trace_compact<false, true, LEAF_TRIANGLE, true>(a); else host_trace_compact<false, false, LEAF_TRIANGLE, true>(a); }
+    } else {
+        if (any) { if (robust) host_trace<float, true, true, LEAF_TRIANGLE, true, 3, false>(base); else host_trace<float, true, false, LEAF_TRIANGLE, true, 3, false>(base); }
+        else { if (robust) host_trace<float, false, true, LEAF_TRIANGLE, true, 3, false>(base); else host_trace<float, false, false, LEAF_TRIANGLE, true, 3, false>(base); }
+    }
+    counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
+    return static_cast<int>(work[1]);
+}
+
+} // extern "C"
