@@ -84,6 +84,37 @@ void host_trace_compact(CompactTraceArgs a) {
 } // namespace
 } // namespace bvh_amd
 
+namespace {
+
+template <typename T, int Leaf, int D, bool Deep>
+void run_variant(const bvh_amd::TraceArgs<T>& a, int any, int robust) {
+    using namespace bvh_amd;
+    if (any) { if (robust) host_trace<T, true, true, Leaf, true, D, Deep>(a); else host_trace<T, true, false, Leaf, true, D, Deep>(a); }
+    else { if (robust) host_trace<T, false, true, Leaf, true, D, Deep>(a); else host_trace<T, false, false, Leaf, true, D, Deep>(a); }
+}
+
+template <typename T>
+int run_any(const void* pairs, uint32_t root_index, const void* prims, const void* rays, size_t n_rays, int dim, int leaf, int any, int robust,
+            uint32_t* deep, uint32_t deep_cap, void* hits, unsigned long long* counters3) {
+    using namespace bvh_amd;
+    unsigned long long work[2] = {0, 0};
+    bvh_amd_counters cnt = {0, 0, 0};
+    TraceArgs<T> a;
+    a.pairs = static_cast<const PairNode<T>*>(pairs);
+    a.prims = static_cast<const T*>(prims); a.rays = static_cast<const T*>(rays);
+    a.hits = static_cast<typename HitOf<T>::Type*>(hits);
+    a.n = n_rays; a.work = work; a.counters = &cnt; a.order = nullptr; a.deep = deep; a.deep_cap = deep_cap;
+    a.root_index = root_index;
+    a.refill_threshold = 1; a.leaf_threshold = 1;
+    if (dim == 2) { if (deep) run_variant<T, LEAF_SPHERE, 2, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 2, false>(a, any, robust); }
+    else if (leaf == LEAF_SPHERE) { if (deep) run_variant<T, LEAF_SPHERE, 3, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 3, false>(a, any, robust); }
+    else { if (deep) run_variant<T, LEAF_TRIANGLE, 3, true>(a, any, robust); else run_variant<T, LEAF_TRIANGLE, 3, false>(a, any, robust); }
+    counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
+    return static_cast<int>(work[1]);
+}
+
+} // namespace
+
 extern "C" {
 
 // compact32 == NULL: the PairNode body; otherwise the compact body. Triangles, counters on. Returns the status word (overflow flag).
@@ -110,6 +141,14 @@ int trace_body_host(const void* pairs64, const void* compact32, uint32_t root_in
     }
     counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
     return static_cast<int>(work[1]);
+}
+
+// Every PairNode variant: is_double, dim 2 / 3, leaf 0 = triangles (12 values) / 1 = spheres (4 values; circles of 3 in 2D), deep = a
+// spill buffer of deep_cap words for stack entries beyond 64 (or NULL). pairs: 64-byte (float) / 128-byte (double) records.
+int trace_body_host_any(int is_double, const void* pairs, uint32_t root_index, const void* prims, const void* rays, size_t n_rays, int dim, int leaf,
+                        int any, int robust, uint32_t* deep, uint32_t deep_cap, void* hits, unsigned long long* counters3) {
+    if (is_double) return run_any<double>(pairs, root_index, prims, rays, n_rays, dim, leaf, any, robust, deep, deep_cap, hits, counters3);
+    return run_any<float>(pairs, root_index, prims, rays, n_rays, dim, leaf, any, robust, deep, deep_cap, hits, counters3);
 }
 
 } // extern "C"

@@ -1,0 +1,161 @@
+"""CPU: the TEXT of the batch traversal kernels (bvh_amd/csrc/trace_body.inc + trace_device.h) compiled for the host by
+tests/cpp/trace_body_host.cpp and run with one emulated lane, against the golden vectors of the unmodified reference: every PairNode
+variant — float / double, triangles / spheres, 3D / 2D circles, closest / any, robust / fast, and the deep-stack (GrowingStack)
+variant on a 300-level chain. It shows that the per-ray logic of the source the device runs reproduces the reference's hits and
+counters; it cannot show anything that needs 64 lanes or the hardware (that is what the -m gpu tests are for).
+The compact variant of the same body is covered by tests/test_compact_pairs.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, load_golden, parse_stream
+
+
+@pytest.fixture(scope="module")
+def body(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("body") / "libtrace_body_host.so")
+    src = os.path.join(ROOT, "tests", "cpp", "trace_body_host.cpp")
+    cmd = ["g++", "-std=c++20", "-O1", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall", "-Wextra", "-Wno-unused-parameter",
+           "-Wno-unknown-pragmas", "-Werror", "-shared", "-fPIC", src, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dll = C.CDLL(out)
+    dll.trace_body_host_any.restype = C.c_int
+    dll.trace_body_host_any.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    return dll
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _aligned(a, align=128):
+    raw = np.empty(a.nbytes + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    out = raw[off:off + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def pair_records(bounds6, index):
+    """relayout_pairs (bvh_amd/csrc/upload.hip): pair p = nodes[2p+1], nodes[2p+2] as one 64-byte (float) / 128-byte (double) record."""
+    dt = bounds6.dtype
+    n_pairs = (len(index) - 1) // 2
+    rec = np.dtype([("lb", dt, (6,)), ("rb", dt, (6,)), ("li", "<u4"), ("ri", "<u4"), ("pad", "<u4", (2 if dt == np.float32 else 6,))])
+    assert rec.itemsize == (64 if dt == np.float32 else 128)
+    out = np.zeros(max(n_pairs, 1), dtype=rec)
+    out["lb"][:n_pairs] = bounds6[1::2][:n_pairs]
+    out["rb"][:n_pairs] = bounds6[2::2][:n_pairs]
+    out["li"][:n_pairs] = index[1::2][:n_pairs].astype(np.uint32)
+    out["ri"][:n_pairs] = index[2::2][:n_pairs].astype(np.uint32)
+    return out
+
+
+def run(body, bounds6, index, prims, rays, dim, leaf, any_hit, robust, deep_words=0):
+    double = bounds6.dtype == np.float64
+    pairs = _aligned(pair_records(bounds6, index))
+    prims = _aligned(np.ascontiguousarray(prims))
+    rays = _aligned(np.ascontiguousarray(rays))
+    hits = _aligned(np.zeros(len(rays), dtype=oracle.HITD if double else oracle.HITF))
+    cnt = np.zeros(3, dtype=np.uint64)
+    deep = np.zeros(max(deep_words, 1), dtype=np.uint32)
+    status = body.trace_body_host_any(int(double), _ptr(pairs), int(index[0]) & 0xFFFFFFFF, _ptr(prims), _ptr(rays), len(rays), dim, leaf,
+                                      int(any_hit), int(robust), _ptr(deep) if deep_words else None, deep_words, _ptr(hits), _ptr(cnt))
+    assert status == 0
+    return hits, cnt
+
+
+def parse_stream2(buf, double):
+    """Bvh<Node<T, 2>>::serialize (bvh.h:221-229 with node.h:31-37 for two dimensions)."""
+    idx = np.dtype("<u8" if double else "<u4")
+    node = np.dtype([("bounds", "<f8" if double else "<f4", (4,)), ("index", idx)])
+    hdr = np.frombuffer(buf, dtype=idx, count=2)
+    nn, npr = int(hdr[0]), int(hdr[1])
+    nodes = np.frombuffer(buf, dtype=node, count=nn, offset=2 * idx.itemsize)
+    ids = np.frombuffer(buf, dtype=idx, count=npr, offset=2 * idx.itemsize + nn * node.itemsize)
+    return nodes, ids.astype(np.uint64)
+
+
+MODES4 = [(a, r) for a in (False, True) for r in (False, True)]
+
+
+@pytest.mark.parametrize("scene", ["cornell", "soup2k", "terrain2k", "soup2k_f64", "spheres2k_f64"])
+@pytest.mark.parametrize("mode", ["serial_low", "parallel_high"])
+def test_body_equals_golden_3d(body, orc, scene, mode):
+    g = load_golden(scene)
+    double = g["prims"].dtype == np.float64
+    nodes, ids = parse_stream(g[f"bvh_{mode}"].tobytes(), double)
+    sphere = "spheres" in scene
+    prims = g["prims"][ids.astype(np.int64)] if sphere else orc.precompute_tris(g["prims"], ids)
+    for any_hit, robust in MODES4:
+        key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
+        rays = g["rays_shadow"] if any_hit else g["rays_closest"]
+        hits, cnt = run(body, nodes["bounds"], nodes["index"], prims, rays, 3, 1 if sphere else 0, any_hit, robust)
+        assert hits.tobytes() == g[f"hits_{key}"].tobytes(), key
+        assert (cnt == g[f"counters_{key}"]).all(), key
+
+
+@pytest.mark.parametrize("scene", ["circles2k_2f", "circles2k_2d"])
+@pytest.mark.parametrize("mode", ["serial_low", "serial_high"])
+def test_body_equals_golden_2d(body, scene, mode):
+    """Node<T, 2>: the device keeps the records three wide with z = 0 (DESIGN.md 5 "2D"); the D = 2 instantiation never looks at z."""
+    g = load_golden(scene)
+    double = g["prims"].dtype == np.float64
+    nodes, ids = parse_stream2(g[f"bvh_{mode}"].tobytes(), double)
+    b6 = np.zeros((len(nodes), 6), dtype=g["prims"].dtype)
+    b6[:, :4] = nodes["bounds"]
+    circles = np.ascontiguousarray(g["prims"][ids.astype(np.int64)])
+    for any_hit, robust in MODES4:
+        key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
+        rays = g["rays_shadow"] if any_hit else g["rays_closest"]
+        hits, cnt = run(body, b6, nodes["index"], circles, rays, 2, 1, any_hit, robust)
+        assert hits.tobytes() == g[f"hits_{key}"].tobytes(), key
+        assert (cnt == g[f"counters_{key}"]).all(), key
+
+
+@pytest.mark.parametrize("depth", [60, 64, 65, 300])
+def test_body_deep_stack(body, orc, depth):
+    """tests/test_gpu_traverse.py::test_trees_deeper_than_the_small_stack on the host-compiled body: up to 64 levels the
+    LDS + scratch stack, beyond that the Deep variant with its spill buffer (the reference's GrowingStack, stack.h:34-46)."""
+    n = depth + 1
+    tris = np.zeros((n, 9), dtype=np.float32)
+    for k in range(n):
+        x = np.float32(4000 - k)
+        tris[k] = [x, -1, -1, x, 1, -1, x, 0, 1]
+    bb, _ = orc.prep_tris(tris)
+    nodes = np.zeros(2 * n - 1, dtype=oracle.NODEF)
+    suffix = bb.copy()
+    for k in range(n - 2, -1, -1):
+        suffix[k, :3] = np.minimum(bb[k, :3], suffix[k + 1, :3])
+        suffix[k, 3:] = np.maximum(bb[k, 3:], suffix[k + 1, 3:])
+    box = lambda b: [b[0], b[3], b[1], b[4], b[2], b[5]]
+    nodes[0]["bounds"], nodes[0]["index"] = box(suffix[0]), 1 << 4
+    for k in range(n - 1):
+        leaf, rest = 2 * k + 1, 2 * k + 2
+        nodes[leaf]["bounds"], nodes[leaf]["index"] = box(bb[k]), (k << 4) | 1
+        if k == n - 2:
+            nodes[rest]["bounds"], nodes[rest]["index"] = box(bb[n - 1]), ((n - 1) << 4) | 1
+        else:
+            nodes[rest]["bounds"], nodes[rest]["index"] = box(suffix[k + 1]), (2 * k + 3) << 4
+    ids = np.arange(n, dtype=np.uint64)
+    ref = orc.from_arrays(nodes, ids)
+    prims = orc.precompute_tris(tris)
+    rng = np.random.default_rng(depth)
+    rays = np.zeros((2000, 8), dtype=np.float32)
+    rays[:, 0] = rng.random(len(rays)) * 100
+    rays[:, 1:3] = (rng.random((len(rays), 2)) - 0.5) * 1.5
+    rays[:, 3] = 1
+    rays[:, 4:6] = (rng.random((len(rays), 2)) - 0.5) * 1e-4
+    rays[:, 7] = np.finfo(np.float32).max
+    rays[::7, 3] = -1
+    deep_words = 0 if depth <= 64 else (depth - 64 + 1)       # launch_traverse: cap = max_depth - 64 + 1 words per lane; one lane here
+    for any_hit, robust in MODES4:
+        want, cw = ref.intersect_tri(prims, rays, any_hit, robust, counters=True)
+        hits, cnt = run(body, nodes["bounds"], nodes["index"], prims, rays, 3, 0, any_hit, robust, deep_words)
+        assert hits.tobytes() == want.tobytes(), (depth, any_hit, robust)
+        assert (cnt == cw).all()
