@@ -36,13 +36,53 @@ inline uint32_t __float_as_uint(float x) { return __builtin_bit_cast(uint32_t, x
 inline float __uint_as_float(uint32_t x) { return __builtin_bit_cast(float, x); }
 inline long long __double_as_longlong(double x) { return __builtin_bit_cast(long long, x); }
 inline double __longlong_as_double(long long x) { return __builtin_bit_cast(double, x); }
-inline uint64_t __ballot(bool p) { return p ? 1ull : 0ull; }     // one lane: lane 0
+#if !defined(BVH_HOST_WAVE64)
+// one lane: lane 0 of a wavefront whose other 63 lanes hold nothing
+inline uint64_t __ballot(bool p) { return p ? 1ull : 0ull; }
 inline int __popcll(uint64_t m) { return __builtin_popcountll(m); }
 template <typename V> inline V __shfl(V v, int) { return v; }
-template <typename V> inline V __shfl_down(V, int) { return V(0); }        // the other 63 lanes hold nothing
+template <typename V> inline V __shfl_down(V, int) { return V(0); }
 template <typename V> inline V atomicAdd(V* p, V v) { V old = *p; *p = old + v; return old; }
 template <typename V> inline V atomicOr(V* p, V v) { V old = *p; *p = old | v; return old; }
 static const struct { unsigned x; } threadIdx = {0}, blockIdx = {0};
+#else
+// BVH_HOST_WAVE64: one wavefront of 64 lanes = 64 fibers (ucontext) run round-robin by on_all_lanes(), switching at the wave
+// intrinsics — every one of them sits in wave-uniform control flow in trace_body.inc, so after one round all lanes stand at the
+// same intrinsic. Real refill / leaf-parking thresholds. Single OS thread: the "atomics" need no atomicity.
+#include <ucontext.h>
+static struct { unsigned x; } threadIdx = {0};                   // set by the scheduler before a lane resumes
+static const struct { unsigned x; } blockIdx = {0};
+static ucontext_t g_main, g_lane[64];
+static uint64_t g_slot[2][64];                                   // double buffered: a lane may run ahead to the next intrinsic
+static unsigned g_phase[64];
+inline void lane_yield() { const unsigned t = threadIdx.x; swapcontext(&g_lane[t], &g_main); threadIdx.x = t; }
+inline int __popcll(uint64_t m) { return __builtin_popcountll(m); }
+inline const uint64_t* wave_exchange(uint64_t mine) {
+    const unsigned t = threadIdx.x, ph = g_phase[t]++ & 1u;
+    g_slot[ph][t] = mine;
+    lane_yield();                                                // ... until every lane has deposited its value
+    return g_slot[ph];
+}
+inline uint64_t __ballot(bool p) {
+    const uint64_t* s = wave_exchange(p ? 1 : 0);
+    uint64_t m = 0;
+    for (int i = 0; i < 64; ++i) m |= s[i] << i;
+    return m;
+}
+template <typename V> inline V wave_read(V v, int src, bool valid) {
+    static_assert(sizeof(V) <= 8);
+    uint64_t bits = 0;
+    std::memcpy(&bits, &v, sizeof(V));
+    const uint64_t* s = wave_exchange(bits);
+    V out = v;
+    if (valid) std::memcpy(&out, &s[src], sizeof(V));
+    return out;
+}
+template <typename V> inline V __shfl(V v, int src) { return wave_read(v, src, true); }
+template <typename V> inline V __shfl_down(V v, int off) { const int src = int(threadIdx.x) + off; return wave_read(v, src & 63, src < 64); }
+template <typename V> inline V atomicAdd(V* p, V v) { V old = *p; *p = old + v; return old; }
+template <typename V> inline V atomicOr(V* p, V v) { V old = *p; *p = old | v; return old; }
+#endif
 using std::min;
 
 // ---- stand-ins for bvh_amd/csrc/common.h (which needs the HIP headers) ------------------------------------------------------
@@ -60,6 +100,42 @@ enum { LEAF_TRIANGLE = 0, LEAF_SPHERE = 1 };
 } // namespace bvh_amd
 
 #include "../../bvh_amd/csrc/trace_device.h"
+
+#if defined(BVH_HOST_WAVE64)
+#include <functional>
+#include <vector>
+constexpr int kHostRefill = 54, kHostLeaf = 8;                   // traverse.hip: kRefillThreshold, kLeafThreshold
+static std::function<void()>* g_lane_fn = nullptr;
+static bool g_lane_done[64];
+static void lane_entry() { (*g_lane_fn)(); g_lane_done[threadIdx.x] = true; swapcontext(&g_lane[threadIdx.x], &g_main); }
+template <typename F> void on_all_lanes(F f) {
+    std::function<void()> fn = f;
+    g_lane_fn = &fn;
+    constexpr size_t kStack = 1 << 20;
+    std::vector<std::vector<char>> stacks(64, std::vector<char>(kStack));
+    for (unsigned t = 0; t < 64; ++t) {
+        getcontext(&g_lane[t]);
+        g_lane[t].uc_stack.ss_sp = stacks[t].data();
+        g_lane[t].uc_stack.ss_size = kStack;
+        g_lane[t].uc_link = &g_main;
+        makecontext(&g_lane[t], lane_entry, 0);
+        g_lane_done[t] = false; g_phase[t] = 0;
+    }
+    for (;;) {                                                   // one round = every live lane runs to its next wave intrinsic
+        unsigned live = 0;
+        for (unsigned t = 0; t < 64; ++t) {
+            if (g_lane_done[t]) continue;
+            threadIdx.x = t;
+            swapcontext(&g_main, &g_lane[t]);
+            live += g_lane_done[t] ? 0 : 1;
+        }
+        if (live == 0) break;
+    }
+}
+#else
+constexpr int kHostRefill = 1, kHostLeaf = 1;                    // one lane: refill as soon as it is idle, leaf code as soon as it waits
+template <typename F> void on_all_lanes(F f) { f(); }
+#endif
 
 namespace bvh_amd {
 namespace {
@@ -89,8 +165,10 @@ namespace {
 template <typename T, int Leaf, int D, bool Deep>
 void run_variant(const bvh_amd::TraceArgs<T>& a, int any, int robust) {
     using namespace bvh_amd;
-    if (any) { if (robust) host_trace<T, true, true, Leaf, true, D, Deep>(a); else host_trace<T, true, false, Leaf, true, D, Deep>(a); }
-    else { if (robust) host_trace<T, false, true, Leaf, true, D, Deep>(a); else host_trace<T, false, false, Leaf, true, D, Deep>(a); }
+    on_all_lanes([&] {
+        if (any) { if (robust) host_trace<T, true, true, Leaf, true, D, Deep>(a); else host_trace<T, true, false, Leaf, true, D, Deep>(a); }
+        else { if (robust) host_trace<T, false, true, Leaf, true, D, Deep>(a); else host_trace<T, false, false, Leaf, true, D, Deep>(a); }
+    });
 }
 
 template <typename T>
@@ -105,7 +183,7 @@ int run_any(const void* pairs, uint32_t root_index, const void* prims, const voi
     a.hits = static_cast<typename HitOf<T>::Type*>(hits);
     a.n = n_rays; a.work = work; a.counters = &cnt; a.order = nullptr; a.deep = deep; a.deep_cap = deep_cap;
     a.root_index = root_index;
-    a.refill_threshold = 1; a.leaf_threshold = 1;
+    a.refill_threshold = kHostRefill; a.leaf_threshold = kHostLeaf;
     if (dim == 2) { if (deep) run_variant<T, LEAF_SPHERE, 2, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 2, false>(a, any, robust); }
     else if (leaf == LEAF_SPHERE) { if (deep) run_variant<T, LEAF_SPHERE, 3, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 3, false>(a, any, robust); }
     else { if (deep) run_variant<T, LEAF_TRIANGLE, 3, true>(a, any, robust); else run_variant<T, LEAF_TRIANGLE, 3, false>(a, any, robust); }
@@ -128,17 +206,18 @@ int trace_body_host(const void* pairs64, const void* compact32, uint32_t root_in
     a.prims = tris12; a.rays = rays8; a.hits = static_cast<bvh_hit3f*>(hits16);
     a.n = n_rays; a.work = work; a.counters = &cnt; a.order = nullptr; a.deep = nullptr; a.deep_cap = 0;
     a.root_index = root_index;
-    a.refill_threshold = 1;                                      // one lane: refill as soon as it is idle,
-    a.leaf_threshold = 1;                                        // run the leaf code as soon as it waits at a leaf
+    a.refill_threshold = kHostRefill; a.leaf_threshold = kHostLeaf;
     a.cpairs = static_cast<const CompactPair*>(compact32);
     const TraceArgs<float>& base = a;
-    if (compact32) {
-        if (any) { if (robust) host_trace_compact<true, true, LEAF_TRIANGLE, true>(a); else host_trace_compact<true, false, LEAF_TRIANGLE, true>(a); }
-        else { if (robust) host_trace_compact<false, true, LEAF_TRIANGLE, true>(a); else host_trace_compact<false, false, LEAF_TRIANGLE, true>(a); }
-    } else {
-        if (any) { if (robust) host_trace<float, true, true, LEAF_TRIANGLE, true, 3, false>(base); else host_trace<float, true, false, LEAF_TRIANGLE, true, 3, false>(base); }
-        else { if (robust) host_trace<float, false, true, LEAF_TRIANGLE, true, 3, false>(base); else host_trace<float, false, false, LEAF_TRIANGLE, true, 3, false>(base); }
-    }
+    on_all_lanes([&] {
+        if (compact32) {
+            if (any) { if (robust) host_trace_compact<true, true, LEAF_TRIANGLE, true>(a); else host_trace_compact<true, false, LEAF_TRIANGLE, true>(a); }
+            else { if (robust) host_trace_compact<false, true, LEAF_TRIANGLE, true>(a); else host_trace_compact<false, false, LEAF_TRIANGLE, true>(a); }
+        } else {
+            if (any) { if (robust) host_trace<float, true, true, LEAF_TRIANGLE, true, 3, false>(base); else host_trace<float, true, false, LEAF_TRIANGLE, true, 3, false>(base); }
+            else { if (robust) host_trace<float, false, true, LEAF_TRIANGLE, true, 3, false>(base); else host_trace<float, false, false, LEAF_TRIANGLE, true, 3, false>(base); }
+        }
+    });
     counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
     return static_cast<int>(work[1]);
 }

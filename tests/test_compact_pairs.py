@@ -288,3 +288,37 @@ def test_kernel_body_on_host_adversarial(walker, body, orc, seed, kind):
                 hits, cnt = _run_body(body, nodes, pairs, recs, prims, rays, any_hit, robust, True)
                 assert hits.tobytes() == ref_hits.tobytes(), (builder, quality, any_hit, robust)
                 assert (cnt == ref_cnt).all()
+
+
+@pytest.fixture(scope="module")
+def body64(tmp_path_factory):
+    """trace_body_host.cpp with -DBVH_HOST_WAVE64: a full wavefront of 64 fibers switching at the wave intrinsics, real thresholds."""
+    out = str(tmp_path_factory.mktemp("body64") / "libtrace_body_host64.so")
+    src = os.path.join(ROOT, "tests", "cpp", "trace_body_host.cpp")
+    cmd = ["g++", "-std=c++20", "-O1", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-strict-aliasing", "-DBVH_HOST_WAVE64", "-Wall", "-Wextra",
+           "-Wno-unused-parameter", "-Wno-unknown-pragmas", "-Werror", "-shared", "-fPIC", src, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dll = C.CDLL(out)
+    dll.trace_body_host.restype = C.c_int
+    dll.trace_body_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return dll
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_kernel_body_full_wavefront(walker, body64, orc, compact):
+    """Both kernel texts as a full 64-lane wavefront (lanes hold different rays, some with a box and some without, some parked at
+    leaves, refills of 54+ idle lanes at a time): hits and counters equal the oracle's."""
+    tris = synth.soup(20000)
+    bb, cc = orc.prep_tris(tris)
+    lo, hi = synth.scene_bounds(tris)
+    bvh = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_HIGH, threads=4)
+    nodes, ids = bvh.nodes(), bvh.prim_ids()
+    rc, pairs, recs = _encode(walker, nodes)
+    assert rc == 0
+    prims = orc.precompute_tris(tris, ids)
+    for any_hit, robust, rays in ((False, True, synth.rays_closest(3000, lo, hi, seed=31)), (True, False, synth.rays_shadow(3000, lo, hi, seed=32))):
+        ref_hits, ref_cnt = bvh.intersect_tri(prims, rays, any_hit, robust, counters=True)
+        hits, cnt = _run_body(body64, nodes, pairs, recs, prims, rays, any_hit, robust, compact)
+        assert hits.tobytes() == ref_hits.tobytes()
+        assert (cnt == ref_cnt).all()

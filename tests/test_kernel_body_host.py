@@ -1,7 +1,7 @@
 """CPU: the TEXT of the batch traversal kernels (bvh_amd/csrc/trace_body.inc + trace_device.h) compiled for the host by
 tests/cpp/trace_body_host.cpp and run with one emulated lane, against the golden vectors of the unmodified reference: every PairNode
 variant — float / double, triangles / spheres, 3D / 2D circles, closest / any, robust / fast, and the deep-stack (GrowingStack)
-variant on a 300-level chain. It shows that the per-ray logic of the source the device runs reproduces the reference's hits and
+variant on a 300-level chain, with one emulated lane and as a full 64-lane wavefront (fibers). It shows that the logic of the source the device runs reproduces the reference's hits and
 counters; it cannot show anything that needs 64 lanes or the hardware (that is what the -m gpu tests are for).
 The compact variant of the same body is covered by tests/test_compact_pairs.py."""
 import ctypes as C
@@ -27,6 +27,24 @@ def body(tmp_path_factory):
     dll.trace_body_host_any.restype = C.c_int
     dll.trace_body_host_any.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    return dll
+
+
+@pytest.fixture(scope="module")
+def body64(tmp_path_factory):
+    """The same source as 64 fibers switching at the wave intrinsics: one full wavefront with the real thresholds."""
+    out = str(tmp_path_factory.mktemp("body64") / "libtrace_body_host64.so")
+    src = os.path.join(ROOT, "tests", "cpp", "trace_body_host.cpp")
+    cmd = ["g++", "-std=c++20", "-O1", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-strict-aliasing", "-DBVH_HOST_WAVE64", "-Wall", "-Wextra",
+           "-Wno-unused-parameter", "-Wno-unknown-pragmas", "-Werror", "-shared", "-fPIC", src, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dll = C.CDLL(out)
+    dll.trace_body_host_any.restype = C.c_int
+    dll.trace_body_host_any.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    dll.trace_body_host.restype = C.c_int
+    dll.trace_body_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return dll
 
 
@@ -63,7 +81,7 @@ def run(body, bounds6, index, prims, rays, dim, leaf, any_hit, robust, deep_word
     rays = _aligned(np.ascontiguousarray(rays))
     hits = _aligned(np.zeros(len(rays), dtype=oracle.HITD if double else oracle.HITF))
     cnt = np.zeros(3, dtype=np.uint64)
-    deep = np.zeros(max(deep_words, 1), dtype=np.uint32)
+    deep = np.zeros(max(64 * deep_words, 1), dtype=np.uint32)  # deep_cap words per lane
     status = body.trace_body_host_any(int(double), _ptr(pairs), int(index[0]) & 0xFFFFFFFF, _ptr(prims), _ptr(rays), len(rays), dim, leaf,
                                       int(any_hit), int(robust), _ptr(deep) if deep_words else None, deep_words, _ptr(hits), _ptr(cnt))
     assert status == 0
@@ -159,3 +177,25 @@ def test_body_deep_stack(body, orc, depth):
         hits, cnt = run(body, nodes["bounds"], nodes["index"], prims, rays, 3, 0, any_hit, robust, deep_words)
         assert hits.tobytes() == want.tobytes(), (depth, any_hit, robust)
         assert (cnt == cw).all()
+
+
+@pytest.mark.parametrize("scene,mode", [("soup2k", "parallel_high"), ("terrain2k", "serial_low"), ("spheres2k_f64", "serial_low")])
+def test_body_full_wavefront_equals_golden(body64, orc, scene, mode):
+    """64 lanes in lockstep, refill threshold 54, leaf parking at 8 (traverse.hip's constants): the wave-level protocol of the body —
+    ticket refill through ballot + popcount + one atomic per wave, parking, draining, the counter reduction — gives the golden
+    hits and counters, not only the per-ray logic."""
+    g = load_golden(scene)
+    double = g["prims"].dtype == np.float64
+    nodes, ids = parse_stream(g[f"bvh_{mode}"].tobytes(), double)
+    sphere = "spheres" in scene
+    prims = g["prims"][ids.astype(np.int64)] if sphere else orc.precompute_tris(g["prims"], ids)
+    for any_hit, robust in ((False, True), (True, False)):
+        key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
+        rays = g["rays_shadow"] if any_hit else g["rays_closest"]
+        hits, cnt = run(body64, nodes["bounds"], nodes["index"], prims, rays, 3, 1 if sphere else 0, any_hit, robust)
+        assert hits.tobytes() == g[f"hits_{key}"].tobytes(), key
+        assert (cnt == g[f"counters_{key}"]).all(), key
+
+
+def test_body_full_wavefront_deep_stack(body64, orc):
+    test_body_deep_stack(body64, orc, 70)
