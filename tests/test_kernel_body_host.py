@@ -1,8 +1,9 @@
 """CPU: the TEXT of the batch traversal kernels (bvh_amd/csrc/trace_body.inc + trace_device.h) compiled for the host by
-tests/cpp/trace_body_host.cpp and run with one emulated lane, against the golden vectors of the unmodified reference: every PairNode
-variant — float / double, triangles / spheres, 3D / 2D circles, closest / any, robust / fast, and the deep-stack (GrowingStack)
-variant on a 300-level chain, with one emulated lane and as a full 64-lane wavefront (fibers). It shows that the logic of the source the device runs reproduces the reference's hits and
-counters; it cannot show anything that needs 64 lanes or the hardware (that is what the -m gpu tests are for).
+tests/cpp/trace_body_host.cpp, against the golden vectors of the unmodified reference: every PairNode variant — float / double,
+triangles / spheres, 3D / 2D circles, closest / any, robust / fast, and the deep-stack (GrowingStack) variant on a 300-level
+chain — run with one emulated lane and, for a subset, as a full 64-lane wavefront (fibers switching at the wave intrinsics, real
+thresholds). It shows that the logic of the source the device runs reproduces the reference's hits and counters; it cannot show
+anything that needs the hardware (that is what the -m gpu tests are for).
 The compact variant of the same body is covered by tests/test_compact_pairs.py."""
 import ctypes as C
 import os
