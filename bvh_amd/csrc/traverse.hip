@@ -48,11 +48,20 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
 }
 
 // EXPERIMENTAL, opt-in (BVH_AMD_PAIRS=compact; compact_pair.h): the same walk, but a lane that has just descended into a node
-// holds that node's box and fetches the 32-byte CompactPair of its children (two requests); after a stack pop it has no box
-// and fetches the 64-byte PairNode (four). Float, 3D, trees of at most 64 levels.
+// holds that node's box and fetches the CompactPair of its children (float: two requests instead of four, double: four instead
+// of seven); after a stack pop it has no box and fetches the PairNode. 3D, trees of at most 64 levels.
 template <bool Any, bool Robust, int Leaf, bool Stats>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) trace_kernel_compact(CompactTraceArgs a) {
     using T = float;
+    constexpr int D = 3;
+    constexpr bool Deep = false;
+#define BVH_TRACE_COMPACT 1
+#include "trace_body.inc"
+#undef BVH_TRACE_COMPACT
+}
+template <bool Any, bool Robust, int Leaf, bool Stats>
+__global__ void __launch_bounds__(kBlock) trace_kernel_compact_f64(CompactTraceArgsT<double> a) {
+    using T = double;
     constexpr int D = 3;
     constexpr bool Deep = false;
 #define BVH_TRACE_COMPACT 1
@@ -121,11 +130,13 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     return BVH_AMD_OK;
 }
 
-// EXPERIMENTAL: the compact-record kernel (float, 3D, trees of at most 64 levels; launch_traverse decides)
-template <bool Any, bool Robust, int Leaf, bool Stats>
-int launch_variant_compact(const BvhImpl<float>& b, const TraceArgs<float>& args, const CompactPair* cpairs, hipStream_t stream) {
+// EXPERIMENTAL: the compact-record kernels (3D, trees of at most 64 levels; launch_traverse decides)
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
+int launch_variant_compact(const BvhImpl<T>& b, const TraceArgs<T>& args, const CompactPairT<T>* cpairs, hipStream_t stream) {
     static thread_local int cached_blocks[16] = {0};
-    auto kernel = trace_kernel_compact<Any, Robust, Leaf, Stats>;
+    void (*kernel)(CompactTraceArgsT<T>);
+    if constexpr (std::is_same_v<T, float>) kernel = trace_kernel_compact<Any, Robust, Leaf, Stats>;
+    else kernel = trace_kernel_compact_f64<Any, Robust, Leaf, Stats>;
     int& blocks = cached_blocks[b.device & 15];
     if (blocks == 0) {
         Grid g;
@@ -136,24 +147,24 @@ int launch_variant_compact(const BvhImpl<float>& b, const TraceArgs<float>& args
     unsigned long long need = (args.n + kBlock - 1) / kBlock;
     int grid = static_cast<int>(need < static_cast<unsigned long long>(blocks) ? need : blocks);
     if (grid < 1) grid = 1;
-    static const std::string symbol = std::string("trace_kernel_compact<") + (Any ? "true" : "false") + ", " + (Robust ? "true" : "false") + ", " +
-                                      std::to_string(Leaf) + ", " + (Stats ? "true" : "false") + ">";
+    static const std::string symbol = std::string(std::is_same_v<T, float> ? "trace_kernel_compact<" : "trace_kernel_compact_f64<") + (Any ? "true" : "false") + ", " +
+                                      (Robust ? "true" : "false") + ", " + std::to_string(Leaf) + ", " + (Stats ? "true" : "false") + ">";
     g_last_kernel = symbol.c_str();
-    CompactTraceArgs cargs;
-    static_cast<TraceArgs<float>&>(cargs) = args;
+    CompactTraceArgsT<T> cargs;
+    static_cast<TraceArgs<T>&>(cargs) = args;
     cargs.cpairs = cpairs;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, cargs);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
     return BVH_AMD_OK;
 }
 
-thread_local const CompactPair* t_cpairs = nullptr;       // set by launch_traverse for the launch it is about to make
+thread_local const void* t_cpairs = nullptr;              // set by launch_traverse for the launch it is about to make
 
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
 int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     if (args.deep) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, true>(b, args, stream, name);
-    if constexpr (std::is_same_v<T, float> && D == 3) {
-        if (t_cpairs) return launch_variant_compact<Any, Robust, Leaf, Stats>(b, args, t_cpairs, stream);
+    if constexpr (D == 3) {
+        if (t_cpairs) return launch_variant_compact<T, Any, Robust, Leaf, Stats>(b, args, static_cast<const CompactPairT<T>*>(t_cpairs), stream);
     }
     return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false>(b, args, stream, name);
 }
@@ -380,16 +391,14 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
             args.deep = static_cast<uint32_t*>(deep_mem); args.deep_cap = static_cast<uint32_t>(cap);
         }
     }
-    // EXPERIMENTAL, off by default: BVH_AMD_PAIRS=compact fetches 32-byte records where it can (compact_pair.h). Float 3D trees of
+    // EXPERIMENTAL, off by default: BVH_AMD_PAIRS=compact fetches the compact records where it can (compact_pair.h): 3D trees of
     // at most 64 levels whose pairs are all representable; anything else silently keeps the PairNode kernel.
     static const bool want_compact = getenv("BVH_AMD_PAIRS") && std::strcmp(getenv("BVH_AMD_PAIRS"), "compact") == 0;
     t_cpairs = nullptr;
-    if constexpr (std::is_same_v<T, float>) {
-        if (want_compact && b.dim == 3 && !args.deep && b.pair_count) {
-            int rc = ensure_compact_pairs(b, stream);
-            if (rc) return release(rc);
-            if (b.compact_state.load() == 1) t_cpairs = b.d_cpairs;
-        }
+    if (want_compact && b.dim == 3 && !args.deep && b.pair_count) {
+        int rc = ensure_compact_pairs<T>(b, stream);
+        if (rc) return release(rc);
+        if (b.compact_state.load() == 1) t_cpairs = b.d_cpairs;
     }
     static const int refill_env = getenv("BVH_AMD_REFILL") ? atoi(getenv("BVH_AMD_REFILL")) : 0;   // tuning knobs
     static const int leaf_env = getenv("BVH_AMD_LEAF") ? atoi(getenv("BVH_AMD_LEAF")) : 0;

@@ -50,3 +50,21 @@ def test_unrepresentable_tree_keeps_pairnode_kernel(orc):
     assert "trace_kernel_compact" not in _last_kernel()
     ref = orc.from_arrays(nodes, ob.prim_ids()).intersect_tri(orc.precompute_tris(tris, ob.prim_ids()), rays, 0, 1, threads=8)
     assert bvh_amd.hits_to_numpy(hits).tobytes() == ref.tobytes()
+
+
+def test_compact_kernel_double_spheres(orc):
+    """The double variant (64-byte records against PairNode<double>'s 128): BASELINE configs[4]'s kind of scene, small."""
+    import bvh_amd
+    sph = synth.spheres(50000)
+    bb, cc = bvh_amd.sphere_bounds(sph)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
+    ids = bvh.prim_ids
+    prims = bvh_amd.gather(sph, bvh.device_prim_ids())
+    lo, hi = synth.scene_bounds(sph)
+    rays = synth.rays_closest(100000, lo, hi, seed=7, dtype=np.float64)
+    hits, cnt = bvh_amd.intersect(bvh, prims, rays, False, True, leaf="sphere", counters=True)
+    assert "trace_kernel_compact_f64" in _last_kernel()
+    ob = orc.from_arrays(bvh.nodes, ids)
+    ref, ref_cnt = ob.intersect_sphere(sph[ids.astype(np.int64)], rays, 0, 1, threads=8, counters=True)
+    assert bvh_amd.hits_to_numpy(hits).tobytes() == ref.tobytes()
+    assert (cnt.cpu().numpy().astype(np.uint64) == ref_cnt).all()

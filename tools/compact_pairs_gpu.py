@@ -1,6 +1,6 @@
 """Developer probe for the EXPERIMENTAL compact traversal records (BVH_AMD_PAIRS=compact; bvh_amd/csrc/compact_pair.h).
 
-    python tools/compact_pairs_gpu.py [soup|terrain|sponza] [n_tris] [n_rays]
+    python tools/compact_pairs_gpu.py [soup|terrain|sponza|spheres64] [n_prims] [n_rays]
 
 Runs itself twice in child processes (the switch is read once per process): PairNode kernel, then compact kernel. Each child
 traces closest-hit (robust + fast) and any-hit rays, prints kernel name, ms and Mrays/s, and writes the hit bytes' checksum; the
@@ -23,28 +23,36 @@ def child(scene, n, nr):
     import torch
     import bvh_amd
     from bvh_amd import synth
-    tris = {"soup": synth.soup, "terrain": synth.terrain, "sponza": synth.sponza_proxy}[scene](n)
-    d_tris = torch.from_numpy(tris).cuda()
-    bb, cc = bvh_amd.tri_bounds(d_tris)
+    spheres = scene == "spheres64"                           # BASELINE configs[4]: double precision, sphere primitives
+    dt = np.float64 if spheres else np.float32
+    leaf = "sphere" if spheres else "tri"
+    if spheres:
+        tris = synth.spheres(n)
+        d_sph = torch.from_numpy(tris).cuda()
+        bb, cc = bvh_amd.sphere_bounds(d_sph)
+    else:
+        tris = {"soup": synth.soup, "terrain": synth.terrain, "sponza": synth.sponza_proxy}[scene](n)
+        d_tris = torch.from_numpy(tris).cuda()
+        bb, cc = bvh_amd.tri_bounds(d_tris)
     bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
-    prims = bvh_amd.precompute_tris(d_tris, bvh.device_prim_ids())
+    prims = bvh_amd.gather(d_sph, bvh.device_prim_ids()) if spheres else bvh_amd.precompute_tris(d_tris, bvh.device_prim_ids())
     lo, hi = synth.scene_bounds(tris)
     res = {"mode": os.environ.get("BVH_AMD_PAIRS", "pairnode"), "runs": []}
     lib = bvh_amd._lib.load()
-    for name, rays_h, any_hit, robust in (("closest_robust", synth.rays_closest(nr, lo, hi), False, True),
-                                          ("closest_fast", synth.rays_closest(nr, lo, hi), False, False),
-                                          ("shadow_robust", synth.rays_shadow(nr, lo, hi), True, True)):
+    for name, rays_h, any_hit, robust in (("closest_robust", synth.rays_closest(nr, lo, hi, dtype=dt), False, True),
+                                          ("closest_fast", synth.rays_closest(nr, lo, hi, dtype=dt), False, False),
+                                          ("shadow_robust", synth.rays_shadow(nr, lo, hi, dtype=dt), True, True)):
         rays = torch.from_numpy(rays_h).cuda()
-        out = torch.empty((nr, 4), dtype=torch.float32, device="cuda")
-        _, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit, robust, counters=True)
+        out = torch.empty((nr, 4), dtype=torch.float64 if spheres else torch.float32, device="cuda")
+        _, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit, robust, leaf=leaf, counters=True)
         for _ in range(2):
-            bvh_amd.intersect(bvh, prims, rays, any_hit, robust, out=out)
+            bvh_amd.intersect(bvh, prims, rays, any_hit, robust, leaf=leaf, out=out)
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
         ev0.record()
         for _ in range(reps):
-            bvh_amd.intersect(bvh, prims, rays, any_hit, robust, out=out)
+            bvh_amd.intersect(bvh, prims, rays, any_hit, robust, leaf=leaf, out=out)
         ev1.record()
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / reps
@@ -55,10 +63,13 @@ def child(scene, n, nr):
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from conftest import parse_stream
             orc = oracle.load_oracle()
-            nodes, ids = parse_stream(bvh.serialize())
+            nodes, ids = parse_stream(bvh.serialize(), spheres)
             cb = orc.from_arrays(nodes, ids)
             ns = min(nr, 200_000)
-            ref = cb.intersect_tri(orc.precompute_tris(tris, ids), rays_h[:ns], any_hit, robust, threads=orc.hardware_threads())
+            if spheres:
+                ref = cb.intersect_sphere(tris[ids.astype(np.int64)], rays_h[:ns], any_hit, robust, threads=orc.hardware_threads())
+            else:
+                ref = cb.intersect_tri(orc.precompute_tris(tris, ids), rays_h[:ns], any_hit, robust, threads=orc.hardware_threads())
             sample_ok = bool(ref.tobytes() == hits[:ns].tobytes())
         res["runs"].append({"name": name, "kernel": lib.bvh_amd_last_kernel_name().decode(), "ms": round(ms, 3),
                             "mrays_s": round(nr / ms / 1e3, 1), "counters": [int(x) for x in cnt.cpu().numpy()],

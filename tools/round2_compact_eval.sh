@@ -14,6 +14,7 @@ timeout 300 python tools/compact_pairs_gpu.py soup 100000 1048576 > "$out/probe_
 timeout 500 python tools/compact_pairs_gpu.py soup 1000000 8388608 > "$out/probe_soup1m.log" 2>&1; echo "probe soup1m rc=$?" | tee -a "$out/summary.log"
 timeout 400 python tools/compact_pairs_gpu.py sponza 262144 8388608 > "$out/probe_sponza.log" 2>&1; echo "probe sponza rc=$?" | tee -a "$out/summary.log"
 timeout 500 python tools/compact_pairs_gpu.py terrain 1000000 8388608 > "$out/probe_terrain.log" 2>&1; echo "probe terrain rc=$?" | tee -a "$out/summary.log"
+timeout 500 python tools/compact_pairs_gpu.py spheres64 1000000 4194304 > "$out/probe_spheres64.log" 2>&1; echo "probe spheres64 (double) rc=$?" | tee -a "$out/summary.log"
 tail -n 5 "$out"/probe_*.log | tee -a "$out/summary.log"
 
 # 2. the whole GPU suite and a fuzz campaign with the switch on (same bit-exact bar as the default path)
