@@ -28,3 +28,6 @@ timeout 400 python bench.py --no-cpu-baseline > "$out/bench_pairnode.json" 2> "$
 BVH_AMD_PAIRS=compact timeout 400 python bench.py --no-cpu-baseline > "$out/bench_compact.json" 2> "$out/bench_compact.err"; echo "bench compact rc=$?" | tee -a "$out/summary.log"
 cat "$out/bench_pairnode.json" "$out/bench_compact.json" | tee -a "$out/summary.log"
 (cd /tmp && BVH_AMD_PAIRS=compact timeout 400 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/prof" -- python "$OLDPWD/bench.py" --steps 10 --no-cpu-baseline > "$OLDPWD/$out/prof_bench.log" 2>&1); echo "rocprof rc=$?" | tee -a "$out/summary.log"
+
+# 4. (optional, ~9 GPU-minutes: run separately if 1.-3. look good) the refill / leaf-parking thresholds again with the cheaper node fetch:
+#    BVH_AMD_PAIRS=compact SWEEP_REFILL=48,54,58 SWEEP_LEAF=4,8,16 timeout 900 python tools/sweep_thresholds.py > gpurun_out/compact/sweep.log 2>&1
