@@ -1,0 +1,123 @@
+"""CPU: bench.py's control flow and its one-line JSON contract, run end to end against a FAKE device.
+
+bench.py needs an MI355X; here torch.cuda and the bvh_amd entry points it calls are replaced by stand-ins backed by the oracle
+(test infrastructure), on a tiny scene, so that a typo in the timed loop, the build table, the roofline / cpu_baseline objects or
+the JSON assembly shows up without a GPU. Nothing about performance is tested, and none of this is a product path."""
+import io
+import json
+import sys
+import types
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+import oracle
+
+
+class _FakeEvent:
+    _clock = 0.0
+
+    def __init__(self, enable_timing=False):
+        self.t = 0.0
+
+    def record(self):
+        _FakeEvent._clock += 1.0
+        self.t = _FakeEvent._clock
+
+    def elapsed_time(self, other):
+        return other.t - self.t
+
+
+class _FakeBvh:
+    def __init__(self, cb):
+        self.cb = cb
+        self.synced = False
+
+    node_count = property(lambda self: self.cb.node_count)
+    nodes = property(lambda self: self.cb.nodes())
+    prim_ids = property(lambda self: self.cb.prim_ids())
+
+    def serialize(self):
+        return self.cb.serialize()
+
+    def sync_host(self):
+        self.synced = True
+
+    def device_prim_ids(self):
+        return self.cb.prim_ids()
+
+
+def test_bench_json_contract(monkeypatch, orc):
+    import torch
+    import bench
+    import bvh_amd
+    from bvh_amd import synth
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *_: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *_: None)
+    monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != "device"}))
+    real_tensor = torch.tensor
+    monkeypatch.setattr(torch, "tensor", lambda *a, **k: real_tensor(*a, **{x: y for x, y in k.items() if x != "device"}))
+
+    state = {}
+
+    def tri_bounds(t):
+        state["tris"] = np.ascontiguousarray(t.numpy() if hasattr(t, "numpy") else t)
+        return orc.prep_tris(state["tris"])
+
+    def build(bb, cc, cfg, thread_pool=None):
+        return _FakeBvh(orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL if thread_pool is not None else oracle.BUILDER_DEFAULT_SERIAL,
+                                  quality=int(cfg.quality), threads=2))
+
+    def precompute_tris(t, ids):
+        return orc.precompute_tris(state["tris"], np.asarray(ids))
+
+    def intersect(bvh, prims, rays, any_hit=False, robust=False, counters=False, out=None, **kw):
+        r = np.ascontiguousarray(rays.numpy() if hasattr(rays, "numpy") else rays)
+        hits, cnt = bvh.cb.intersect_tri(prims, r, any_hit, robust, threads=2, counters=True)
+        h = torch.from_numpy(hits.view(np.float32).reshape(-1, 4).copy())
+        if out is not None:
+            out.copy_(h)
+            h = out
+        return (h, torch.from_numpy(cnt.astype(np.int64))) if counters else h
+
+    monkeypatch.setattr(bvh_amd, "tri_bounds", tri_bounds)
+    monkeypatch.setattr(bvh_amd.DefaultBuilder, "build", staticmethod(build))
+    monkeypatch.setattr(bvh_amd, "precompute_tris", precompute_tris)
+    monkeypatch.setattr(bvh_amd, "intersect", intersect)
+    fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"fake_kernel")
+    monkeypatch.setattr(bvh_amd._lib, "load", lambda: fake_lib)
+    monkeypatch.setitem(bench.WORKLOADS, "soup_1m", ("soup", 3000, "tiny stand-in scene of the contract test"))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--rays", "4096", "--cpu-sample", "2048"])
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(var, raising=False)
+
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "build"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["unit"] == "Mrays/s" and out["scaling"] == "weak"
+    assert out["dtype"] == "f32" and out["vs_baseline"] is None and out["higher_is_better"] is True
+    assert "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # algorithmic bytes per ray from the batch's own counters
+    assert abs(rf["bytes_per_ray"] - (32 + 56 * rf["P_node_pairs_per_ray"] + 48 * rf["T_prim_tests_per_ray"] + 16)) < 0.5
+    cb = out["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["gpu_matches_cpu_hits"] is True and cb["gpu_tree_equals_cpu_tree"] is True
+    b = out["build"]
+    assert set(b["all_qualities_ms"]) == {"low", "medium", "high"} and b["ms_with_host_mirror"] >= b["ms"] > 0
