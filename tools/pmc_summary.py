@@ -8,7 +8,7 @@ from collections import defaultdict
 
 def main(root, match="trace_kernel"):
     out = []
-    for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
+    for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(path)):
             name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
@@ -17,7 +17,7 @@ def main(root, match="trace_kernel"):
             acc[key][1] += 1
         for (k, c), (s, n) in sorted(acc.items()):
             if match in k:
-                out.append(f"{os.path.basename(os.path.dirname(path))},\"{k}\",{c},{n},{s / n:.1f}")
+                out.append(f"{os.path.relpath(path, root).split(os.sep)[0]},\"{k}\",{c},{n},{s / n:.1f}")
     print("pass,kernel,counter,dispatches,avg_per_dispatch")
     print("\n".join(out))
 
