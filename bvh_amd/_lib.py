@@ -53,6 +53,7 @@ _SIGS = {
     "bvh_amd_version": (C.c_char_p, []),
     "bvh_amd_last_kernel_name": (C.c_char_p, []),
     "bvh_amd_reinsertion_stats": (None, [C.POINTER(C.c_uint)]),
+    "bvh_amd_probe_record_walk": (_I, [_P, C.c_uint32, C.c_uint32, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
     "bvh_amd_device_count": (_I, []),
     "bvh_amd_device_name": (_I, [_I, C.c_char_p, _Z]),
     "bvh_thread_pool_create": (_P, [_Z]),
@@ -93,6 +94,8 @@ _SIGS_T = {
     "bvh{S}_load": (_P, [_P]),
     "bvh{S}_serialize": (_Z, [_P, _P, _Z]),
     "bvh{S}_deserialize": (_P, [_P, _Z]),
+    "bvh{S}_serialize_device": (_Z, [_P, _P, _Z, _P]),
+    "bvh{S}_deserialize_device": (_P, [_P, _Z, _P]),
     "bvh{S}_get_node": (_P, [_P, _Z]),
     "bvh{S}_get_prim_id": (_Z, [_P, _Z]),
     "bvh{S}_get_prim_count": (_Z, [_P]),

@@ -212,6 +212,26 @@ class Bvh:
         _torch()
         return Bvh(getattr(lib, f"bvh{s}_deserialize")(data, len(data)), s)
 
+    def serialize_device(self):
+        """Bvh::serialize (bvh.h:221-229) into HBM: a uint8 torch tensor holding the reference's byte stream, written from the
+        resident nodes on the current stream (no host copy). This is the RCCL broadcast payload."""
+        torch = _torch()
+        n = self._f("bvh{S}_serialize_device")(self._h, None, 0, _stream())
+        buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+        if self._f("bvh{S}_serialize_device")(self._h, buf.data_ptr(), n, _stream()) != n:
+            raise _lib.BvhAmdError(_lib.last_error())
+        return buf
+
+    @staticmethod
+    def deserialize_device(buf, dtype=np.float32, dim: int = 3) -> "Bvh":
+        """Bvh::deserialize (bvh.h:231-243) of a byte stream resident in HBM (uint8 torch tensor): kernels and device-to-device
+        copies only; the stream's structure is validated on the device."""
+        torch = _torch()
+        s = _suffix(np.dtype(dtype), dim)
+        if not (buf.is_cuda and buf.dtype == torch.uint8 and buf.is_contiguous()):
+            raise TypeError("deserialize_device takes a contiguous uint8 tensor resident on the GPU")
+        return Bvh(getattr(_lib.load(), f"bvh{s}_deserialize_device")(buf.data_ptr(), buf.numel(), _stream()), s)
+
     def intersect_ray(self, ray, leaf_fn, any_hit: bool = False, robust: bool = False, inner_fn=None, start=None):
         """Bvh::intersect<IsAnyHit, IsRobust>(ray, start, stack, leaf_fn, inner_fn) (bvh.h:72-73) for ONE ray with host
         callbacks, over bvhXX_intersect_ray_visit: leaf_fn(tmax, begin, end) -> (was_hit, new_tmax) receives a BVH-order

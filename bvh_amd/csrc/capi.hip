@@ -163,7 +163,8 @@ typename CTypes<T>::Bvh* deserialize(const void* bytes, size_t size) {
     I hdr[2];
     std::memcpy(hdr, p, sizeof(hdr)); p += sizeof(hdr);
     size_t nn = hdr[0], np = hdr[1];
-    if (size < 2 * sizeof(I) + nn * sizeof(HostNode<T>) + np * sizeof(I)) { set_error("deserialize: truncated stream"); return nullptr; }
+    if (nn > size / sizeof(HostNode<T>) || np > size / sizeof(I) ||           // (bounded first: a crafted header must not overflow the sum)
+        size < 2 * sizeof(I) + nn * sizeof(HostNode<T>) + np * sizeof(I)) { set_error("deserialize: truncated stream"); return nullptr; }
     auto b = std::make_unique<BvhImpl<T>>();
     b->nodes.resize(nn);
     std::memcpy(b->nodes.data(), p, nn * sizeof(HostNode<T>)); p += nn * sizeof(HostNode<T>);
@@ -185,7 +186,9 @@ typename CTypes<T>::Bvh* load(FILE* f) {
     using I = typename IndexOf<T>::Type;
     I hdr[2] = {0, 0};
     if (fread(hdr, sizeof(I), 2, f) != 2) { set_error("load: truncated stream"); return nullptr; }
-    std::vector<uint8_t> buf(2 * sizeof(I) + size_t(hdr[0]) * sizeof(HostNode<T>) + size_t(hdr[1]) * sizeof(I));
+    std::vector<uint8_t> buf;
+    try { buf.resize(2 * sizeof(I) + size_t(hdr[0]) * sizeof(HostNode<T>) + size_t(hdr[1]) * sizeof(I)); }
+    catch (const std::exception&) { set_error("load: the header asks for more memory than there is"); return nullptr; }   // (never across the C ABI)
     std::memcpy(buf.data(), hdr, sizeof(hdr));
     size_t rest = buf.size() - sizeof(hdr);
     if (fread(buf.data() + sizeof(hdr), 1, rest, f) != rest) { set_error("load: truncated stream"); return nullptr; }
@@ -211,6 +214,16 @@ int make_nodes_resident(BvhImpl<T>& b) {
         BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
     }
     return BVH_AMD_OK;
+}
+
+// Bvh::serialize into / Bvh::deserialize out of DEVICE memory (wire.hip): the broadcast payload never visits the host.
+template <typename T>
+size_t serialize_device(BvhImpl<T>* pb, void* d_out, size_t cap, void* stream) {
+    if (!pb) { set_error("serialize_device: null bvh"); return 0; }
+    const size_t need = wire_size<T>(*pb);
+    if (!d_out || cap < need) return need;
+    if (make_nodes_resident<T>(*pb)) return 0;
+    return serialize_to_device<T>(*pb, d_out, cap, static_cast<hipStream_t>(stream));
 }
 
 // Runs `op` (optimize / refit) on the resident reference-layout nodes, then refreshes the traversal records and (if it was
@@ -383,7 +396,9 @@ typename CTypes2<T>::Bvh* load2(FILE* f) {
     using I = typename IndexOf<T>::Type;
     I hdr[2] = {0, 0};
     if (fread(hdr, sizeof(I), 2, f) != 2) { set_error("load: truncated stream"); return nullptr; }
-    std::vector<uint8_t> buf(2 * sizeof(I) + size_t(hdr[0]) * sizeof(HostNode2<T>) + size_t(hdr[1]) * sizeof(I));
+    std::vector<uint8_t> buf;
+    try { buf.resize(2 * sizeof(I) + size_t(hdr[0]) * sizeof(HostNode2<T>) + size_t(hdr[1]) * sizeof(I)); }
+    catch (const std::exception&) { set_error("load: the header asks for more memory than there is"); return nullptr; }
     std::memcpy(buf.data(), hdr, sizeof(hdr));
     const size_t rest = buf.size() - sizeof(hdr);
     if (fread(buf.data() + sizeof(hdr), 1, rest, f) != rest) { set_error("load: truncated stream"); return nullptr; }
@@ -538,6 +553,9 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_load(FILE* f) { return f ? load<T>(f) : nullptr; }                                             \
     size_t bvh##S##_serialize(const bvh##S* b, void* out, size_t cap) { return b ? serialize<T>(*impl<T>(b), out, cap) : 0; } \
     bvh##S* bvh##S##_deserialize(const void* bytes, size_t size) { return deserialize<T>(bytes, size); }            \
+    size_t bvh##S##_serialize_device(bvh##S* b, void* d_out, size_t cap, void* stream) { return serialize_device<T>(impl<T>(b), d_out, cap, stream); } \
+    bvh##S* bvh##S##_deserialize_device(const void* d_bytes, size_t size, void* stream) {                           \
+        return handle<T>(deserialize_from_device<T>(d_bytes, size, 3, static_cast<hipStream_t>(stream))); }         \
     bvh_node##S* bvh##S##_get_node(bvh##S* b, size_t i) {                                                          \
         if (impl<T>(b)->sync_host() != BVH_AMD_OK) return nullptr;                                                   \
         return reinterpret_cast<bvh_node##S*>(&impl<T>(b)->nodes[i]); }                                              \
@@ -634,6 +652,9 @@ BVH_AMD_IMPL_RAY(double, 3d, bvh_intersect_callbackd, bvh_amd_ray_visitord, 3, i
     bvh##S* bvh##S##_load(FILE* f) { return f ? load2<T>(f) : nullptr; }                                            \
     size_t bvh##S##_serialize(const bvh##S* b, void* out, size_t cap) { return b ? serialize2<T>(*impl2<T>(b), out, cap) : 0; } \
     bvh##S* bvh##S##_deserialize(const void* bytes, size_t size) { return deserialize2<T>(bytes, size); }           \
+    size_t bvh##S##_serialize_device(bvh##S* b, void* d_out, size_t cap, void* stream) { return serialize_device<T>(impl2<T>(b), d_out, cap, stream); } \
+    bvh##S* bvh##S##_deserialize_device(const void* d_bytes, size_t size, void* stream) {                           \
+        return handle2<T>(deserialize_from_device<T>(d_bytes, size, 2, static_cast<hipStream_t>(stream))); }        \
     bvh_node##S* bvh##S##_get_node(bvh##S* b, size_t i) {                                                          \
         if (impl2<T>(b)->sync_host2() != BVH_AMD_OK) return nullptr;                                                 \
         return reinterpret_cast<bvh_node##S*>(&impl2<T>(b)->nodes2[i]); }                                            \

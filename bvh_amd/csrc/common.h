@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <atomic>
 #include <mutex>
@@ -146,6 +147,14 @@ struct SahScope {
 template <typename T> int upload_bvh(BvhImpl<T>& b, hipStream_t stream);
 template <typename T> int tree_depth(const BvhImpl<T>& b, hipStream_t stream);   // fills b.max_depth (cached)
 template <typename T> int ensure_compact_pairs(const BvhImpl<T>& b, hipStream_t stream);   // fills b.d_cpairs / b.compact_state (cached)
+
+template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
+
+// wire.hip: the Bvh::serialize byte stream in device memory, and the structural checks the traversal records rely on
+template <typename T> size_t wire_size(const BvhImpl<T>& b);
+template <typename T> size_t serialize_to_device(const BvhImpl<T>& b, void* d_out, size_t cap, hipStream_t stream);
+template <typename T> BvhImpl<T>* deserialize_from_device(const void* d_bytes, size_t size, int dim, hipStream_t stream);
+template <typename T> int validate_resident_nodes(const HostNode<T>* d_nodes, size_t nn, size_t np, hipStream_t stream, const char* who);
 
 // traverse.hip
 template <typename T>

@@ -236,7 +236,8 @@ int upload_bvh(BvhImpl<T>& b, hipStream_t stream) {
     HostNode<T>* d_nodes = nullptr;
     BVH_HIP_TRY(hipMalloc(&d_nodes, b.nodes.size() * sizeof(HostNode<T>)), BVH_AMD_ERR_HIP);
     hipError_t e = hipMemcpyAsync(d_nodes, b.nodes.data(), b.nodes.size() * sizeof(HostNode<T>), hipMemcpyHostToDevice, stream);
-    int rc = e == hipSuccess ? relayout_on_device(b, d_nodes, stream) : fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
+    int rc = e == hipSuccess ? validate_resident_nodes<T>(d_nodes, b.nodes.size(), b.prim_ids.size(), stream, "upload") : fail(BVH_AMD_ERR_HIP, hipGetErrorString(e));
+    if (rc == BVH_AMD_OK) rc = relayout_on_device(b, d_nodes, stream);
     if (rc == BVH_AMD_OK) {
         std::vector<uint32_t> ids(b.prim_ids.size());
         for (size_t i = 0; i < ids.size(); ++i) ids[i] = static_cast<uint32_t>(b.prim_ids[i]);

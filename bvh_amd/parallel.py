@@ -57,24 +57,53 @@ def broadcast_tensor(t, shape_hint=None, src: int = 0, dtype=None, device=None):
     return t
 
 
-def broadcast_scene(bvh, prims, src: int = 0):
-    """Rank `src` holds (Bvh, BVH-ordered primitive tensor); every rank returns its own device-resident copy."""
+def broadcast_scene(bvh, prims, src: int = 0, timing: dict = None):
+    """Rank `src` holds (Bvh, BVH-ordered primitive tensor); every rank returns its own device-resident copy.
+
+    The payload is the reference's `Bvh::serialize` byte stream (bvh.h:221-229) written into HBM by `Bvh.serialize_device`, one
+    `torch.distributed.broadcast` of that device buffer (backend nccl = RCCL over xGMI: root-to-all, no ring), and
+    `Bvh.deserialize_device` on the receivers; then the primitive array the same way. With RCCL no payload byte touches the
+    host on any rank. (gloo, CPU tests only: gloo cannot move device memory, so the same device buffers are staged through
+    host tensors around the collective.) `timing`, if given, receives {"broadcast_ms", "payload_bytes"} (wall time of the whole
+    exchange on this rank, device-synchronised)."""
+    import time
     import torch
     import torch.distributed as dist
     from .api import Bvh
     rank = dist.get_rank()
-    flag = torch.tensor([0 if (rank != src or bvh.dtype == np.float32) else 1], dtype=torch.int64,
-                        device="cuda" if dist.get_backend() == "nccl" else "cpu")
-    dist.broadcast(flag, src)
-    dtype = np.float64 if int(flag.item()) else np.float32
-    stream = broadcast_bytes(bvh.serialize() if rank == src else None, src)
+    on_device = dist.get_backend() == "nccl"
+    coll = "cuda" if on_device else "cpu"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    meta = torch.zeros(5, dtype=torch.int64, device=coll)      # stream bytes, is_double, dim, prims rows, prims cols
+    buf = None
+    if rank == src:
+        buf = bvh.serialize_device()
+        meta[0], meta[1], meta[2] = buf.numel(), int(bvh.dtype == np.float64), bvh.dim
+        meta[3], meta[4] = prims.shape[0], prims.shape[1]
+    dist.broadcast(meta, src)
+    m = [int(v) for v in meta.tolist()]
+    dtype = np.float64 if m[1] else np.float32
+    tdt = torch.float64 if m[1] else torch.float32
+    if on_device:
+        if rank != src:
+            buf = torch.empty(m[0], dtype=torch.uint8, device="cuda")
+            prims = torch.empty((m[3], m[4]), dtype=tdt, device="cuda")
+        dist.broadcast(buf, src)
+        dist.broadcast(prims, src)
+    else:
+        hbuf = buf.cpu() if rank == src else torch.empty(m[0], dtype=torch.uint8)
+        hprims = prims.cpu() if rank == src else torch.empty((m[3], m[4]), dtype=tdt)
+        dist.broadcast(hbuf, src)
+        dist.broadcast(hprims, src)
+        if rank != src:
+            buf, prims = hbuf.cuda(), hprims.cuda()
     if rank != src:
-        bvh = Bvh.deserialize(stream, dtype=dtype)
-    tdt = torch.float64 if dtype == np.float64 else torch.float32
-    if dist.get_backend() == "nccl":
-        prims = broadcast_tensor(prims, src=src, dtype=tdt)
-    else:                                                     # CPU collectives (tests): stage through host memory
-        prims = broadcast_tensor(prims.cpu() if rank == src else None, src=src, dtype=tdt, device="cpu").cuda()
+        bvh = Bvh.deserialize_device(buf, dtype=dtype, dim=m[2])
+    torch.cuda.synchronize()
+    if timing is not None:
+        timing["broadcast_ms"] = (time.perf_counter() - t0) * 1e3
+        timing["payload_bytes"] = m[0] + m[3] * m[4] * (8 if m[1] else 4)
     return bvh, prims
 
 

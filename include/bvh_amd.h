@@ -134,6 +134,11 @@ BVH_AMD_API void bvh_amd_device_free(void* d_ptr);
 BVH_AMD_API int bvh_amd_copy_to_device(void* d_dst, const void* h_src, size_t bytes);
 BVH_AMD_API int bvh_amd_copy_to_host(void* h_dst, const void* d_src, size_t bytes);
 BVH_AMD_API int bvh_amd_synchronize(void* stream);
+/* Measurement aid for bench.py (csrc/probe.hip): mean launch time of a dependent walk over a table of 64-byte records (word 0 of
+ * a record = index of the next one), one record in flight per lane — the rate the memory system gives the traversal's access
+ * pattern when nothing else is in the way. Not used by any product path. */
+BVH_AMD_API int bvh_amd_probe_record_walk(const void* d_table, uint32_t n_records, uint32_t steps, int blocks_per_cu, int reps,
+                                          float* ms_out, unsigned long long* records_out, void* stream);
 
 /* ---- thread pool (c_api/bvh.h:90-91). Kept for signature compatibility; the GPU grid replaces it.
  * A non-NULL pool selects the reference's *parallel* builder semantics (mini-trees). ------------- */
@@ -246,6 +251,16 @@ BVH_AMD_API size_t bvh3f_serialize(const struct bvh3f*, void* out, size_t cap);
 BVH_AMD_API size_t bvh3d_serialize(const struct bvh3d*, void* out, size_t cap);
 BVH_AMD_API struct bvh3f* bvh3f_deserialize(const void* bytes, size_t size);
 BVH_AMD_API struct bvh3d* bvh3d_deserialize(const void* bytes, size_t size);
+/* The same stream in DEVICE memory (bvh.h:221-243, node.h:90-102): written from / turned into the resident nodes by kernels and
+ * device-to-device copies, so the RCCL broadcast of a scene moves no payload byte through the host (deserialize reads the
+ * 16-byte header and the root node only). d_out / d_bytes must be aligned to the index type (4 bytes float, 8 double).
+ * serialize: returns the stream size, writes (asynchronously on `stream`) only if cap suffices, 0 on error.
+ * deserialize: validates the structure the traversal relies on (children adjacent at an odd index, leaf ranges inside prim_ids);
+ * the buffer may be released when the call returns. */
+BVH_AMD_API size_t bvh3f_serialize_device(struct bvh3f*, void* d_out, size_t cap, void* stream);
+BVH_AMD_API size_t bvh3d_serialize_device(struct bvh3d*, void* d_out, size_t cap, void* stream);
+BVH_AMD_API struct bvh3f* bvh3f_deserialize_device(const void* d_bytes, size_t size, void* stream);
+BVH_AMD_API struct bvh3d* bvh3d_deserialize_device(const void* d_bytes, size_t size, void* stream);
 
 /* ---- accessors (c_api/bvh.h:148-203), on the host mirror -------------------------------------- */
 BVH_AMD_API struct bvh_node3f* bvh3f_get_node(struct bvh3f*, size_t);
@@ -383,6 +398,8 @@ BVH_AMD_API void bvh2f_save(const struct bvh2f*, FILE*);
 BVH_AMD_API struct bvh2f* bvh2f_load(FILE*);
 BVH_AMD_API size_t bvh2f_serialize(const struct bvh2f*, void* out, size_t capacity);
 BVH_AMD_API struct bvh2f* bvh2f_deserialize(const void* bytes, size_t size);
+BVH_AMD_API size_t bvh2f_serialize_device(struct bvh2f*, void* d_out, size_t cap, void* stream);
+BVH_AMD_API struct bvh2f* bvh2f_deserialize_device(const void* d_bytes, size_t size, void* stream);
 BVH_AMD_API struct bvh_node2f* bvh2f_get_node(struct bvh2f*, size_t);
 BVH_AMD_API size_t bvh2f_get_prim_id(const struct bvh2f*, size_t);
 BVH_AMD_API size_t bvh2f_get_prim_count(const struct bvh2f*);
@@ -424,6 +441,8 @@ BVH_AMD_API void bvh2d_save(const struct bvh2d*, FILE*);
 BVH_AMD_API struct bvh2d* bvh2d_load(FILE*);
 BVH_AMD_API size_t bvh2d_serialize(const struct bvh2d*, void* out, size_t capacity);
 BVH_AMD_API struct bvh2d* bvh2d_deserialize(const void* bytes, size_t size);
+BVH_AMD_API size_t bvh2d_serialize_device(struct bvh2d*, void* d_out, size_t cap, void* stream);
+BVH_AMD_API struct bvh2d* bvh2d_deserialize_device(const void* d_bytes, size_t size, void* stream);
 BVH_AMD_API struct bvh_node2d* bvh2d_get_node(struct bvh2d*, size_t);
 BVH_AMD_API size_t bvh2d_get_prim_id(const struct bvh2d*, size_t);
 BVH_AMD_API size_t bvh2d_get_prim_count(const struct bvh2d*);

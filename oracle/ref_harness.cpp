@@ -35,6 +35,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -216,6 +217,33 @@ void parallel_chunks(size_t n, int threads, F&& fn) {
 
 // The leaf lambda below is the closest-hit / any-hit pattern of test/benchmark.cpp:277-298 and
 // test/simple_example.cpp:81-92 (permuted primitives: the BVH-order index i addresses prims[i]).
+// rays [rb, re) through `b`, one after the other (what one worker does)
+template <typename T, size_t D, bool Any, bool Robust, typename Prim, typename LeafTest>
+void trace_range(const BvhN<T, D>* b, const Prim* prims, const T* rays8, size_t rb, size_t re, typename HitOf<T>::Type* out,
+                 LeafTest& leaf_test, uint64_t& pairs, uint64_t& tests, uint64_t& leaves)
+{
+    for (size_t r = rb; r < re; ++r) {
+        const T* q = rays8 + (2 * D + 2) * r;                 // {org[D], dir[D], tmin, tmax}
+        Vec<T, D> org, dir;
+        for (size_t k = 0; k < D; ++k) { org[k] = q[k]; dir[k] = q[D + k]; }
+        Ray<T, D> ray(org, dir, q[2 * D], q[2 * D + 1]);
+        typename HitOf<T>::Type h{};
+        h.prim = ORC_INVALID; h.t = q[2 * D + 1]; h.u = 0; h.v = 0;
+        SmallStack<typename BvhN<T, D>::Index, 64> stack;
+        b->template intersect<Any, Robust>(ray, b->get_root().index, stack,
+            [&](size_t begin, size_t end) {
+                ++leaves;
+                for (size_t i = begin; i < end; ++i) {
+                    ++tests;
+                    leaf_test(prims[i], ray, i, h);
+                }
+                return h.prim != ORC_INVALID;
+            },
+            [&](const Node<T, D>&, const Node<T, D>&) { ++pairs; });
+        out[r] = h;
+    }
+}
+
 template <typename T, size_t D, bool Any, bool Robust, typename Prim, typename LeafTest>
 void intersect_all(const BvhN<T, D>* b, const Prim* prims, const T* rays8, size_t nrays, int threads,
                    typename HitOf<T>::Type* out, uint64_t* counters, LeafTest&& leaf_test)
@@ -223,26 +251,7 @@ void intersect_all(const BvhN<T, D>* b, const Prim* prims, const T* rays8, size_
     std::vector<uint64_t> cnt(3 * std::max(threads, 1), 0);
     parallel_chunks(nrays, threads, [&](size_t rb, size_t re, int slot) {
         uint64_t pairs = 0, tests = 0, leaves = 0;
-        for (size_t r = rb; r < re; ++r) {
-            const T* q = rays8 + (2 * D + 2) * r;                 // {org[D], dir[D], tmin, tmax}
-            Vec<T, D> org, dir;
-            for (size_t k = 0; k < D; ++k) { org[k] = q[k]; dir[k] = q[D + k]; }
-            Ray<T, D> ray(org, dir, q[2 * D], q[2 * D + 1]);
-            typename HitOf<T>::Type h{};
-            h.prim = ORC_INVALID; h.t = q[2 * D + 1]; h.u = 0; h.v = 0;
-            SmallStack<typename BvhN<T, D>::Index, 64> stack;
-            b->template intersect<Any, Robust>(ray, b->get_root().index, stack,
-                [&](size_t begin, size_t end) {
-                    ++leaves;
-                    for (size_t i = begin; i < end; ++i) {
-                        ++tests;
-                        leaf_test(prims[i], ray, i, h);
-                    }
-                    return h.prim != ORC_INVALID;
-                },
-                [&](const Node<T, D>&, const Node<T, D>&) { ++pairs; });
-            out[r] = h;
-        }
+        trace_range<T, D, Any, Robust>(b, prims, rays8, rb, re, out, leaf_test, pairs, tests, leaves);
         cnt[3 * slot + 0] += pairs; cnt[3 * slot + 1] += tests; cnt[3 * slot + 2] += leaves;
     });
     if (counters) {
@@ -250,6 +259,33 @@ void intersect_all(const BvhN<T, D>* b, const Prim* prims, const T* rays8, size_
         for (size_t i = 0; i < cnt.size(); i += 3) {
             counters[0] += cnt[i]; counters[1] += cnt[i + 1]; counters[2] += cnt[i + 2];
         }
+    }
+}
+
+// The CPU baseline of bench.py: the ray array split by the reference's own ParallelExecutor::for_each
+// (executor.h:51-61: one chunk per worker of a persistent ThreadPool), each worker running the benchmark.cpp:277-298 loop;
+// `reps` timed passes after one untimed pass, seconds per pass in `seconds`.
+template <typename T, bool Any, bool Robust>
+void bench_tri(const Bvh3<T>* b, const T* tris12, const T* rays8, size_t nrays, int threads, int reps,
+               typename HitOf<T>::Type* out, double* seconds)
+{
+    auto prims = reinterpret_cast<const PrecomputedTri<T>*>(tris12);
+    auto leaf_test = [](const PrecomputedTri<T>& tri, Ray<T, 3>& ray, size_t i, typename HitOf<T>::Type& h) {
+        if (auto hit = tri.intersect(ray)) {
+            std::tie(ray.tmax, h.u, h.v) = *hit;
+            h.t = ray.tmax;
+            h.prim = static_cast<decltype(h.prim)>(i);
+        }
+    };
+    ThreadPool pool(static_cast<size_t>(std::max(threads, 0)));
+    ParallelExecutor executor(pool);
+    for (int rep = -1; rep < reps; ++rep) {
+        const auto t0 = std::chrono::steady_clock::now();
+        executor.for_each(0, nrays, [&](size_t rb, size_t re) {
+            uint64_t pairs = 0, tests = 0, leaves = 0;
+            trace_range<T, 3, Any, Robust>(b, prims, rays8, rb, re, out, leaf_test, pairs, tests, leaves);
+        });
+        if (rep >= 0) seconds[rep] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 }
 
@@ -364,6 +400,9 @@ REF_IMPL(double, 2, 2d)
 REF_IMPL_TRI(float, 3f)
 REF_IMPL_TRI(double, 3d)
 
+ORC_EXPORT void ref_bench_tri3f(void* h, const float* tris12, const float* rays8, size_t n, int any, int robust, int threads, int reps,
+                                orc_hitf* out, double* seconds) {
+    DISPATCH4(bench_tri, float, any, robust, static_cast<const Bvh3<float>*>(h), tris12, rays8, n, threads, reps, out, seconds); }
 ORC_EXPORT int ref_hardware_threads(void) { return static_cast<int>(std::thread::hardware_concurrency()); }
 
 } // extern "C"

@@ -92,8 +92,8 @@ def test_bench_json_contract(monkeypatch, orc):
     monkeypatch.setattr(bvh_amd, "intersect", intersect)
     fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"fake_kernel")
     monkeypatch.setattr(bvh_amd._lib, "load", lambda: fake_lib)
-    monkeypatch.setitem(bench.WORKLOADS, "soup_1m", ("soup", 3000, "tiny stand-in scene of the contract test"))
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--rays", "4096", "--cpu-sample", "2048"])
+    monkeypatch.setitem(bench.WORKLOADS, "soup_1m", ("soup", 3000, "tiny stand-in scene of the contract test", "3000-tri stand-in"))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--rays", "4096", "--cpu-sample", "2048", "--no-probe"])
     for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(var, raising=False)
 
@@ -119,5 +119,13 @@ def test_bench_json_contract(monkeypatch, orc):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["gpu_matches_cpu_hits"] is True and cb["gpu_tree_equals_cpu_tree"] is True
+    assert out["metric"] == "Mrays/s closest-hit (3000-tri stand-in)"           # the label follows the workload
+    assert rf["traffic"] is None and "traffic_source" in rf                     # no --pmc pass is recorded for this workload: never a stale number
+    rb = out["roofline_binding"]
+    assert rb["bound"] == "l2_miss_path" and rb["achieved"] is None and rb["peak"] is None and rb["frac"] is None
     b = out["build"]
+    for q in ("low", "medium", "high"):
+        r = b["roofline"][q]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 1.0 < r["mean_split_ancestors"] < 40.0
+        assert abs(r["bytes_per_tri"] - (76.0 + 76.0 * r["mean_split_ancestors"] + 28.0 * out["config"]["nodes"] / 3000)) < 60.0
     assert set(b["all_qualities_ms"]) == {"low", "medium", "high"} and b["ms_with_host_mirror"] >= b["ms"] > 0
