@@ -84,6 +84,7 @@ _SIGS_T = {
     "bvh{S}_optimize": (None, [_P, _P]),
     "bvh{S}_optimize_config": (_I, [_P, _P]),
     "bvh{S}_refit": (None, [_P]),
+    "bvh{S}_refit_status": (_I, [_P]),
     "bvh{S}_sync_device": (_I, [_P]),
     "bvh{S}_append_node": (None, [_P]),
     "bvh{S}_remove_last_node": (None, [_P]),

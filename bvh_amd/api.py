@@ -168,17 +168,12 @@ class Bvh:
                                       3 if max_iter_count is None else int(max_iter_count))
             _lib.check(self._f("bvh{S}_optimize_config")(self._h, C.byref(cfg)), "optimize")
             return
-        _lib.load().bvh_amd_last_error()
-        before = self._lib.bvh_amd_last_error()
-        self._f("bvh{S}_optimize")(None, self._h)
-        err = self._lib.bvh_amd_last_error()
-        if err and err != before and b"optimize" in err:
-            raise _lib.BvhAmdError(err.decode())
+        _lib.check(self._f("bvh{S}_optimize_config")(self._h, None), "optimize")      # NULL config = the reference's defaults
 
     def refit(self):
         """Bvh::refit (bvh.h:211-218) on the device; pushes host-side node edits first."""
         _torch()
-        self._f("bvh{S}_refit")(self._h)
+        _lib.check(self._f("bvh{S}_refit_status")(self._h), "refit")
 
     def set_node_bbox(self, node_id: int, lo, hi):
         """bvh_nodeXX_set_bbox on the host mirror (takes effect on the device at the next refit()/sync_device())."""

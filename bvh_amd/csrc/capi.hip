@@ -457,6 +457,16 @@ template <typename P> P* loud(P* result, const char* what) {
     return result;
 }
 
+// bvhXX_optimize / bvhXX_refit return void in the reference and cannot fail there; here a HIP error or a search-stack overflow would
+// leave the tree un-optimised, un-refitted or half updated with nobody the wiser: say why and stop (callers that want to handle
+// the failure use the int-returning bvhXX_optimize_config / bvhXX_refit_status).
+inline void loud_or_abort(int rc, const char* what) {
+    if (rc != BVH_AMD_OK) {
+        std::fprintf(stderr, "bvh_amd: %s failed: %s\n", what, g_error.c_str());
+        std::abort();
+    }
+}
+
 // The reference's functions return void and cannot fail; a failure here would otherwise read as "no intersection".
 template <typename T, int D, typename Callback>
 void intersect_ray_legacy(const BvhImpl<T>* b, const void* ray, const Callback* callback, unsigned flags) {
@@ -529,9 +539,10 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes<T>(nodes, nn, ids, np); }                                                                 \
     void bvh##S##_destroy(bvh##S* b) { delete impl<T>(b); }                                                         \
-    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(impl<T>(b)); }                         \
+    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { loud_or_abort(optimize<T>(impl<T>(b)), "bvh" #S "_optimize"); } \
     int bvh##S##_optimize_config(bvh##S* b, const bvh_amd_optimize_config* c) { return optimize_config<T>(impl<T>(b), c); } \
-    void bvh##S##_refit(bvh##S* b) { (void)refit<T>(impl<T>(b)); }                                                  \
+    void bvh##S##_refit(bvh##S* b) { loud_or_abort(refit<T>(impl<T>(b)), "bvh" #S "_refit"); }                     \
+    int bvh##S##_refit_status(bvh##S* b) { return refit<T>(impl<T>(b)); }                                           \
     int bvh##S##_sync_device(bvh##S* b) { return sync_device<T>(impl<T>(b)); }                                       \
     void bvh##S##_append_node(bvh##S* b) {                                                                          \
         if (impl<T>(b)->sync_host() != BVH_AMD_OK) return;                                                           \
@@ -625,9 +636,10 @@ BVH_AMD_IMPL_RAY(double, 3d, bvh_intersect_callbackd, bvh_amd_ray_visitord, 3, i
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes2<T>(nodes, nn, ids, np); }                                                                \
     void bvh##S##_destroy(bvh##S* b) { delete impl2<T>(b); }                                                        \
-    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { (void)optimize<T>(impl2<T>(b)); }                        \
+    void bvh##S##_optimize(bvh_thread_pool*, bvh##S* b) { loud_or_abort(optimize<T>(impl2<T>(b)), "bvh" #S "_optimize"); } \
     int bvh##S##_optimize_config(bvh##S* b, const bvh_amd_optimize_config* c) { return optimize_config<T>(impl2<T>(b), c); } \
-    void bvh##S##_refit(bvh##S* b) { (void)refit<T>(impl2<T>(b)); }                                                 \
+    void bvh##S##_refit(bvh##S* b) { loud_or_abort(refit<T>(impl2<T>(b)), "bvh" #S "_refit"); }                    \
+    int bvh##S##_refit_status(bvh##S* b) { return refit<T>(impl2<T>(b)); }                                          \
     int bvh##S##_sync_device(bvh##S* b) { return sync_device<T>(impl2<T>(b)); }                                      \
     void bvh##S##_append_node(bvh##S* b) {                                                                          \
         if (impl2<T>(b)->sync_host2() != BVH_AMD_OK) return;                                                         \

@@ -124,9 +124,13 @@ struct BvhImpl {
     // Batch launches are re-entrant like the reference's Bvh::intersect on a const Bvh: every launch takes the next of
     // kWorkSlots {ray ticket counter, status word} slots, so launches of one BVH issued from several threads / on several streams
     // do not share a counter (up to kWorkSlots of them in flight at a time).
+    // A slot is handed out again after kWorkSlots further launches; the launch that re-uses it is ordered behind the launch
+    // that had it before (an event per slot), so a 65th launch in flight never shares a counter with a running one.
     static constexpr uint32_t kWorkSlots = 64, kWorkStride = 8;        // slots of 64 bytes
-    unsigned long long* d_work = nullptr;      // kWorkSlots x kWorkStride words: [0] ray counter, [1] status word
+    unsigned long long* d_work = nullptr;      // kWorkSlots x kWorkStride words: [0] ray ticket counter of the launch that holds the slot
     mutable std::atomic<uint32_t> work_next{0};
+    mutable hipEvent_t work_done[kWorkSlots] = {};      // recorded behind the slot's latest launch (created on first use)
+    mutable std::mutex work_mutex;
     ~BvhImpl();
 };
 

@@ -63,7 +63,7 @@ struct TraceArgs {
     const T* rays;
     typename HitOf<T>::Type* hits;
     unsigned long long n;
-    unsigned long long* work;                  // [0] next ray ticket, [1] status (stack overflow)
+    unsigned long long* work;                  // [0] next ray ticket of this launch
     bvh_amd_counters* counters;
     const uint32_t* order;                     // optional: ticket -> ray index (coherence sort); results are unaffected
     uint32_t* deep;                            // stack entries beyond 64, deep_cap per resident lane (trees deeper than 64 levels only)

@@ -24,8 +24,10 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace bvh_amd {
 
@@ -345,7 +347,26 @@ struct StepContext {                           // one per calling thread: the pe
         return BVH_AMD_OK;
     }
 };
-thread_local StepContext t_step;
+// One context per NESTING DEPTH of the per-ray entry points on the calling thread: a leaf callback may itself call
+// bvhXX_intersect_ray* / Bvh::intersect on another (or the same) BVH — two-level / instanced scenes, which the reference's
+// stack-local design allows (bvh_impl.h:244) — and the outer walk is still replaying its log, its pinned buffers and its
+// snapshots when that happens. The inner call therefore claims the next context instead of re-using (or re-allocating) the
+// outer one's.
+struct StepContextPool {
+    std::vector<std::unique_ptr<StepContext>> contexts;
+    size_t depth = 0;
+};
+thread_local StepContextPool t_steps;
+struct StepContextClaim {
+    StepContext* ctx;
+    StepContextClaim() {
+        if (t_steps.depth == t_steps.contexts.size()) t_steps.contexts.push_back(std::make_unique<StepContext>());
+        ctx = t_steps.contexts[t_steps.depth++].get();
+    }
+    ~StepContextClaim() { --t_steps.depth; }
+    StepContextClaim(const StepContextClaim&) = delete;
+    StepContextClaim& operator=(const StepContextClaim&) = delete;
+};
 
 } // namespace
 
@@ -359,8 +380,16 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     if (!d_prims || !d_rays || !d_hits) return fail(BVH_AMD_ERR_ARG, "intersect_rays: null device pointer");
     if (b.node_count == 0 || !b.d_work) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device copy");
     if (b.pair_count && !b.d_pairs) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device nodes");
-    unsigned long long* work = b.d_work + size_t{b.work_next.fetch_add(1) % BvhImpl<T>::kWorkSlots} * BvhImpl<T>::kWorkStride;
-    BVH_HIP_TRY(hipMemsetAsync(work, 0, 2 * sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
+    const uint32_t slot = b.work_next.fetch_add(1) % BvhImpl<T>::kWorkSlots;
+    unsigned long long* work = b.d_work + size_t{slot} * BvhImpl<T>::kWorkStride;
+    hipEvent_t slot_event = nullptr;
+    {   // whoever used this slot kWorkSlots launches ago (possibly on another stream) must be done before it is zeroed again
+        std::lock_guard<std::mutex> lock(b.work_mutex);
+        if (!b.work_done[slot]) BVH_HIP_TRY(hipEventCreateWithFlags(&b.work_done[slot], hipEventDisableTiming), BVH_AMD_ERR_HIP);
+        else BVH_HIP_TRY(hipStreamWaitEvent(stream, b.work_done[slot], 0), BVH_AMD_ERR_HIP);
+        slot_event = b.work_done[slot];
+    }
+    BVH_HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
     if (d_counters) BVH_HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream), BVH_AMD_ERR_HIP);
     TraceArgs<T> args;
     args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
@@ -372,6 +401,7 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     void* deep_mem = nullptr;
     void* sort_mem = nullptr;
     auto release = [&](int rc) {
+        (void)hipEventRecord(slot_event, stream);             // the slot is free again once everything queued so far has run
         if (deep_mem) (void)hipFreeAsync(deep_mem, stream);
         if (sort_mem) (void)hipFreeAsync(sort_mem, stream);
         return rc;
@@ -447,7 +477,8 @@ int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bo
     }
     // SmallStack<Index, 64> of bvh_impl.h:244 for every tree it can hold, as deep as the tree needs otherwise
     const uint32_t cap = static_cast<uint32_t>(std::max(64, b.max_depth.load() + 2));
-    StepContext& c = t_step;
+    StepContextClaim claim;                                   // released when this call returns, callbacks included
+    StepContext& c = *claim.ctx;
     int rc = c.ensure(b.device, cap);
     if (rc) return rc;
     uint32_t* in = c.pinned;

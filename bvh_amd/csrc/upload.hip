@@ -152,6 +152,7 @@ BvhImpl<T>::~BvhImpl() {
         if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_prim_ids) (void)hipFree(d_prim_ids);
         if (d_work) (void)hipFree(d_work);
+        for (hipEvent_t& e : work_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (d_nodes) (void)hipFree(d_nodes);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }

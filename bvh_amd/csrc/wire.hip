@@ -57,25 +57,42 @@ __global__ void __launch_bounds__(256) k_wire_ids_in(const I* in, size_t n, uint
 // What the traversal records rely on (upload.hip: pair p = nodes[2p + 1], nodes[2p + 2]): every inner node's children are an
 // adjacent pair that starts at an odd id inside the array, every leaf's range lies inside prim_ids. A stream from an untrusted
 // source that breaks this would be walked with misaligned pairs / out-of-bounds reads; it is refused instead.
+// `refs[p]` counts the inner nodes whose children are pair p. With every pair referenced exactly once and node 0 referenced by
+// nobody, whatever is reachable from the root is a tree: a walk from the root cannot run in a cycle, and the depth computed
+// for the traversal stack bounds it.
 template <typename T>
-__global__ void __launch_bounds__(256) k_validate_nodes(const HostNode<T>* nodes, size_t nn, size_t np, uint32_t* bad) {
+__global__ void __launch_bounds__(256) k_validate_nodes(const HostNode<T>* nodes, size_t nn, size_t np, uint32_t* refs, uint32_t* bad) {
     const size_t i = blockIdx.x * size_t{256} + threadIdx.x;
     if (i >= nn) return;
     const auto index = nodes[i].index;
     const uint64_t first = static_cast<uint64_t>(index) >> kCountBits, count = static_cast<uint64_t>(index) & kCountMask;
-    if (count == 0) { if ((first & 1u) == 0 || first + 1 >= nn) atomicOr(bad, 1u); }
-    else if (first + count > np) atomicOr(bad, 2u);
+    if (count == 0) {
+        if ((first & 1u) == 0 || first + 1 >= nn) atomicOr(bad, 1u);
+        else atomicAdd(&refs[first >> 1], 1u);
+    } else if (first + count > np) atomicOr(bad, 2u);
+}
+__global__ void __launch_bounds__(256) k_validate_refs(const uint32_t* refs, size_t n_pairs, uint32_t* bad) {
+    const size_t p = blockIdx.x * size_t{256} + threadIdx.x;
+    if (p < n_pairs && refs[p] != 1u) atomicOr(bad, 8u);
 }
 
 template <typename T>
 int check_nodes(const HostNode<T>* d_nodes, size_t nn, size_t np, uint32_t* d_bad, hipStream_t stream, const char* who) {
-    hipLaunchKernelGGL(k_validate_nodes<T>, dim3(static_cast<unsigned>((nn + 255) / 256)), dim3(256), 0, stream, d_nodes, nn, np, d_bad);
-    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    const size_t n_pairs = (nn - 1) / 2;
+    uint32_t* refs = nullptr;
+    BVH_HIP_TRY(hipMalloc(&refs, std::max<size_t>(n_pairs, 1) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
+    hipError_t e = hipMemsetAsync(refs, 0, std::max<size_t>(n_pairs, 1) * sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(k_validate_nodes<T>, dim3(static_cast<unsigned>((nn + 255) / 256)), dim3(256), 0, stream, d_nodes, nn, np, refs, d_bad);
+    if (n_pairs) hipLaunchKernelGGL(k_validate_refs, dim3(static_cast<unsigned>((n_pairs + 255) / 256)), dim3(256), 0, stream, refs, n_pairs, d_bad);
+    if (e == hipSuccess) e = hipGetLastError();
     uint32_t bad = 0;
-    BVH_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(refs);
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
     if (bad & 1u) return fail(BVH_AMD_ERR_ARG, std::string(who) + ": an inner node's children are not an adjacent pair at an odd index inside the node array");
     if (bad & 2u) return fail(BVH_AMD_ERR_ARG, std::string(who) + ": a leaf's primitive range lies outside prim_ids");
+    if (bad & 8u) return fail(BVH_AMD_ERR_ARG, std::string(who) + ": some sibling pair is the child of no inner node or of several (not a tree)");
     if (bad & 4u) return fail(BVH_AMD_ERR_UNSUPPORTED, std::string(who) + ": primitive id beyond 2^28 (32-bit device indices)");
     return BVH_AMD_OK;
 }

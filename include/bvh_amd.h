@@ -227,6 +227,11 @@ BVH_AMD_API int bvh3d_optimize_config(struct bvh3d*, const struct bvh_amd_optimi
  * After editing WITHOUT refit/optimize, call bvhXX_sync_device before tracing (additive; 0 on success). */
 BVH_AMD_API void bvh3f_refit(struct bvh3f*);
 BVH_AMD_API void bvh3d_refit(struct bvh3d*);
+/* The void functions above (c_api/bvh.h:218-229) cannot report a failure: on one (HIP error, reinsertion search-stack overflow)
+ * they print the reason and abort rather than leave a half-updated tree behind. Callers that want to handle it use
+ * bvhXX_optimize_config (NULL config = the reference's defaults) and bvhXX_refit_status: 0 or a negative code + bvh_amd_last_error(). */
+BVH_AMD_API int bvh3f_refit_status(struct bvh3f*);
+BVH_AMD_API int bvh3d_refit_status(struct bvh3d*);
 BVH_AMD_API int bvh3f_sync_device(struct bvh3f*);
 BVH_AMD_API int bvh3d_sync_device(struct bvh3d*);
 BVH_AMD_API void bvh3f_append_node(struct bvh3f*);
@@ -388,6 +393,7 @@ BVH_AMD_API void bvh2f_destroy(struct bvh2f*);
 BVH_AMD_API void bvh2f_optimize(struct bvh_thread_pool*, struct bvh2f*);
 BVH_AMD_API int bvh2f_optimize_config(struct bvh2f*, const struct bvh_amd_optimize_config*);
 BVH_AMD_API void bvh2f_refit(struct bvh2f*);
+BVH_AMD_API int bvh2f_refit_status(struct bvh2f*);
 BVH_AMD_API int bvh2f_sync_device(struct bvh2f*);
 BVH_AMD_API void bvh2f_append_node(struct bvh2f*);
 BVH_AMD_API void bvh2f_remove_last_node(struct bvh2f*);
@@ -431,6 +437,7 @@ BVH_AMD_API void bvh2d_destroy(struct bvh2d*);
 BVH_AMD_API void bvh2d_optimize(struct bvh_thread_pool*, struct bvh2d*);
 BVH_AMD_API int bvh2d_optimize_config(struct bvh2d*, const struct bvh_amd_optimize_config*);
 BVH_AMD_API void bvh2d_refit(struct bvh2d*);
+BVH_AMD_API int bvh2d_refit_status(struct bvh2d*);
 BVH_AMD_API int bvh2d_sync_device(struct bvh2d*);
 BVH_AMD_API void bvh2d_append_node(struct bvh2d*);
 BVH_AMD_API void bvh2d_remove_last_node(struct bvh2d*);

@@ -338,3 +338,54 @@ def test_callback_walk_on_a_tree_deeper_than_the_small_stack(orc):
             leaves += calls[0]
             assert state["prim"] == (int(want["prim"][j]) if want["prim"][j] != oracle.INVALID else -1)
         assert (pairs, leaves) == (int(cnt[0]), int(cnt[2]))
+
+
+@pytest.mark.gpu
+def test_nested_per_ray_walks_two_level_scene(orc):
+    """A leaf callback that itself traces another BVH (two-level / instanced scenes: what the reference's stack-local
+    Bvh::intersect allows, bvh_impl.h:244). The inner walk must not disturb the outer walk's log, snapshots or buffers: the
+    outer callback sequence with nesting equals the sequence without, and every inner result equals the standalone one — also
+    when the inner BVH is much deeper than the outer one (its context has to be its own, not a re-allocation of the outer's)."""
+    import oracle
+    import bvh_amd
+    f = np.float32
+    outer_tris = synth.sponza_proxy(20000)
+    inner_tris = synth.soup(30000, seed=17, jitter=0.02)
+    lo, hi = synth.scene_bounds(outer_tris)
+    inner_tris = (inner_tris.reshape(-1, 3) * (hi - lo).astype(f) + lo.astype(f)).reshape(-1, 9).astype(f)     # same place as the outer scene
+    bvhs, prims = [], []
+    for tris, q in ((outer_tris, bvh_amd.Quality.Low), (inner_tris, bvh_amd.Quality.High)):
+        bb, cc = bvh_amd.tri_bounds(tris)
+        b = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=q))
+        bvhs.append(b)
+        prims.append(orc.precompute_tris(tris, b.prim_ids))
+    outer, inner = bvhs
+    rays = synth.rays_closest(120, lo, hi)
+    n_nested = 0
+    for ray in rays:
+        # standalone answers first
+        leaf_i, state_i = _tri_leaf(prims[1], ray, f)
+        inner.intersect_ray(ray, leaf_i, robust=True)
+        alone_inner = dict(state_i)
+        plain_calls = []
+        leaf_o, state_o = _tri_leaf(prims[0], ray, f)
+
+        def plain(tmax, begin, end, leaf=leaf_o, log=plain_calls):
+            log.append((begin, end, float(tmax)))
+            return leaf(tmax, begin, end)
+        outer.intersect_ray(ray, plain, robust=True)
+        alone_outer = dict(state_o)
+        # now the same outer walk with an inner walk inside every leaf callback
+        nested_calls = []
+        leaf_o2, state_o2 = _tri_leaf(prims[0], ray, f)
+
+        def nested(tmax, begin, end, leaf=leaf_o2, log=nested_calls):
+            log.append((begin, end, float(tmax)))
+            leaf_n, state_n = _tri_leaf(prims[1], ray, f)
+            inner.intersect_ray(ray, leaf_n, robust=True)                 # re-enters the per-ray API on this thread
+            assert state_n == alone_inner
+            return leaf(tmax, begin, end)
+        outer.intersect_ray(ray, nested, robust=True)
+        assert nested_calls == plain_calls and state_o2 == alone_outer
+        n_nested += len(nested_calls)
+    assert n_nested > 100
