@@ -54,6 +54,7 @@ _SIGS = {
     "bvh_amd_last_kernel_name": (C.c_char_p, []),
     "bvh_amd_reinsertion_stats": (None, [C.POINTER(C.c_uint)]),
     "bvh_amd_probe_record_walk": (_I, [_P, C.c_uint32, C.c_uint32, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
+    "bvh_amd_release_cached_memory": (_I, []),
     "bvh_amd_device_count": (_I, []),
     "bvh_amd_device_name": (_I, [_I, C.c_char_p, _Z]),
     "bvh_thread_pool_create": (_P, [_Z]),

@@ -334,10 +334,22 @@ __global__ void __launch_bounds__(256) k_emit_small(BuildCtx<T> c, uint32_t n_sm
     }
 }
 
+// Scratch buffer from the stream-ordered pool (common.h: scratch_alloc): allocated on, and released in the order of, the stream
+// of the operation in progress on this thread. A buffer whose pointer is taken over by a BvhImpl (p = nullptr here) is later
+// released with hipFree, which accepts pool memory.
 template <typename T> struct DevBuf {
     T* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t count) { return hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)); }
+    hipStream_t stream = nullptr;
+    bool pooled = false;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { scratch_free(p, stream, pooled); }
+    hipError_t alloc(size_t count) {
+        scratch_free(p, stream, pooled);
+        p = nullptr;
+        return scratch_alloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T), &stream, &pooled);
+    }
 };
 
 

@@ -407,6 +407,7 @@ template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size
 template <typename T>
 int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T ratio,
                             bool optimize, uint32_t log2_grid, hipStream_t stream) {
+    StreamScope scratch_on(stream);
     BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
     DevBuf<HostNode<T>> final_nodes;
     DevBuf<uint32_t> final_ids;

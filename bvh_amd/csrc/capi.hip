@@ -491,6 +491,18 @@ const char* bvh_amd_version(void) { return "bvh_amd 0.1 (gfx950)"; }
 const char* bvh_amd_last_kernel_name(void) { return last_kernel_name(); }
 void bvh_amd_reinsertion_stats(unsigned out[2]) { if (out) reinsertion_stats(out); }
 
+// Scratch blocks of finished builds stay cached in the current device's stream-ordered pool (common.h: scratch_alloc); this hands
+// them back to the driver (waits for the device first).
+int bvh_amd_release_cached_memory(void) {
+    int dev = 0;
+    BVH_HIP_TRY(hipGetDevice(&dev), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipDeviceSynchronize(), BVH_AMD_ERR_HIP);
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return BVH_AMD_OK; }
+    BVH_HIP_TRY(hipMemPoolTrimTo(pool, 0), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
+}
+
 int bvh_amd_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

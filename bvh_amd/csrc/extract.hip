@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) k_extract_level(const HostNode<T>* nodes,
 // d_nodes / d_ids: the source BVH resident on the device. Fills `out` (resident; host mirror lazy).
 template <typename T>
 int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_count, const uint32_t* d_ids, size_t root_id, hipStream_t stream) {
+    StreamScope scratch_on(stream);
     if (root_id >= node_count) return fail(BVH_AMD_ERR_ARG, "extract: root_id out of range");
     const uint32_t n = static_cast<uint32_t>(node_count);
     BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);

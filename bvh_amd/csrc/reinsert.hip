@@ -938,6 +938,7 @@ __global__ void __launch_bounds__(256) k_refit(HostNode<T>* nodes, const uint32_
 
 template <typename T>
 int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) {   // (dimension-independent: z stays (+0, +0) in 2D)
+    StreamScope scratch_on(stream);
     const uint32_t n = static_cast<uint32_t>(node_count);
     if (n < 3) return BVH_AMD_OK;
     DevBuf<uint32_t> parent, arrived;
@@ -965,6 +966,7 @@ template <typename T>
 int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim, double batch_size_ratio,
                                         size_t iterations) {
     using U = typename Ord<T>::U;
+    StreamScope scratch_on(stream);
     const uint32_t n = static_cast<uint32_t>(node_count);
     if (n < 2 || iterations == 0) return BVH_AMD_OK;
     if (!(batch_size_ratio >= 0.0)) return fail(BVH_AMD_ERR_ARG, "optimize: batch_size_ratio must be >= 0");

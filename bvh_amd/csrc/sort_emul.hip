@@ -248,6 +248,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* out, uint32_t n, con
 } // namespace
 
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_host, hipStream_t stream) {
+    StreamScope scratch_on(stream);
     // out[i] = sum of in[0..i); total optionally returned to the host
     if (n == 0) { if (total_host) *total_host = 0; return BVH_AMD_OK; }
     const uint32_t blocks = (n + kScanBlock - 1) / kScanBlock;
@@ -278,6 +279,7 @@ template <typename K>
 int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream,
                      uint32_t* hist_buf) {
     if (n == 0 || batch == 0) return BVH_AMD_OK;
+    StreamScope scratch_on(stream);
     const uint32_t bpa = (n + kRadixTile - 1) / kRadixTile;
     DevBuf<uint32_t> hist;
     if (hist_buf) hist.p = hist_buf;                          // caller-owned scratch: fully asynchronous
@@ -295,13 +297,14 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
     }
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
     if (hist_buf) { hist.p = nullptr; return BVH_AMD_OK; }
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // hist is freed on return
+    if (!hist.pooled) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // hist is freed on return (the pool frees in stream order)
     return BVH_AMD_OK;
 }
 
 // d_ids: batch * n, overwritten with iota then sorted like std::sort with comp(i, j) = key(a,i) < key(a,j).
 template <typename T>
 int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, uint32_t astride, uint32_t istride, hipStream_t stream) {
+    StreamScope scratch_on(stream);
     if (n == 0 || batch == 0) return BVH_AMD_OK;
     const uint32_t total = n * batch;
     hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, stream, d_ids, n, total);

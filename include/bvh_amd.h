@@ -134,6 +134,10 @@ BVH_AMD_API void bvh_amd_device_free(void* d_ptr);
 BVH_AMD_API int bvh_amd_copy_to_device(void* d_dst, const void* h_src, size_t bytes);
 BVH_AMD_API int bvh_amd_copy_to_host(void* h_dst, const void* d_src, size_t bytes);
 BVH_AMD_API int bvh_amd_synchronize(void* stream);
+/* Builds, optimize and the sorts take their scratch from the device's stream-ordered memory pool and leave it cached there for
+ * the next call (a 10M-triangle build uses a few GB); this returns the cached blocks to the driver. BVH_AMD_POOL=0 in the
+ * environment disables the caching altogether (plain hipMalloc / hipFree). */
+BVH_AMD_API int bvh_amd_release_cached_memory(void);
 /* Measurement aid for bench.py (csrc/probe.hip): mean launch time of a dependent walk over a table of 64-byte records (word 0 of
  * a record = index of the next one), one record in flight per lane — the rate the memory system gives the traversal's access
  * pattern when nothing else is in the way. Not used by any product path. */
