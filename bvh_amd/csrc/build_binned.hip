@@ -514,12 +514,27 @@ __global__ void k_forest_prepare(BuildCtx<T> c, uint32_t n_groups) {
     *c.counters = z;
 }
 
-// tree_node_off[g] = sum of (2 * ic + 1) over earlier trees (g <= a few thousand: one lane)
+// tree_node_off[g] = sum of (2 * ic + 1) over earlier trees: one block, tiles of 1024 trees with a running carry
 template <typename T>
-__global__ void k_forest_offsets(BuildCtx<T> c, uint32_t n_groups, uint32_t* tree_node_off) {
-    uint32_t run = 0;
-    for (uint32_t g = 0; g < n_groups; ++g) { tree_node_off[g] = run; run += 2 * c.nodes[g].ic + 1; }
-    tree_node_off[n_groups] = run;
+__global__ void __launch_bounds__(1024) k_forest_offsets(BuildCtx<T> c, uint32_t n_groups, uint32_t* tree_node_off) {
+    __shared__ uint32_t warp_sums[16];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_groups; base += 1024) {
+        const uint32_t g = base + threadIdx.x;
+        const uint32_t v = g < n_groups ? 2 * c.nodes[g].ic + 1 : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= static_cast<uint32_t>(d)) incl += o; }
+        if (lane == 63) warp_sums[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16; ++w) { const uint32_t x = warp_sums[w]; if (w < wave) before += x; all += x; }
+        __syncthreads();
+        if (g < n_groups) tree_node_off[g] = carry + before + incl - v;
+        carry += all;
+    }
+    if (threadIdx.x == 0) tree_node_off[n_groups] = carry;
 }
 
 } // namespace
@@ -602,7 +617,7 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
         rc = number_nodes<T>(c, level_start, stream);
         if (rc) return rc;
         BVH_HIP_TRY(tree_node_off.alloc(n_groups + 1), BVH_AMD_ERR_HIP);
-        hipLaunchKernelGGL(k_forest_offsets<T>, dim3(1), dim3(1), 0, stream, c, n_groups, tree_node_off.p);
+        hipLaunchKernelGGL(k_forest_offsets<T>, dim3(1), dim3(1024), 0, stream, c, n_groups, tree_node_off.p);
         BVH_HIP_TRY(hipMemcpyAsync(&total_nodes, tree_node_off.p + n_groups, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
         BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
         BVH_HIP_TRY(trees.alloc(total_nodes), BVH_AMD_ERR_HIP);

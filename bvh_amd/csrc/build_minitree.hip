@@ -142,6 +142,85 @@ __global__ void __launch_bounds__(64) k_merge_cells(const uint32_t* hist, uint32
     if (lane == 0) { group_begin[groups] = run; sc->n_groups = groups; }
 }
 
+// The same for grids of at most kMergeBlockCells cells (the default 16^3 and up to 25^3... i.e. log2_grid_dim <= 4) by ONE block:
+// with P = exclusive prefix sums of the cell counts, the bin the reference opens at cell k absorbs cell j > k exactly while
+// P[j + 1] - P[k] <= threshold (:87-88: the running size plus the next cell's), so next(k) = the first j > k with
+// P[j + 1] > P[k] + threshold is a binary search per cell, all cells at once; the bins are the orbit of cell 0 under next
+// (one lane hops through LDS, a few hundred hops), empty bins are dropped (:93-96) and the surviving bins are numbered by a scan.
+// 1.39 ms -> ~0.05 ms at the default grid.
+constexpr uint32_t kMergeBlockCells = 16384;
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* warp_sums, uint32_t& total) {      // 1024 threads
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= static_cast<uint32_t>(d)) incl += o; }
+    if (lane == 63) warp_sums[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+    for (uint32_t w = 0; w < 16; ++w) { const uint32_t x = warp_sums[w]; if (w < wave) base += x; all += x; }
+    __syncthreads();
+    total = all;
+    return base + incl - v;
+}
+__global__ void __launch_bounds__(1024) k_merge_cells_block(const uint32_t* hist, uint32_t cells, int merge, uint32_t threshold, uint32_t* group_of,
+                                                            uint32_t* group_begin, MtScalars* sc) {
+    __shared__ uint32_t P[kMergeBlockCells + 1];             // P[k] = primitives in cells [0, k)
+    __shared__ uint32_t nxt[kMergeBlockCells];               // next(k), later: 1 where a non-empty bin starts
+    __shared__ uint32_t warp_sums[16];
+    constexpr uint32_t kPer = kMergeBlockCells / 1024;       // consecutive cells per thread
+    const uint32_t t = threadIdx.x, first = t * kPer;
+    uint32_t cnt[kPer], local = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) { cnt[q] = first + q < cells ? hist[first + q] : 0u; local += cnt[q]; }
+    uint32_t total = 0;
+    uint32_t run = block_exclusive_scan(local, warp_sums, total);
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) { if (first + q <= cells) P[first + q] = run; run += cnt[q]; }
+    if (t == 0) P[cells] = total;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t k = first + q;
+        if (k >= cells) break;
+        uint32_t j = k + 1;
+        if (merge) {
+            const uint64_t limit = uint64_t{P[k]} + threshold;
+            uint32_t lo = k + 1, hi = cells;                  // smallest j in [k + 1, cells] with j == cells or P[j + 1] > limit
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (P[mid + 1] > limit) hi = mid; else lo = mid + 1; }
+            j = lo;
+        }
+        nxt[k] = j;
+    }
+    __syncthreads();
+    if (t == 0) {                                             // the bins: 0, next(0), next(next(0)), ...; keep the non-empty ones
+        uint32_t k = 0;
+        while (k < cells) {
+            const uint32_t j = nxt[k];
+            nxt[k] = (P[j] != P[k] ? 0x80000000u : 0u) | j;   // bit 31: a surviving bin starts here
+            k = j;
+        }
+    }
+    __syncthreads();
+    uint32_t starts[kPer], nstart = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t k = first + q;
+        // only cells on the orbit carry the flag; off-orbit cells still hold a plain next() below 2^31
+        starts[q] = k < cells && (nxt[k] & 0x80000000u) ? 1u : 0u;
+        nstart += starts[q];
+    }
+    uint32_t groups = 0;
+    uint32_t g = block_exclusive_scan(nstart, warp_sums, groups);     // bins that start before this thread's cells
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t k = first + q;
+        if (k >= cells) break;
+        if (starts[q]) { group_begin[g] = P[k]; ++g; }
+        if (cnt[q] != 0) group_of[k] = g - 1;                 // the latest bin started at or before k (a non-empty cell always lies in one)
+    }
+    if (t == 0) { group_begin[groups] = total; sc->n_groups = groups; }
+}
+
 __global__ void __launch_bounds__(256) k_group_keys(const uint32_t* codes, const uint32_t* group_of, uint32_t n, uint32_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -315,8 +394,12 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     hipLaunchKernelGGL(k_cells<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_centers, n32, keybox.p, grid_dim, cells, codes.p,
                        hist.p);
     const uint32_t merge_threshold = static_cast<uint32_t>(std::min<size_t>(cfg.parallel_threshold, 0x7fffffffu));   // counts stay below 2^28
-    hipLaunchKernelGGL(k_merge_cells, dim3(1), dim3(64), 0, stream, hist.p, cells, prune ? 1 : 0, merge_threshold, group_of.p, group_begin.p,
-                       scalars.p);
+    if (cells <= kMergeBlockCells)
+        hipLaunchKernelGGL(k_merge_cells_block, dim3(1), dim3(1024), 0, stream, hist.p, cells, prune ? 1 : 0, merge_threshold, group_of.p, group_begin.p,
+                           scalars.p);
+    else
+        hipLaunchKernelGGL(k_merge_cells, dim3(1), dim3(64), 0, stream, hist.p, cells, prune ? 1 : 0, merge_threshold, group_of.p, group_begin.p,
+                           scalars.p);
     hipLaunchKernelGGL(k_group_keys, dim3((n32 + 255) / 256), dim3(256), 0, stream, codes.p, group_of.p, n32, keys.p, ids.p);
     int key_bits = 1;                                         // group ids are below min(cells, n)
     while (key_bits < 32 && (size_t{1} << key_bits) < max_groups) ++key_bits;

@@ -106,14 +106,19 @@ __global__ void __launch_bounds__(kRadixThreads) k_radix_scatter(const K* keys, 
 // std::sort partition phase
 // ---------------------------------------------------------------------------------------------------
 struct SortSeg { uint32_t first, last, depth; };      // indices into the batched id array
-struct SortCounters { uint32_t next, pad[3]; };
+// Rounds run back to back without the host looking at anything: round r reads how many segments round r - 1 produced from
+// next[r] (next[0] is unused: the first round's count comes with the launch) and appends to next[r + 1]. A segment starts with
+// depth 2 lg n and loses one per round (stl_algo.h:1945-1957), so 2 lg n + 1 rounds always suffice; rounds that find no
+// segment cost one small launch.
+constexpr uint32_t kSortMaxRounds = 66;
+struct SortCounters { uint32_t next[kSortMaxRounds + 2]; uint32_t error; };
 
 template <typename T>
 struct SortCtx {
     uint32_t* ids;              // batch * n
     const T* keys;              // key(a, id) = keys[a * astride + id * istride]
     uint32_t n, astride, istride;
-    SortSeg* segs; SortSeg* segs_next;
+    SortSeg* segs; SortSeg* segs_next;                  // round r reads segs (r even) / segs_next (r odd) and appends to the other
     uint32_t* ltab; uint32_t* rtab;                     // batch * n scratch
     SortCounters* counters;
     uint32_t seg_cap;
@@ -122,10 +127,15 @@ struct SortCtx {
 constexpr int kSortThreads = 512;
 
 template <typename T>
-__global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c) {
+__global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, uint32_t round, uint32_t first_count) {
     __shared__ uint32_t wsum_l[8], wsum_r[8];
     __shared__ uint32_t sh_k;
-    const SortSeg sg = c.segs[blockIdx.x];
+    const uint32_t n_active = round == 0 ? first_count : min(c.counters->next[round], c.seg_cap);
+    const SortSeg* segs_in = (round & 1u) ? c.segs_next : c.segs;
+    SortSeg* segs_out = (round & 1u) ? c.segs : c.segs_next;
+  for (uint32_t seg_id = blockIdx.x; seg_id < n_active; seg_id += gridDim.x) {
+    __syncthreads();                                     // (the previous segment's shared scalars are done with)
+    const SortSeg sg = segs_in[seg_id];
     const uint32_t arr = sg.first / c.n;
     const T* kb = c.keys + size_t{arr} * c.astride;
     const uint32_t istride = c.istride;
@@ -134,7 +144,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c) {
     const uint32_t first = sg.first, last = sg.last, len = last - first;
     if (sg.depth == 0) {                                 // __partial_sort(first, last, last): heap sort
         if (threadIdx.x == 0) partial_sort_replay(ids + first, long(len), long(len), key);
-        return;
+        continue;
     }
     if (threadIdx.x == 0) {                              // __move_median_to_first(first, first + 1, mid, last - 1)
         const uint32_t a = first + 1, b = first + len / 2, cc = last - 1;
@@ -196,11 +206,13 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c) {
         const uint32_t cb[2] = { first, cut }, ce[2] = { cut, last };
         for (int s = 0; s < 2; ++s) {
             if (ce[s] - cb[s] > 16) {                                    // _S_threshold
-                const uint32_t slot = atomicAdd(&c.counters->next, 1u);
-                if (slot < c.seg_cap) c.segs_next[slot] = SortSeg{ cb[s], ce[s], sg.depth - 1 };
+                const uint32_t slot = atomicAdd(&c.counters->next[round + 1], 1u);
+                if (slot < c.seg_cap) segs_out[slot] = SortSeg{ cb[s], ce[s], sg.depth - 1 };
+                else atomicOr(&c.counters->error, 1u);
             }
         }
     }
+  }
 }
 
 template <typename T>
@@ -329,18 +341,17 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
         SortCtx<T> c;
         c.ids = d_ids; c.keys = d_keys; c.n = n; c.astride = astride; c.istride = istride;
         c.segs = seg_a.p; c.segs_next = seg_b.p; c.ltab = ltab.p; c.rtab = rtab.p; c.counters = counters.p; c.seg_cap = seg_cap;
-        uint32_t active = batch;
-        while (active) {
-            BVH_HIP_TRY(hipMemsetAsync(counters.p, 0, sizeof(SortCounters), stream), BVH_AMD_ERR_HIP);
-            hipLaunchKernelGGL(k_sort_partition<T>, dim3(active), dim3(kSortThreads), 0, stream, c);
-            BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-            SortCounters h;
-            BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-            BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
-            if (h.next > seg_cap) return fail(BVH_AMD_ERR_OVERFLOW, "std_sort_ids: segment capacity exceeded");
-            active = h.next;
-            std::swap(c.segs, c.segs_next);
-        }
+        BVH_HIP_TRY(hipMemsetAsync(counters.p, 0, sizeof(SortCounters), stream), BVH_AMD_ERR_HIP);
+        const uint32_t rounds = 2 * lg + 1;                   // <= kSortMaxRounds for any 32-bit n
+        // one block per segment; disjoint segments of more than 16 ids each bound their number, a grid-stride loop covers the rest
+        const uint32_t grid = std::max<uint32_t>(batch, std::min<uint32_t>(total / 17 + 1, 2048u));
+        for (uint32_t r = 0; r < rounds; ++r)
+            hipLaunchKernelGGL(k_sort_partition<T>, dim3(r == 0 ? batch : grid), dim3(kSortThreads), 0, stream, c, r, batch);
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        uint32_t err = 0;
+        BVH_HIP_TRY(hipMemcpyAsync(&err, &counters.p->error, sizeof(err), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        if (err) return fail(BVH_AMD_ERR_OVERFLOW, "std_sort_ids: segment capacity exceeded");
     }
     // __final_insertion_sort == stable sort by key of the current arrangement
     hipLaunchKernelGGL(k_make_sort_keys<T>, dim3((total + 255) / 256), dim3(256), 0, stream, d_ids, d_keys, n, total, astride, istride, skeys.p);
