@@ -426,10 +426,11 @@ def gather(records, perm):
 
 
 def intersect(bvh: Bvh, prims, rays, any_hit: bool = False, robust: bool = False, leaf: str = "tri",
-              counters: bool = False, out=None, sort_rays: bool = False):
+              counters: bool = False, out=None, sort_rays: bool = False, original_ids: bool = False):
     """Batched Bvh::intersect<IsAnyHit, IsRobust> (bvh.h:160-182) with the closest/any-hit leaf loop of
     test/benchmark.cpp:281-291. prims are in BVH order. Returns a torch tensor of hit records
-    ((n,4) of the BVH scalar type; view with hits_to_numpy) and, optionally, (pairs, tests, leaves)."""
+    ((n,4) of the BVH scalar type; view with hits_to_numpy) and, optionally, (pairs, tests, leaves). original_ids: report
+    the original primitive id (bvh.prim_ids[i]) instead of the BVH-order index i the reference's leaf callback sees."""
     torch = _torch()
     lib = _lib.load()
     s = bvh._s
@@ -444,7 +445,8 @@ def intersect(bvh: Bvh, prims, rays, any_hit: bool = False, robust: bool = False
     if out is None:
         out = torch.empty((n, 4), dtype=dt, device=r.device)
     cnt = torch.zeros(3, dtype=torch.int64, device=r.device) if counters else None
-    flags = (RayFlags.ANY_HIT if any_hit else 0) | (RayFlags.ROBUST if robust else 0) | (RayFlags.SORTED if sort_rays else 0)
+    flags = (RayFlags.ANY_HIT if any_hit else 0) | (RayFlags.ROBUST if robust else 0) | (RayFlags.SORTED if sort_rays else 0) | \
+            (8 if original_ids else 0)                        # BVH_AMD_RAY_ORIGINAL_IDS: hit.prim = bvh.prim_ids[BVH-order index]
     fn = getattr(lib, f"bvh{s}_intersect_rays_{'tri' if leaf == 'tri' else 'sphere'}")
     _lib.check(fn(bvh._h, p.data_ptr(), r.data_ptr(), n, int(flags), out.data_ptr(),
                   cnt.data_ptr() if counters else None, _stream()), "intersect_rays")

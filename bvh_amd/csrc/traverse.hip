@@ -94,6 +94,15 @@ __global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n
     vals[i] = i;
 }
 
+// BVH_AMD_RAY_ORIGINAL_IDS: BVH-order index -> bvh.prim_ids[index] in place (misses keep BVH_AMD_INVALID)
+template <typename H>
+__global__ void __launch_bounds__(256) original_ids_kernel(H* hits, size_t n, const uint32_t* prim_ids, uint32_t prim_count) {
+    const size_t i = blockIdx.x * size_t{256} + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = hits[i].prim;
+    if (p < prim_count) hits[i].prim = prim_ids[p];
+}
+
 struct Grid { int blocks = 0; };
 
 template <typename K>
@@ -373,6 +382,15 @@ struct StepContextClaim {
 const char* last_kernel_name() { return g_last_kernel; }
 
 template <typename T>
+static int to_original_ids(const BvhImpl<T>& b, typename HitOf<T>::Type* d_hits, size_t n, hipStream_t stream) {
+    if (!b.d_prim_ids) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device prim ids");
+    hipLaunchKernelGGL(original_ids_kernel<typename HitOf<T>::Type>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, d_hits, n,
+                       b.d_prim_ids, static_cast<uint32_t>(b.prim_count));
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
+}
+
+template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
                     typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream)
 {
@@ -436,7 +454,9 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     args.leaf_threshold = leaf_env > 0 ? leaf_env : kLeafThreshold;
     if (b.dim == 2) {                                         // Node<T, 2>: circles only (tri.h has no 2D intersector)
         if (leaf_kind != LEAF_SPHERE) return release(fail(BVH_AMD_ERR_ARG, "intersect_rays: a 2D BVH traces circles (Sphere<T, 2>) only"));
-        return release(dispatch<T, LEAF_SPHERE, 2>(b, args, flags, d_counters != nullptr, stream));
+        int rc2 = dispatch<T, LEAF_SPHERE, 2>(b, args, flags, d_counters != nullptr, stream);
+        if (rc2 == BVH_AMD_OK && (flags & BVH_AMD_RAY_ORIGINAL_IDS)) rc2 = to_original_ids<T>(b, d_hits, n, stream);
+        return release(rc2);
     }
     if ((flags & BVH_AMD_RAY_SORTED) && n > 4096 && n < (size_t{1} << 31)) {
         const uint32_t n32 = static_cast<uint32_t>(n);
@@ -456,8 +476,10 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         if (rc) return release(rc);
         args.order = vals;
     }
-    if (leaf_kind == LEAF_TRIANGLE) return release(dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream));
-    return release(dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream));
+    int rc = leaf_kind == LEAF_TRIANGLE ? dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream)
+                                        : dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream);
+    if (rc == BVH_AMD_OK && (flags & BVH_AMD_RAY_ORIGINAL_IDS)) rc = to_original_ids<T>(b, d_hits, n, stream);
+    return release(rc);
 }
 
 

@@ -111,7 +111,9 @@ struct bvh_amd_counters { unsigned long long node_pairs, prim_tests, leaves; };
 enum bvh_amd_ray_flags {
     BVH_AMD_RAY_ANY_HIT = 1u,  /* Bvh::intersect<IsAnyHit = true>: no near/far reordering, stop at first hit */
     BVH_AMD_RAY_ROBUST  = 2u,  /* Bvh::intersect<IsRobust = true>: Ize's robust slab test (node.h:68-77)      */
-    BVH_AMD_RAY_SORTED  = 4u   /* internal ray reordering for coherence; per-ray results are unchanged           */
+    BVH_AMD_RAY_SORTED  = 4u,  /* internal ray reordering for coherence; per-ray results are unchanged           */
+    BVH_AMD_RAY_ORIGINAL_IDS = 8u  /* hit.prim = the ORIGINAL primitive id bvh.prim_ids[i] (what c_api_example.c:265-268 looks up per
+                                      hit) instead of the BVH-order index i: one more pass over the hit records, on the device    */
 };
 
 /* Which reference builder a device build reproduces (bit-exact node/prim order). */

@@ -272,3 +272,27 @@ def test_concurrent_batches_on_one_bvh(orc):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_original_primitive_ids_flag(orc):
+    """BVH_AMD_RAY_ORIGINAL_IDS: hit.prim is bvh.prim_ids[BVH-order index] (SURVEY.md 8b "required extension"), misses stay invalid."""
+    import bvh_amd
+    for dt, leaf in ((np.float32, "tri"), (np.float64, "sphere")):
+        if leaf == "tri":
+            geo = synth.soup(20_000, seed=4, jitter=0.02, dtype=dt)
+            bb, cc = bvh_amd.tri_bounds(geo)
+        else:
+            geo = synth.spheres(20_000, dtype=dt)
+            bb, cc = bvh_amd.sphere_bounds(geo)
+        bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+        prims = bvh_amd.precompute_tris(geo, bvh.device_prim_ids()) if leaf == "tri" else bvh_amd.gather(geo, bvh.device_prim_ids())
+        lo, hi = synth.scene_bounds(geo)
+        rays = synth.rays_closest(50_000, lo, hi, dtype=dt)
+        a = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, prims, rays, robust=True, leaf=leaf))
+        b = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, prims, rays, robust=True, leaf=leaf, original_ids=True))
+        hit = a["prim"] != oracle.INVALID
+        assert hit.sum() > 1000 and (~hit).sum() > 0
+        ids = bvh.prim_ids
+        assert (b["prim"][hit].astype(np.uint64) == ids[a["prim"][hit].astype(np.int64)]).all()
+        assert (b["prim"][~hit] == a["prim"][~hit]).all()
+        assert a["t"].tobytes() == b["t"].tobytes() and a["u"].tobytes() == b["u"].tobytes()
