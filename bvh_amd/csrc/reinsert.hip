@@ -523,242 +523,11 @@ __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_no
     for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.get(j).id;
 }
 
-// ---- the replacement loop as a systolic pipeline on ONE wavefront (round 2) ----------------------------------------------------
-// A lone wave is bound by its instruction count, and the loops above spend it on ONE replacement at a time (~240 instructions).
-// Here one instruction sequence advances EVERY replacement in flight. Lane-by-lane model, checked against libstdc++ on thousands
-// of random and tie-saturated streams with LDS parts of 1 .. 13 levels: tools/heap_sys_sim.cpp (this kernel is its transcription).
-//   controller  lane i = level i of the ancestor chain of the last slot k - 1. The chain's values cv and the values sv of the chain
-//               nodes' siblings live in registers for the whole loop (their memory copies go stale and are written back at the
-//               end). v = cv[L] sinks in from the root: how far it follows the chain is decided for all levels at once (one
-//               ballot); the chain shifts up one lane; where the hole leaves the chain into a sibling's subtree an off-chain PASS
-//               (hole, v) starts. Then x is inserted into the chain top-down (= push_heap; the carry-out is the next v).
-//   pipeline    lane l = the pass whose hole is at heap level l (at most one per level). A tick: every pass reads the two children of
-//               its hole, moves the smaller up if it is <= v (ties: right child, stl_heap.h:232) and follows it one lane down
-//               (DPP wave shift), or drops v. The first write of a pass is the new value of the sibling it started at -> sv.
-//               A new pass enters only if its level is free and the pass one level down is not filling one of its children.
-//   deferred    a pass that reaches the last LDS level is parked as a task (hole, v) (lane i keeps task i), its LDS entry marked as
-//               an open hole; tasks in different subtrees are independent and are sifted 64 at a time, one lane each, through
-//               HBM. Whoever is about to read an open hole, or a sibling value whose pass was parked (`stale`), resolves first.
-// ~2 ticks (of ~30 instructions) + ~60 controller instructions per replacement instead of ~240.
-// lane i <- lane i - 1 / lane i + 1 with zero where no lane exists (bound_ctrl: no register to pre-load)
-__device__ inline uint32_t dpp_prev(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x138, 0xf, 0xf, true)); }
-__device__ inline uint32_t dpp_next(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x130, 0xf, 0xf, true)); }
-__device__ inline float dpp_prev(float v) { return __uint_as_float(dpp_prev(__float_as_uint(v))); }
-__device__ inline float dpp_next(float v) { return __uint_as_float(dpp_next(__float_as_uint(v))); }
-__device__ inline double dpp_prev(double v) {
-    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
-    return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(dpp_prev(static_cast<uint32_t>(b >> 32))) << 32) | dpp_prev(static_cast<uint32_t>(b))));
-}
-__device__ inline double dpp_next(double v) {
-    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
-    return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(dpp_next(static_cast<uint32_t>(b >> 32))) << 32) | dpp_next(static_cast<uint32_t>(b))));
-}
-template <typename T> __device__ inline Ent<T> dpp_prev(const Ent<T>& e) { Ent<T> r; r.cost = dpp_prev(e.cost); r.id = dpp_prev(e.id); return r; }
-template <typename T> __device__ inline Ent<T> dpp_next(const Ent<T>& e) { Ent<T> r; r.cost = dpp_next(e.cost); r.id = dpp_next(e.id); return r; }
-// The heap's LDS part sits one entry above a 16-byte aligned base, so that the two children of a node (positions 2p + 1, 2p + 2)
-// are one aligned 16-byte word for 8-byte entries: one ds_read_b128 per tick and lane.
-typedef uint32_t heap_u32x4 __attribute__((ext_vector_type(4)));
-__device__ inline void load_children(const WaveHeap<float>& h, uint32_t left, Ent<float>& e1, Ent<float>& e2) {
-    const auto* q = reinterpret_cast<const __attribute__((address_space(3))) heap_u32x4*>(&h.lds[left]);
-    const heap_u32x4 w = *q;
-    e1.cost = __uint_as_float(w.x); e1.id = w.y; e2.cost = __uint_as_float(w.z); e2.id = w.w;
-}
-__device__ inline void load_children(const WaveHeap<double>& h, uint32_t left, Ent<double>& e1, Ent<double>& e2) {
-    e1 = h.get_lds(left); e2 = h.get_lds(left + 1);
-}
-
-// BelowLds: the heap has more entries than fit in LDS (k - 1 >= HeapCap): every child of an LDS-level node is inside the pop
-// range, so the pipeline carries no range checks; passes that reach the last LDS level are parked. Otherwise the heap ends inside
-// LDS: range checks, nothing is ever parked.
-template <typename T, bool BelowLds>
-__global__ void __launch_bounds__(64) k_heap_select_sys(const T* cost, uint32_t n_nodes, uint32_t target, Ent<T>* glob, uint32_t* out_ids,
-                                                        unsigned long long* dbg) {
-    unsigned long long t_tick = 0, t_ctrl = 0, t_all = 0, n_tick = 0, n_repl = 0, t_chunk = 0;
-    const unsigned long long t_begin = dbg ? __builtin_readcyclecounter() : 0;
-    extern __shared__ __attribute__((aligned(16))) unsigned char heap_lds[];
-    WaveHeap<T> h;
-    h.lds = (typename WaveHeap<T>::LdsEnt*)heap_lds + 1;      // (see load_children)
-    h.glob = (typename WaveHeap<T>::GlobEnt*)glob;
-    auto* stage = (__attribute__((address_space(3))) T*)(heap_lds + (size_t{HeapCap<T>::v} + 1) * sizeof(Ent<T>));
-    h.cap = HeapCap<T>::v;
-    h.cap_level = HeapLevels<T>::v - 1;
-    constexpr int kCapLevel = HeapLevels<T>::v - 1;
-    const int lane = threadIdx.x;
-    const uint32_t head = min(n_nodes, target + 1);
-    const uint32_t k = head - 1;                              // (k >= 64: checked by the host)
-    const uint32_t range = k - 1;                             // pops work on positions [0, k - 2]
-    constexpr uint32_t cap = HeapCap<T>::v;
-    for (uint32_t j = lane; j < min(k, cap); j += 64) h.set_lds(j, h.get_glob(j));
-    heap_sync();
-    // ---- chain lanes
-    const int L = 31 - __clz(static_cast<int>(k));            // level of position k - 1
-    const bool on_chain = lane <= L;
-    const uint32_t cpos = on_chain ? (k >> (L - lane)) - 1 : 0u;
-    const bool cir = on_chain && lane >= 1 && (cpos & 1u) == 0;                      // the chain node is a right child
-    const uint32_t spos = (on_chain && lane >= 1) ? (cir ? cpos - 1 : cpos + 1) : 0u;
-    const bool has_sib = on_chain && lane >= 1 && spos < range;
-    Ent<T> cv{}, sv{};
-    if (on_chain) cv = h.get(cpos);
-    if (has_sib) sv = h.get(spos);
-    // what lane d needs to know about level d + 1
-    const bool hc_n = lane + 1 < L;
-    const bool hs_n = dpp_next(static_cast<uint32_t>(has_sib)) != 0;
-    const bool cir_n = dpp_next(static_cast<uint32_t>(cir)) != 0;
-    const bool both_n = hc_n && hs_n;
-    // ---- pipeline lanes: pos != 0 = a pass whose hole is at `pos` (position 0 is never an off-chain hole), pv = its value
-    uint32_t pos = 0;
-    Ent<T> pv{};
-    int first_lane = -1;                                      // the lane whose pass has not written yet (its first write -> sv)
-    // ---- deferred tasks
-    uint32_t n_tasks = 0, task_pos = 0;
-    Ent<T> task_value{};
-    uint64_t stale = 0;                                       // bit i: sv of lane i is owed by a parked pass
-
-    auto resolve_tasks = [&]() {
-        if (n_tasks) {
-            if (static_cast<uint32_t>(lane) < n_tasks) lane_adjust_heap(h, task_pos, range, task_value);
-            heap_sync();
-            n_tasks = 0;
-        }
-        if (stale) {
-            if ((stale >> lane) & 1u) sv = h.get(spos);
-            stale = 0;
-        }
-    };
-    auto add_task = [&](uint32_t p, const Ent<T>& v) {        // wave-uniform arguments
-        if (static_cast<uint32_t>(lane) == n_tasks) { task_pos = p; task_value = v; }
-        if (p < cap) { if (lane == 0) h.lds[p].id = kOpenHole; heap_sync(); }
-        if (++n_tasks == 64) resolve_tasks();
-    };
-    auto tick = [&]() {
-        const unsigned long long tk0 = dbg ? __builtin_readcyclecounter() : 0;
-        struct TickTimer { unsigned long long* dbg; unsigned long long t0; unsigned long long& acc; unsigned long long& n;
-                           __device__ ~TickTimer() { if (dbg) { acc += __builtin_readcyclecounter() - t0; ++n; } } } timer{dbg, tk0, t_tick, n_tick};
-        const bool live = pos != 0;
-        if (!__ballot(live)) return;
-        const uint32_t left = 2 * pos + 1;
-        const bool hasl = BelowLds ? live : (live && left < range), hasr = BelowLds ? live : (live && left + 1 < range);
-        Ent<T> e1{}, e2{};
-        if (BelowLds) { if (live) load_children(h, left, e1, e2); }
-        else { if (hasl) e1 = h.get_lds(left); if (hasr) e2 = h.get_lds(left + 1); }
-        if (BelowLds && __ballot(live && (e1.id == kOpenHole || e2.id == kOpenHole))) {   // a child is still owed by a parked pass
-            resolve_tasks();
-            if (live) load_children(h, left, e1, e2);
-        }
-        const bool take_left = hasr ? (e2.cost > e1.cost) : true;             // comp(second, second - 1): take the left child
-        const Ent<T> m = take_left ? e1 : e2;
-        const uint32_t mpos = take_left ? left : left + 1;
-        const bool go = hasl && !(m.cost > pv.cost);
-        const Ent<T> wr = go ? m : pv;
-        if (live) h.set_lds(pos, wr);
-        if (first_lane >= 0) { if (lane == first_lane) sv = wr; first_lane = -1; }
-        heap_sync();
-        // every pass moves one level = one lane down
-        pos = dpp_prev(go ? mpos : 0u);
-        pv = dpp_prev(pv);
-        if (BelowLds) {                                       // the pass that arrived at the last LDS level (its children are in HBM) is parked
-            const uint32_t pp = lane_value(pos, kCapLevel);
-            if (pp) {
-                Ent<T> tv; tv.cost = lane_value(pv.cost, kCapLevel); tv.id = lane_value(pv.id, kCapLevel);
-                if (lane == kCapLevel) pos = 0;
-                add_task(pp, tv);
-            }
-        }
-    };
-
-    T root_cost = lane_value(cv.cost, 0);
-    for (uint32_t chunk = head; chunk < n_nodes; chunk += kStreamChunk) {   // :96-103, kStreamChunk costs per HBM round trip
-        bool any = false;
-        const unsigned long long th0 = dbg ? __builtin_readcyclecounter() : 0;
-#pragma unroll
-        for (uint32_t q = 0; q < kStreamChunk / 64; ++q) {
-            const uint32_t i = chunk + q * 64 + lane;
-            const T c_hbm = i < n_nodes ? cost[i] : T(0);
-            any = any || (i < n_nodes && root_cost < c_hbm);  // the heap minimum only grows: a failed test stays failed
-            stage[q * 64 + lane] = c_hbm;
-        }
-        if (!__ballot(any)) continue;
-        heap_sync();
-        if (dbg) t_chunk += __builtin_readcyclecounter() - th0;
-        for (uint32_t q = 0; q < kStreamChunk / 64; ++q) {
-            const uint32_t base = chunk + q * 64;
-            if (base >= n_nodes) break;
-            const T c = stage[q * 64 + lane];
-            uint64_t mask = __ballot(base + lane < n_nodes && root_cost < c);
-            while (mask) {
-                const int jx = __ffsll(static_cast<long long>(mask)) - 1;
-                mask &= mask - 1;
-                const T cj = lane_value(c, jx);
-                if (!(root_cost < cj)) continue;
-                Ent<T> x; x.cost = cj; x.id = base + jx;
-                const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0;
-                // ---- pop_heap: v = the last element sinks in from the root
-                Ent<T> v; v.cost = lane_value(cv.cost, L); v.id = lane_value(cv.id, L);
-                Ent<T> nc = dpp_next(cv), ns = dpp_next(sv);  // level d + 1 as lane d sees it
-                int dstar = 0;
-                bool enters = false;
-                for (;;) {
-                    // both children exist: the sibling wins iff it is the smaller one, ties to the right child (stl_heap.h:232)
-                    const bool sib_wins = cir_n ? (nc.cost > ns.cost) : !(ns.cost > nc.cost);
-                    const bool pick_sib = hs_n && (!hc_n || sib_wins), pick_chain = hc_n && !(both_n && sib_wins);
-                    const bool cont = lane < L && pick_chain && !(nc.cost > v.cost);
-                    const bool ent = lane < L && pick_sib && !(ns.cost > v.cost);
-                    const uint64_t contmask = __ballot(cont);
-                    dstar = __ffsll(static_cast<long long>(~contmask)) - 1;
-                    enters = (__ballot(ent) >> dstar) & 1u;
-                    if (stale & ((uint64_t{2} << (dstar + 1)) - 2)) {           // a sibling value the decision looked at is owed
-                        resolve_tasks();
-                        ns = dpp_next(sv);
-                        continue;
-                    }
-                    break;
-                }
-                if (lane < dstar) cv = nc;
-                else if (lane == dstar) cv = enters ? ns : v;
-                if (enters) {
-                    const int lvl = dstar + 1;
-                    const uint32_t p = lane_value(spos, lvl);
-                    const bool in_pipeline = BelowLds ? lvl < kCapLevel : true;   // its children are LDS entries (or it has none)
-                    if (in_pipeline) {
-                        for (;;) {
-                            const uint64_t lm = __ballot(pos != 0);
-                            bool blocked = (lm >> lvl) & 1u;
-                            if (!blocked && ((lm >> (lvl + 1)) & 1u)) blocked = (lane_value(pos, lvl + 1) - 1) / 2 == p;
-                            if (!blocked) break;
-                            tick();
-                        }
-                        if (lane == lvl) { pos = p; pv = v; }
-                        first_lane = lvl;
-                    } else {
-                        add_task(p, v);
-                        if (n_tasks) stale |= uint64_t{1} << lvl;          // (add_task may just have resolved everything, this one included)
-                        else if (lane == lvl) sv = h.get(spos);
-                    }
-                }
-                // ---- back() = x; push_heap: x is inserted into the chain, the element it pushes off the end becomes the last one
-                {
-                    const uint64_t swapmask = __ballot(lane < L && cv.cost > x.cost);
-                    const int i0 = swapmask ? __ffsll(static_cast<long long>(swapmask)) - 1 : L;
-                    const Ent<T> pc = dpp_prev(cv);
-                    if (lane > i0 && lane <= L) cv = pc;
-                    else if (lane == i0) cv = x;
-                }
-                root_cost = lane_value(cv.cost, 0);
-                if (dbg) { t_ctrl += __builtin_readcyclecounter() - tc0; ++n_repl; }
-                tick();
-            }
-        }
-    }
-    while (__ballot(pos != 0)) tick();
-    resolve_tasks();
-    if (dbg && lane == 0) {
-        t_all = __builtin_readcyclecounter() - t_begin;
-        dbg[0] = t_all; dbg[1] = t_tick; dbg[2] = t_ctrl; dbg[3] = n_tick; dbg[4] = n_repl; dbg[5] = t_chunk;
-    }
-    if (on_chain) h.set(cpos, cv);
-    heap_sync();
-    for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.get(j).id;
-}
+// (Round 2 also built the replacement loop as a systolic pipeline on ONE wavefront — lanes = levels of the ancestor chain for the
+//  controller, lanes = heap levels for the off-chain passes, every pass in flight advanced by one shared instruction sequence; lane
+//  model tools/heap_sys_sim.cpp, kernel in git history (k_heap_select_sys). Exact on the whole GPU suite, 207 instructions per
+//  replacement instead of ~290, but a lone wavefront retires one instruction per ~11 clocks on this kind of VALU <-> SALU
+//  ping-pong (ballot, ffs, readlane, DPP): 2050 clocks per replacement against 1860 for the two-wave loop below. Not kept.)
 
 // ---- the replacement loop on TWO wavefronts (heaps that reach below LDS) -----------------------------------------------------
 // A lone wave is bound by its instruction count, so the work of one replacement is split in the order it happens:
@@ -1241,18 +1010,11 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
     const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>) + kStreamChunk * sizeof(T);
     const bool below_lds = k >= 1 && k - 1 >= HeapCap<T>::v;
     const char* pipe_knob = std::getenv("BVH_AMD_HEAP_PIPE");                      // 0: the one-wave replacement loop
-    const bool use_pipe = !(pipe_knob && std::atoi(pipe_knob) == 0) && !(std::getenv("BVH_AMD_HEAP") && std::strcmp(std::getenv("BVH_AMD_HEAP"), "wave") == 0);
+    const bool use_pipe = !(pipe_knob && std::atoi(pipe_knob) == 0);
     const size_t pipe_lds = heap_lds + kQueueCap * sizeof(PipeToken<T>) + sizeof(PipeCtrl);
     if (below_lds && use_pipe)
         BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select_pipe<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pipe_lds)),
                     BVH_AMD_ERR_HIP);
-    // BVH_AMD_HEAP: sys (default) = the systolic one-wave pipeline, pipe = two waves (heaps below LDS), wave = one replacement at a time
-    const char* heap_knob = std::getenv("BVH_AMD_HEAP");
-    const bool use_sys = k >= 64 && !(heap_knob && (std::strcmp(heap_knob, "pipe") == 0 || std::strcmp(heap_knob, "wave") == 0));
-    const size_t sys_lds = heap_lds + sizeof(Ent<T>);          // (the LDS part of the heap sits one entry above the base there)
-    auto sys_kernel = below_lds ? k_heap_select_sys<T, true> : k_heap_select_sys<T, false>;
-    if (use_sys)
-        BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(sys_lds)), BVH_AMD_ERR_HIP);
     auto heap_kernel = below_lds ? k_heap_select<T, true> : k_heap_select<T, false>;
     BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(heap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(heap_lds)),
                 BVH_AMD_ERR_HIP);
@@ -1290,22 +1052,7 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
                         hipLaunchKernelGGL(k_make_heap_level<T>, dim3((count + 63) / 64), dim3(64), 0, stream, heap_g.p, k, first, count);
                     }
                 }
-                if (use_sys)
-                {
-                    static unsigned long long* d_dbg = nullptr;
-                    const bool want_dbg = std::getenv("BVH_AMD_HEAP_DEBUG") != nullptr;
-                    if (want_dbg && !d_dbg) (void)hipMalloc(&d_dbg, 64);
-                    hipLaunchKernelGGL(sys_kernel, dim3(1), dim3(64), sys_lds, stream, cost.p, n, batch, heap_g.p, cand.p, want_dbg ? d_dbg : nullptr);
-                    if (want_dbg) {
-                        unsigned long long hd[8] = {};
-                        (void)hipStreamSynchronize(stream);
-                        (void)hipMemcpy(hd, d_dbg, 48, hipMemcpyDeviceToHost);
-                        std::fprintf(stderr, "[heap_sys] cycles all=%llu tick=%llu ctrl=%llu chunk=%llu ticks=%llu repl=%llu -> per repl: all %.0f, tick %.0f (%.2f ticks x %.0f), ctrl %.0f, chunk %.0f\n",
-                                     hd[0], hd[1], hd[2], hd[5], hd[3], hd[4], double(hd[0]) / hd[4], double(hd[1]) / hd[4], double(hd[3]) / hd[4],
-                                     double(hd[1]) / hd[3], double(hd[2]) / hd[4], double(hd[5]) / hd[4]);
-                    }
-                }
-                else if (below_lds && use_pipe)
+                if (below_lds && use_pipe)
                     hipLaunchKernelGGL(k_heap_select_pipe<T>, dim3(1), dim3(128), pipe_lds, stream, cost.p, n, batch, heap_g.p, cand.p, scalars.p);
                 else
                     hipLaunchKernelGGL(heap_kernel, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
