@@ -24,6 +24,9 @@
 
 #include "build_common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace bvh_amd {
 
 using namespace bld;
@@ -410,6 +413,302 @@ __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) 
     if (lane == 0) A.ic = (ncount - 1) / 2;
 }
 
+
+// ---- Phase B, level-synchronous (round 2) ---------------------------------------------------------------------------------------
+// k_small above walks the subtree node by node like the reference's stack does: ~60 strictly sequential node steps for a
+// 64-primitive subtree, each with most of the wave idle (a node of 8 primitives uses 8 lanes). The RESULT of that walk does not
+// depend on its order: a node's split only looks at its own primitives (kept in its own contiguous lane range), and the reference's
+// numbering follows from the shape of the finished subtree (children of the inner node with pre-order rank r — fewer primitives
+// first, ties: second child, top_down_sah_builder.h:116-121 — live at 1 + 2r, 2 + 2r; the same rule Phase C applies to the big nodes).
+// So here all nodes of one LEVEL are split at once, up to kSlots nodes per pass: bins per slot in LDS (the same atomics, the same
+// sweep_axis per (slot, axis) lane), one ballot for all partitions (each lane masks it with its node's lane range), child boxes by
+// LDS atomics per child with the last-zero tracking of Phase A; nodes are numbered level by level while the subtree grows and
+// renumbered at the end by inner counts (bottom-up over the levels) and ranks (top-down). ~10 passes instead of ~60 node steps.
+constexpr int kSlots = 8;
+
+template <typename T>
+struct LevelLds {
+    typename Ord<T>::U lo[kSlots][3][kBins][3], hi[kSlots][3][kBins][3];
+    uint32_t cnt[kSlots][3][kBins];
+    typename Ord<T>::U cbox_lo[2 * kSlots][3], cbox_hi[2 * kSlots][3];     // child boxes of this pass (side 0 = left range, 1 = right range)
+    uint32_t czlo[2 * kSlots][3], czhi[2 * kSlots][3];                     // last lane with a zero bound << 1 | its sign
+    T axis_cost[kSlots][3];
+    uint32_t axis_bin[kSlots][3];
+    // per slot decisions
+    uint32_t s_node[kSlots], s_mode[kSlots], s_axis[kSlots], s_wide[kSlots], s_cut[kSlots], s_child[kSlots], s_first[kSlots];
+    T s_plane[kSlots];
+    // nodes of the subtree in the order they are created (level by level)
+    T nbox[2 * kSmall][6];
+    uint8_t nb[2 * kSmall], ne[2 * kSmall], nparent[2 * kSmall], nwhich[2 * kSmall], nchild[2 * kSmall], nic[2 * kSmall], nrank[2 * kSmall];
+    uint8_t slot_of[2 * kSmall];
+    uint32_t ltab[kSmall], rtab[kSmall], perm[kSmall];
+    T keys[kSmall];
+};
+enum : uint32_t { SM_LEAF = 0, SM_PARTITION = 1, SM_FALLBACK = 2 };
+
+template <typename T>
+__global__ void __launch_bounds__(128) k_small_levels(BuildCtx<T> c, uint32_t n_small) {
+    __shared__ LevelLds<T> lds_all[2];
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 2 + (threadIdx.x >> 6);
+    if (w >= n_small) return;
+    LevelLds<T>& L = lds_all[threadIdx.x >> 6];
+    const uint32_t node_id = c.small_list[w];
+    ANode<T>& A = c.nodes[node_id];
+    const uint32_t B = A.begin, s = A.end - A.begin;
+    HostNode<T>* stage = c.stage + 2ull * B;
+    using I = typename IndexOf<T>::Type;
+
+    uint32_t id = 0;
+    T ctr[3] = {0, 0, 0}, blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0};
+    if (lane < int(s)) {
+        id = c.ids[B + lane];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ctr[k] = c.centers[3ull * id + k]; blo[k] = c.bboxes[6ull * id + k]; bhi[k] = c.bboxes[6ull * id + 3 + k]; }
+    }
+    if (lane < 3) { L.nbox[0][lane] = A.lo[lane]; L.nbox[0][3 + lane] = A.hi[lane]; }
+    if (lane == 0) { L.nb[0] = 0; L.ne[0] = static_cast<uint8_t>(s); L.nparent[0] = 0; L.nwhich[0] = 0; L.nchild[0] = 0; }
+    const uint64_t lanes_below = (uint64_t{1} << lane) - 1;
+    const bool in_tree = lane < int(s);
+    uint32_t my_node = 0;                                     // the deepest node created so far that holds this lane's primitive
+    uint32_t n_nodes = 1;                                     // nodes created so far (wave-uniform)
+    uint32_t level_first[kSmall + 2];                         // (registers would be too many: kept small by the loop bound below)
+    uint32_t n_levels = 0;
+    uint32_t lvl_begin = 0, lvl_end = 1;                      // node ids of the current level
+    // level boundaries are needed again for the numbering: at most 64 levels (every level has at least one node that splits)
+    __shared__ uint8_t level_start_all[2][kSmall + 2];
+    uint8_t* level_start = level_start_all[threadIdx.x >> 6];
+    (void)level_first;
+    wave_sync();
+
+    while (lvl_begin < lvl_end) {
+        if (lane == 0) level_start[n_levels] = static_cast<uint8_t>(lvl_begin);
+        ++n_levels;
+        for (uint32_t pass_first = lvl_begin; pass_first < lvl_end; pass_first += kSlots) {
+            const uint32_t n_slots = min(static_cast<uint32_t>(kSlots), lvl_end - pass_first);
+            // ---- my slot, my node's range and box
+            const bool mine = in_tree && my_node >= pass_first && my_node < pass_first + n_slots;
+            const uint32_t slot = mine ? my_node - pass_first : 0u;
+            const uint32_t lb = mine ? L.nb[my_node] : 0u, le = mine ? L.ne[my_node] : 0u;
+            const uint32_t cnt = le - lb;
+            T nlo[3] = {0, 0, 0}, nhi[3] = {0, 0, 0};
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { nlo[k] = L.nbox[my_node][k]; nhi[k] = L.nbox[my_node][3 + k]; }
+            }
+            const bool splits = mine && cnt > c.min_leaf;                 // top_down_sah_builder.h:89
+            // ---- fill_bins for every slot of the pass
+            {
+                const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
+                for (uint32_t q = lane; q < n_slots * 3 * kBins * 3; q += 64) { (&L.lo[0][0][0][0])[q] = lo0; (&L.hi[0][0][0][0])[q] = hi0; }
+                for (uint32_t q = lane; q < n_slots * 3 * kBins; q += 64) (&L.cnt[0][0][0])[q] = 0;
+                for (uint32_t q = lane; q < 2 * n_slots * 3; q += 64) {
+                    (&L.cbox_lo[0][0])[q] = lo0; (&L.cbox_hi[0][0])[q] = hi0; (&L.czlo[0][0])[q] = 0; (&L.czhi[0][0])[q] = 0;
+                }
+            }
+            wave_sync();
+            if (splits) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T scale = T(kBins) / (nhi[k] - nlo[k]);
+                    const T shift = (-nlo[k]) * scale;
+                    const uint32_t b = bin_of(Ord<T>::fma_(ctr[k], scale, shift));
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { atomicMin(&L.lo[slot][k][b][j], Ord<T>::enc(blo[j])); atomicMax(&L.hi[slot][k][b][j], Ord<T>::enc(bhi[j])); }
+                    atomicAdd(&L.cnt[slot][k][b], 1u);
+                }
+            }
+            wave_sync();
+            // ---- find_best_split: lane (slot, axis) sweeps one axis of one slot
+            if (static_cast<uint32_t>(lane) < 3 * n_slots) {
+                const int sl = lane / 3, k = lane % 3;
+                if (k < c.dim) {
+                    T cost; uint32_t bin;
+                    sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
+                        for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(L.lo[sl][k][i][j]); hi[j] = Ord<T>::dec(L.hi[sl][k][i][j]); }
+                        n = L.cnt[sl][k][i];
+                    }, cost, bin, c.dim, c.sah_log);
+                    L.axis_cost[sl][k] = cost;
+                    L.axis_bin[sl][k] = bin;
+                }
+            }
+            wave_sync();
+            // ---- try_split's decision, one lane per slot (binned_sah_builder.h:128-148)
+            if (static_cast<uint32_t>(lane) < n_slots) {
+                const uint32_t nd = pass_first + lane;
+                const uint32_t nbg = L.nb[nd], nen = L.ne[nd], ncnt = nen - nbg;
+                T blo6[3], bhi6[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { blo6[k] = L.nbox[nd][k]; bhi6[k] = L.nbox[nd][3 + k]; }
+                uint32_t mode = SM_LEAF, axis = 0;
+                T plane = T(0);
+                const int wide = widest_axis(blo6, bhi6, c.dim);
+                if (ncnt > c.min_leaf) {
+                    uint32_t best_bin = kBins / 2; T best_cost = Ord<T>::kMax; int best_axis = wide;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (k >= c.dim) continue;
+                        const T cst = L.axis_cost[lane][k];
+                        if (cst < best_cost) { best_cost = cst; best_bin = L.axis_bin[lane][k]; best_axis = k; }
+                    }
+                    const T stay = half_area(blo6, bhi6, c.dim) * (sah_prims<T>(ncnt, c.sah_log) - c.sah_ratio);
+                    if (best_cost >= stay) {
+                        if (ncnt > c.max_leaf) mode = SM_FALLBACK;            // else: leaf
+                    } else {
+                        mode = SM_PARTITION;
+                        axis = static_cast<uint32_t>(best_axis);
+                        plane = Ord<T>::fma_((bhi6[best_axis] - blo6[best_axis]) / T(kBins), static_cast<T>(best_bin), blo6[best_axis]);
+                    }
+                }
+                L.s_node[lane] = nd; L.s_mode[lane] = mode; L.s_axis[lane] = axis; L.s_wide[lane] = static_cast<uint32_t>(wide);
+                L.s_plane[lane] = plane; L.s_cut[lane] = 0; L.s_child[lane] = 0; L.s_first[lane] = 0;
+            }
+            wave_sync();
+            // ---- std::partition of every slot at once (Hoare permutation inside the node's lane range)
+            uint32_t mode = mine ? L.s_mode[slot] : SM_LEAF;
+            const uint64_t my_range = mine ? (((le >= 64 ? ~uint64_t{0} : ((uint64_t{1} << le) - 1))) & ~((uint64_t{1} << lb) - 1)) : 0;
+            bool fallback = mode == SM_FALLBACK;
+            int src = lane;
+            uint32_t cut = 0;
+            {
+                const uint32_t ax = mine ? L.s_axis[slot] : 0u;
+                const T key = ax == 0 ? ctr[0] : (ax == 1 ? ctr[1] : ctr[2]);
+                const bool pred = mode == SM_PARTITION && key < L.s_plane[slot];
+                const uint64_t tmask = __ballot(pred) & my_range;
+                const uint32_t m = __popcll(tmask);
+                if (mode == SM_PARTITION && (m == 0 || m == cnt)) { fallback = true; mode = SM_FALLBACK; }   // :152-153
+                const bool part = mode == SM_PARTITION;
+                const uint32_t boundary = lb + m;
+                const bool lv = part && uint32_t(lane) < boundary && !pred;
+                const bool rv = part && uint32_t(lane) >= boundary && pred;
+                const uint64_t lmask = __ballot(lv) & my_range, rmask = __ballot(rv) & my_range;
+                const uint32_t lrank = __popcll(lmask & lanes_below);
+                const uint32_t rrank = __popcll(rmask & ~(lanes_below | (uint64_t{1} << lane)));   // descending rank
+                if (lv) L.ltab[lb + lrank] = lane;
+                if (rv) L.rtab[lb + rrank] = lane;
+                wave_sync();
+                if (lv) src = L.rtab[lb + lrank];
+                if (rv) src = L.ltab[lb + rrank];
+                if (part) cut = boundary;
+            }
+            id = __shfl(id, src);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ctr[k] = __shfl(ctr[k], src); blo[k] = __shfl(blo[k], src); bhi[k] = __shfl(bhi[k], src); }
+            // ---- fallback_split (:118-126) of the slots that need one: std::partial_sort replayed by one lane each
+            uint64_t fb_lanes = __ballot(fallback);
+            if (fb_lanes) {
+                const uint32_t wide = mine ? L.s_wide[slot] : 0u;
+                const T key = wide == 0 ? ctr[0] : (wide == 1 ? ctr[1] : ctr[2]);
+                L.keys[lane] = key;
+                L.perm[lane] = lane;
+                wave_sync();
+                const uint32_t mid = (B + lb + B + le + 1) / 2 - B;          // absolute indices, :119
+                if (fallback && uint32_t(lane) == lb) {                      // one lane per falling-back node
+                    const T* keys = L.keys;
+                    partial_sort_replay(L.perm + lb, long(mid - lb), long(cnt), [=](uint32_t q) { return keys[q]; });
+                }
+                wave_sync();
+                const int fsrc = fallback ? static_cast<int>(L.perm[lane]) : lane;
+                id = __shfl(id, fsrc);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { ctr[k] = __shfl(ctr[k], fsrc); blo[k] = __shfl(blo[k], fsrc); bhi[k] = __shfl(bhi[k], fsrc); }
+                if (fallback) cut = mid;
+            }
+            const bool split = mine && mode != SM_LEAF;
+            // the first lane of every splitting node publishes the cut
+            if (split && uint32_t(lane) == lb) { L.s_cut[slot] = cut; L.s_mode[slot] = mode; }
+            // ---- child boxes: every primitive joins its side's box (order-independent min / max + the last-zero rule)
+            const uint32_t side = split && uint32_t(lane) >= cut ? 1u : 0u;
+            if (split) {
+                const uint32_t cb = 2 * slot + side;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    atomicMin(&L.cbox_lo[cb][k], Ord<T>::enc(blo[k])); atomicMax(&L.cbox_hi[cb][k], Ord<T>::enc(bhi[k]));
+                    if (blo[k] == T(0)) atomicMax(&L.czlo[cb][k], (static_cast<uint32_t>(lane) << 1) | Ord<T>::sign(blo[k]));
+                    if (bhi[k] == T(0)) atomicMax(&L.czhi[cb][k], (static_cast<uint32_t>(lane) << 1) | Ord<T>::sign(bhi[k]));
+                }
+            }
+            wave_sync();
+            // ---- one lane per slot creates the two children (SATO order) in slot order
+            {
+                const bool creates = static_cast<uint32_t>(lane) < n_slots && L.s_mode[lane] != SM_LEAF;
+                const uint64_t cm = __ballot(creates);
+                if (creates) {
+                    const uint32_t nd = L.s_node[lane];
+                    const uint32_t child = n_nodes + 2 * __popcll(cm & lanes_below);
+                    T clo[2][3], chi[2][3];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            clo[q][k] = decode_bound<T>(L.cbox_lo[2 * lane + q][k], L.czlo[2 * lane + q][k]);
+                            chi[q][k] = decode_bound<T>(L.cbox_hi[2 * lane + q][k], L.czhi[2 * lane + q][k]);
+                        }
+                    const int first = half_area(clo[0], chi[0], c.dim) < half_area(clo[1], chi[1], c.dim) ? 1 : 0;   // SATO (:99-107)
+                    const uint32_t nbg = L.nb[nd], nen = L.ne[nd], ct = L.s_cut[lane];
+                    const uint32_t rb[2] = { nbg, ct }, re[2] = { ct, nen };
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        L.nbox[child][k] = clo[first][k];         L.nbox[child][3 + k] = chi[first][k];
+                        L.nbox[child + 1][k] = clo[1 - first][k]; L.nbox[child + 1][3 + k] = chi[1 - first][k];
+                    }
+                    L.nb[child] = static_cast<uint8_t>(rb[first]);         L.ne[child] = static_cast<uint8_t>(re[first]);
+                    L.nb[child + 1] = static_cast<uint8_t>(rb[1 - first]); L.ne[child + 1] = static_cast<uint8_t>(re[1 - first]);
+                    L.nparent[child] = static_cast<uint8_t>(nd); L.nparent[child + 1] = static_cast<uint8_t>(nd);
+                    L.nwhich[child] = 0; L.nwhich[child + 1] = 1;
+                    L.nchild[child] = 0; L.nchild[child + 1] = 0;
+                    L.nchild[nd] = static_cast<uint8_t>(child);
+                    L.s_child[lane] = child; L.s_first[lane] = static_cast<uint32_t>(first);
+                }
+                n_nodes += 2 * __popcll(cm);
+            }
+            wave_sync();
+            if (split) my_node = L.s_child[slot] + (side != L.s_first[slot] ? 1u : 0u);
+            wave_sync();
+        }
+        lvl_begin = lvl_end;
+        lvl_end = n_nodes;
+    }
+    if (lane == 0) level_start[n_levels] = static_cast<uint8_t>(n_nodes);
+    wave_sync();
+    // ---- the reference's numbering: inner counts bottom-up, pre-order ranks top-down (Phase C's rule, within the subtree)
+    for (uint32_t lv = n_levels; lv-- > 0;) {
+        const uint32_t f = level_start[lv], e = level_start[lv + 1];
+        for (uint32_t t = f + lane; t < e; t += 64) {
+            const uint32_t ch = L.nchild[t];
+            L.nic[t] = ch ? static_cast<uint8_t>(1 + L.nic[ch] + L.nic[ch + 1]) : 0;
+        }
+        wave_sync();
+    }
+    if (lane == 0) L.nrank[0] = 0;
+    wave_sync();
+    for (uint32_t lv = 0; lv < n_levels; ++lv) {
+        const uint32_t f = level_start[lv], e = level_start[lv + 1];
+        for (uint32_t t = f + lane; t < e; t += 64) {
+            const uint32_t ch = L.nchild[t];
+            if (ch) {
+                const uint32_t c0 = L.ne[ch] - L.nb[ch], c1 = L.ne[ch + 1] - L.nb[ch + 1];
+                const uint32_t r = L.nrank[t];
+                if (c0 < c1) { L.nrank[ch] = static_cast<uint8_t>(r + 1); L.nrank[ch + 1] = static_cast<uint8_t>(r + 1 + L.nic[ch]); }   // fewer primitives first,
+                else         { L.nrank[ch + 1] = static_cast<uint8_t>(r + 1); L.nrank[ch] = static_cast<uint8_t>(r + 1 + L.nic[ch + 1]); } // ties: the second child
+            }
+        }
+        wave_sync();
+    }
+    for (uint32_t t = lane; t < n_nodes; t += 64) {
+        HostNode<T> rec;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rec.bounds[2 * k] = L.nbox[t][k]; rec.bounds[2 * k + 1] = L.nbox[t][3 + k]; }
+        const uint32_t ch = L.nchild[t];
+        if (ch) rec.index = static_cast<I>(1 + 2 * L.nrank[t]) << kCountBits;
+        else rec.index = (static_cast<I>(B + L.nb[t]) << kCountBits) | static_cast<I>(L.ne[t] - L.nb[t]);
+        const uint32_t fid = t == 0 ? 0u : 1u + 2u * L.nrank[L.nparent[t]] + L.nwhich[t];
+        stage[fid] = rec;
+    }
+    if (lane < int(s)) c.ids[B + lane] = id;
+    if (lane == 0) A.ic = L.nic[0];
+}
+
 } // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -473,7 +772,11 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
         n_active = h.n_active_next;
         n_tasks = h.n_tasks_next;
     }
-    if (!overflow && h.n_small) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, stream, c, h.n_small);
+    if (!overflow && h.n_small) {
+        static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
+        if (dfs) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, stream, c, h.n_small);
+        else hipLaunchKernelGGL(k_small_levels<T>, dim3((h.n_small + 1) / 2), dim3(128), 0, stream, c, h.n_small);
+    }
     return BVH_AMD_OK;
 }
 
