@@ -230,6 +230,7 @@ def main():
             bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)   # warm-up build (allocations, code load)
             times, times_host = [], []
             for _ in range(5 if qname != "high" else 3):                          # median of >= 5 after a warm-up
+                bvh_q = None                                                      # (destroying the previous BVH is not part of a build)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 bb, cc = bvh_amd.tri_bounds(d_tris)

@@ -142,13 +142,13 @@ __global__ void __launch_bounds__(64) k_merge_cells(const uint32_t* hist, uint32
     if (lane == 0) { group_begin[groups] = run; sc->n_groups = groups; }
 }
 
-// The same for grids of at most kMergeBlockCells cells (the default 16^3 and up to 25^3... i.e. log2_grid_dim <= 4) by ONE block:
-// with P = exclusive prefix sums of the cell counts, the bin the reference opens at cell k absorbs cell j > k exactly while
+// The same for grids of at most kMergeBlockCells cells (log2_grid_dim <= 4, the default 16^3 included) by ONE block: with P =
+// exclusive prefix sums of the cell counts, the bin the reference opens at cell k absorbs cell j > k exactly while
 // P[j + 1] - P[k] <= threshold (:87-88: the running size plus the next cell's), so next(k) = the first j > k with
-// P[j + 1] > P[k] + threshold is a binary search per cell, all cells at once; the bins are the orbit of cell 0 under next
-// (one lane hops through LDS, a few hundred hops), empty bins are dropped (:93-96) and the surviving bins are numbered by a scan.
-// 1.39 ms -> ~0.05 ms at the default grid.
-constexpr uint32_t kMergeBlockCells = 16384;
+// P[j + 1] > P[k] + threshold is a binary search per cell, all cells at once; the bins are the orbit of cell 0 under next, marked by
+// pointer doubling (reach <- reach | J(reach), J <- J o J: log2(cells) rounds); empty bins are dropped (:93-96) and the surviving
+// bins are numbered by a scan. Without merging (pruning off) every cell is its own bin. 1.39 ms -> ~0.03 ms at the default grid.
+constexpr uint32_t kMergeBlockCells = 4096;
 __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* warp_sums, uint32_t& total) {      // 1024 threads
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -165,7 +165,9 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* warp_sums,
 __global__ void __launch_bounds__(1024) k_merge_cells_block(const uint32_t* hist, uint32_t cells, int merge, uint32_t threshold, uint32_t* group_of,
                                                             uint32_t* group_begin, MtScalars* sc) {
     __shared__ uint32_t P[kMergeBlockCells + 1];             // P[k] = primitives in cells [0, k)
-    __shared__ uint32_t nxt[kMergeBlockCells];               // next(k), later: 1 where a non-empty bin starts
+    __shared__ uint32_t nxt[kMergeBlockCells];               // next(k); bit 31: a non-empty bin starts at k
+    __shared__ uint32_t jmp[2][kMergeBlockCells];            // next^(2^d), double-buffered
+    __shared__ uint8_t reach[kMergeBlockCells];              // k lies on the orbit of cell 0
     __shared__ uint32_t warp_sums[16];
     constexpr uint32_t kPer = kMergeBlockCells / 1024;       // consecutive cells per thread
     const uint32_t t = threadIdx.x, first = t * kPer;
@@ -192,13 +194,27 @@ __global__ void __launch_bounds__(1024) k_merge_cells_block(const uint32_t* hist
         nxt[k] = j;
     }
     __syncthreads();
-    if (t == 0) {                                             // the bins: 0, next(0), next(next(0)), ...; keep the non-empty ones
-        uint32_t k = 0;
-        while (k < cells) {
-            const uint32_t j = nxt[k];
-            nxt[k] = (P[j] != P[k] ? 0x80000000u : 0u) | j;   // bit 31: a surviving bin starts here
-            k = j;
+    // the bins: 0, next(0), next(next(0)), ...; `cells` acts as the end marker (a fixed point of next)
+    for (uint32_t k = t; k < cells; k += 1024) { jmp[0][k] = nxt[k]; reach[k] = k == 0 ? 1 : 0; }
+    __syncthreads();
+    if (merge) {
+        int cur = 0;
+        for (uint32_t span = 1; span < cells; span <<= 1) {   // after the round: reach = {next^i(0) : i < 2 span}, jmp[cur] = next^(2 span)
+            for (uint32_t k = t; k < cells; k += 1024) {
+                const uint32_t j = jmp[cur][k];
+                if (reach[k] && j < cells) reach[j] = 1;      // (benign race: every writer stores 1)
+                jmp[cur ^ 1][k] = j < cells ? jmp[cur][j] : cells;
+            }
+            cur ^= 1;
+            __syncthreads();
         }
+    } else {
+        for (uint32_t k = t; k < cells; k += 1024) reach[k] = 1;
+        __syncthreads();
+    }
+    for (uint32_t k = t; k < cells; k += 1024) {
+        const uint32_t j = nxt[k];
+        if (reach[k] && P[j] != P[k]) nxt[k] = 0x80000000u | j;          // a surviving (non-empty) bin starts here
     }
     __syncthreads();
     uint32_t starts[kPer], nstart = 0;

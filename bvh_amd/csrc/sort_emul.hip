@@ -259,26 +259,38 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* out, uint32_t n, con
 
 } // namespace
 
-int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_host, hipStream_t stream) {
-    StreamScope scratch_on(stream);
-    // out[i] = sum of in[0..i); total optionally returned to the host
-    if (n == 0) { if (total_host) *total_host = 0; return BVH_AMD_OK; }
+// out[i] = sum of in[0..i) (in == out allowed), entirely in stream order: blocks of 4096, their sums scanned recursively, offsets
+// added back. d_total (device, optional) receives the grand total.
+static int scan_u32_async(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total, hipStream_t stream) {
     const uint32_t blocks = (n + kScanBlock - 1) / kScanBlock;
     DevBuf<uint32_t> sums, sums_scanned;
     BVH_HIP_TRY(sums.alloc(blocks), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(sums_scanned.alloc(blocks), BVH_AMD_ERR_HIP);
     hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(1024), 0, stream, in, out, n, sums.p);
-    uint32_t total = 0;
     if (blocks > 1) {
-        int rc = exclusive_scan_u32(sums.p, sums_scanned.p, blocks, &total, stream);
+        BVH_HIP_TRY(sums_scanned.alloc(blocks), BVH_AMD_ERR_HIP);
+        int rc = scan_u32_async(sums.p, sums_scanned.p, blocks, d_total, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, sums_scanned.p);
-    } else if (total_host) {
-        BVH_HIP_TRY(hipMemcpyAsync(&total, sums.p, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    } else if (d_total) {
+        BVH_HIP_TRY(hipMemcpyAsync(d_total, sums.p, 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
     }
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
-    if (total_host) *total_host = total;
+    if (!sums.pooled) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);     // plain hipFree of the scratch on return
+    return BVH_AMD_OK;
+}
+
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_host, hipStream_t stream) {
+    StreamScope scratch_on(stream);
+    // out[i] = sum of in[0..i); total optionally returned to the host (then, and only then, the stream is synchronised)
+    if (n == 0) { if (total_host) *total_host = 0; return BVH_AMD_OK; }
+    DevBuf<uint32_t> d_total;
+    if (total_host) BVH_HIP_TRY(d_total.alloc(1), BVH_AMD_ERR_HIP);
+    int rc = scan_u32_async(in, out, n, total_host ? d_total.p : nullptr, stream);
+    if (rc) return rc;
+    if (total_host) {
+        BVH_HIP_TRY(hipMemcpyAsync(total_host, d_total.p, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    }
     return BVH_AMD_OK;
 }
 
@@ -302,7 +314,12 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, n, bpa, shift, hist.p);
-        hipLaunchKernelGGL(k_radix_scan, dim3(batch), dim3(1024), 0, stream, hist.p, 256 * bpa);
+        if (256 * bpa > 16384) {                              // long histograms: the multi-block scan (one block per array crawls: 1 ms at 10M keys)
+            for (uint32_t a = 0; a < batch; ++a) {
+                int rc = scan_u32_async(hist.p + size_t{a} * 256 * bpa, hist.p + size_t{a} * 256 * bpa, 256 * bpa, nullptr, stream);
+                if (rc) return rc;
+            }
+        } else hipLaunchKernelGGL(k_radix_scan, dim3(batch), dim3(1024), 0, stream, hist.p, 256 * bpa);
         hipLaunchKernelGGL(k_radix_scatter<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, vin, kout, vout, n, bpa, shift, hist.p);
         std::swap(kin, kout);
         std::swap(vin, vout);

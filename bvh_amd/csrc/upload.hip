@@ -186,7 +186,11 @@ int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t st
     if (b.d_cpairs) { (void)hipFree(b.d_cpairs); b.d_cpairs = nullptr; }
     b.compact_state = 0;
     if (b.pair_count) {
-        BVH_HIP_TRY(hipMalloc(&b.d_pairs, b.pair_count * sizeof(PairNode<T>)), BVH_AMD_ERR_HIP);
+        // (from the stream-ordered pool when it is on: a plain hipMalloc of the 10M-triangle scene's 0.5 GB of records costs ~2 ms;
+        //  BvhImpl releases it with hipFree, which accepts pool memory)
+        StreamScope scratch_on(stream);
+        hipStream_t used = nullptr; bool pooled = false;
+        BVH_HIP_TRY(scratch_alloc(reinterpret_cast<void**>(&b.d_pairs), b.pair_count * sizeof(PairNode<T>), &used, &pooled), BVH_AMD_ERR_HIP);
         unsigned grid = static_cast<unsigned>((b.pair_count + 255) / 256);
         hipLaunchKernelGGL(relayout_pairs<T>, dim3(grid), dim3(256), 0, stream, d_nodes, b.pair_count, b.d_pairs);
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);

@@ -12,7 +12,9 @@ reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 tris = torch.from_numpy({"soup": synth.soup, "terrain": synth.terrain, "sponza": synth.sponza_proxy}[scene](n)).cuda()
 cfg = bvh_amd.Config(quality=bvh_amd.Quality(q))
 ts = []
+b = None
 for r in range(reps + 1):
+    b = None                                                  # (destroying the previous BVH is not part of a build)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     bb, cc = bvh_amd.tri_bounds(tris)
     b = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=bvh_amd.ThreadPool() if pool else None)
