@@ -15,6 +15,9 @@
 
 #include "build_common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace bvh_amd {
 
 using namespace bld;
@@ -430,6 +433,243 @@ __global__ void __launch_bounds__(256) k_small_sweep(SweepCtx<T> c, uint32_t n_s
     if (lane == 0) A.ic = (ncount - 1) / 2;
 }
 
+
+// ---- the same, level-synchronous (round 2; cf. build_binned.hip: k_small_levels) ------------------------------------------------
+// All nodes of one level of the subtree are split at once. The sweeps become SEGMENTED scans over the nodes' contiguous position
+// ranges (a scan step only joins a neighbour that lies inside the lane's own node), the arg-min over a node is a segmented min-scan
+// read at the node's last position, the stable partitions of the other two orders use one ballot masked with the node's range, the
+// child boxes are LDS atomics per child with the last-zero rule, and the reference's numbering is recovered at the end from inner
+// counts (bottom-up over the levels) and ranks (top-down): fewer primitives first, ties: the second child.
+template <typename T>
+struct LevelSweepLds {
+    uint32_t perm[3][kSmall];
+    uint32_t next[kSmall];
+    uint32_t markslot[kSmall];
+    T nbox[2 * kSmall][6];
+    typename Ord<T>::U cbox_lo[kSmall][3], cbox_hi[kSmall][3];
+    uint32_t czlo[kSmall][3], czhi[kSmall][3];
+    uint8_t nb[2 * kSmall], ne[2 * kSmall], nparent[2 * kSmall], nwhich[2 * kSmall], nchild[2 * kSmall], nfirst[2 * kSmall], nic[2 * kSmall], nrank[2 * kSmall];
+    uint8_t level_start[kSmall + 2];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(128) k_small_sweep_levels(SweepCtx<T> c, uint32_t n_small) {
+    __shared__ LevelSweepLds<T> lds_all[2];
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 2 + (threadIdx.x >> 6);
+    if (w >= n_small) return;
+    LevelSweepLds<T>& L = lds_all[threadIdx.x >> 6];
+    ANode<T>& A = c.b.nodes[c.b.small_list[w]];
+    const uint32_t B = A.begin, s = A.end - A.begin;
+    HostNode<T>* stage = c.b.stage + 2ull * B;
+    const uint64_t lanes_below = (uint64_t{1} << lane) - 1;
+    using I = typename IndexOf<T>::Type;
+
+    // slot `lane` holds the primitive at position B + lane of the axis-0 order
+    uint32_t id = 0xFFFFFFFFu;
+    T blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0};
+    if (lane < int(s)) {
+        id = c.ord[0][B + lane];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { blo[k] = c.b.bboxes[6ull * id + k]; bhi[k] = c.b.bboxes[6ull * id + 3 + k]; }
+    }
+    L.perm[0][lane] = lane;
+    for (int k = 1; k < 3; ++k) {
+        const uint32_t want = lane < int(s) ? c.ord[k][B + lane] : 0xFFFFFFFEu;
+        uint32_t slot = lane;
+        for (uint32_t t = 0; t < s; ++t) if (__shfl(id, int(t)) == want) slot = t;
+        L.perm[k][lane] = slot;
+    }
+    if (lane < 3) { L.nbox[0][lane] = A.lo[lane]; L.nbox[0][3 + lane] = A.hi[lane]; }
+    if (lane == 0) { L.nb[0] = 0; L.ne[0] = static_cast<uint8_t>(s); L.nparent[0] = 0; L.nwhich[0] = 0; L.nchild[0] = 0; L.nfirst[0] = 0; }
+    const bool in_tree = lane < int(s);
+    uint32_t my_node = 0;                                     // node that holds POSITION `lane` (positions, not slots, belong to nodes)
+    uint32_t n_nodes = 1, n_levels = 0, lvl_begin = 0, lvl_end = 1;
+    wave_sync();
+
+    while (lvl_begin < lvl_end) {
+        if (lane == 0) L.level_start[n_levels] = static_cast<uint8_t>(lvl_begin);
+        ++n_levels;
+        const bool mine = in_tree && my_node >= lvl_begin;                 // my node belongs to this level (older nodes are leaves)
+        const uint32_t lb = mine ? L.nb[my_node] : 0u, le = mine ? L.ne[my_node] : 0u;
+        const uint32_t cnt = le - lb;
+        T nlo[3] = {0, 0, 0}, nhi[3] = {0, 0, 0};
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { nlo[k] = L.nbox[my_node][k]; nhi[k] = L.nbox[my_node][3 + k]; }
+        }
+        const bool tries = mine && cnt > c.b.min_leaf;
+        const uint64_t my_range = mine ? (((le >= 64 ? ~uint64_t{0} : ((uint64_t{1} << le) - 1))) & ~((uint64_t{1} << lb) - 1)) : 0;
+        bool split = false;
+        uint32_t cut = 0;
+        {
+            const T stay = half_area(nlo, nhi, c.b.dim) * (sah_prims<T>(cnt, c.b.sah_log) - c.b.sah_ratio);
+            const uint32_t mid = (B + lb + B + le + 1) / 2 - B;
+            uint32_t best_pos = mid; T best_cost = stay; uint32_t best_axis = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k >= c.b.dim) continue;                   // (wave-uniform)
+                const int src = L.perm[k][lane];
+                Box6<T> v;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { v.lo[q] = __shfl(blo[q], src); v.hi[q] = __shfl(bhi[q], src); }
+                if (!tries) v = empty_box<T>();
+                // segmented suffix scan (towards higher positions) and prefix scan inside [lb, le)
+                Box6<T> suf = v, pre = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    Box6<T> o;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { o.lo[q] = __shfl_down(suf.lo[q], off); o.hi[q] = __shfl_down(suf.hi[q], off); }
+                    if (uint32_t(lane + off) < le) suf = join(o, suf);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { o.lo[q] = __shfl_up(pre.lo[q], off); o.hi[q] = __shfl_up(pre.hi[q], off); }
+                    if (lane >= off && uint32_t(lane - off) >= lb && tries) pre = join(o, pre);
+                }
+                const T cr = half_area(suf.lo, suf.hi, c.b.dim) * sah_prims<T>(le - uint32_t(lane), c.b.sah_log);    // cost of [lane, le)
+                const T cr_next = __shfl_down(cr, 1);
+                T cost = __builtin_inff();
+                uint32_t pos = 0xFFFFFFFFu;
+                if (tries && uint32_t(lane) + 1 < le) {
+                    const T cl = half_area(pre.lo, pre.hi, c.b.dim) * sah_prims<T>(uint32_t(lane) + 1 - lb, c.b.sah_log);
+                    const T tot = cl + cr_next;
+                    if (tot < cost) { cost = tot; pos = lane + 1; }
+                }
+                // segmented arg-min: inclusive min-scan over [lb, lane], the node's result sits at position le - 1
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const T oc = __shfl_up(cost, off);
+                    const uint32_t op = __shfl_up(pos, off);
+                    if (lane >= off && uint32_t(lane - off) >= lb && tries && (oc < cost || (oc == cost && op < pos))) { cost = oc; pos = op; }
+                }
+                const int last = tries ? int(le) - 1 : lane;
+                cost = __shfl(cost, last);
+                pos = __shfl(pos, last);
+                if (cost < best_cost) { best_cost = cost; best_pos = pos; best_axis = k; }
+            }
+            bool do_split = tries;
+            if (tries && best_cost >= stay) {
+                if (cnt <= c.b.max_leaf) do_split = false;
+                else { best_pos = mid; best_axis = static_cast<uint32_t>(widest_axis(nlo, nhi, c.b.dim)); }
+            }
+            // mark_primitives + stable_partition of the other two orders, every splitting node at once
+            L.markslot[lane] = 0;
+            wave_sync();
+            if (do_split) L.markslot[L.perm[best_axis][lane]] = uint32_t(lane) < best_pos ? 1u : 0u;
+            wave_sync();
+            for (uint32_t k = 0; k < 3; ++k) {
+                const bool act = do_split && k != best_axis;
+                const uint32_t slot = L.perm[k][lane];
+                const bool flag = act && L.markslot[slot] != 0;
+                const uint64_t tmask = __ballot(flag) & my_range, fmask = __ballot(act && !flag) & my_range;
+                if (act) L.next[flag ? lb + __popcll(tmask & lanes_below) : best_pos + __popcll(fmask & lanes_below)] = slot;
+                wave_sync();
+                if (act) L.perm[k][lane] = L.next[lane];
+                wave_sync();
+            }
+            split = do_split;
+            cut = best_pos;
+        }
+        // ---- the children: ids in position order of the splitting nodes, boxes in axis-0 position order (compute_bbox)
+        const bool creates = split && uint32_t(lane) == lb;
+        const uint64_t cm = __ballot(creates);
+        const uint32_t new_first = n_nodes;
+        if (creates) L.nchild[my_node] = static_cast<uint8_t>(new_first + 2 * __popcll(cm & lanes_below));
+        for (uint32_t q = lane; q < 2 * static_cast<uint32_t>(__popcll(cm)) * 3; q += 64) {
+            (&L.cbox_lo[0][0])[q] = Ord<T>::enc(Ord<T>::kMax); (&L.cbox_hi[0][0])[q] = Ord<T>::enc(-Ord<T>::kMax);
+            (&L.czlo[0][0])[q] = 0; (&L.czhi[0][0])[q] = 0;
+        }
+        wave_sync();
+        const uint32_t side = split && uint32_t(lane) >= cut ? 1u : 0u;
+        {
+            const int src = L.perm[0][lane];
+            T plo[3], phi[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { plo[q] = __shfl(blo[q], src); phi[q] = __shfl(bhi[q], src); }
+            if (split) {
+                const uint32_t cb = L.nchild[my_node] - new_first + side;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    atomicMin(&L.cbox_lo[cb][k], Ord<T>::enc(plo[k])); atomicMax(&L.cbox_hi[cb][k], Ord<T>::enc(phi[k]));
+                    if (plo[k] == T(0)) atomicMax(&L.czlo[cb][k], (static_cast<uint32_t>(lane) << 1) | Ord<T>::sign(plo[k]));
+                    if (phi[k] == T(0)) atomicMax(&L.czhi[cb][k], (static_cast<uint32_t>(lane) << 1) | Ord<T>::sign(phi[k]));
+                }
+            }
+        }
+        wave_sync();
+        if (creates) {
+            const uint32_t child = L.nchild[my_node], cb = child - new_first;
+            T clo[2][3], chi[2][3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    clo[q][k] = decode_bound<T>(L.cbox_lo[cb + q][k], L.czlo[cb + q][k]);
+                    chi[q][k] = decode_bound<T>(L.cbox_hi[cb + q][k], L.czhi[cb + q][k]);
+                }
+            const int first = half_area(clo[0], chi[0], c.b.dim) < half_area(clo[1], chi[1], c.b.dim) ? 1 : 0;     // SATO
+            const uint32_t rb[2] = { lb, cut }, re[2] = { cut, le };
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                L.nbox[child][k] = clo[first][k];         L.nbox[child][3 + k] = chi[first][k];
+                L.nbox[child + 1][k] = clo[1 - first][k]; L.nbox[child + 1][3 + k] = chi[1 - first][k];
+            }
+            L.nb[child] = static_cast<uint8_t>(rb[first]);         L.ne[child] = static_cast<uint8_t>(re[first]);
+            L.nb[child + 1] = static_cast<uint8_t>(rb[1 - first]); L.ne[child + 1] = static_cast<uint8_t>(re[1 - first]);
+            L.nparent[child] = static_cast<uint8_t>(my_node); L.nparent[child + 1] = static_cast<uint8_t>(my_node);
+            L.nwhich[child] = 0; L.nwhich[child + 1] = 1;
+            L.nchild[child] = 0; L.nchild[child + 1] = 0;
+            L.nfirst[my_node] = static_cast<uint8_t>(first);
+        }
+        n_nodes += 2 * __popcll(cm);
+        wave_sync();
+        if (split) my_node = L.nchild[my_node] + (side != L.nfirst[my_node] ? 1u : 0u);
+        wave_sync();
+        lvl_begin = lvl_end;
+        lvl_end = n_nodes;
+    }
+    if (lane == 0) L.level_start[n_levels] = static_cast<uint8_t>(n_nodes);
+    wave_sync();
+    // ---- the reference's numbering (cf. k_small_levels)
+    for (uint32_t lv = n_levels; lv-- > 0;) {
+        const uint32_t f = L.level_start[lv], e = L.level_start[lv + 1];
+        for (uint32_t t = f + lane; t < e; t += 64) {
+            const uint32_t ch = L.nchild[t];
+            L.nic[t] = ch ? static_cast<uint8_t>(1 + L.nic[ch] + L.nic[ch + 1]) : 0;
+        }
+        wave_sync();
+    }
+    if (lane == 0) L.nrank[0] = 0;
+    wave_sync();
+    for (uint32_t lv = 0; lv < n_levels; ++lv) {
+        const uint32_t f = L.level_start[lv], e = L.level_start[lv + 1];
+        for (uint32_t t = f + lane; t < e; t += 64) {
+            const uint32_t ch = L.nchild[t];
+            if (ch) {
+                const uint32_t c0 = L.ne[ch] - L.nb[ch], c1 = L.ne[ch + 1] - L.nb[ch + 1];
+                const uint32_t r = L.nrank[t];
+                if (c0 < c1) { L.nrank[ch] = static_cast<uint8_t>(r + 1); L.nrank[ch + 1] = static_cast<uint8_t>(r + 1 + L.nic[ch]); }
+                else         { L.nrank[ch + 1] = static_cast<uint8_t>(r + 1); L.nrank[ch] = static_cast<uint8_t>(r + 1 + L.nic[ch + 1]); }
+            }
+        }
+        wave_sync();
+    }
+    for (uint32_t t = lane; t < n_nodes; t += 64) {
+        HostNode<T> rec;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rec.bounds[2 * k] = L.nbox[t][k]; rec.bounds[2 * k + 1] = L.nbox[t][3 + k]; }
+        const uint32_t ch = L.nchild[t];
+        if (ch) rec.index = static_cast<I>(1 + 2 * L.nrank[t]) << kCountBits;
+        else rec.index = (static_cast<I>(B + L.nb[t]) << kCountBits) | static_cast<I>(L.ne[t] - L.nb[t]);
+        const uint32_t fid = t == 0 ? 0u : 1u + 2u * L.nrank[L.nparent[t]] + L.nwhich[t];
+        stage[fid] = rec;
+    }
+    // prim_ids = the axis-0 order (sweep_sah_builder.h:66)
+    const uint32_t out_id = __shfl(id, int(L.perm[0][lane]));
+    if (lane < int(s)) c.ord[0][B + lane] = out_id;
+    if (lane == 0) A.ic = L.nic[0];
+}
+
 } // namespace
 
 // SweepSahBuilder core: nodes in the reference layout into `final_nodes`, prim ids (= the axis-0 order) in ord[0..n).
@@ -517,7 +757,11 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
             return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
         }
         const uint32_t n_nodes_a = h.n_nodes, n_small = h.n_small;
-        if (n_small) hipLaunchKernelGGL(k_small_sweep<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, sc, n_small);
+        if (n_small) {
+            static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
+            if (dfs) hipLaunchKernelGGL(k_small_sweep<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, sc, n_small);
+            else hipLaunchKernelGGL(k_small_sweep_levels<T>, dim3((n_small + 1) / 2), dim3(128), 0, stream, sc, n_small);
+        }
         BvhImpl<T> sizes;                                      // only its node vector length is used
         rc = number_and_emit<T>(sizes, c, level_start, n_nodes_a, n_small, final_nodes, stream);
         if (rc) return rc;
