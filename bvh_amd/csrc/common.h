@@ -112,10 +112,6 @@ struct BvhImpl {
     size_t pair_count = 0;
     uint32_t* d_prim_ids = nullptr;            // prim_count
     uint32_t root_index = 0;                   // nodes[0].index narrowed to 32 bits
-    // EXPERIMENTAL (BVH_AMD_PAIRS=compact, compact_pair.h; 3D): compact records next to d_pairs, built lazily by the first
-    // batch traversal that asks for them. compact_state: 0 = not built, 1 = usable, -1 = some pair is not representable.
-    mutable void* d_cpairs = nullptr;          // CompactPairT<T>[pair_count]
-    mutable std::atomic<int> compact_state{0};
     // Deepest level of the tree (root = 0), computed lazily on the device by the first batch traversal after a (re)layout.
     // The traversal stack never holds more entries than that: trees up to 64 levels use LDS + per-lane scratch (the
     // reference's SmallStack<Index, 64>), deeper ones additionally spill to d_deep (its GrowingStack, stack.h:34-46).
@@ -167,7 +163,6 @@ void scratch_free(void* p, hipStream_t stream, bool pooled);
 // upload.hip
 template <typename T> int upload_bvh(BvhImpl<T>& b, hipStream_t stream);
 template <typename T> int tree_depth(const BvhImpl<T>& b, hipStream_t stream);   // fills b.max_depth (cached)
-template <typename T> int ensure_compact_pairs(const BvhImpl<T>& b, hipStream_t stream);   // fills b.d_cpairs / b.compact_state (cached)
 
 template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
 

@@ -4,8 +4,6 @@
 // Expects common.h (or the test's stand-ins for it) to have been included: PairNode, HitOf, kCountBits, kCountMask, kWave, LEAF_*.
 #pragma once
 
-#include "compact_pair.h"
-
 // An empty asm the value must pass through: stops the compiler from fusing the loads on either side of it.
 #if defined(__HIPCC__)
 #define BVH_AMD_KEEP_APART(v) asm volatile("" : "+v"(v))
@@ -140,39 +138,6 @@ __device__ inline void store_hit(bvh_hit3d* out, uint32_t prim, double t, double
     q[0] = make_double2(__longlong_as_double(static_cast<long long>(prim)), t);
     q[1] = make_double2(u, v);
 }
-
-// EXPERIMENTAL (compact_pair.h): what a lane of the compact kernels fetches for pair p. With the box of the node whose children
-// these are: the CompactPair (float: two 16-byte requests, double: four); without (after a stack pop): the PairNode (four / seven).
-// The leading bytes of either record are fetched by requests every lane makes; only the rest depends on have_box.
-__device__ inline void load_compact_or_pair(bool have_box, const CompactPairT<float>* cpairs, const PairNode<float>* pairs, uint32_t p, const float (&box)[6],
-                                            float (&lb)[6], float (&rb)[6], uint32_t& li, uint32_t& ri) {
-    const uint4* q = have_box ? reinterpret_cast<const uint4*>(cpairs + p) : reinterpret_cast<const uint4*>(pairs + p);
-    const uint4 x0 = q[0], x1 = q[1];
-    uint4 x2 = make_uint4(0u, 0u, 0u, 0u);
-    uint2 x3 = make_uint2(0u, 0u);
-    if (!have_box) { x2 = q[2]; x3 = reinterpret_cast<const uint2*>(q)[6]; }
-    const uint32_t w[14] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y };
-    compact_unpack(have_box, box, w, lb, rb, li, ri);
-}
-__device__ inline void load_compact_or_pair(bool have_box, const CompactPairT<double>* cpairs, const PairNode<double>* pairs, uint32_t p, const double (&box)[6],
-                                            double (&lb)[6], double (&rb)[6], uint32_t& li, uint32_t& ri) {
-    const double2* q = have_box ? reinterpret_cast<const double2*>(cpairs + p) : reinterpret_cast<const double2*>(pairs + p);
-    const double2 v0 = q[0], v1 = q[1], v2 = q[2];
-    double2 w0 = make_double2(0.0, 0.0), w1 = w0, w2 = w0;
-    uint2 cw = make_uint2(0u, 0u), fw = make_uint2(0u, 0u);
-    if (have_box) cw = reinterpret_cast<const uint2*>(q)[6];
-    else { w0 = q[3]; w1 = q[4]; w2 = q[5]; fw = reinterpret_cast<const uint2*>(q)[12]; }
-    const double x[6] = { v0.x, v0.y, v1.x, v1.y, v2.x, v2.y };
-    const double y[6] = { w0.x, w0.y, w1.x, w1.y, w2.x, w2.y };
-    compact_unpack_planes<double>(have_box, box, x, y, cw.x, cw.y, fw.x, fw.y, lb, rb, li, ri);
-}
-
-// Argument block of trace_kernel_compact (EXPERIMENTAL, compact_pair.h): TraceArgs + the compact records.
-template <typename T>
-struct CompactTraceArgsT : TraceArgs<T> {
-    const CompactPairT<T>* cpairs;
-};
-using CompactTraceArgs = CompactTraceArgsT<float>;
 
 } // namespace
 

@@ -17,7 +17,6 @@
 // Compiled with -ffp-contract=off; division and sqrt are the correctly rounded forms.
 
 #include "common.h"
-#include "compact_pair.h"
 #include "trace_device.h"
 
 #include <algorithm>
@@ -35,40 +34,17 @@ namespace {
 
 thread_local const char* g_last_kernel = "";
 
-// NOTE (measured, profiles/README.md): the L1 (TCP) processes ~1 lane-request per clock for divergent 16-byte loads, so
-// the four requests of a 64-byte pair record are the kernel's floor (4.9 G requests per 2^24-ray launch). A
-// quad-cooperative fetch (4 lanes x 16 B of one record per instruction + LDS transpose) was tried and is 3-4x SLOWER:
-// requests are charged per lane, not per line, and idle lanes then cost as much as active ones.
+// NOTE (measured, profiles/r02_traversal_experiments.md): on the 1M-triangle soup this kernel's L2 misses (55 G 64-byte sectors/s)
+// run at 0.96 of the rate at which the memory system serves a dependent random walk over 64-byte records (57 G/s, bench.py's
+// record-walk probe): what binds it is misses per ray, not instructions, L1 requests or occupancy. Tried and rejected on hardware:
+// 32-byte "compact" records next to the PairNodes (-37 % L1 requests, 7 % slower), v_max/v_min slab test, ds_read pop, buffer
+// loads, a quad-cooperative fetch through LDS (3-4x slower), an LDS cache of the top of the tree (27 % slower), ray sorting.
 // D = 2: Bvh<Node<T, 2>> with circles (Sphere<T, 2>, stride 3) and 6-value rays. The pair records stay three wide (their z
 // bounds are zero and never looked at): only the per-ray constants, the slab test and the leaf test run over D axes.
 // Deep = true (trees of more than 64 levels only): stack entries beyond the 64 of SmallStack spill to HBM (GrowingStack).
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3, bool Deep = false>
 __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
-#define BVH_TRACE_COMPACT 0
 #include "trace_body.inc"
-#undef BVH_TRACE_COMPACT
-}
-
-// EXPERIMENTAL, opt-in (BVH_AMD_PAIRS=compact; compact_pair.h): the same walk, but a lane that has just descended into a node
-// holds that node's box and fetches the CompactPair of its children (float: two requests instead of four, double: four instead
-// of seven); after a stack pop it has no box and fetches the PairNode. 3D, trees of at most 64 levels.
-template <bool Any, bool Robust, int Leaf, bool Stats>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) trace_kernel_compact(CompactTraceArgs a) {
-    using T = float;
-    constexpr int D = 3;
-    constexpr bool Deep = false;
-#define BVH_TRACE_COMPACT 1
-#include "trace_body.inc"
-#undef BVH_TRACE_COMPACT
-}
-template <bool Any, bool Robust, int Leaf, bool Stats>
-__global__ void __launch_bounds__(kBlock) trace_kernel_compact_f64(CompactTraceArgsT<double> a) {
-    using T = double;
-    constexpr int D = 3;
-    constexpr bool Deep = false;
-#define BVH_TRACE_COMPACT 1
-#include "trace_body.inc"
-#undef BVH_TRACE_COMPACT
 }
 
 // Coherence key of a ray: Morton code of its origin cell (32^3 grid over the root box) above the direction octant.
@@ -141,42 +117,9 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     return BVH_AMD_OK;
 }
 
-// EXPERIMENTAL: the compact-record kernels (3D, trees of at most 64 levels; launch_traverse decides)
-template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
-int launch_variant_compact(const BvhImpl<T>& b, const TraceArgs<T>& args, const CompactPairT<T>* cpairs, hipStream_t stream) {
-    static thread_local int cached_blocks[16] = {0};
-    void (*kernel)(CompactTraceArgsT<T>);
-    if constexpr (std::is_same_v<T, float>) kernel = trace_kernel_compact<Any, Robust, Leaf, Stats>;
-    else kernel = trace_kernel_compact_f64<Any, Robust, Leaf, Stats>;
-    int& blocks = cached_blocks[b.device & 15];
-    if (blocks == 0) {
-        Grid g;
-        int rc = persistent_grid(kernel, b.device, g);
-        if (rc) return rc;
-        blocks = g.blocks;
-    }
-    unsigned long long need = (args.n + kBlock - 1) / kBlock;
-    int grid = static_cast<int>(need < static_cast<unsigned long long>(blocks) ? need : blocks);
-    if (grid < 1) grid = 1;
-    static const std::string symbol = std::string(std::is_same_v<T, float> ? "trace_kernel_compact<" : "trace_kernel_compact_f64<") + (Any ? "true" : "false") + ", " +
-                                      (Robust ? "true" : "false") + ", " + std::to_string(Leaf) + ", " + (Stats ? "true" : "false") + ">";
-    g_last_kernel = symbol.c_str();
-    CompactTraceArgsT<T> cargs;
-    static_cast<TraceArgs<T>&>(cargs) = args;
-    cargs.cpairs = cpairs;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, cargs);
-    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-    return BVH_AMD_OK;
-}
-
-thread_local const void* t_cpairs = nullptr;              // set by launch_traverse for the launch it is about to make
-
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
 int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     if (args.deep) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, true>(b, args, stream, name);
-    if constexpr (D == 3) {
-        if (t_cpairs) return launch_variant_compact<T, Any, Robust, Leaf, Stats>(b, args, static_cast<const CompactPairT<T>*>(t_cpairs), stream);
-    }
     return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false>(b, args, stream, name);
 }
 
@@ -438,15 +381,6 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
             BVH_HIP_TRY(hipMallocAsync(&deep_mem, lanes * cap * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
             args.deep = static_cast<uint32_t*>(deep_mem); args.deep_cap = static_cast<uint32_t>(cap);
         }
-    }
-    // EXPERIMENTAL, off by default: BVH_AMD_PAIRS=compact fetches the compact records where it can (compact_pair.h): 3D trees of
-    // at most 64 levels whose pairs are all representable; anything else silently keeps the PairNode kernel.
-    static const bool want_compact = getenv("BVH_AMD_PAIRS") && std::strcmp(getenv("BVH_AMD_PAIRS"), "compact") == 0;
-    t_cpairs = nullptr;
-    if (want_compact && b.dim == 3 && !args.deep && b.pair_count) {
-        int rc = ensure_compact_pairs<T>(b, stream);
-        if (rc) return release(rc);
-        if (b.compact_state.load() == 1) t_cpairs = b.d_cpairs;
     }
     static const int refill_env = getenv("BVH_AMD_REFILL") ? atoi(getenv("BVH_AMD_REFILL")) : 0;   // tuning knobs
     static const int leaf_env = getenv("BVH_AMD_LEAF") ? atoi(getenv("BVH_AMD_LEAF")) : 0;

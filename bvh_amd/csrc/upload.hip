@@ -1,6 +1,5 @@
 // Device copy of a reference-layout BVH: sibling pairs re-laid out as aligned PairNode records.
 #include "common.h"
-#include "compact_pair.h"
 
 #include <mutex>
 
@@ -54,60 +53,7 @@ __global__ void __launch_bounds__(256) k_depth_jump(const uint32_t* anc, const u
     if (max_out) atomicMax(max_out, d);
 }
 
-// compact_pair.h: the CompactPair of pair p is encoded against the box of the node whose children p holds, i.e. against one
-// of the two boxes of p's parent pair q. One thread per q encodes the records of its (up to two) inner children. The root's own
-// pair has no parent pair and keeps a zero record: the walk enters it without a box and reads the PairNode there.
-template <typename T>
-__global__ void __launch_bounds__(256) k_compact_encode(const PairNode<T>* pairs, uint32_t n_pairs, CompactPairT<T>* out, uint32_t* bad) {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= n_pairs) return;
-    const PairNode<T> parent = pairs[q];
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const uint32_t word = side ? parent.ri : parent.li;
-        if (word & kCountMask) continue;
-        const uint32_t p = word >> (kCountBits + 1);
-        if (p >= n_pairs) { atomicOr(bad, 2u); continue; }
-        const PairNode<T> rec = pairs[p];
-        CompactPairT<T> c = {};
-        if (compact_encode<T>(side ? parent.rb : parent.lb, rec.lb, rec.rb, rec.li, rec.ri, c)) out[p] = c;
-        else atomicOr(bad, 1u);
-    }
-}
-
 } // namespace
-
-template <typename T>
-int ensure_compact_pairs(const BvhImpl<T>& b, hipStream_t stream) {
-    if (b.compact_state.load() != 0) return BVH_AMD_OK;
-    static std::mutex once;
-    std::lock_guard<std::mutex> lock(once);
-    if (b.compact_state.load() != 0) return BVH_AMD_OK;
-    if (b.pair_count == 0 || !b.d_pairs) { b.compact_state = -1; return BVH_AMD_OK; }
-    const uint32_t n = static_cast<uint32_t>(b.pair_count);
-    CompactPairT<T>* recs = nullptr;
-    uint32_t* d_bad = nullptr;
-    BVH_HIP_TRY(hipMalloc(&recs, size_t{n} * sizeof(CompactPairT<T>)), BVH_AMD_ERR_HIP);
-    hipError_t e = hipMalloc(&d_bad, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemsetAsync(recs, 0, size_t{n} * sizeof(CompactPairT<T>), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream);
-    uint32_t bad = 0;
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_compact_encode<T>, dim3((n + 255) / 256), dim3(256), 0, stream, b.d_pairs, n, recs, d_bad);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (d_bad) (void)hipFree(d_bad);
-    if (e != hipSuccess) { (void)hipFree(recs); return fail(BVH_AMD_ERR_HIP, std::string("ensure_compact_pairs: ") + hipGetErrorString(e)); }
-    if (bad) { (void)hipFree(recs); b.compact_state = -1; return BVH_AMD_OK; }     // the PairNode kernel serves this BVH
-    b.d_cpairs = recs;
-    b.compact_state = 1;
-    return BVH_AMD_OK;
-}
-
-template int ensure_compact_pairs<float>(const BvhImpl<float>&, hipStream_t);
-template int ensure_compact_pairs<double>(const BvhImpl<double>&, hipStream_t);
 
 template <typename T>
 int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
@@ -149,7 +95,6 @@ BvhImpl<T>::~BvhImpl() {
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
         if (d_pairs) (void)hipFree(d_pairs);
-        if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_prim_ids) (void)hipFree(d_prim_ids);
         if (d_work) (void)hipFree(d_work);
         for (hipEvent_t& e : work_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -183,8 +128,6 @@ int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t st
     b.pair_count = (b.node_count - 1) / 2;
     b.max_depth = -1;
     if (b.d_pairs) { (void)hipFree(b.d_pairs); b.d_pairs = nullptr; }
-    if (b.d_cpairs) { (void)hipFree(b.d_cpairs); b.d_cpairs = nullptr; }
-    b.compact_state = 0;
     if (b.pair_count) {
         // (from the stream-ordered pool when it is on: a plain hipMalloc of the 10M-triangle scene's 0.5 GB of records costs ~2 ms;
         //  BvhImpl releases it with hipFree, which accepts pool memory)

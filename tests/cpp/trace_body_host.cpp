@@ -1,9 +1,9 @@
 // TEST INFRASTRUCTURE (CPU, no GPU): compiles the text of the batch traversal kernels — bvh_amd/csrc/trace_body.inc with the device
 // helpers of bvh_amd/csrc/trace_device.h — for the HOST and runs it with ONE emulated lane (refill and leaf thresholds 1, the
 // wave intrinsics reduced to their single-lane meaning). What it can show: the per-ray logic of the very source the device runs —
-// record addressing, the box bookkeeping of the compact variant, push / pop, the leaf loop — gives the oracle's hits and counters.
-// What it cannot show: anything that needs 64 lanes or the hardware (divergence, LDS layout across lanes, occupancy, speed).
-// tests/test_compact_pairs.py drives it. Nothing here is shipped; the product runs this body on the device only.
+// record addressing, push / pop, the leaf loop — gives the oracle's hits and counters (and, with -DBVH_HOST_WAVE64, the wave-level
+// protocol: 64 fibers switching at the wave intrinsics). What it cannot show: anything that needs the hardware (LDS layout across
+// lanes, occupancy, speed). tests/test_kernel_body_host.py drives it. Nothing here is shipped; the product runs this body on the device only.
 //
 // Built by the test with: g++ -std=c++20 -O1 -mavx2 -mfma -ffp-contract=off -fno-strict-aliasing -shared -fPIC.
 #include <algorithm>
@@ -142,48 +142,7 @@ namespace {
 
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D, bool Deep>
 void host_trace(TraceArgs<T> a) {
-#define BVH_TRACE_COMPACT 0
 #include "../../bvh_amd/csrc/trace_body.inc"
-#undef BVH_TRACE_COMPACT
-}
-
-template <bool Any, bool Robust, int Leaf, bool Stats>
-void host_trace_compact(CompactTraceArgs a) {
-    using T = float;
-    constexpr int D = 3;
-    constexpr bool Deep = false;
-#define BVH_TRACE_COMPACT 1
-#include "../../bvh_amd/csrc/trace_body.inc"
-#undef BVH_TRACE_COMPACT
-}
-
-template <bool Any, bool Robust, int Leaf, bool Stats>
-void host_trace_compact_f64(CompactTraceArgsT<double> a) {
-    using T = double;
-    constexpr int D = 3;
-    constexpr bool Deep = false;
-#define BVH_TRACE_COMPACT 1
-#include "../../bvh_amd/csrc/trace_body.inc"
-#undef BVH_TRACE_COMPACT
-}
-
-// k_compact_encode (bvh_amd/csrc/upload.hip) on the host: the record of pair p against the box its parent pair holds for it
-template <typename T>
-int encode_records(const PairNode<T>* pairs, size_t n_pairs, CompactPairT<T>* out) {
-    std::memset(static_cast<void*>(out), 0, n_pairs * sizeof(CompactPairT<T>));
-    int bad = 0;
-    for (size_t q = 0; q < n_pairs; ++q) {
-        for (int side = 0; side < 2; ++side) {
-            const uint32_t word = side ? pairs[q].ri : pairs[q].li;
-            if (word & kCountMask) continue;
-            const uint32_t p = word >> (kCountBits + 1);
-            if (p >= n_pairs) { bad |= 2; continue; }
-            CompactPairT<T> c = {};
-            if (compact_encode<T>(side ? pairs[q].rb : pairs[q].lb, pairs[p].lb, pairs[p].rb, pairs[p].li, pairs[p].ri, c)) out[p] = c;
-            else bad |= 1;
-        }
-    }
-    return bad;
 }
 
 } // namespace
@@ -217,38 +176,18 @@ int run_any(const void* pairs, uint32_t root_index, const void* prims, const voi
     else if (leaf == LEAF_SPHERE) { if (deep) run_variant<T, LEAF_SPHERE, 3, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 3, false>(a, any, robust); }
     else { if (deep) run_variant<T, LEAF_TRIANGLE, 3, true>(a, any, robust); else run_variant<T, LEAF_TRIANGLE, 3, false>(a, any, robust); }
     counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
-    return static_cast<int>(work[1]);
+    return 0;
 }
 
 } // namespace
 
 extern "C" {
 
-// compact32 == NULL: the PairNode body; otherwise the compact body. Triangles, counters on. Returns the status word (overflow flag).
-int trace_body_host(const void* pairs64, const void* compact32, uint32_t root_index, const float* tris12, const float* rays8, size_t n_rays,
+// The float / triangle / 3D body with counters on (`unused` keeps the historical signature). Returns 0.
+int trace_body_host(const void* pairs64, const void* unused, uint32_t root_index, const float* tris12, const float* rays8, size_t n_rays,
                     int any, int robust, void* hits16, unsigned long long* counters3) {
-    using namespace bvh_amd;
-    unsigned long long work[2] = {0, 0};
-    bvh_amd_counters cnt = {0, 0, 0};
-    CompactTraceArgs a;
-    a.pairs = static_cast<const PairNode<float>*>(pairs64);
-    a.prims = tris12; a.rays = rays8; a.hits = static_cast<bvh_hit3f*>(hits16);
-    a.n = n_rays; a.work = work; a.counters = &cnt; a.order = nullptr; a.deep = nullptr; a.deep_cap = 0;
-    a.root_index = root_index;
-    a.refill_threshold = kHostRefill; a.leaf_threshold = kHostLeaf;
-    a.cpairs = static_cast<const CompactPair*>(compact32);
-    const TraceArgs<float>& base = a;
-    on_all_lanes([&] {
-        if (compact32) {
-            if (any) { if (robust) host_trace_compact<true, true, LEAF_TRIANGLE, true>(a); else host_trace_compact<true, false, LEAF_TRIANGLE, true>(a); }
-            else { if (robust) host_trace_compact<false, true, LEAF_TRIANGLE, true>(a); else host_trace_compact<false, false, LEAF_TRIANGLE, true>(a); }
-        } else {
-            if (any) { if (robust) host_trace<float, true, true, LEAF_TRIANGLE, true, 3, false>(base); else host_trace<float, true, false, LEAF_TRIANGLE, true, 3, false>(base); }
-            else { if (robust) host_trace<float, false, true, LEAF_TRIANGLE, true, 3, false>(base); else host_trace<float, false, false, LEAF_TRIANGLE, true, 3, false>(base); }
-        }
-    });
-    counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
-    return static_cast<int>(work[1]);
+    (void)unused;
+    return run_any<float>(pairs64, root_index, tris12, rays8, n_rays, 3, bvh_amd::LEAF_TRIANGLE, any, robust, nullptr, 0, hits16, counters3);
 }
 
 // Every PairNode variant: is_double, dim 2 / 3, leaf 0 = triangles (12 values) / 1 = spheres (4 values; circles of 3 in 2D), deep = a
@@ -257,39 +196,6 @@ int trace_body_host_any(int is_double, const void* pairs, uint32_t root_index, c
                         int any, int robust, uint32_t* deep, uint32_t deep_cap, void* hits, unsigned long long* counters3) {
     if (is_double) return run_any<double>(pairs, root_index, prims, rays, n_rays, dim, leaf, any, robust, deep, deep_cap, hits, counters3);
     return run_any<float>(pairs, root_index, prims, rays, n_rays, dim, leaf, any, robust, deep, deep_cap, hits, counters3);
-}
-
-// Compact records for a PairNode array of either type (out: n_pairs x 32 bytes for float, x 64 bytes for double).
-int compact_encode_records(int is_double, const void* pairs, size_t n_pairs, void* out) {
-    using namespace bvh_amd;
-    if (is_double) return encode_records<double>(static_cast<const PairNode<double>*>(pairs), n_pairs, static_cast<CompactPairT<double>*>(out));
-    return encode_records<float>(static_cast<const PairNode<float>*>(pairs), n_pairs, static_cast<CompactPairT<float>*>(out));
-}
-
-// The compact body for double (3D): leaf 0 = triangles, 1 = spheres.
-int trace_body_host_compact_f64(const void* pairs128, const void* compact64, uint32_t root_index, const double* prims, const double* rays8, size_t n_rays,
-                                int leaf, int any, int robust, void* hits32, unsigned long long* counters3) {
-    using namespace bvh_amd;
-    unsigned long long work[2] = {0, 0};
-    bvh_amd_counters cnt = {0, 0, 0};
-    CompactTraceArgsT<double> a;
-    a.pairs = static_cast<const PairNode<double>*>(pairs128);
-    a.prims = prims; a.rays = rays8; a.hits = static_cast<bvh_hit3d*>(hits32);
-    a.n = n_rays; a.work = work; a.counters = &cnt; a.order = nullptr; a.deep = nullptr; a.deep_cap = 0;
-    a.root_index = root_index;
-    a.refill_threshold = kHostRefill; a.leaf_threshold = kHostLeaf;
-    a.cpairs = static_cast<const CompactPairT<double>*>(compact64);
-    on_all_lanes([&] {
-        if (leaf == LEAF_SPHERE) {
-            if (any) { if (robust) host_trace_compact_f64<true, true, LEAF_SPHERE, true>(a); else host_trace_compact_f64<true, false, LEAF_SPHERE, true>(a); }
-            else { if (robust) host_trace_compact_f64<false, true, LEAF_SPHERE, true>(a); else host_trace_compact_f64<false, false, LEAF_SPHERE, true>(a); }
-        } else {
-            if (any) { if (robust) host_trace_compact_f64<true, true, LEAF_TRIANGLE, true>(a); else host_trace_compact_f64<true, false, LEAF_TRIANGLE, true>(a); }
-            else { if (robust) host_trace_compact_f64<false, true, LEAF_TRIANGLE, true>(a); else host_trace_compact_f64<false, false, LEAF_TRIANGLE, true>(a); }
-        }
-    });
-    counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
-    return static_cast<int>(work[1]);
 }
 
 } // extern "C"

@@ -3,8 +3,7 @@ tests/cpp/trace_body_host.cpp, against the golden vectors of the unmodified refe
 triangles / spheres, 3D / 2D circles, closest / any, robust / fast, and the deep-stack (GrowingStack) variant on a 300-level
 chain — run with one emulated lane and, for a subset, as a full 64-lane wavefront (fibers switching at the wave intrinsics, real
 thresholds). It shows that the logic of the source the device runs reproduces the reference's hits and counters; it cannot show
-anything that needs the hardware (that is what the -m gpu tests are for).
-The compact variant of the same body is covered by tests/test_compact_pairs.py."""
+anything that needs the hardware (that is what the -m gpu tests are for)."""
 import ctypes as C
 import os
 import subprocess
@@ -14,15 +13,6 @@ import pytest
 
 import oracle
 from conftest import ROOT, load_golden, parse_stream
-
-
-def _compact_signatures(dll):
-    dll.trace_body_host.restype = C.c_int
-    dll.trace_body_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    dll.compact_encode_records.restype = C.c_int
-    dll.compact_encode_records.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
-    dll.trace_body_host_compact_f64.restype = C.c_int
-    dll.trace_body_host_compact_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +27,6 @@ def body(tmp_path_factory):
     dll.trace_body_host_any.restype = C.c_int
     dll.trace_body_host_any.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-    _compact_signatures(dll)
     return dll
 
 
@@ -54,7 +43,6 @@ def body64(tmp_path_factory):
     dll.trace_body_host_any.restype = C.c_int
     dll.trace_body_host_any.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-    _compact_signatures(dll)
     return dll
 
 
@@ -209,36 +197,3 @@ def test_body_full_wavefront_equals_golden(body64, orc, scene, mode):
 
 def test_body_full_wavefront_deep_stack(body64, orc):
     test_body_deep_stack(body64, orc, 70)
-
-
-def run_compact_f64(body, bounds6, index, prims, rays, leaf, any_hit, robust):
-    pairs = _aligned(pair_records(bounds6, index))
-    n_pairs = (len(index) - 1) // 2
-    recs = _aligned(np.zeros((max(n_pairs, 1), 16), dtype=np.uint32))             # 64-byte CompactPairT<double>
-    assert body.compact_encode_records(1, _ptr(pairs), n_pairs, _ptr(recs)) == 0
-    prims = _aligned(np.ascontiguousarray(prims))
-    rays = _aligned(np.ascontiguousarray(rays))
-    hits = _aligned(np.zeros(len(rays), dtype=oracle.HITD))
-    cnt = np.zeros(3, dtype=np.uint64)
-    status = body.trace_body_host_compact_f64(_ptr(pairs), _ptr(recs), int(index[0]) & 0xFFFFFFFF, _ptr(prims), _ptr(rays), len(rays), leaf,
-                                              int(any_hit), int(robust), _ptr(hits), _ptr(cnt))
-    assert status == 0
-    return hits, cnt
-
-
-@pytest.mark.parametrize("scene", ["soup2k_f64", "spheres2k_f64"])
-@pytest.mark.parametrize("mode", ["serial_low", "parallel_high"])
-def test_compact_body_f64_equals_golden(body, body64, orc, scene, mode):
-    """The compact variant for double (EXPERIMENTAL; 64-byte records against PairNode<double>'s 128): one lane for every mode,
-    a full wavefront for one closest-hit and one any-hit mode."""
-    g = load_golden(scene)
-    nodes, ids = parse_stream(g[f"bvh_{mode}"].tobytes(), True)
-    sphere = "spheres" in scene
-    prims = g["prims"][ids.astype(np.int64)] if sphere else orc.precompute_tris(g["prims"], ids)
-    for any_hit, robust in MODES4:
-        key = f"{mode}_{'any' if any_hit else 'closest'}_{'robust' if robust else 'fast'}"
-        rays = g["rays_shadow"] if any_hit else g["rays_closest"]
-        for b in ([body, body64] if any_hit != robust else [body]):
-            hits, cnt = run_compact_f64(b, nodes["bounds"], nodes["index"], prims, rays, 1 if sphere else 0, any_hit, robust)
-            assert hits.tobytes() == g[f"hits_{key}"].tobytes(), key
-            assert (cnt == g[f"counters_{key}"]).all(), key
