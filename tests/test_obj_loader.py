@@ -1,0 +1,68 @@
+"""CPU: bvh_amd/obj.py follows the reference's OBJ loader (test/load_obj.cpp:57-96) — fan triangulation, 1-based and negative
+indices, `i/t/n` forms, comments, `vt` / `vn` records ignored — and tools/kernel_isa.py hashes the bench kernel of the built library."""
+import os
+
+import numpy as np
+import pytest
+
+from bvh_amd import obj
+from conftest import ROOT, load_golden
+
+
+def test_obj_semantics(tmp_path):
+    text = """# a comment
+v 0 0 0
+v 1 0 0
+v 1 1 0
+vt 0.5 0.5
+vn 0 0 1
+v 0 1 0.25
+v 2 2 2
+
+f 1 2 3 4
+f -4/1/1 -3//1 -2/2
+f 1/1 3/1 5/1 4 2
+g ignored
+f 1 2
+"""
+    p = tmp_path / "m.obj"
+    p.write_text(text)
+    t = obj.load_obj(str(p))
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0.25], [2, 2, 2]], dtype=np.float32)
+    want = []
+    for face in ([0, 1, 2, 3], [1, 2, 3], [0, 2, 4, 3, 1]):                       # (-4 .. -2 count back from the five vertices read)
+        for i in range(2, len(face)):
+            want.append(np.concatenate([v[face[0]], v[face[i - 1]], v[face[i]]]))
+    assert t.dtype == np.float32 and t.shape == (len(want), 9)
+    assert t.tobytes() == np.asarray(want, dtype=np.float32).tobytes()            # "f 1 2" has no third vertex: no triangle
+
+
+def test_obj_round_trip_and_reference_cornell_box(tmp_path):
+    rng = np.random.default_rng(3)
+    tris = rng.standard_normal((500, 9)).astype(np.float32) * np.float32(123.456)
+    p = tmp_path / "r.obj"
+    obj.save_obj(str(p), tris)
+    assert obj.load_obj(str(p)).tobytes() == tris.tobytes()                       # %.9g round-trips float32 through strtof
+    ref = "/root/reference/test/cornell_box.obj"
+    if os.path.exists(ref):                                                       # the authoring container: the golden fixture's triangles
+        assert obj.load_obj(ref).tobytes() == load_golden("cornell")["prims"].tobytes()
+    assert obj.load_obj(str(tmp_path / "missing.obj") if False else str(p)).shape[1] == 9
+    empty = tmp_path / "e.obj"
+    empty.write_text("v 0 0 0\n")
+    assert obj.load_obj(str(empty)).shape == (0, 9)
+
+
+def test_kernel_isa_hash_of_the_built_library():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_isa import kernel_isa_hash
+    from bvh_amd import _lib, build
+    build.build()
+    h = kernel_isa_hash(_lib.LIB_PATH, "trace_kernel<float, false, true, 0, false, 3, false>")
+    assert h is not None and len(h) == 40
+    assert h == kernel_isa_hash(_lib.LIB_PATH, "trace_kernel<float, false, true, 0, false, 3, false>")
+    assert kernel_isa_hash(_lib.LIB_PATH, "no_such_kernel<int>") is None
+    import json
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    key = "soup_1m|high|pool|robust|16777216"
+    assert rec[key]["isa_sha1"] == h, "profiles/pmc_traffic.json was traced on another build of the bench kernel: re-run tools/pmc_traffic.py"
