@@ -326,11 +326,9 @@ __global__ void __launch_bounds__(64) k_extract(ExtractArgs<T> a, int pass) {
     if (r == 0) {                                             // the whole mini-tree moves (:239-240)
         n_nodes = a.tree_off[t + 1] - a.tree_off[t];
         n_prims = a.group_begin[t + 1] - gb;
-        if (pass) {
-            root_rec = rebased(tree[0], static_cast<uint32_t>(tree[0].index >> kCountBits));
-            for (uint32_t j = 1; j < n_nodes; ++j) a.out_nodes[node_base + j] = rebased(tree[j], static_cast<uint32_t>(tree[j].index >> kCountBits));
-            for (uint32_t p = 0; p < n_prims; ++p) a.out_ids[prim_base + p] = a.ids[gb + p];
-        }
+        // (the nodes and ids of a whole tree are copied by k_extract_whole, one block per cut: a tree of 12 k primitives
+        //  copied by this one lane was 3.5 ms of the 10M-triangle Low build)
+        if (pass) root_rec = rebased(tree[0], static_cast<uint32_t>(tree[0].index >> kCountBits));
     } else {
         uint2 stack[kWalkStack];
         int sp = 0;
@@ -367,6 +365,27 @@ __global__ void __launch_bounds__(64) k_extract(ExtractArgs<T> a, int pass) {
         a.top_boxes[6ull * i + 3 + k] = hi;
         a.top_centers[3ull * i + k] = (hi + lo) * T(0.5);    // bbox.h:30
     }
+}
+
+// the copy of a cut that is a whole mini-tree (r == 0, :239-240 + copy_node :275-279), one block per cut
+template <typename T>
+__global__ void __launch_bounds__(256) k_extract_whole(ExtractArgs<T> a) {
+    using I = typename IndexOf<T>::Type;
+    const uint32_t i = blockIdx.x;
+    const uint2 cut = a.cuts[i];
+    if (cut.y != 0) return;
+    const uint32_t t = cut.x;
+    const HostNode<T>* tree = a.trees + a.tree_off[t];
+    const uint32_t gb = a.group_begin[t];
+    const uint32_t node_base = a.top_nodes - 1 + a.node_off[i], prim_base = a.prim_off[i];
+    const uint32_t n_nodes = a.tree_off[t + 1] - a.tree_off[t], n_prims = a.group_begin[t + 1] - gb;
+    for (uint32_t j = 1 + threadIdx.x; j < n_nodes; j += 256) {
+        HostNode<T> nd = tree[j];
+        const uint32_t cnt = static_cast<uint32_t>(nd.index & kCountMask), first = static_cast<uint32_t>(nd.index >> kCountBits);
+        nd.index = cnt ? ((static_cast<I>(prim_base + first) << kCountBits) | cnt) : (static_cast<I>(node_base + first) << kCountBits);
+        a.out_nodes[node_base + j] = nd;
+    }
+    for (uint32_t p = threadIdx.x; p < n_prims; p += 256) a.out_ids[prim_base + p] = a.ids[gb + p];
 }
 
 // top nodes into the final array; top leaves become the cut roots (:282-288)
@@ -480,6 +499,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     BVH_HIP_TRY(final_nodes.alloc(total_nodes), BVH_AMD_ERR_HIP);
     ea.out_nodes = final_nodes.p;
     hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 1);
+    hipLaunchKernelGGL(k_extract_whole<T>, dim3(n_cuts), dim3(256), 0, stream, ea);
     BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
     if (hs.error) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree deeper than the pruning walk stack");
