@@ -765,8 +765,7 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
         hipLaunchKernelGGL(k_child_bounds<T>, dim3(n_tasks), dim3(256), 0, stream, c);
         hipLaunchKernelGGL(k_finalize<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipMemcpyAsync(&h, c.counters, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        { int rb_ = readback(&h, c.counters, sizeof(h), stream); if (rb_) return rb_; }
         overflow = h.error != 0;
         level_start.push_back(h.n_nodes);
         n_active = h.n_active_next;
@@ -864,8 +863,7 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
         hipLaunchKernelGGL(k_init_root<T>, dim3(root_grid), dim3(256), 0, stream, c, true);
         hipLaunchKernelGGL(k_make_root<T>, dim3(1), dim3(1), 0, stream, c);
         Counters h;
-        BVH_HIP_TRY(hipMemcpyAsync(&h, c.counters, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        { int rb_ = readback(&h, c.counters, sizeof(h), stream); if (rb_) return rb_; }
         std::vector<uint32_t> level_start{0, 1};              // A-node id ranges per level
         bool overflow = false;
         rc = run_binned_phases(c, h, level_start, overflow, stream);
@@ -907,8 +905,7 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
         hipLaunchKernelGGL(k_forest_prepare<T>, dim3(1), dim3(1), 0, stream, c, n_groups);
         hipLaunchKernelGGL(k_forest_roots<T>, dim3(n_groups), dim3(256), 0, stream, c, d_group_begin);
         Counters h;
-        BVH_HIP_TRY(hipMemcpyAsync(&h, c.counters, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        { int rb_ = readback(&h, c.counters, sizeof(h), stream); if (rb_) return rb_; }
         std::vector<uint32_t> level_start{0, n_groups};
         bool overflow = false;
         rc = run_binned_phases(c, h, level_start, overflow, stream);
@@ -921,8 +918,7 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
         if (rc) return rc;
         BVH_HIP_TRY(tree_node_off.alloc(n_groups + 1), BVH_AMD_ERR_HIP);
         hipLaunchKernelGGL(k_forest_offsets<T>, dim3(1), dim3(1024), 0, stream, c, n_groups, tree_node_off.p);
-        BVH_HIP_TRY(hipMemcpyAsync(&total_nodes, tree_node_off.p + n_groups, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        { int rb_ = readback(&total_nodes, tree_node_off.p + n_groups, sizeof(uint32_t), stream); if (rb_) return rb_; }
         BVH_HIP_TRY(trees.alloc(total_nodes), BVH_AMD_ERR_HIP);
         c.tree_node_off = tree_node_off.p;
         c.tree_begin = d_group_begin;

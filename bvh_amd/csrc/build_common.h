@@ -549,8 +549,7 @@ int number_and_emit(BvhImpl<T>& out, const BuildCtx<T>& c, const std::vector<uin
     int rc = number_nodes<T>(c, level_start, stream);
     if (rc) return rc;
     ANode<T> root;
-    BVH_HIP_TRY(hipMemcpyAsync(&root, c.nodes, sizeof(root), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    { int rb_ = readback(&root, c.nodes, sizeof(root), stream); if (rb_) return rb_; }
     const size_t total_nodes = 2 * size_t{root.ic} + 1;
     BVH_HIP_TRY(final_nodes.alloc(total_nodes), BVH_AMD_ERR_HIP);
     hipLaunchKernelGGL(k_emit_tree<T>, dim3((n_nodes_a + 255) / 256), dim3(256), 0, stream, c, n_nodes_a, final_nodes.p);
@@ -579,8 +578,7 @@ int finish_build(BvhImpl<T>& out, DevBuf<HostNode<T>>& final_nodes, uint32_t* d_
         BVH_HIP_TRY(hipMemcpyAsync(out.d_prim_ids, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
     }
     HostNode<T> root;
-    BVH_HIP_TRY(hipMemcpyAsync(&root, final_nodes.p, sizeof(root), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    { int rb_ = readback(&root, final_nodes.p, sizeof(root), stream); if (rb_) return rb_; }
     if (out.d_nodes) (void)hipFree(out.d_nodes);
     out.d_nodes = final_nodes.p;
     out.d_nodes_count = out.node_count;

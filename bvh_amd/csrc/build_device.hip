@@ -1,7 +1,9 @@
 // Dispatch of DefaultBuilder's modes (reference default_builder.h:33-62) onto the device builders.
 #include "common.h"
 
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
 
 namespace bvh_amd {
 
@@ -47,6 +49,67 @@ hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t* stream_used, bool*
 void scratch_free(void* p, hipStream_t stream, bool pooled) {
     if (!p) return;
     if (pooled) (void)hipFreeAsync(p, stream); else (void)hipFree(p);
+}
+
+namespace {
+
+constexpr size_t kReadbackWords = 64;
+
+__global__ void __launch_bounds__(64) k_readback(const uint32_t* src, uint32_t words, uint32_t* host, uint32_t seq) {
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 0; w < words; ++w) host[1 + w] = src[w];
+        // the payload before the sequence number, both visible to the polling host while the kernel is still retiring
+        __hip_atomic_store(&host[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+struct ReadbackSlot {                          // one per calling thread and device
+    int device = -1;
+    uint32_t* pinned = nullptr;
+    uint32_t seq = 0;
+    bool broken = false;
+    ~ReadbackSlot() { if (pinned) (void)hipHostFree(pinned); }
+};
+
+} // namespace
+
+int readback(void* dst, const void* d_src, size_t bytes, hipStream_t stream) {
+    static const bool blocking = std::getenv("BVH_AMD_READBACK") && std::strcmp(std::getenv("BVH_AMD_READBACK"), "sync") == 0;
+    static thread_local ReadbackSlot slot;
+    int dev = -1;
+    BVH_HIP_TRY(hipGetDevice(&dev), BVH_AMD_ERR_HIP);
+    const bool fits = bytes % 4 == 0 && bytes / 4 <= kReadbackWords && reinterpret_cast<uintptr_t>(d_src) % 4 == 0;
+    if (!blocking && fits && !slot.broken) {
+        if (slot.device != dev) {
+            if (slot.pinned) { (void)hipHostFree(slot.pinned); slot.pinned = nullptr; }
+            if (hipHostMalloc(reinterpret_cast<void**>(&slot.pinned), (kReadbackWords + 1) * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess) {
+                (void)hipGetLastError();
+                slot.broken = true;
+            } else {
+                slot.pinned[0] = 0; slot.seq = 0; slot.device = dev;
+            }
+        }
+        if (!slot.broken) {
+            const uint32_t seq = ++slot.seq ? slot.seq : ++slot.seq;          // never 0
+            hipLaunchKernelGGL(k_readback, dim3(1), dim3(64), 0, stream, static_cast<const uint32_t*>(d_src), static_cast<uint32_t>(bytes / 4), slot.pinned, seq);
+            BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+            const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            bool arrived = false;
+            for (uint32_t spin = 0;; ++spin) {
+                if (__atomic_load_n(&slot.pinned[0], __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+                if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() > give_up) break;
+            }
+            if (!arrived) {                                   // long-running work ahead of us on the stream: block like everybody else
+                BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+                if (__atomic_load_n(&slot.pinned[0], __ATOMIC_ACQUIRE) != seq) return fail(BVH_AMD_ERR_HIP, "readback: the copy kernel did not run");
+            }
+            std::memcpy(dst, slot.pinned + 1, bytes);
+            return BVH_AMD_OK;
+        }
+    }
+    BVH_HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    return BVH_AMD_OK;
 }
 
 template <typename T>

@@ -441,8 +441,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     int rc = radix_sort_pairs<uint32_t>(keys.p, ids.p, keys_tmp.p, vals_tmp.p, n32, 1, key_bits, stream);   // stable: ids ascending per group (:124)
     if (rc) return rc;
     MtScalars hs;
-    BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    { int rb_ = readback(&hs, scalars.p, sizeof(hs), stream); if (rb_) return rb_; }
     const uint32_t n_trees = hs.n_groups;
 
     DevBuf<HostNode<T>> trees;
@@ -500,8 +499,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     ea.out_nodes = final_nodes.p;
     hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 1);
     hipLaunchKernelGGL(k_extract_whole<T>, dim3(n_cuts), dim3(256), 0, stream, ea);
-    BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    { int rb_ = readback(&hs, scalars.p, sizeof(hs), stream); if (rb_) return rb_; }
     if (hs.error) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree deeper than the pruning walk stack");
 
     // ---- build_top_bvh: sweep SAH with one cut root per leaf, then the splice

@@ -724,8 +724,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         hipLaunchKernelGGL(k_init_root<T>, dim3(root_grid), dim3(256), 0, stream, c, false);
         hipLaunchKernelGGL(k_make_root<T>, dim3(1), dim3(1), 0, stream, c);
         Counters h;
-        BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        { int rb_ = readback(&h, counters.p, sizeof(h), stream); if (rb_) return rb_; }
 
         std::vector<uint32_t> level_start{0, 1};
         uint32_t n_active = h.n_active_next, n_tasks = h.n_tasks_next;
@@ -745,8 +744,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
             hipLaunchKernelGGL(k_child_bounds<T>, dim3(n_tasks), dim3(256), 0, stream, c);
             hipLaunchKernelGGL(k_finalize<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
             BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-            BVH_HIP_TRY(hipMemcpyAsync(&h, counters.p, sizeof(h), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-            BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+            { int rb_ = readback(&h, counters.p, sizeof(h), stream); if (rb_) return rb_; }
             overflow = h.error != 0;
             level_start.push_back(h.n_nodes);
             n_active = h.n_active_next;

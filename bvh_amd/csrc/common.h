@@ -160,6 +160,13 @@ bool scratch_pool_enabled();                   // build_device.hip: configures t
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t* stream_used, bool* pooled);
 void scratch_free(void* p, hipStream_t stream, bool pooled);
 
+// A few bytes (<= 256, 4-byte aligned) from device memory to the host, in stream order, WITHOUT a stream synchronisation: a
+// one-lane kernel copies them into coherent pinned host memory and publishes a sequence number, the host spins on it (falls back to
+// hipMemcpyAsync + hipStreamSynchronize after a timeout or when pinned memory is unavailable). When it returns, everything queued on
+// the stream before it has run. The builders size their next launch ~20 times per build from such a read; a blocking
+// synchronisation costs 30-60 us of idle GPU each time, the poll a fraction of that. BVH_AMD_READBACK=sync restores the blocking form.
+int readback(void* dst, const void* d_src, size_t bytes, hipStream_t stream);     // build_device.hip
+
 // upload.hip
 template <typename T> int upload_bvh(BvhImpl<T>& b, hipStream_t stream);
 template <typename T> int tree_depth(const BvhImpl<T>& b, hipStream_t stream);   // fills b.max_depth (cached)

@@ -288,8 +288,7 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* 
     int rc = scan_u32_async(in, out, n, total_host ? d_total.p : nullptr, stream);
     if (rc) return rc;
     if (total_host) {
-        BVH_HIP_TRY(hipMemcpyAsync(total_host, d_total.p, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        { int rb_ = readback(total_host, d_total.p, 4, stream); if (rb_) return rb_; }
     }
     return BVH_AMD_OK;
 }
@@ -366,8 +365,7 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
             hipLaunchKernelGGL(k_sort_partition<T>, dim3(r == 0 ? batch : grid), dim3(kSortThreads), 0, stream, c, r, batch);
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
         uint32_t err = 0;
-        BVH_HIP_TRY(hipMemcpyAsync(&err, &counters.p->error, sizeof(err), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        { int rb_ = readback(&err, &counters.p->error, sizeof(err), stream); if (rb_) return rb_; }
         if (err) return fail(BVH_AMD_ERR_OVERFLOW, "std_sort_ids: segment capacity exceeded");
     }
     // __final_insertion_sort == stable sort by key of the current arrangement
