@@ -925,7 +925,7 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
         hipLaunchKernelGGL(k_emit_tree<T>, dim3((h.n_nodes + 255) / 256), dim3(256), 0, stream, c, h.n_nodes, trees.p);
         if (h.n_small) hipLaunchKernelGGL(k_emit_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, stream, c, h.n_small, trees.p);
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // workspace dies here
+        if (!scratch_pool_enabled()) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // plain hipFree of the workspace on return (the pool frees in stream order)
         return BVH_AMD_OK;
     }
     return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");

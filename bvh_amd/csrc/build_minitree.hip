@@ -250,13 +250,26 @@ template <typename T> __device__ inline T node_half_area(const HostNode<T>& nd) 
 }
 template <typename T> __device__ inline bool node_is_leaf(const HostNode<T>& nd) { return (nd.index & kCountMask) != 0; }
 
-// avg_area summed in tree order (:209-213)
+// avg_area summed in tree order (:209-213): the SUM is serial (its rounding depends on the order), the loads are not — the block
+// fetches the root areas of 1024 trees at a time into LDS, one lane adds them in order (0.29 ms -> ~0.02 ms for 724 trees)
 template <typename T>
-__global__ void k_prune_threshold(const HostNode<T>* trees, const uint32_t* tree_off, uint32_t n_trees, T ratio, T* threshold) {
+__global__ void __launch_bounds__(1024) k_prune_threshold(const HostNode<T>* trees, const uint32_t* tree_off, uint32_t n_trees, T ratio, T* threshold) {
+    __shared__ T area[1024];
     T avg = T(0);
-    for (uint32_t t = 0; t < n_trees; ++t) avg += node_half_area(trees[tree_off[t]]);
-    avg /= static_cast<T>(n_trees);
-    *threshold = avg * ratio;
+    for (uint32_t base = 0; base < n_trees; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        if (t < n_trees) area[threadIdx.x] = node_half_area(trees[tree_off[t]]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t m = min(1024u, n_trees - base);
+            for (uint32_t q = 0; q < m; ++q) avg += area[q];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        avg /= static_cast<T>(n_trees);
+        *threshold = avg * ratio;
+    }
 }
 
 // The cut DFS (:216-232): pass 0 counts the cuts of each tree, pass 1 writes them at cut_off[tree].
@@ -459,7 +472,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
         BVH_HIP_TRY(threshold.alloc(1), BVH_AMD_ERR_HIP);
         BVH_HIP_TRY(cut_count.alloc(n_trees), BVH_AMD_ERR_HIP);
         BVH_HIP_TRY(cut_off.alloc(n_trees), BVH_AMD_ERR_HIP);
-        hipLaunchKernelGGL(k_prune_threshold<T>, dim3(1), dim3(1), 0, stream, trees.p, tree_off.p, n_trees, prune_ratio, threshold.p);
+        hipLaunchKernelGGL(k_prune_threshold<T>, dim3(1), dim3(1024), 0, stream, trees.p, tree_off.p, n_trees, prune_ratio, threshold.p);
         const unsigned tg = (n_trees + 63) / 64;
         hipLaunchKernelGGL(k_prune_walk<T>, dim3(tg), dim3(64), 0, stream, trees.p, tree_off.p, n_trees, threshold.p, 0, cut_count.p,
                            static_cast<const uint32_t*>(nullptr), static_cast<uint2*>(nullptr), scalars.p);
@@ -468,7 +481,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
         BVH_HIP_TRY(cuts.alloc(n_cuts), BVH_AMD_ERR_HIP);
         hipLaunchKernelGGL(k_prune_walk<T>, dim3(tg), dim3(64), 0, stream, trees.p, tree_off.p, n_trees, threshold.p, 1, cut_count.p,
                            cut_off.p, cuts.p, scalars.p);
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        if (!scratch_pool_enabled()) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // plain hipFree of the workspace on return (the pool frees in stream order)
     } else {
         BVH_HIP_TRY(cuts.alloc(n_cuts), BVH_AMD_ERR_HIP);
         hipLaunchKernelGGL(k_whole_trees_as_cuts, dim3((n_trees + 255) / 256), dim3(256), 0, stream, n_trees, cuts.p);
@@ -512,7 +525,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     hipLaunchKernelGGL(k_splice_top<T>, dim3((ea.top_nodes + 255) / 256), dim3(256), 0, stream, top.p, top_ord.p, ea.top_nodes, cut_roots.p,
                        final_nodes.p);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    if (!scratch_pool_enabled()) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // plain hipFree of the workspace on return (the pool frees in stream order)
     return BVH_AMD_OK;
 }
 

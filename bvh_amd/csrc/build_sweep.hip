@@ -764,7 +764,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         rc = number_and_emit<T>(sizes, c, level_start, n_nodes_a, n_small, final_nodes, stream);
         if (rc) return rc;
         total_nodes = sizes.node_count;
-        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // workspace dies here
+        if (!scratch_pool_enabled()) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // plain hipFree of the workspace on return (the pool frees in stream order)
         return BVH_AMD_OK;
     }
     return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
