@@ -339,16 +339,18 @@ __global__ void __launch_bounds__(256) k_emit_small(BuildCtx<T> c, uint32_t n_sm
 // released with hipFree, which accepts pool memory.
 template <typename T> struct DevBuf {
     T* p = nullptr;
-    hipStream_t stream = nullptr;
-    bool pooled = false;
+    ScratchTag tag;
+    bool pooled = false;                       // mirrors tag.pooled (read by the callers that must synchronise before a plain hipFree)
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { scratch_free(p, stream, pooled); }
+    ~DevBuf() { scratch_free(p, tag); }
     hipError_t alloc(size_t count) {
-        scratch_free(p, stream, pooled);
+        scratch_free(p, tag);
         p = nullptr;
-        return scratch_alloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T), &stream, &pooled);
+        const hipError_t e = scratch_alloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T), &tag);
+        pooled = tag.pooled;
+        return e;
     }
 };
 

@@ -1,9 +1,13 @@
 // Dispatch of DefaultBuilder's modes (reference default_builder.h:33-62) onto the device builders.
 #include "common.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace bvh_amd {
 
@@ -40,15 +44,88 @@ bool scratch_pool_enabled() {
     return usable[dev];
 }
 
-hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t* stream_used, bool* pooled) {
-    *pooled = scratch_pool_enabled();
-    *stream_used = ambient_stream();
-    return *pooled ? hipMallocAsync(p, bytes, *stream_used) : hipMalloc(p, bytes);
+namespace {
+
+// Freed scratch blocks by (device, stream), each list ordered by capacity; `clock` orders evictions (oldest first).
+struct CachedBlock { void* p; uint64_t age; };
+struct ScratchCache {
+    std::mutex m;
+    std::map<std::pair<int, hipStream_t>, std::multimap<size_t, CachedBlock>> lists;
+    size_t cached_bytes[64] = {};
+    uint64_t clock = 0;
+    size_t limit = size_t{8192} << 20;
+    ScratchCache() {
+        if (const char* e = std::getenv("BVH_AMD_CACHE_MB")) limit = static_cast<size_t>(std::max(0ll, std::atoll(e))) << 20;
+    }
+};
+ScratchCache& scratch_cache() { static ScratchCache* c = new ScratchCache; return *c; }      // outlives the runtime's own teardown
+
+} // namespace
+
+hipError_t scratch_alloc(void** p, size_t bytes, ScratchTag* tag) {
+    tag->pooled = scratch_pool_enabled();
+    tag->stream = ambient_stream();
+    tag->capacity = bytes;
+    if (!tag->pooled) return hipMalloc(p, bytes);
+    ScratchCache& c = scratch_cache();
+    int dev = 0;
+    if (c.limit && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lock(c.m);
+        auto l = c.lists.find({ dev, tag->stream });
+        if (l != c.lists.end()) {
+            auto it = l->second.lower_bound(bytes);
+            if (it != l->second.end() && it->first <= bytes + bytes / 4 + 4096) {       // near fit only: a big block must not serve small requests
+                *p = it->second.p;
+                tag->capacity = it->first;
+                c.cached_bytes[dev] -= it->first;
+                l->second.erase(it);
+                return hipSuccess;
+            }
+        }
+    }
+    return hipMallocAsync(p, bytes, tag->stream);
 }
 
-void scratch_free(void* p, hipStream_t stream, bool pooled) {
+void scratch_free(void* p, const ScratchTag& tag) {
     if (!p) return;
-    if (pooled) (void)hipFreeAsync(p, stream); else (void)hipFree(p);
+    if (!tag.pooled) { (void)hipFree(p); return; }
+    ScratchCache& c = scratch_cache();
+    int dev = 0;
+    if (c.limit && tag.capacity <= c.limit && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lock(c.m);
+        c.lists[{ dev, tag.stream }].emplace(tag.capacity, CachedBlock{ p, ++c.clock });
+        c.cached_bytes[dev] += tag.capacity;
+        while (c.cached_bytes[dev] > c.limit) {              // over the bound: the oldest block of this device goes back to the pool
+            std::multimap<size_t, CachedBlock>* from = nullptr;
+            std::multimap<size_t, CachedBlock>::iterator oldest;
+            hipStream_t on = nullptr;
+            for (auto& l : c.lists) {
+                if (l.first.first != dev) continue;
+                for (auto it = l.second.begin(); it != l.second.end(); ++it)
+                    if (!from || it->second.age < oldest->second.age) { from = &l.second; oldest = it; on = l.first.second; }
+            }
+            if (!from) break;
+            if (hipFreeAsync(oldest->second.p, on) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(oldest->second.p); }   // (a stream destroyed since)
+            c.cached_bytes[dev] -= oldest->first;
+            from->erase(oldest);
+        }
+        return;
+    }
+    (void)hipFreeAsync(p, tag.stream);
+}
+
+void scratch_cache_flush() {
+    ScratchCache& c = scratch_cache();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(c.m);
+    for (auto l = c.lists.begin(); l != c.lists.end();) {
+        if (l->first.first != dev) { ++l; continue; }
+        for (auto& b : l->second)
+            if (hipFreeAsync(b.second.p, l->first.second) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(b.second.p); }
+        l = c.lists.erase(l);
+    }
+    if (dev >= 0 && dev < 64) c.cached_bytes[dev] = 0;
 }
 
 namespace {

@@ -496,6 +496,7 @@ void bvh_amd_reinsertion_stats(unsigned out[2]) { if (out) reinsertion_stats(out
 int bvh_amd_release_cached_memory(void) {
     int dev = 0;
     BVH_HIP_TRY(hipGetDevice(&dev), BVH_AMD_ERR_HIP);
+    scratch_cache_flush();
     BVH_HIP_TRY(hipDeviceSynchronize(), BVH_AMD_ERR_HIP);
     hipMemPool_t pool = nullptr;
     if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return BVH_AMD_OK; }

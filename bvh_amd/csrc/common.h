@@ -157,8 +157,20 @@ struct StreamScope {
     StreamScope& operator=(const StreamScope&) = delete;
 };
 bool scratch_pool_enabled();                   // build_device.hip: configures the current device's default pool on first use
-hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t* stream_used, bool* pooled);
-void scratch_free(void* p, hipStream_t stream, bool pooled);
+// On top of the pool sits a small block cache (build_device.hip): hipMallocAsync / hipFreeAsync still cost ~5 / ~13 us of host
+// time per call (measured, tools/src/alloc_bench.hip), ~1 ms over the ~60 scratch buffers of a build, so a freed block is kept
+// per (device, stream) and handed to the next request of about the same size ON THE SAME STREAM (stream order makes that safe
+// without any synchronisation, exactly like the pool's own reuse). A block whose pointer is taken over by a BvhImpl simply never
+// comes back to the cache; the BvhImpl releases it with hipFree, which accepts pool memory. BVH_AMD_CACHE_MB bounds the cached
+// bytes per device (default 8192; 0 turns the cache off).
+struct ScratchTag {                            // what scratch_free needs to know about a block
+    hipStream_t stream = nullptr;
+    size_t capacity = 0;                       // bytes actually behind the pointer (>= the request)
+    bool pooled = false;
+};
+hipError_t scratch_alloc(void** p, size_t bytes, ScratchTag* tag);
+void scratch_free(void* p, const ScratchTag& tag);
+void scratch_cache_flush();                    // hands every cached block of the current device back to the pool (hipFreeAsync)
 
 // A few bytes (<= 256, 4-byte aligned) from device memory to the host, in stream order, WITHOUT a stream synchronisation: a
 // one-lane kernel copies them into coherent pinned host memory and publishes a sequence number, the host spins on it (falls back to

@@ -304,28 +304,27 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
     if (n == 0 || batch == 0) return BVH_AMD_OK;
     StreamScope scratch_on(stream);
     const uint32_t bpa = (n + kRadixTile - 1) / kRadixTile;
-    DevBuf<uint32_t> hist;
-    if (hist_buf) hist.p = hist_buf;                          // caller-owned scratch: fully asynchronous
-    else BVH_HIP_TRY(hist.alloc(size_t{batch} * 256 * bpa), BVH_AMD_ERR_HIP);
+    DevBuf<uint32_t> own;
+    if (!hist_buf) BVH_HIP_TRY(own.alloc(size_t{batch} * 256 * bpa), BVH_AMD_ERR_HIP);
+    uint32_t* const hist = hist_buf ? hist_buf : own.p;       // caller-owned scratch: fully asynchronous
     K* kin = keys; K* kout = keys_tmp; uint32_t* vin = vals; uint32_t* vout = vals_tmp;
     int passes = (bits + 7) / 8;
     if (passes & 1) ++passes;                             // even number of passes: the result lands in keys/vals
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, n, bpa, shift, hist.p);
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, n, bpa, shift, hist);
         if (256 * bpa > 16384) {                              // long histograms: the multi-block scan (one block per array crawls: 1 ms at 10M keys)
             for (uint32_t a = 0; a < batch; ++a) {
-                int rc = scan_u32_async(hist.p + size_t{a} * 256 * bpa, hist.p + size_t{a} * 256 * bpa, 256 * bpa, nullptr, stream);
+                int rc = scan_u32_async(hist + size_t{a} * 256 * bpa, hist + size_t{a} * 256 * bpa, 256 * bpa, nullptr, stream);
                 if (rc) return rc;
             }
-        } else hipLaunchKernelGGL(k_radix_scan, dim3(batch), dim3(1024), 0, stream, hist.p, 256 * bpa);
-        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, vin, kout, vout, n, bpa, shift, hist.p);
+        } else hipLaunchKernelGGL(k_radix_scan, dim3(batch), dim3(1024), 0, stream, hist, 256 * bpa);
+        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, vin, kout, vout, n, bpa, shift, hist);
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-    if (hist_buf) { hist.p = nullptr; return BVH_AMD_OK; }
-    if (!hist.pooled) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // hist is freed on return (the pool frees in stream order)
+    if (!hist_buf && !own.pooled) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // hist is freed on return (the pool frees in stream order)
     return BVH_AMD_OK;
 }
 

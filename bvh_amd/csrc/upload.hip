@@ -132,8 +132,8 @@ int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t st
         // (from the stream-ordered pool when it is on: a plain hipMalloc of the 10M-triangle scene's 0.5 GB of records costs ~2 ms;
         //  BvhImpl releases it with hipFree, which accepts pool memory)
         StreamScope scratch_on(stream);
-        hipStream_t used = nullptr; bool pooled = false;
-        BVH_HIP_TRY(scratch_alloc(reinterpret_cast<void**>(&b.d_pairs), b.pair_count * sizeof(PairNode<T>), &used, &pooled), BVH_AMD_ERR_HIP);
+        ScratchTag tag;
+        BVH_HIP_TRY(scratch_alloc(reinterpret_cast<void**>(&b.d_pairs), b.pair_count * sizeof(PairNode<T>), &tag), BVH_AMD_ERR_HIP);
         unsigned grid = static_cast<unsigned>((b.pair_count + 255) / 256);
         hipLaunchKernelGGL(relayout_pairs<T>, dim3(grid), dim3(256), 0, stream, d_nodes, b.pair_count, b.d_pairs);
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
