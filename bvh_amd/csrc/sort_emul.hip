@@ -26,22 +26,28 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // stable LSD radix sort
 // ---------------------------------------------------------------------------------------------------
-constexpr int kRadixTile = 4096;        // elements per block
-constexpr int kRadixThreads = 256;
+// Elements per block: 16 per lane; 2-byte keys afford the larger tile in LDS (longer runs per digit = fuller lines written).
+template <typename K> struct RadixShape {
+    static constexpr int kTile = sizeof(K) == 2 ? 8192 : 4096;
+    static constexpr int kThreads = kTile / 16;
+    static constexpr int kWaves = kThreads / 64;
+};
+constexpr int kRadixMinTile = 4096;     // sizes the histogram scratch for any key type
 
 template <typename K>
-__global__ void __launch_bounds__(kRadixThreads) k_radix_hist(const K* keys, uint32_t n, uint32_t blocks_per_array, int shift,
-                                                              uint32_t* hist) {
+__global__ void __launch_bounds__(RadixShape<K>::kThreads) k_radix_hist(const K* keys, uint32_t n, uint32_t blocks_per_array, int shift,
+                                                                       uint32_t* hist) {
+    constexpr int kTile = RadixShape<K>::kTile, kThreads = RadixShape<K>::kThreads;
     __shared__ uint32_t h[256];
     const uint32_t arr = blockIdx.x / blocks_per_array, blk = blockIdx.x % blocks_per_array;
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     const size_t base = size_t{arr} * n;
-    const uint32_t b = blk * kRadixTile, e = min(n, b + kRadixTile);
-    for (uint32_t i = b + threadIdx.x; i < e; i += uint32_t(kRadixThreads))
+    const uint32_t b = blk * kTile, e = min(n, b + kTile);
+    for (uint32_t i = b + threadIdx.x; i < e; i += uint32_t(kThreads))
         atomicAdd(&h[(keys[base + i] >> shift) & 0xFF], 1u);
     __syncthreads();
-    hist[(size_t{arr} * 256 + threadIdx.x) * blocks_per_array + blk] = h[threadIdx.x];    // digit-major, block-minor
+    if (threadIdx.x < 256) hist[(size_t{arr} * 256 + threadIdx.x) * blocks_per_array + blk] = h[threadIdx.x];    // digit-major, block-minor
 }
 
 // exclusive scan of one array's histogram (256 * blocks entries), one block per array
@@ -64,41 +70,90 @@ __global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* hist, uint32_t en
     for (uint32_t i = b; i < e; ++i) { uint32_t v = h[i]; h[i] = run; run += v; }
 }
 
+// Stable scatter of one tile. Wave w owns the w-th slice of the tile (16 elements per lane, kept in registers) and counts its
+// digits into a private LDS histogram; the block turns the histograms into tile-local cursors (digit start + the lower waves'
+// counts); each wave then ranks its elements 64 at a time (ballot match, no block barrier) and drops them at their tile-local
+// sorted position in LDS; finally the tile is written out in sorted order, so that consecutive lanes store consecutive
+// addresses of one digit's run (scattering straight from the ranking loop wrote 8-16 byte pieces and ran 2-3x slower).
+// Equal digits keep their input order (lower wave first, then step, then lane). vals == nullptr: the values are the input
+// positions (first pass over fresh keys); keys_out == nullptr: the keys are not needed any more (last pass).
 template <typename K>
-__global__ void __launch_bounds__(kRadixThreads) k_radix_scatter(const K* keys, const uint32_t* vals, K* keys_out, uint32_t* vals_out,
-                                                                 uint32_t n, uint32_t blocks_per_array, int shift, const uint32_t* hist) {
-    __shared__ uint32_t running[256];
-    __shared__ uint32_t wave_cnt[4][256];
+__global__ void __launch_bounds__(RadixShape<K>::kThreads) k_radix_scatter(const K* keys, const uint32_t* vals, K* keys_out, uint32_t* vals_out,
+                                                                          uint32_t n, uint32_t blocks_per_array, int shift, const uint32_t* hist) {
+    constexpr int kTile = RadixShape<K>::kTile, kThreads = RadixShape<K>::kThreads, kWaves = RadixShape<K>::kWaves, kSteps = 16;
+    __shared__ uint32_t cursor[kWaves][256];
+    __shared__ uint32_t lstart[256], goff[256], part[256];
+    __shared__ K skey[kTile];
+    __shared__ uint32_t sval[kTile];
     const uint32_t arr = blockIdx.x / blocks_per_array, blk = blockIdx.x % blocks_per_array;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    running[threadIdx.x] = hist[(size_t{arr} * 256 + threadIdx.x) * blocks_per_array + blk];
+    for (int i = threadIdx.x; i < kWaves * 256; i += kThreads) (&cursor[0][0])[i] = 0;
+    __syncthreads();
     const size_t base = size_t{arr} * n;
-    const uint32_t b = blk * kRadixTile, e = min(n, b + kRadixTile);
-    for (uint32_t tile = b; tile < e; tile += kRadixThreads) {
-        for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
+    const uint32_t b = blk * uint32_t(kTile), e = min(n, b + uint32_t(kTile));
+    const uint32_t first = b + wave * uint32_t(kSteps * 64) + lane;
+    K key[kSteps]; uint32_t val[kSteps];
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+        const uint32_t i = first + s * 64;
+        key[s] = 0; val[s] = 0;
+        if (i < e) {
+            key[s] = keys[base + i]; val[s] = vals ? vals[base + i] : i;
+            atomicAdd(&cursor[wave][(key[s] >> shift) & 0xFF], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) total += cursor[w][threadIdx.x];
+        part[threadIdx.x] = total;
+    }
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                         // inclusive scan of the 256 digit totals
+        uint32_t v = 0;
+        if (threadIdx.x < 256 && int(threadIdx.x) >= off) v = part[threadIdx.x - off];
         __syncthreads();
-        const uint32_t i = tile + threadIdx.x;
-        const bool in = i < e;
-        K key = 0; uint32_t val = 0, d = 0;
-        if (in) { key = keys[base + i]; val = vals[base + i]; d = (key >> shift) & 0xFF; }
+        if (threadIdx.x < 256) part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x < 256) {
+        uint32_t run = part[threadIdx.x] - total;
+        lstart[threadIdx.x] = run;
+        goff[threadIdx.x] = hist[(size_t{arr} * 256 + threadIdx.x) * blocks_per_array + blk];
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { const uint32_t c = cursor[w][threadIdx.x]; cursor[w][threadIdx.x] = run; run += c; }
+    }
+    __syncthreads();
+    uint32_t* mine = cursor[wave];
+    const uint64_t below = (uint64_t{1} << lane) - 1;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+        const bool in = first + s * 64 < e;
+        const uint32_t d = (key[s] >> shift) & 0xFF;
         uint64_t same = __ballot(in);
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
             const uint64_t bal = __ballot((d >> bit) & 1);
             same &= ((d >> bit) & 1) ? bal : ~bal;
         }
-        const uint32_t rank_in_wave = __popcll(same & ((uint64_t{1} << lane) - 1));
-        if (in && rank_in_wave == 0) wave_cnt[wave][d] = __popcll(same);
-        __syncthreads();
         if (in) {
-            uint32_t before = running[d] + rank_in_wave;
-            for (int w = 0; w < wave; ++w) before += wave_cnt[w][d];
-            keys_out[base + before] = key;
-            vals_out[base + before] = val;
+            const uint32_t rank = __popcll(same & below);
+            const uint32_t at = mine[d];                              // every lane of the group reads before its leader advances the cursor
+            __builtin_amdgcn_wave_barrier();
+            if (rank == 0) mine[d] = at + __popcll(same);
+            skey[at + rank] = key[s];
+            sval[at + rank] = val[s];
         }
-        __syncthreads();
-        running[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < e - b; j += uint32_t(kThreads)) {
+        const K k = skey[j];
+        const uint32_t d = (k >> shift) & 0xFF;
+        const size_t at = base + goff[d] + (j - lstart[d]);
+        if (keys_out) keys_out[at] = k;
+        vals_out[at] = sval[j];
     }
 }
 
@@ -296,14 +351,15 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* 
 
 // Stable sort of `batch` independent arrays of n (key, value) pairs by the low `bits` bits of the key.
 // keys/vals are overwritten with the result; tmp buffers have the same sizes.
-size_t radix_sort_hist_words(uint32_t n, uint32_t batch) { return size_t{batch} * 256 * ((n + kRadixTile - 1) / kRadixTile); }
+size_t radix_sort_hist_words(uint32_t n, uint32_t batch) { return size_t{batch} * 256 * ((n + kRadixMinTile - 1) / kRadixMinTile); }
 
 template <typename K>
 int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream,
-                     uint32_t* hist_buf) {
+                     uint32_t* hist_buf, bool iota_vals, bool keys_wanted) {
     if (n == 0 || batch == 0) return BVH_AMD_OK;
     StreamScope scratch_on(stream);
-    const uint32_t bpa = (n + kRadixTile - 1) / kRadixTile;
+    constexpr int kTile = RadixShape<K>::kTile, kThreads = RadixShape<K>::kThreads;
+    const uint32_t bpa = (n + kTile - 1) / kTile;
     DevBuf<uint32_t> own;
     if (!hist_buf) BVH_HIP_TRY(own.alloc(size_t{batch} * 256 * bpa), BVH_AMD_ERR_HIP);
     uint32_t* const hist = hist_buf ? hist_buf : own.p;       // caller-owned scratch: fully asynchronous
@@ -312,14 +368,15 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
     if (passes & 1) ++passes;                             // even number of passes: the result lands in keys/vals
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, n, bpa, shift, hist);
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kThreads), 0, stream, kin, n, bpa, shift, hist);
         if (256 * bpa > 16384) {                              // long histograms: the multi-block scan (one block per array crawls: 1 ms at 10M keys)
             for (uint32_t a = 0; a < batch; ++a) {
                 int rc = scan_u32_async(hist + size_t{a} * 256 * bpa, hist + size_t{a} * 256 * bpa, 256 * bpa, nullptr, stream);
                 if (rc) return rc;
             }
         } else hipLaunchKernelGGL(k_radix_scan, dim3(batch), dim3(1024), 0, stream, hist, 256 * bpa);
-        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(batch * bpa), dim3(kRadixThreads), 0, stream, kin, vin, kout, vout, n, bpa, shift, hist);
+        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(batch * bpa), dim3(kThreads), 0, stream, kin, p == 0 && iota_vals ? nullptr : vin,
+                           p == passes - 1 && !keys_wanted ? nullptr : kout, vout, n, bpa, shift, hist);
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
@@ -372,8 +429,9 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
     return radix_sort_pairs<U>(skeys.p, d_ids, skeys_tmp.p, vals_tmp.p, n, batch, int(sizeof(U) * 8), stream);
 }
 
-template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*);
-template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*);
+template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool);
+template int radix_sort_pairs<uint16_t>(uint16_t*, uint32_t*, uint16_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool);
+template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool);
 template int std_sort_ids<float>(uint32_t*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 template int std_sort_ids<double>(uint32_t*, const double*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 
