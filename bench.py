@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--obj", default=None, help="trace this Wavefront OBJ mesh (reference loader semantics, bvh_amd/obj.py) instead of a synthetic workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="rays of the CPU baseline sample (>= 1 s of work on the host cores)")
+    ap.add_argument("--no-reorder", action="store_true", help="trace the rays in the order given (BVH_AMD_RAY_UNSORTED)")
     ap.add_argument("--no-probe", action="store_true", help="skip the record-walk probe behind roofline_binding.peak")
     return ap.parse_args()
 
@@ -263,11 +264,15 @@ def main():
     rays = torch.from_numpy(rays_h).cuda()
     hits = torch.empty((args.rays, 4), dtype=torch.float32, device="cuda")
 
+    sort_rays = False if args.no_reorder else None            # None: the library decides (include/bvh_amd.h: BVH_AMD_RAY_SORTED)
+    record_bytes = (bvh.node_count // 2) * 64
+    reordered = (not args.no_reorder) and args.rays >= (1 << 20) and record_bytes > (32 << 20)
+
     def step():
-        bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, out=hits)
+        bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, out=hits, sort_rays=sort_rays)
 
     # traversal statistics of this batch (stats variant of the kernel; equal to the oracle's counters, tests/)
-    _, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, counters=True)
+    _, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, counters=True, sort_rays=sort_rays)
     cnt = cnt.cpu().numpy()
     P, T = cnt[0] / args.rays, cnt[1] / args.rays
     b_ray = 32.0 + 56.0 * P + 48.0 * T + 16.0            # ray + node pairs + triangles + hit record
@@ -279,6 +284,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    lib = bvh_amd._lib.load()
+    lib.bvh_amd_kernel_timing(1)                              # a pair of HIP events on the launch stream around the traversal kernel
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(args.steps):
@@ -289,7 +296,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))   # HIP events, launch stream
+    pass_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))     # whole pass: reordering + kernel
+    import ctypes
+    kt = (ctypes.c_float * 256)()
+    got = ctypes.c_size_t(0)
+    bvh_amd._lib.check(lib.bvh_amd_kernel_times(kt, min(args.steps, 256), ctypes.byref(got)), "kernel_times")
+    lib.bvh_amd_kernel_timing(0)
+    kernel_ms = float(np.mean(kt[:got.value])) if got.value else pass_ms                     # the traversal kernel alone
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if distributed:
@@ -321,7 +334,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}; {'robust' if robust else 'fast'} traversal, DefaultBuilder "
                                    f"{'serial' if args.serial_builder else 'with thread pool (mini-trees)'} Quality::{args.quality.capitalize()} "
-                                   f"built on the GPU (the reference's default configuration is thread pool + High)",
+                                   f"built on the GPU (the reference's default configuration is thread pool + High)"
+                                   + ("; rays reordered for coherence inside the timed pass (library default for this tree size)" if reordered else ""),
                        "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(args.rays),
                        "parallelism": f"rays sharded x{world}, BVH broadcast over RCCL" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -330,7 +344,10 @@ def main():
                          "achieved_is": "algorithmic bytes (SURVEY.md 8d: 32 + 56 P + 48 T + 16 per ray) / kernel time; `traffic` is what the "
                                         "L2's fabric side actually moved",
                          "kernel": kernel_name,
-                         "kernel_ms": round(kernel_ms, 4), "bytes_per_ray": round(b_ray, 1),
+                         "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
+                         "ray_reordering": ("on: 15-bit origin-cell/octant key + two radix passes inside every timed pass, "
+                                            f"{round(pass_ms - kernel_ms, 3)} ms of it" if reordered else "off"),
+                         "bytes_per_ray": round(b_ray, 1),
                          "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)},
             "roofline_binding": binding,
             "build": {"mtris_s": round(n_tris / (build_ms * 1e-3) / 1e6, 2), "ms": round(build_ms, 3),

@@ -52,6 +52,8 @@ _SIGS = {
     "bvh_amd_last_error": (C.c_char_p, []),
     "bvh_amd_version": (C.c_char_p, []),
     "bvh_amd_last_kernel_name": (C.c_char_p, []),
+    "bvh_amd_kernel_timing": (None, [C.c_int]),
+    "bvh_amd_kernel_times": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "bvh_amd_reinsertion_stats": (None, [C.POINTER(C.c_uint)]),
     "bvh_amd_probe_record_walk": (_I, [_P, C.c_uint32, C.c_uint32, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
     "bvh_amd_release_cached_memory": (_I, []),

@@ -29,6 +29,7 @@ class RayFlags(enum.IntFlag):
     ANY_HIT = 1
     ROBUST = 2
     SORTED = 4
+    UNSORTED = 16
 
 
 class _Builder(enum.IntEnum):
@@ -426,7 +427,7 @@ def gather(records, perm):
 
 
 def intersect(bvh: Bvh, prims, rays, any_hit: bool = False, robust: bool = False, leaf: str = "tri",
-              counters: bool = False, out=None, sort_rays: bool = False, original_ids: bool = False):
+              counters: bool = False, out=None, sort_rays=None, original_ids: bool = False):
     """Batched Bvh::intersect<IsAnyHit, IsRobust> (bvh.h:160-182) with the closest/any-hit leaf loop of
     test/benchmark.cpp:281-291. prims are in BVH order. Returns a torch tensor of hit records
     ((n,4) of the BVH scalar type; view with hits_to_numpy) and, optionally, (pairs, tests, leaves). original_ids: report
@@ -445,7 +446,7 @@ def intersect(bvh: Bvh, prims, rays, any_hit: bool = False, robust: bool = False
     if out is None:
         out = torch.empty((n, 4), dtype=dt, device=r.device)
     cnt = torch.zeros(3, dtype=torch.int64, device=r.device) if counters else None
-    flags = (RayFlags.ANY_HIT if any_hit else 0) | (RayFlags.ROBUST if robust else 0) | (RayFlags.SORTED if sort_rays else 0) | \
+    flags = (RayFlags.ANY_HIT if any_hit else 0) | (RayFlags.ROBUST if robust else 0) | (0 if sort_rays is None else RayFlags.SORTED if sort_rays else RayFlags.UNSORTED) | \
             (8 if original_ids else 0)                        # BVH_AMD_RAY_ORIGINAL_IDS: hit.prim = bvh.prim_ids[BVH-order index]
     fn = getattr(lib, f"bvh{s}_intersect_rays_{'tri' if leaf == 'tri' else 'sphere'}")
     _lib.check(fn(bvh._h, p.data_ptr(), r.data_ptr(), n, int(flags), out.data_ptr(),

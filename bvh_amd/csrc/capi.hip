@@ -489,6 +489,11 @@ extern "C" {
 const char* bvh_amd_last_error(void) { return g_error.c_str(); }
 const char* bvh_amd_version(void) { return "bvh_amd 0.1 (gfx950)"; }
 const char* bvh_amd_last_kernel_name(void) { return last_kernel_name(); }
+void bvh_amd_kernel_timing(int on) { kernel_timing(on != 0); }
+int bvh_amd_kernel_times(float* ms_out, size_t capacity, size_t* count_out) {
+    if (!ms_out && capacity) return fail(BVH_AMD_ERR_ARG, "bvh_amd_kernel_times: null output");
+    return kernel_times(ms_out, capacity, count_out);
+}
 void bvh_amd_reinsertion_stats(unsigned out[2]) { if (out) reinsertion_stats(out); }
 
 // Scratch blocks of finished builds stay cached in the current device's stream-ordered pool (common.h: scratch_alloc); this hands

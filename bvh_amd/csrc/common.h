@@ -122,8 +122,8 @@ struct BvhImpl {
     // do not share a counter (up to kWorkSlots of them in flight at a time).
     // A slot is handed out again after kWorkSlots further launches; the launch that re-uses it is ordered behind the launch
     // that had it before (an event per slot), so a 65th launch in flight never shares a counter with a running one.
-    static constexpr uint32_t kWorkSlots = 64, kWorkStride = 8;        // slots of 64 bytes
-    unsigned long long* d_work = nullptr;      // kWorkSlots x kWorkStride words: [0] ray ticket counter of the launch that holds the slot
+    static constexpr uint32_t kWorkSlots = 64, kWorkStride = 128;      // slots of 1 KB: eight ticket counters 128 bytes apart
+    unsigned long long* d_work = nullptr;      // kWorkSlots x kWorkStride words: the ticket counters of the launch that holds the slot
     mutable std::atomic<uint32_t> work_next{0};
     mutable hipEvent_t work_done[kWorkSlots] = {};      // recorded behind the slot's latest launch (created on first use)
     mutable std::mutex work_mutex;
@@ -196,6 +196,8 @@ template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
                     typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream);
 const char* last_kernel_name();
+void kernel_timing(bool on);                                  // traverse.hip
+int kernel_times(float* ms_out, size_t capacity, size_t* count_out);
 template <typename T>
 int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bool any, bool robust,
                         bool (*leaf_fn)(void*, T*, size_t, size_t), void (*inner_fn)(void*, size_t), void* user);

@@ -54,6 +54,8 @@ template <typename T> __device__ inline T dot3(T a0, T a1, T a2, T b0, T b1, T b
 }
 template <typename T> __device__ inline T dot2(T a0, T a1, T b0, T b1) { return (T(0) + a0 * b0) + a1 * b1; }   // Vec<T, 2>
 
+constexpr uint32_t kTicketStride = 16;       // ticket counters 128 bytes apart
+
 template <typename T>
 struct TraceArgs {
     const PairNode<T>* pairs;
@@ -61,7 +63,9 @@ struct TraceArgs {
     const T* rays;
     typename HitOf<T>::Type* hits;
     unsigned long long n;
-    unsigned long long* work;                  // [0] next ray ticket of this launch
+    unsigned long long* work;                  // next ray ticket of part p of this launch at work[p * kTicketStride]
+    unsigned long long part_size;              // tickets [p * part_size, min(n, (p + 1) * part_size)) form part p (a multiple of 64)
+    uint32_t parts;                            // 1, or one part per XCD (see trace_body.inc: refill)
     bvh_amd_counters* counters;
     const uint32_t* order;                     // optional: ticket -> ray index (coherence sort); results are unaffected
     uint32_t* deep;                            // stack entries beyond 64, deep_cap per resident lane (trees deeper than 64 levels only)

@@ -34,6 +34,16 @@ namespace {
 
 thread_local const char* g_last_kernel = "";
 
+// Optional timing of the traversal kernel alone (bench.py's roofline: the coherence sort in front of it is not the kernel):
+// the calling thread's latest launches, a pair of events each.
+struct KernelTimer {
+    static constexpr size_t kRing = 256;
+    bool on = false;
+    size_t count = 0;
+    std::pair<hipEvent_t, hipEvent_t> ring[kRing] = {};
+};
+KernelTimer& kernel_timer() { static thread_local KernelTimer t; return t; }
+
 // NOTE (measured, profiles/r02_traversal_experiments.md): on the 1M-triangle soup this kernel's L2 misses (55 G 64-byte sectors/s)
 // run at 0.96 of the rate at which the memory system serves a dependent random walk over 64-byte records (57 G/s, bench.py's
 // record-walk probe): what binds it is misses per ray, not instructions, L1 requests or occupancy. Tried and rejected on hardware:
@@ -113,8 +123,21 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
                                       (Robust ? "true" : "false") + ", " + std::to_string(Leaf) + ", " + (Stats ? "true" : "false") + ", " + std::to_string(D) +
                                       ", " + (Deep ? "true" : "false") + ">";
     g_last_kernel = symbol.c_str();
+    KernelTimer& timer = kernel_timer();
+    hipEvent_t stop = nullptr;
+    if (timer.on) {                                           // bvh_amd_kernel_timing: events on the launch stream around this kernel only
+        std::pair<hipEvent_t, hipEvent_t>& ev = timer.ring[timer.count % KernelTimer::kRing];
+        if (!ev.first) {
+            BVH_HIP_TRY(hipEventCreate(&ev.first), BVH_AMD_ERR_HIP);
+            BVH_HIP_TRY(hipEventCreate(&ev.second), BVH_AMD_ERR_HIP);
+        }
+        BVH_HIP_TRY(hipEventRecord(ev.first, stream), BVH_AMD_ERR_HIP);
+        stop = ev.second;
+        ++timer.count;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    if (stop) BVH_HIP_TRY(hipEventRecord(stop, stream), BVH_AMD_ERR_HIP);
     return BVH_AMD_OK;
 }
 
@@ -325,6 +348,24 @@ struct StepContextClaim {
 
 const char* last_kernel_name() { return g_last_kernel; }
 
+void kernel_timing(bool on) {
+    KernelTimer& t = kernel_timer();
+    t.on = on;
+    t.count = 0;
+}
+
+int kernel_times(float* ms_out, size_t capacity, size_t* count_out) {
+    KernelTimer& t = kernel_timer();
+    const size_t have = std::min<size_t>(t.count, KernelTimer::kRing), n = std::min(have, capacity);
+    for (size_t i = 0; i < n; ++i) {                          // the latest `n` launches, oldest first
+        const std::pair<hipEvent_t, hipEvent_t>& ev = t.ring[(t.count - n + i) % KernelTimer::kRing];
+        BVH_HIP_TRY(hipEventSynchronize(ev.second), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipEventElapsedTime(&ms_out[i], ev.first, ev.second), BVH_AMD_ERR_HIP);
+    }
+    if (count_out) *count_out = n;
+    return BVH_AMD_OK;
+}
+
 template <typename T>
 static int to_original_ids(const BvhImpl<T>& b, typename HitOf<T>::Type* d_hits, size_t n, hipStream_t stream) {
     if (!b.d_prim_ids) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device prim ids");
@@ -351,12 +392,17 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         else BVH_HIP_TRY(hipStreamWaitEvent(stream, b.work_done[slot], 0), BVH_AMD_ERR_HIP);
         slot_event = b.work_done[slot];
     }
-    BVH_HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipMemsetAsync(work, 0, BvhImpl<T>::kWorkStride * sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
     if (d_counters) BVH_HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream), BVH_AMD_ERR_HIP);
     TraceArgs<T> args;
     args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
     args.n = n; args.work = work; args.counters = d_counters; args.root_index = b.root_index;
     args.order = nullptr;
+    // one ticket range per XCD (trace_body.inc: refill): free for incoherent batches, a win for every batch whose neighbouring
+    // rays are close (coherence-sorted below, or generated that way by the caller)
+    static const int parts_env = getenv("BVH_AMD_PARTS") ? atoi(getenv("BVH_AMD_PARTS")) : 0;            // tuning knob
+    args.parts = parts_env > 0 ? std::min(parts_env, 8) : (n >= 65536 ? 8 : 1);
+    args.part_size = ((n + args.parts - 1) / args.parts + 63) / 64 * 64;
     args.deep = nullptr; args.deep_cap = 0;
     // Scratch that only some launches need is allocated and freed in stream order (hipMallocAsync / hipFreeAsync), so that
     // concurrent launches of one BVH never share it.
@@ -393,9 +439,14 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         if (rc2 == BVH_AMD_OK && (flags & BVH_AMD_RAY_ORIGINAL_IDS)) rc2 = to_original_ids<T>(b, d_hits, n, stream);
         return release(rc2);
     }
-    if ((flags & BVH_AMD_RAY_SORTED) && n > 4096 && n < (size_t{1} << 31)) {
+    // Reordering pays where the walk misses the L2s (tools/sorted_probe.py, 16M uniform rays: 1M-triangle soup 11.9 -> 9.65 ms,
+    // 10M-triangle mesh 13.9 -> 9.2 ms) and costs a few per cent where it does not (262k-triangle Sponza proxy, 1M rays: 0.32 ->
+    // 0.36 ms), hence the default below.
+    const bool reorder = (flags & BVH_AMD_RAY_SORTED) ? n > 4096
+                       : !(flags & BVH_AMD_RAY_UNSORTED) && n >= (size_t{1} << 20) && b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
+    if (reorder && n < (size_t{1} << 31)) {
         const uint32_t n32 = static_cast<uint32_t>(n);
-        const size_t words = 3 * n + 2 + radix_sort_hist_words(n32, 1);          // vals + tmp (u32), keys + tmp (u16), histogram
+        const size_t words = 3 * n + 8 + radix_sort_hist_words(n32, 1);          // vals + tmp (u32), keys + tmp (u16), histogram
         hipError_t e = hipMallocAsync(&sort_mem, words * sizeof(uint32_t), stream);
         if (e != hipSuccess) return release(fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: hipMallocAsync: ") + hipGetErrorString(e)));
         uint32_t *vals = static_cast<uint32_t*>(sort_mem), *vt = vals + n, *hist = vt + n;

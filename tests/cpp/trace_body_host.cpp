@@ -150,6 +150,8 @@ void host_trace(TraceArgs<T> a) {
 
 namespace {
 
+uint32_t g_parts = 1;                          // ticket ranges of the emulated launch (trace_body_host_set_parts)
+
 template <typename T, int Leaf, int D, bool Deep>
 void run_variant(const bvh_amd::TraceArgs<T>& a, int any, int robust) {
     using namespace bvh_amd;
@@ -163,13 +165,13 @@ template <typename T>
 int run_any(const void* pairs, uint32_t root_index, const void* prims, const void* rays, size_t n_rays, int dim, int leaf, int any, int robust,
             uint32_t* deep, uint32_t deep_cap, void* hits, unsigned long long* counters3) {
     using namespace bvh_amd;
-    unsigned long long work[2] = {0, 0};
+    unsigned long long work[8 * kTicketStride] = {};
     bvh_amd_counters cnt = {0, 0, 0};
     TraceArgs<T> a;
     a.pairs = static_cast<const PairNode<T>*>(pairs);
     a.prims = static_cast<const T*>(prims); a.rays = static_cast<const T*>(rays);
     a.hits = static_cast<typename HitOf<T>::Type*>(hits);
-    a.n = n_rays; a.work = work; a.counters = &cnt; a.order = nullptr; a.deep = deep; a.deep_cap = deep_cap;
+    a.n = n_rays; a.work = work; a.parts = g_parts; a.part_size = g_parts > 1 ? ((n_rays + g_parts - 1) / g_parts + 63) / 64 * 64 : n_rays; a.counters = &cnt; a.order = nullptr; a.deep = deep; a.deep_cap = deep_cap;
     a.root_index = root_index;
     a.refill_threshold = kHostRefill; a.leaf_threshold = kHostLeaf;
     if (dim == 2) { if (deep) run_variant<T, LEAF_SPHERE, 2, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 2, false>(a, any, robust); }
@@ -182,6 +184,9 @@ int run_any(const void* pairs, uint32_t root_index, const void* prims, const voi
 } // namespace
 
 extern "C" {
+
+// Number of ticket ranges (1..8) the following emulated launches cut their rays into.
+void trace_body_host_set_parts(int parts) { g_parts = parts < 1 ? 1u : parts > 8 ? 8u : static_cast<uint32_t>(parts); }
 
 // The float / triangle / 3D body with counters on (`unused` keeps the historical signature). Returns 0.
 int trace_body_host(const void* pairs64, const void* unused, uint32_t root_index, const float* tris12, const float* rays8, size_t n_rays,

@@ -90,7 +90,13 @@ def test_bench_json_contract(monkeypatch, orc):
     monkeypatch.setattr(bvh_amd.DefaultBuilder, "build", staticmethod(build))
     monkeypatch.setattr(bvh_amd, "precompute_tris", precompute_tris)
     monkeypatch.setattr(bvh_amd, "intersect", intersect)
-    fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"fake_kernel")
+    def fake_kernel_times(ms_out, capacity, count_out):
+        for i in range(capacity):
+            ms_out[i] = 1.0
+        count_out._obj.value = capacity
+        return 0
+    fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"fake_kernel", bvh_amd_kernel_timing=lambda on: None,
+                                     bvh_amd_kernel_times=fake_kernel_times)
     monkeypatch.setattr(bvh_amd._lib, "load", lambda: fake_lib)
     monkeypatch.setitem(bench.WORKLOADS, "soup_1m", ("soup", 3000, "tiny stand-in scene of the contract test", "3000-tri stand-in"))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--rays", "4096", "--cpu-sample", "2048", "--no-probe"])

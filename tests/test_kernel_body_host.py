@@ -197,3 +197,22 @@ def test_body_full_wavefront_equals_golden(body64, orc, scene, mode):
 
 def test_body_full_wavefront_deep_stack(body64, orc):
     test_body_deep_stack(body64, orc, 70)
+
+
+@pytest.mark.parametrize("parts", [2, 8])
+def test_body_full_wavefront_ticket_ranges(body64, orc, parts):
+    """The tickets of a launch cut into several ranges with a counter each (what a coherence-sorted launch does, one range per
+    XCD): a wave that finds its range used up moves on to the next one, every ray is traced exactly once, the golden hits and
+    counters come out; also with fewer rays than ranges x 64."""
+    g = load_golden("soup2k")
+    nodes, ids = parse_stream(g["bvh_parallel_high"].tobytes(), False)
+    prims = orc.precompute_tris(g["prims"], ids)
+    body64.trace_body_host_set_parts(parts)
+    try:
+        for count in (len(g["rays_closest"]), 100, 1):
+            hits, cnt = run(body64, nodes["bounds"], nodes["index"], prims, g["rays_closest"][:count], 3, 0, False, True)
+            assert hits.tobytes() == g["hits_parallel_high_closest_robust"][:count].tobytes(), count
+            if count == len(g["rays_closest"]):
+                assert (cnt == g["counters_parallel_high_closest_robust"]).all()
+    finally:
+        body64.trace_body_host_set_parts(1)
