@@ -17,8 +17,15 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kLdsDepth = 20;
-constexpr int kRefillThreshold = 54;          // refill when at least this many lanes of the wave are idle (swept: profiles/README.md)
-constexpr int kLeafThreshold = 8;             // run the leaf code when at least this many lanes wait at a leaf
+// Refill when at least this many lanes of the wave are idle / run the leaf code when at least this many lanes wait at a leaf.
+// Swept on the device (profiles/README.md): a walk served by the L1 / L2s (small trees, coherence-sorted batches) is bound by
+// issue slots and wants its lanes refilled early (soup_1m sorted: 1744 Mrays/s at 54 / 8, 1970 at 36 / 12; Sponza proxy 5.07 ->
+// 5.77 Grays/s, terrain 5.35 -> 6.59); an unsorted batch on a tree beyond the L2s is bound by the fabric's miss path and is
+// best with rare, full refills (1404 at 54 / 8, 1382 at 36 / 12).
+constexpr int kRefillThreshold = 36;
+constexpr int kLeafThreshold = 12;
+constexpr int kRefillThresholdMissBound = 54;
+constexpr int kLeafThresholdMissBound = 8;
 
 
 template <typename T> struct Num;

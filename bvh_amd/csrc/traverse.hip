@@ -433,6 +433,7 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     static const int leaf_env = getenv("BVH_AMD_LEAF") ? atoi(getenv("BVH_AMD_LEAF")) : 0;
     args.refill_threshold = refill_env > 0 ? refill_env : kRefillThreshold;
     args.leaf_threshold = leaf_env > 0 ? leaf_env : kLeafThreshold;
+    const bool beyond_l2 = b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
     if (b.dim == 2) {                                         // Node<T, 2>: circles only (tri.h has no 2D intersector)
         if (leaf_kind != LEAF_SPHERE) return release(fail(BVH_AMD_ERR_ARG, "intersect_rays: a 2D BVH traces circles (Sphere<T, 2>) only"));
         int rc2 = dispatch<T, LEAF_SPHERE, 2>(b, args, flags, d_counters != nullptr, stream);
@@ -443,7 +444,12 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     // 10M-triangle mesh 13.9 -> 9.2 ms) and costs a few per cent where it does not (262k-triangle Sponza proxy, 1M rays: 0.32 ->
     // 0.36 ms), hence the default below.
     const bool reorder = (flags & BVH_AMD_RAY_SORTED) ? n > 4096
-                       : !(flags & BVH_AMD_RAY_UNSORTED) && n >= (size_t{1} << 20) && b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
+                       : !(flags & BVH_AMD_RAY_UNSORTED) && n >= (size_t{1} << 20) && beyond_l2;
+    if (beyond_l2 && !(reorder && n < (size_t{1} << 31))) {
+        // a walk that mostly misses the L2s is bound by the fabric, not by issue slots: fuller refills, fewer of them (trace_device.h)
+        if (refill_env <= 0) args.refill_threshold = kRefillThresholdMissBound;
+        if (leaf_env <= 0) args.leaf_threshold = kLeafThresholdMissBound;
+    }
     if (reorder && n < (size_t{1} << 31)) {
         const uint32_t n32 = static_cast<uint32_t>(n);
         const size_t words = 3 * n + 8 + radix_sort_hist_words(n32, 1);          // vals + tmp (u32), keys + tmp (u16), histogram
