@@ -265,8 +265,6 @@ def main():
     hits = torch.empty((args.rays, 4), dtype=torch.float32, device="cuda")
 
     sort_rays = False if args.no_reorder else None            # None: the library decides (include/bvh_amd.h: BVH_AMD_RAY_SORTED)
-    record_bytes = (bvh.node_count // 2) * 64
-    reordered = (not args.no_reorder) and args.rays >= (1 << 20) and record_bytes > (32 << 20)
 
     def step():
         bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, out=hits, sort_rays=sort_rays)
@@ -274,6 +272,7 @@ def main():
     # traversal statistics of this batch (stats variant of the kernel; equal to the oracle's counters, tests/)
     _, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, counters=True, sort_rays=sort_rays)
     cnt = cnt.cpu().numpy()
+    reordered = bool(bvh_amd._lib.load().bvh_amd_last_launch_reordered())
     P, T = cnt[0] / args.rays, cnt[1] / args.rays
     b_ray = 32.0 + 56.0 * P + 48.0 * T + 16.0            # ray + node pairs + triangles + hit record
 

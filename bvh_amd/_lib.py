@@ -52,6 +52,7 @@ _SIGS = {
     "bvh_amd_last_error": (C.c_char_p, []),
     "bvh_amd_version": (C.c_char_p, []),
     "bvh_amd_last_kernel_name": (C.c_char_p, []),
+    "bvh_amd_last_launch_reordered": (C.c_int, []),
     "bvh_amd_kernel_timing": (None, [C.c_int]),
     "bvh_amd_kernel_times": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "bvh_amd_reinsertion_stats": (None, [C.POINTER(C.c_uint)]),

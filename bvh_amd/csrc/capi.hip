@@ -489,6 +489,7 @@ extern "C" {
 const char* bvh_amd_last_error(void) { return g_error.c_str(); }
 const char* bvh_amd_version(void) { return "bvh_amd 0.1 (gfx950)"; }
 const char* bvh_amd_last_kernel_name(void) { return last_kernel_name(); }
+int bvh_amd_last_launch_reordered(void) { return last_launch_reordered() ? 1 : 0; }
 void bvh_amd_kernel_timing(int on) { kernel_timing(on != 0); }
 int bvh_amd_kernel_times(float* ms_out, size_t capacity, size_t* count_out) {
     if (!ms_out && capacity) return fail(BVH_AMD_ERR_ARG, "bvh_amd_kernel_times: null output");

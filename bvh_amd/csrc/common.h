@@ -117,6 +117,10 @@ struct BvhImpl {
     // reference's SmallStack<Index, 64>), deeper ones additionally spill to d_deep (its GrowingStack, stack.h:34-46).
     // (the spill buffer and the scratch of the optional ray-coherence sort are stream-ordered allocations of each launch)
     mutable std::atomic<int> max_depth{-1};
+    // Sum over the inner nodes of area(node) / area(root) = the pair records a random line through the scene is expected to fetch
+    // (upload.hip: tree_depth fills it together with max_depth, before max_depth). Low for scenes a ray crosses quickly, in the
+    // hundreds for a soup; decides whether reordering a ray batch is worth its fixed cost per ray (traverse.hip).
+    mutable std::atomic<float> expected_visits{0.0f};
     // Batch launches are re-entrant like the reference's Bvh::intersect on a const Bvh: every launch takes the next of
     // kWorkSlots {ray ticket counter, status word} slots, so launches of one BVH issued from several threads / on several streams
     // do not share a counter (up to kWorkSlots of them in flight at a time).
@@ -196,6 +200,7 @@ template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
                     typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream);
 const char* last_kernel_name();
+bool last_launch_reordered();
 void kernel_timing(bool on);                                  // traverse.hip
 int kernel_times(float* ms_out, size_t capacity, size_t* count_out);
 template <typename T>

@@ -18,14 +18,12 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kLdsDepth = 20;
 // Refill when at least this many lanes of the wave are idle / run the leaf code when at least this many lanes wait at a leaf.
-// Swept on the device (profiles/README.md): a walk served by the L1 / L2s (small trees, coherence-sorted batches) is bound by
-// issue slots and wants its lanes refilled early (soup_1m sorted: 1744 Mrays/s at 54 / 8, 1970 at 36 / 12; Sponza proxy 5.07 ->
-// 5.77 Grays/s, terrain 5.35 -> 6.59); an unsorted batch on a tree beyond the L2s is bound by the fabric's miss path and is
-// best with rare, full refills (1404 at 54 / 8, 1382 at 36 / 12).
+// Swept on the device (profiles/README.md): a walk served by the L1 / L2s (small trees, coherent or coherence-sorted batches) is
+// bound by issue slots and wants its lanes refilled early (soup_1m sorted: 1744 Mrays/s at 54 / 8, 1970 at 36 / 12; Sponza proxy
+// 5.07 -> 5.77 Grays/s, 1M-triangle terrain 5.35 -> 6.59). Only a walk that misses the L2s all the time (unsorted uniform rays on
+// the 1M soup) would rather have rare, full refills, and by little: 1404 Mrays/s at 54 / 8, 1382 at 36 / 12.
 constexpr int kRefillThreshold = 36;
 constexpr int kLeafThreshold = 12;
-constexpr int kRefillThresholdMissBound = 54;
-constexpr int kLeafThresholdMissBound = 8;
 
 
 template <typename T> struct Num;
@@ -59,6 +57,16 @@ template <typename T> __device__ inline T pick_max(T a, T b) { return a > b ? a 
 template <typename T> __device__ inline T dot3(T a0, T a1, T a2, T b0, T b1, T b2) {   // vec.h:98-100
     return ((T(0) + a0 * b0) + a1 * b1) + a2 * b2;
 }
+// A ds_read_b32 the optimiser may neither drop nor merge with a load from another address space.
+__device__ inline uint32_t lds_word(const uint32_t* shared) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const volatile uint32_t LdsWord;
+    return *(LdsWord*)shared;
+#else
+    return *shared;                                // (tests/cpp/trace_body_host.cpp compiles the body for the host)
+#endif
+}
+
 template <typename T> __device__ inline T dot2(T a0, T a1, T b0, T b1) { return (T(0) + a0 * b0) + a1 * b1; }   // Vec<T, 2>
 
 constexpr uint32_t kTicketStride = 16;       // ticket counters 128 bytes apart

@@ -33,6 +33,7 @@ namespace bvh_amd {
 namespace {
 
 thread_local const char* g_last_kernel = "";
+thread_local bool g_last_reordered = false;
 
 // Optional timing of the traversal kernel alone (bench.py's roofline: the coherence sort in front of it is not the kernel):
 // the calling thread's latest launches, a pair of events each.
@@ -347,6 +348,7 @@ struct StepContextClaim {
 } // namespace
 
 const char* last_kernel_name() { return g_last_kernel; }
+bool last_launch_reordered() { return g_last_reordered; }
 
 void kernel_timing(bool on) {
     KernelTimer& t = kernel_timer();
@@ -374,6 +376,8 @@ static int to_original_ids(const BvhImpl<T>& b, typename HitOf<T>::Type* d_hits,
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
     return BVH_AMD_OK;
 }
+
+constexpr float kReorderMinVisits = 100.0f;
 
 template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
@@ -440,17 +444,16 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         if (rc2 == BVH_AMD_OK && (flags & BVH_AMD_RAY_ORIGINAL_IDS)) rc2 = to_original_ids<T>(b, d_hits, n, stream);
         return release(rc2);
     }
+    // Reordering has a fixed cost per ray (~0.02 ns for the keys and the sort, plus the indirection in the kernel) and saves a share
+    // of the L2 misses, so it needs a tree beyond the L2s AND rays that fetch many records: the 1M-triangle terrain (expected visits
+    // 32, 16 measured) loses 16 % with it, the 1M soup (358 expected, 70 measured) gains 40 %.
     // Reordering pays where the walk misses the L2s (tools/sorted_probe.py, 16M uniform rays: 1M-triangle soup 11.9 -> 9.65 ms,
     // 10M-triangle mesh 13.9 -> 9.2 ms) and costs a few per cent where it does not (262k-triangle Sponza proxy, 1M rays: 0.32 ->
     // 0.36 ms), hence the default below.
     const bool reorder = (flags & BVH_AMD_RAY_SORTED) ? n > 4096
-                       : !(flags & BVH_AMD_RAY_UNSORTED) && n >= (size_t{1} << 20) && beyond_l2;
-    if (beyond_l2 && !(reorder && n < (size_t{1} << 31))) {
-        // a walk that mostly misses the L2s is bound by the fabric, not by issue slots: fuller refills, fewer of them (trace_device.h)
-        if (refill_env <= 0) args.refill_threshold = kRefillThresholdMissBound;
-        if (leaf_env <= 0) args.leaf_threshold = kLeafThresholdMissBound;
-    }
-    if (reorder && n < (size_t{1} << 31)) {
+                       : !(flags & BVH_AMD_RAY_UNSORTED) && n >= (size_t{1} << 20) && beyond_l2 && b.expected_visits.load() >= kReorderMinVisits;
+    g_last_reordered = reorder && n < (size_t{1} << 31);
+    if (g_last_reordered) {
         const uint32_t n32 = static_cast<uint32_t>(n);
         const size_t words = 3 * n + 8 + radix_sort_hist_words(n32, 1);          // vals + tmp (u32), keys + tmp (u16), histogram
         hipError_t e = hipMallocAsync(&sort_mem, words * sizeof(uint32_t), stream);

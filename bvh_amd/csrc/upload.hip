@@ -53,6 +53,29 @@ __global__ void __launch_bounds__(256) k_depth_jump(const uint32_t* anc, const u
     if (max_out) atomicMax(max_out, d);
 }
 
+// Sum over the inner nodes of half-area(node) / half-area(root), in units of 2^-16 (integer, so that the sum does not depend on
+// the order of the atomics): the number of pair records a random line through the root box is expected to fetch.
+template <typename T>
+__global__ void __launch_bounds__(256) k_expected_visits(const PairNode<T>* pairs, uint32_t n_pairs, double inv_root_area, unsigned long long* sum) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long mine = 0;
+    if (p < n_pairs) {
+        const PairNode<T>& q = pairs[p];
+        auto share = [&](const T* b, uint32_t index) -> unsigned long long {
+            if ((index & kCountMask) != 0) return 0;                              // a leaf fetches no further record
+            const double x = double(b[1]) - double(b[0]), y = double(b[3]) - double(b[2]), z = double(b[5]) - double(b[4]);
+            const double r = (x * y + y * z + z * x) * inv_root_area;
+            return r > 0 ? static_cast<unsigned long long>(fmin(r, 1.0) * 65536.0) : 0;   // (NaN / empty boxes count nothing)
+        };
+        mine = share(q.lb, q.li) + share(q.rb, q.ri);
+    }
+    __shared__ unsigned long long part[4];
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+}
+
 } // namespace
 
 template <typename T>
@@ -64,10 +87,18 @@ int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
     if (b.pair_count == 0) { b.max_depth = 0; return BVH_AMD_OK; }
     const uint32_t n = static_cast<uint32_t>(b.pair_count);
     uint32_t* buf = nullptr;
-    BVH_HIP_TRY(hipMalloc(&buf, (size_t{4} * n + 1) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
-    uint32_t *anc = buf, *dist = buf + n, *anc2 = buf + 2 * size_t{n}, *dist2 = buf + 3 * size_t{n}, *d_max = buf + 4 * size_t{n};
-    hipError_t e = hipMemsetAsync(d_max, 0, 4, stream);
+    BVH_HIP_TRY(hipMalloc(&buf, (size_t{4} * n + 4) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
+    uint32_t *anc = buf, *dist = buf + n, *anc2 = buf + 2 * size_t{n}, *dist2 = buf + 3 * size_t{n};
+    uint32_t* d_max = buf + 4 * size_t{n};                    // {max depth, pad, 64-bit sum of expected visits}: 16-byte aligned
+    unsigned long long* d_visits = reinterpret_cast<unsigned long long*>(d_max + 2);
+    hipError_t e = hipMemsetAsync(d_max, 0, 16, stream);
     const unsigned grid = (n + 255) / 256;
+    {
+        const double x = double(b.root_bounds[1]) - double(b.root_bounds[0]), y = double(b.root_bounds[3]) - double(b.root_bounds[2]),
+                     z = b.dim == 3 ? double(b.root_bounds[5]) - double(b.root_bounds[4]) : 0.0;
+        const double area = x * y + y * z + z * x;
+        hipLaunchKernelGGL(k_expected_visits<T>, dim3(grid), dim3(256), 0, stream, b.d_pairs, n, area > 0 ? 1.0 / area : 0.0, d_visits);
+    }
     hipLaunchKernelGGL(k_depth_identity, dim3(grid), dim3(256), 0, stream, n, anc, dist);
     hipLaunchKernelGGL(k_depth_init<T>, dim3(grid), dim3(256), 0, stream, b.d_pairs, n, b.root_index >> (kCountBits + 1), anc, dist);
     int rounds = 1;
@@ -76,12 +107,14 @@ int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
         hipLaunchKernelGGL(k_depth_jump, dim3(grid), dim3(256), 0, stream, anc, dist, n, anc2, dist2, r == rounds - 1 ? d_max : nullptr);
         std::swap(anc, anc2); std::swap(dist, dist2);
     }
-    uint32_t deepest = 0;
+    uint32_t words[4] = {0, 0, 0, 0};
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&deepest, d_max, 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(words, d_max, 16, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(buf);
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("tree_depth: ") + hipGetErrorString(e));
+    const uint32_t deepest = words[0];
+    b.expected_visits = static_cast<float>(static_cast<double>((static_cast<unsigned long long>(words[3]) << 32) | words[2]) / 65536.0);
     b.max_depth = static_cast<int>(deepest) + 1;              // pairs at distance d from the root pair hold nodes of level d + 1
     return BVH_AMD_OK;
 }

@@ -114,7 +114,8 @@ enum bvh_amd_ray_flags {
     BVH_AMD_RAY_SORTED  = 4u,  /* always reorder the batch internally for coherence (a 15-bit origin-cell / direction-octant key,
                                   two radix passes, ~0.3 ms per 16M rays); per-ray results are unchanged. With neither this
                                   flag nor BVH_AMD_RAY_UNSORTED the library decides: it reorders batches of >= 1M rays on trees
-                                  whose node records exceed the 32 MB of L2 (where it is worth +20..50 % on incoherent rays) */
+                                  whose node records exceed the 32 MB of L2 and through which a random line is expected to fetch
+                                  >= 100 records (sum of area(node) / area(root) over the inner nodes): +40..50 % there      */
     BVH_AMD_RAY_UNSORTED = 16u, /* never reorder (rays already coherent, or no scratch memory to spare: 12 bytes per ray)  */
     BVH_AMD_RAY_ORIGINAL_IDS = 8u  /* hit.prim = the ORIGINAL primitive id bvh.prim_ids[i] (what c_api_example.c:265-268 looks up per
                                       hit) instead of the BVH-order index i: one more pass over the hit records, on the device    */
@@ -353,6 +354,8 @@ BVH_AMD_API int bvh_amd_radix_sort_pairs_u32(uint32_t* d_keys, uint32_t* d_vals,
 
 /* Name and average duration source for profiling: the kernel symbol the last intersect call used. */
 BVH_AMD_API const char* bvh_amd_last_kernel_name(void);
+/* 1 when the calling thread's latest 3D batch traversal reordered its rays internally (BVH_AMD_RAY_SORTED, or the default rule). */
+BVH_AMD_API int bvh_amd_last_launch_reordered(void);
 /* Measurement aid: with timing on, every batch traversal launched by the calling thread records a pair of events on its stream
  * around the traversal kernel alone (not the optional ray reordering in front of it). bvh_amd_kernel_times waits for and returns
  * the durations (ms) of the latest min(capacity, 256) launches since timing was switched on, oldest first. */

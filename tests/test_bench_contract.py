@@ -95,7 +95,7 @@ def test_bench_json_contract(monkeypatch, orc):
             ms_out[i] = 1.0
         count_out._obj.value = capacity
         return 0
-    fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"fake_kernel", bvh_amd_kernel_timing=lambda on: None,
+    fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"fake_kernel", bvh_amd_kernel_timing=lambda on: None, bvh_amd_last_launch_reordered=lambda: 0,
                                      bvh_amd_kernel_times=fake_kernel_times)
     monkeypatch.setattr(bvh_amd._lib, "load", lambda: fake_lib)
     monkeypatch.setitem(bench.WORKLOADS, "soup_1m", ("soup", 3000, "tiny stand-in scene of the contract test", "3000-tri stand-in"))
