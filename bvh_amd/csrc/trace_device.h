@@ -36,6 +36,8 @@ template <> struct Num<float> {
     __device__ static float sqrt_(float x) { return __builtin_sqrtf(x); }
     __device__ static float abs_(float x) { return __builtin_fabsf(x); }
     __device__ static float copysign_(float a, float b) { return __builtin_copysignf(a, b); }
+    __device__ static float max_num(float a, float b) { return __builtin_fmaxf(a, b); }      // v_max_f32: the non-NaN operand wins
+    __device__ static float min_num(float a, float b) { return __builtin_fminf(a, b); }
 };
 template <> struct Num<double> {
     static constexpr double kMax = 1.7976931348623157e+308, kEps = 2.220446049250313e-16;
@@ -48,6 +50,8 @@ template <> struct Num<double> {
     __device__ static double sqrt_(double x) { return __builtin_sqrt(x); }
     __device__ static double abs_(double x) { return __builtin_fabs(x); }
     __device__ static double copysign_(double a, double b) { return __builtin_copysign(a, b); }
+    __device__ static double max_num(double a, double b) { return __builtin_fmax(a, b); }
+    __device__ static double min_num(double a, double b) { return __builtin_fmin(a, b); }
 };
 
 // utils.h:41-43 — must stay compare+select: the second operand wins on NaN and on equality.

@@ -53,6 +53,7 @@ KernelTimer& kernel_timer() { static thread_local KernelTimer t; return t; }
 // D = 2: Bvh<Node<T, 2>> with circles (Sphere<T, 2>, stride 3) and 6-value rays. The pair records stay three wide (their z
 // bounds are zero and never looked at): only the per-ray constants, the slab test and the leaf test run over D axes.
 // Deep = true (trees of more than 64 levels only): stack entries beyond the 64 of SmallStack spill to HBM (GrowingStack).
+// (70 VGPRs = 7 waves per SIMD; forcing 8 with amdgpu_waves_per_eu fits in 63 without spills and runs 16 % slower on soup_1m)
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3, bool Deep = false>
 __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
 #include "trace_body.inc"

@@ -139,11 +139,19 @@ def test_edge_cases(orc):
     base[::11, 4] = -0.0
     base[::13, 3:6] = [0, 0, 1]
     base[::17, 3:6] = 0.0         # fully degenerate direction
+    base[5::19, 6] = np.nan       # NaN tmin / tmax: every node test fails (robust_max keeps a NaN accumulator, utils.h:41-43)
+    base[3::23, 7] = np.nan
+    base[2::29, 0] = np.nan       # NaN origin / direction: every slab is NaN, every node is visited
+    base[4::31, 4] = np.nan
+    base[6::37, 6] = np.inf
+    base[8::41, 7] = -np.inf
     for n in (1, 63, 64, 65, 255, 257, 4097):
         for robust in (False, True):
-            h = bvh_amd.hits_to_numpy(bvh_amd.intersect(bvh, prims, base[:n], False, robust))
-            oh = ob.intersect_tri(oprims, base[:n], 0, robust)
-            assert h.tobytes() == oh.tobytes(), (n, robust)
+            for any_hit in (False, True):
+                got, cg = bvh_amd.intersect(bvh, prims, base[:n], any_hit, robust, counters=True)
+                oh, cw = ob.intersect_tri(oprims, base[:n], any_hit, robust, counters=True)
+                assert bvh_amd.hits_to_numpy(got).tobytes() == oh.tobytes(), (n, robust, any_hit)
+                assert (cg.cpu().numpy().astype(np.uint64) == cw).all(), (n, robust, any_hit)
     torch.cuda.synchronize()
 
 

@@ -216,3 +216,26 @@ def test_body_full_wavefront_ticket_ranges(body64, orc, parts):
                 assert (cnt == g["counters_parallel_high_closest_robust"]).all()
     finally:
         body64.trace_body_host_set_parts(1)
+
+
+def test_body_nan_and_infinite_rays(body64, orc):
+    """The slab test keeps its bounds with the hardware's min / max (the non-NaN operand wins) instead of the reference's
+    robust_min / robust_max (the second operand wins on NaN); they differ only for a NaN tmin / tmax, which the body flags per ray.
+    Rays with NaN / infinite tmin, tmax, origin and direction components give the reference's hits AND its visit counters."""
+    g = load_golden("soup2k")
+    nodes, ids = parse_stream(g["bvh_parallel_high"].tobytes(), False)
+    ref = orc.from_arrays(nodes, ids)
+    prims = orc.precompute_tris(g["prims"], ids)
+    rays = g["rays_closest"][:1200].copy()
+    rays[5::19, 6] = np.nan
+    rays[3::23, 7] = np.nan
+    rays[2::29, 0] = np.nan
+    rays[4::31, 4] = np.nan
+    rays[6::37, 6] = np.inf
+    rays[8::41, 7] = -np.inf
+    rays[::7, 3] = 0.0
+    for any_hit, robust in MODES4:
+        want, cw = ref.intersect_tri(prims, rays, any_hit, robust, counters=True)
+        hits, cnt = run(body64, nodes["bounds"], nodes["index"], prims, rays, 3, 0, any_hit, robust)
+        assert hits.tobytes() == want.tobytes(), (any_hit, robust)
+        assert (cnt == cw).all(), (any_hit, robust)
