@@ -471,3 +471,53 @@ def test_refit_on_device_built_tree_is_identity(orc):
     before = bvh.serialize()
     bvh.refit()                                                # builder output already satisfies parent = union(children)
     assert bvh.serialize() == before
+
+
+def test_scratch_block_cache_across_streams_and_release(orc):
+    """Build scratch comes from a block cache per (device, stream) in front of the stream-ordered pool (common.h: scratch_alloc):
+    builds of different sizes interleaved on two streams, a flush of the cache in between, and repeated builds that re-use the
+    cached blocks all give the reference's trees."""
+    import torch
+    import bvh_amd
+    lib = bvh_amd._lib.load()
+    scenes = [synth.soup(n, seed=s) for n, s in ((30_000, 1), (90_000, 2), (31_000, 3), (200_000, 4))]
+    want = []
+    for tris in scenes:
+        bb, cc = orc.prep_tris(tris)
+        want.append([orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=q).serialize() for q in (0, 2)])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        built = []
+        for i, tris in enumerate(scenes):
+            with torch.cuda.stream(streams[(i + rep) % 2]):
+                d = torch.from_numpy(tris).cuda()
+                bb, cc = bvh_amd.tri_bounds(d)
+                for q in (0, 2):
+                    built.append((i, q, bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality(q)), thread_pool=bvh_amd.ThreadPool())))
+        torch.cuda.synchronize()
+        for i, q, b in built:
+            assert b.serialize() == want[i][q // 2], (rep, i, q)
+        del built
+        if rep == 1:
+            assert lib.bvh_amd_release_cached_memory() == 0
+
+
+@pytest.mark.parametrize("cache_mb", ["0", "1"])
+def test_scratch_block_cache_off_and_tiny(cache_mb):
+    """BVH_AMD_CACHE_MB=0 (no block cache: every request goes to the pool) and =1 (every build overflows the bound and evicts): the
+    golden streams still come out. Own process: the bound is read once."""
+    import subprocess, sys, os
+    code = (
+        "import numpy as np, bvh_amd, sys\n"
+        "sys.path.insert(0, 'tests')\n"
+        "from conftest import load_golden\n"
+        "g = load_golden('soup2k')\n"
+        "for rep in range(3):\n"
+        "    bb, cc = bvh_amd.tri_bounds(g['prims'])\n"
+        "    for q, name in ((0, 'low'), (2, 'high')):\n"
+        "        b = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality(q)), thread_pool=bvh_amd.ThreadPool())\n"
+        "        assert b.serialize() == g['bvh_parallel_' + name].tobytes(), (rep, name)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, BVH_AMD_CACHE_MB=cache_mb), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -96,6 +96,13 @@ def test_high_quality_1m_invariants_and_traversal_properties():
     # the coherence-sorted launch returns the same records
     sorted_run = bvh_amd.intersect(bvh, prims, rays, robust=True, sort_rays=True)
     assert bool((sorted_run.view(torch.int32) == closest.view(torch.int32)).all())
+    assert bvh_amd._lib.load().bvh_amd_last_launch_reordered() == 1
+    # ... and so do the launch that is told not to reorder and the one left to the library's own rule
+    for choice in (False, None):
+        run = bvh_amd.intersect(bvh, prims, rays, robust=True, sort_rays=choice)
+        assert bool((run.view(torch.int32) == closest.view(torch.int32)).all())
+        # (this tree — 60 MB of records, ~360 expected record fetches per line — and 4M rays are what the default rule reorders)
+        assert bvh_amd._lib.load().bvh_amd_last_launch_reordered() == (0 if choice is False else 1)
     # counters are additive over a split of the batch
     _, c_a = bvh_amd.intersect(bvh, prims, rays[: nr // 3].contiguous(), robust=True, counters=True)
     _, c_b = bvh_amd.intersect(bvh, prims, rays[nr // 3:].contiguous(), robust=True, counters=True)
