@@ -326,6 +326,10 @@ def main():
                    "what": "L2 misses of the kernel (FETCH_SIZE / 64 B per launch / kernel time) over the record rate of a dependent random "
                            "walk through a table of the working set's size, one 64-byte record in flight per lane (bvh_amd_probe_record_walk)",
                    "probe": probe}
+        if binding["frac"] is not None:
+            binding["reading"] = ("this ceiling binds the kernel: only fewer L2 misses per ray can make it faster" if binding["frac"] >= 0.85 else
+                                  "the walk is off the miss path (rays picked up in a coherent order, one stretch of it per XCD): waves now wait for "
+                                  "the slowest lane of a step; SQ / TCP / TCC counters in profiles/r02_trace_soup1m_sorted_pmc_sq.csv")
         out = {
             "metric": f"Mrays/s closest-hit ({label})", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -341,7 +345,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_frac": None if traffic is None else round(traffic / HBM_PEAK_GBS, 4), "traffic_source": traffic_note,
                          "achieved_is": "algorithmic bytes (SURVEY.md 8d: 32 + 56 P + 48 T + 16 per ray) / kernel time; `traffic` is what the "
-                                        "L2's fabric side actually moved",
+                                        "L2's fabric side actually moved. frac > 1 means L1 / L2 serve re-referenced nodes faster than HBM could "
+                                        "stream the algorithmic bytes",
                          "kernel": kernel_name,
                          "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
                          "ray_reordering": ("on: 15-bit origin-cell/octant key + two radix passes inside every timed pass, "

@@ -24,6 +24,7 @@ def build_timed(bb, cc, cfg, pool, reps=3):
     bvh = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)
     ts = []
     for _ in range(reps):
+        bvh = None                                            # (destroying the previous BVH is not part of a build)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         bvh = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
