@@ -115,7 +115,7 @@ def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample, quality, seria
     }
 
 
-def pmc_traffic(args, robust, kernel_name):
+def pmc_traffic(args, robust, kernel_name, reordered):
     """HBM-side bytes per launch of the traced kernel from SEPARATE rocprofv3 --pmc passes of this same command (FETCH_SIZE
     and WRITE_SIZE cannot be collected inside a timed run): tools/pmc_traffic.py records them in profiles/pmc_traffic.json
     together with a sha1 of the traced kernel's instructions. Returns (record or None, note): the counts are only quoted for a
@@ -123,7 +123,8 @@ def pmc_traffic(args, robust, kernel_name):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None, "no profiles/pmc_traffic.json"
-    key = f"{args.workload}|{args.quality}|{'serial' if args.serial_builder else 'pool'}|{'robust' if robust else 'fast'}|{args.rays}"
+    key = (f"{args.workload}|{args.quality}|{'serial' if args.serial_builder else 'pool'}|{'robust' if robust else 'fast'}|{args.rays}|"
+           f"{'reordered' if reordered else 'as_given'}")
     rec = json.load(open(path)).get(key)
     if rec is None:
         return None, f"no --pmc pass recorded for {key}"
@@ -313,7 +314,7 @@ def main():
         value = total_rays / elapsed / 1e6
         achieved = b_ray * args.rays / (kernel_ms * 1e-3) / 1e9
         kernel_name = bvh_amd._lib.load().bvh_amd_last_kernel_name().decode()
-        rec, traffic_note = pmc_traffic(args, robust, kernel_name)
+        rec, traffic_note = pmc_traffic(args, robust, kernel_name, reordered)
         traffic = None if rec is None else round((rec["fetch_kb"] + rec["write_kb"]) * 1024.0 / (kernel_ms * 1e-3) / 1e9, 1)
         # The ceiling that binds this kernel (profiles/r02_traversal_experiments.md): its L2 misses against the rate at which the
         # memory system serves a dependent walk over random 64-byte records, measured live by csrc/probe.hip.

@@ -64,5 +64,5 @@ def test_kernel_isa_hash_of_the_built_library():
     assert kernel_isa_hash(_lib.LIB_PATH, "no_such_kernel<int>") is None
     import json
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    key = "soup_1m|high|pool|robust|16777216"
+    key = "soup_1m|high|pool|robust|16777216|reordered"
     assert rec[key]["isa_sha1"] == h, "profiles/pmc_traffic.json was traced on another build of the bench kernel: re-run tools/pmc_traffic.py"

@@ -53,14 +53,15 @@ def main():
     ap.add_argument("--workload", default="soup_1m"); ap.add_argument("--quality", default="high")
     ap.add_argument("--serial-builder", action="store_true"); ap.add_argument("--fast", action="store_true")
     a, _ = ap.parse_known_args(bench_args)
-    key = f"{a.workload}|{a.quality}|{'serial' if a.serial_builder else 'pool'}|{'fast' if a.fast else 'robust'}|{rays}"
+    order = "reordered" if str(line["roofline"].get("ray_reordering", "off")).startswith("on") else "as_given"
+    key = f"{a.workload}|{a.quality}|{'serial' if a.serial_builder else 'pool'}|{'fast' if a.fast else 'robust'}|{rays}|{order}"
     doc = {}
     if os.path.exists(out_path):
         doc = json.load(open(out_path))
     doc["_doc"] = ("HBM-side traffic per launch of the bench's traversal kernel from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in KB, "
                    "mean over the kernel's dispatches; tools/pmc_traffic.py). Requests are 64-byte record sectors, so the guide's 2x wide-stream "
                    "correction does not apply. isa_sha1 = tools/kernel_isa.py of the traced kernel: bench.py quotes the counts only for a library "
-                   "whose kernel hashes the same. Key: workload|quality|builder|traversal|rays per launch.")
+                   "whose kernel hashes the same. Key: workload|quality|builder|traversal|rays per launch|rays reordered by the call or traced as given.")
     doc[key] = {"fetch_kb": round(sums["FETCH_SIZE"][0], 1), "write_kb": round(sums["WRITE_SIZE"][0], 1),
                 "dispatches": [sums["FETCH_SIZE"][1], sums["WRITE_SIZE"][1]], "kernel": kernel,
                 "isa_sha1": kernel_isa_hash(_lib.LIB_PATH, kernel), "kernel_ms_unprofiled": line["roofline"]["kernel_ms"], "round": 2}
