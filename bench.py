@@ -350,7 +350,7 @@ def main():
                                         "stream the algorithmic bytes",
                          "kernel": kernel_name,
                          "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
-                         "ray_reordering": ("on: 15-bit origin-cell/octant key + two radix passes inside every timed pass, "
+                         "ray_reordering": ("on: 21-bit origin-cell/octant key + three radix passes inside every timed pass, "
                                             f"{round(pass_ms - kernel_ms, 3)} ms of it" if reordered else "off"),
                          "bytes_per_ray": round(b_ray, 1),
                          "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)},

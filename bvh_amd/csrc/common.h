@@ -223,9 +223,10 @@ int launch_shade_eyelight(const T* d_tris12, const T* d_rays, const typename Hit
 // sort_emul.hip
 template <typename K>
 int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream,
-                     uint32_t* hist_buf = nullptr, bool iota_vals = false, bool keys_wanted = true);
+                     uint32_t* hist_buf = nullptr, bool iota_vals = false, bool keys_wanted = true, uint32_t** vals_result = nullptr);
 // (iota_vals: `vals` need not be initialised, the values are the input positions 0..n-1 of each array; keys_wanted = false: only
-//  the values are sorted on return, `keys` is left in an unspecified state)
+//  the values are sorted on return, `keys` is left in an unspecified state; vals_result != nullptr: exactly ceil(bits / 8) passes,
+//  *vals_result = whichever of vals / vals_tmp holds the sorted values, keys unspecified)
 size_t radix_sort_hist_words(uint32_t n, uint32_t batch);
 template <typename T>
 int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, uint32_t astride, uint32_t istride, hipStream_t stream);

@@ -355,7 +355,8 @@ size_t radix_sort_hist_words(uint32_t n, uint32_t batch) { return size_t{batch} 
 
 template <typename K>
 int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream,
-                     uint32_t* hist_buf, bool iota_vals, bool keys_wanted) {
+                     uint32_t* hist_buf, bool iota_vals, bool keys_wanted, uint32_t** vals_result) {
+    if (vals_result) *vals_result = vals;
     if (n == 0 || batch == 0) return BVH_AMD_OK;
     StreamScope scratch_on(stream);
     constexpr int kTile = RadixShape<K>::kTile, kThreads = RadixShape<K>::kThreads;
@@ -365,7 +366,8 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
     uint32_t* const hist = hist_buf ? hist_buf : own.p;       // caller-owned scratch: fully asynchronous
     K* kin = keys; K* kout = keys_tmp; uint32_t* vin = vals; uint32_t* vout = vals_tmp;
     int passes = (bits + 7) / 8;
-    if (passes & 1) ++passes;                             // even number of passes: the result lands in keys/vals
+    if ((passes & 1) && !vals_result) ++passes;           // even number of passes: the result lands in keys/vals
+    // (a caller that passes vals_result takes the values wherever the last pass leaves them and gives up the keys)
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kThreads), 0, stream, kin, n, bpa, shift, hist);
@@ -381,6 +383,7 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
         std::swap(vin, vout);
     }
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    if (vals_result) *vals_result = vin;                  // (after the last swap: where the final pass wrote)
     if (!hist_buf && !own.pooled) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // hist is freed on return (the pool frees in stream order)
     return BVH_AMD_OK;
 }
@@ -429,9 +432,9 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
     return radix_sort_pairs<U>(skeys.p, d_ids, skeys_tmp.p, vals_tmp.p, n, batch, int(sizeof(U) * 8), stream);
 }
 
-template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool);
-template int radix_sort_pairs<uint16_t>(uint16_t*, uint32_t*, uint16_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool);
-template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool);
+template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**);
+template int radix_sort_pairs<uint16_t>(uint16_t*, uint32_t*, uint16_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**);
+template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**);
 template int std_sort_ids<float>(uint32_t*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 template int std_sort_ids<double>(uint32_t*, const double*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 

@@ -59,12 +59,13 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
 #include "trace_body.inc"
 }
 
-// Coherence key of a ray: Morton code of its origin cell (16^3 grid over the root box) above the direction octant, 15 bits, so
-// that two 8-bit radix passes order the batch. Rays of one key start in the same cell and descend the same way first; any order
-// gives the same per-ray results. Measured on 16M uniform rays (tools/ray_order_probe.py): the 1M-triangle soup 11.95 -> 9.20 ms,
-// a 10M-triangle mesh 13.9 -> 8.8 ms; finer cells or more direction bits buy < 2 % more, octant-major keys lose on the 10M mesh.
+// Coherence key of a ray: Morton code of its origin cell (64^3 grid over the root box) above the direction octant, 21 bits, three
+// 8-bit radix passes. Rays of one key start in the same cell and descend the same way first; any order gives the same per-ray
+// results. Measured with one ticket range per XCD on 2^24 uniform rays, rays physically permuted (tools/ray_order_probe.py,
+// kernel ms): 1M-triangle soup 12.09 as given, 7.52 / 7.28 / 7.25 with 4 / 5 / 6 bits per axis + octant; 10M-triangle mesh 13.92,
+// 7.79 / 7.41 / 7.09; octant-major and direction-cube keys lose (soup 7.81, mesh 8.25). The third pass costs ~0.13 ms.
 template <typename T>
-__global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint16_t* keys) {
+__global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     T r[8];
@@ -75,12 +76,12 @@ __global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n
     for (int k = 0; k < 3; ++k) {
         T v = q[k];
         v = v > T(0) ? v : T(0);                              // (NaN origins land in cell 0)
-        uint32_t c = v >= T(15) ? 15u : static_cast<uint32_t>(v);
-        uint32_t s = (c & 1u) | ((c & 2u) << 2) | ((c & 4u) << 4) | ((c & 8u) << 6);
+        uint32_t c = v >= T(63) ? 63u : static_cast<uint32_t>(v);
+        uint32_t s = (c & 1u) | ((c & 2u) << 2) | ((c & 4u) << 4) | ((c & 8u) << 6) | ((c & 16u) << 8) | ((c & 32u) << 10);
         code |= s << k;
     }
     const uint32_t oct = (Num<T>::sign(r[3]) ? 1u : 0u) | (Num<T>::sign(r[4]) ? 2u : 0u) | (Num<T>::sign(r[5]) ? 4u : 0u);
-    keys[i] = static_cast<uint16_t>((code << 3) | oct);
+    keys[i] = (code << 3) | oct;
 }
 
 // BVH_AMD_RAY_ORIGINAL_IDS: BVH-order index -> bvh.prim_ids[index] in place (misses keep BVH_AMD_INVALID)
@@ -456,22 +457,22 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     g_last_reordered = reorder && n < (size_t{1} << 31);
     if (g_last_reordered) {
         const uint32_t n32 = static_cast<uint32_t>(n);
-        const size_t words = 3 * n + 8 + radix_sort_hist_words(n32, 1);          // vals + tmp (u32), keys + tmp (u16), histogram
+        const size_t words = 4 * n + radix_sort_hist_words(n32, 1);              // keys + tmp, indices + tmp, histogram
         hipError_t e = hipMallocAsync(&sort_mem, words * sizeof(uint32_t), stream);
         if (e != hipSuccess) return release(fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: hipMallocAsync: ") + hipGetErrorString(e)));
-        uint32_t *vals = static_cast<uint32_t*>(sort_mem), *vt = vals + n, *hist = vt + n;
-        uint16_t *keys = reinterpret_cast<uint16_t*>(hist + radix_sort_hist_words(n32, 1)), *kt = keys + n + (n & 1);
+        uint32_t *keys = static_cast<uint32_t*>(sort_mem), *vals = keys + n, *kt = vals + n, *vt = kt + n, *hist = vt + n;
         T lo[3], sc[3];
         for (int k = 0; k < 3; ++k) {
             const T ext = b.root_bounds[2 * k + 1] - b.root_bounds[2 * k];
             lo[k] = b.root_bounds[2 * k];
-            sc[k] = ext > T(0) ? T(16) / ext : T(0);
+            sc[k] = ext > T(0) ? T(64) / ext : T(0);
         }
         hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2],
                            keys);
-        int rc = radix_sort_pairs<uint16_t>(keys, vals, kt, vt, n32, 1, 15, stream, hist, /*iota_vals=*/true, /*keys_wanted=*/false);
+        uint32_t* order = nullptr;
+        int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, 21, stream, hist, /*iota_vals=*/true, /*keys_wanted=*/false, &order);
         if (rc) return release(rc);
-        args.order = vals;
+        args.order = order;
     }
     int rc = leaf_kind == LEAF_TRIANGLE ? dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream)
                                         : dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream);

@@ -33,28 +33,39 @@ def main():
     olo, ohi = rays[:, :3].min(0).values, rays[:, :3].max(0).values
     octant = ((rays[:, 3] < 0).to(torch.int64) | ((rays[:, 4] < 0).to(torch.int64) << 1) | ((rays[:, 5] < 0).to(torch.int64) << 2))
     orders = {"as generated": None}
-    for bits in (3, 4, 5, 8):
-        orders[f"origin morton {bits}b"] = torch.argsort(morton(rays[:, :3], olo, ohi, bits), stable=True)
-    for bits in (3, 4, 5):
-        orders[f"origin morton {bits}b + octant"] = torch.argsort((morton(rays[:, :3], olo, ohi, bits) << 3) | octant, stable=True)
-    for bits in (3, 4, 5, 8):
-        orders[f"octant + origin morton {bits}b"] = torch.argsort((octant << 24) | morton(rays[:, :3], olo, ohi, bits), stable=True)
-    # origin cell, then the direction quantised on a 4x4x4 cube (6 bits)
+    m = lambda bits: morton(rays[:, :3], olo, ohi, bits)
+    def fine(bits_coarse, bits_fine):                         # the low `bits_fine` bits per axis below a coarse cell of `bits_coarse` bits per axis
+        full = m(bits_coarse + bits_fine)
+        return full >> (3 * bits_fine), full & ((1 << (3 * bits_fine)) - 1)
     dq = ((rays[:, 3:6] / rays[:, 3:6].abs().max(1, keepdim=True).values * 0.5 + 0.5).clamp(0, 1 - 1e-6) * 4).to(torch.int64)
     dkey = dq[:, 0] | (dq[:, 1] << 2) | (dq[:, 2] << 4)
-    orders["origin morton 4b + dir 6b"] = torch.argsort((morton(rays[:, :3], olo, ohi, 4) << 6) | dkey, stable=True)
-    orders["dir 6b + origin morton 4b"] = torch.argsort((dkey << 12) | morton(rays[:, :3], olo, ohi, 4), stable=True)
+    keys = {
+        "origin 4b + octant (library)": (m(4) << 3) | octant,
+        "origin 5b + octant": (m(5) << 3) | octant,
+        "origin 6b + octant": (m(6) << 3) | octant,
+        "octant + origin 4b": (octant << 12) | m(4),
+        "octant + origin 5b": (octant << 15) | m(5),
+        "origin 3b + octant + fine 1b": (fine(3, 1)[0] << 6) | (octant << 3) | fine(3, 1)[1],
+        "origin 3b + octant + fine 2b": (fine(3, 2)[0] << 9) | (octant << 6) | fine(3, 2)[1],
+        "origin 2b + octant + fine 2b": (fine(2, 2)[0] << 9) | (octant << 6) | fine(2, 2)[1],
+        "origin 2b + octant + fine 3b": (fine(2, 3)[0] << 12) | (octant << 9) | fine(2, 3)[1],
+        "origin 1b + octant + fine 4b": (fine(1, 4)[0] << 15) | (octant << 12) | fine(1, 4)[1],
+        "origin 4b + dir 6b": (m(4) << 6) | dkey,
+        "origin 3b + dir 6b + fine 1b": (fine(3, 1)[0] << 9) | (dkey << 3) | fine(3, 1)[1],
+    }
+    for name, k in keys.items():
+        orders[name] = torch.argsort(k, stable=True)
     out = torch.empty((nr, 4), dtype=torch.float32, device="cuda")
     base = None
     for name, perm in orders.items():
         r = rays if perm is None else rays[perm].contiguous()
         for _ in range(2):
-            bvh_amd.intersect(bvh, prims, r, any_hit, not any_hit, out=out)
+            bvh_amd.intersect(bvh, prims, r, any_hit, not any_hit, out=out, sort_rays=False)
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(5):
-            bvh_amd.intersect(bvh, prims, r, any_hit, not any_hit, out=out)
+            bvh_amd.intersect(bvh, prims, r, any_hit, not any_hit, out=out, sort_rays=False)
         ev1.record(); torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / 5
         if perm is None:
