@@ -502,10 +502,11 @@ def test_scratch_block_cache_across_streams_and_release(orc):
             assert lib.bvh_amd_release_cached_memory() == 0
 
 
-@pytest.mark.parametrize("cache_mb", ["0", "1"])
-def test_scratch_block_cache_off_and_tiny(cache_mb):
-    """BVH_AMD_CACHE_MB=0 (no block cache: every request goes to the pool) and =1 (every build overflows the bound and evicts): the
-    golden streams still come out. Own process: the bound is read once."""
+@pytest.mark.parametrize("knob", ["BVH_AMD_CACHE_MB=0", "BVH_AMD_CACHE_MB=1", "BVH_AMD_POOL=0"])
+def test_scratch_block_cache_off_and_tiny(knob):
+    """BVH_AMD_CACHE_MB=0 (no block cache: every request goes to the pool), =1 (every build overflows the bound and evicts) and
+    BVH_AMD_POOL=0 (plain hipMalloc / hipFree with the synchronisations that needs): the golden streams still come out. Own process:
+    the knobs are read once."""
     import subprocess, sys, os
     code = (
         "import numpy as np, bvh_amd, sys\n"
@@ -519,5 +520,5 @@ def test_scratch_block_cache_off_and_tiny(cache_mb):
         "        assert b.serialize() == g['bvh_parallel_' + name].tobytes(), (rep, name)\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, BVH_AMD_CACHE_MB=cache_mb), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **dict([knob.split("=")])), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
