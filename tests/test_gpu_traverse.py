@@ -43,6 +43,12 @@ def test_golden_hits(scene, mode, any_hit, robust):
     assert (cnt.cpu().numpy().astype(np.uint64) == g[f"counters_{key}"]).all()
     hits2 = bvh_amd.intersect(bvh, prims, rays, any_hit, robust, leaf="sphere" if "spheres" in scene else "tri")
     assert bvh_amd.hits_to_numpy(hits2).tobytes() == g[f"hits_{key}"].tobytes()
+    # the batch repeated until it is long enough to be reordered inside the call (every scalar type / leaf / variant): same records
+    reps = 4096 // len(rays) + 2
+    many = np.tile(rays, (reps, 1))
+    hits3 = bvh_amd.intersect(bvh, prims, many, any_hit, robust, leaf="sphere" if "spheres" in scene else "tri", sort_rays=True)
+    assert bvh_amd._lib.load().bvh_amd_last_launch_reordered() == 1
+    assert bvh_amd.hits_to_numpy(hits3).tobytes() == np.tile(g[f"hits_{key}"], reps).tobytes()
 
 
 def test_prep_kernels_match_oracle(orc):
