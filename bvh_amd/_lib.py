@@ -60,6 +60,16 @@ _SIGS = {
     "bvh_amd_release_cached_memory": (_I, []),
     "bvh_amd_device_count": (_I, []),
     "bvh_amd_device_name": (_I, [_I, C.c_char_p, _Z]),
+    "bvh_amd_device_select": (_I, [_I]),
+    "bvh_amd_device_current": (_I, []),
+    "bvh_amd_comm_unique_id": (_I, [_P]),
+    "bvh_amd_comm_create": (_P, [_P, _I, _I]),
+    "bvh_amd_comm_adopt": (_P, [_P]),
+    "bvh_amd_comm_destroy": (None, [_P]),
+    "bvh_amd_comm_rank": (_I, [_P]),
+    "bvh_amd_comm_size": (_I, [_P]),
+    "bvh_amd_comm_handle": (_P, [_P]),
+    "bvh_amd_comm_broadcast": (_I, [_P, _P, _Z, _I, _P]),
     "bvh_thread_pool_create": (_P, [_Z]),
     "bvh_thread_pool_destroy": (None, [_P]),
     "bvh_amd_gather": (_I, [_P, _P, _Z, _Z, _P, _P]),
@@ -101,6 +111,8 @@ _SIGS_T = {
     "bvh{S}_deserialize": (_P, [_P, _Z]),
     "bvh{S}_serialize_device": (_Z, [_P, _P, _Z, _P]),
     "bvh{S}_deserialize_device": (_P, [_P, _Z, _P]),
+    "bvh{S}_broadcast": (_P, [_P, _I, _P, _P, _Z, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _P]),
+    "bvh{S}_replicate": (_I, [_P, _P, _Z, _I, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "bvh{S}_get_node": (_P, [_P, _Z]),
     "bvh{S}_get_prim_id": (_Z, [_P, _Z]),
     "bvh{S}_get_prim_count": (_Z, [_P]),

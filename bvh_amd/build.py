@@ -58,7 +58,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     raise RuntimeError(f"hipcc failed on {s}")
     objs = [os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if jobs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # librccl: the scene broadcast of the multi-GPU path lives inside the library (csrc/replicate.hip)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             sys.stderr.write(r.stdout + r.stderr)

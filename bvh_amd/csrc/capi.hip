@@ -212,8 +212,12 @@ int make_nodes_resident(BvhImpl<T>& b) {
         BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
     } else if (b.host_valid) {                                 // the host mirror may have been edited through bvh_node* pointers
         BVH_HIP_TRY(hipMemcpy(b.d_nodes, b.nodes.data(), bytes, hipMemcpyHostToDevice), BVH_AMD_ERR_HIP);
+    } else {
+        return BVH_AMD_OK;                                     // resident nodes written by the device builders / a validated upload
     }
-    return BVH_AMD_OK;
+    // whatever came from the host mirror may have been edited by the caller (bvh_node*_set_*): the kernels that walk these nodes
+    // (refit, optimize, extract, the traversal records built from them) rely on the structure wire.hip checks
+    return validate_resident_nodes<T>(b.d_nodes, b.node_count, b.prim_count, nullptr, "sync (host mirror -> device)");
 }
 
 // Bvh::serialize into / Bvh::deserialize out of DEVICE memory (wire.hip): the broadcast payload never visits the host.
@@ -480,6 +484,11 @@ void intersect_ray_legacy(const BvhImpl<T>* b, const void* ray, const Callback* 
 }
 
 } // namespace
+
+template <typename T> int nodes_resident(BvhImpl<T>& b) { return make_nodes_resident<T>(b); }
+template int nodes_resident<float>(BvhImpl<float>&);
+template int nodes_resident<double>(BvhImpl<double>&);
+
 } // namespace bvh_amd
 
 using namespace bvh_amd;

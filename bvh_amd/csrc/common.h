@@ -193,6 +193,7 @@ template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d
 template <typename T> size_t wire_size(const BvhImpl<T>& b);
 template <typename T> size_t serialize_to_device(const BvhImpl<T>& b, void* d_out, size_t cap, hipStream_t stream);
 template <typename T> BvhImpl<T>* deserialize_from_device(const void* d_bytes, size_t size, int dim, hipStream_t stream);
+template <typename T> int nodes_resident(BvhImpl<T>& b);   // capi.hip: reference-layout nodes resident on the device, host edits pushed and re-validated
 template <typename T> int validate_resident_nodes(const HostNode<T>* d_nodes, size_t nn, size_t np, hipStream_t stream, const char* who);
 
 // traverse.hip

@@ -57,9 +57,11 @@ __global__ void __launch_bounds__(256) k_wire_ids_in(const I* in, size_t n, uint
 // What the traversal records rely on (upload.hip: pair p = nodes[2p + 1], nodes[2p + 2]): every inner node's children are an
 // adjacent pair that starts at an odd id inside the array, every leaf's range lies inside prim_ids. A stream from an untrusted
 // source that breaks this would be walked with misaligned pairs / out-of-bounds reads; it is refused instead.
-// `refs[p]` counts the inner nodes whose children are pair p. With every pair referenced exactly once and node 0 referenced by
-// nobody, whatever is reachable from the root is a tree: a walk from the root cannot run in a cycle, and the depth computed
-// for the traversal stack bounds it.
+// `refs[p]` counts the inner nodes whose children are pair p. Node 0 belongs to no pair, so a cycle reachable from the root
+// needs a pair with two parents: with no pair referenced more than once, whatever is reachable from the root is a tree, a walk
+// from the root cannot run in a cycle, and the depth computed for the traversal stack bounds it. Pairs nobody references
+// (nodes left unused after append_node / remove_last_node edits, hand-built arrays) are never visited and are tolerated, as
+// the reference tolerates them.
 template <typename T>
 __global__ void __launch_bounds__(256) k_validate_nodes(const HostNode<T>* nodes, size_t nn, size_t np, uint32_t* refs, uint32_t* bad) {
     const size_t i = blockIdx.x * size_t{256} + threadIdx.x;
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(256) k_validate_nodes(const HostNode<T>* nodes
 }
 __global__ void __launch_bounds__(256) k_validate_refs(const uint32_t* refs, size_t n_pairs, uint32_t* bad) {
     const size_t p = blockIdx.x * size_t{256} + threadIdx.x;
-    if (p < n_pairs && refs[p] != 1u) atomicOr(bad, 8u);
+    if (p < n_pairs && refs[p] > 1u) atomicOr(bad, 8u);
 }
 
 template <typename T>
@@ -92,7 +94,7 @@ int check_nodes(const HostNode<T>* d_nodes, size_t nn, size_t np, uint32_t* d_ba
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
     if (bad & 1u) return fail(BVH_AMD_ERR_ARG, std::string(who) + ": an inner node's children are not an adjacent pair at an odd index inside the node array");
     if (bad & 2u) return fail(BVH_AMD_ERR_ARG, std::string(who) + ": a leaf's primitive range lies outside prim_ids");
-    if (bad & 8u) return fail(BVH_AMD_ERR_ARG, std::string(who) + ": some sibling pair is the child of no inner node or of several (not a tree)");
+    if (bad & 8u) return fail(BVH_AMD_ERR_ARG, std::string(who) + ": some sibling pair is the child of several inner nodes (not a tree)");
     if (bad & 4u) return fail(BVH_AMD_ERR_UNSUPPORTED, std::string(who) + ": primitive id beyond 2^28 (32-bit device indices)");
     return BVH_AMD_OK;
 }

@@ -1,11 +1,19 @@
 """Multi-GPU: ray batches shard embarrassingly; the only exchange is one broadcast of the scene.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo" in CPU tests).
-The BVH travels in the reference's own byte format (Bvh::serialize, reference bvh.h:221-229) followed by the
-BVH-ordered primitive array; a broadcast from the building rank is bound by one xGMI link per peer with all
-peers served in parallel, so no ring collective is used anywhere. Build: replicas only.
+One process per GPU. The exchange itself runs INSIDE libbvh_amd.so (csrc/replicate.hip: `bvh_amd_comm_*`, `bvhXX_broadcast`):
+the building rank writes the reference's byte stream (Bvh::serialize, reference bvh.h:221-229) into HBM straight from its
+resident nodes, RCCL broadcasts that device buffer and the BVH-ordered primitive array root-to-all over xGMI, every other rank
+turns the received buffer into resident nodes + traversal records on its device — no payload byte visits a host.
+`torch.distributed` is plumbing only: it carries the 128-byte RCCL unique id to the ranks (any backend) and provides the
+barrier of bench.py. Build: replicas only.
+
+Where RCCL cannot be used — the CPU test-suite and the one-GPU functional runs, where several ranks share a device and
+ncclCommInitRank refuses — the same device buffers are staged through host tensors around a `torch.distributed` (gloo)
+broadcast: `transport="staged"`. The transport actually used is reported in `timing["transport"]`.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 
@@ -33,11 +41,6 @@ def broadcast_bytes(data, src: int = 0, device=None) -> bytes:
     return data if rank == src else buf.cpu().numpy().tobytes()
 
 
-def _coll_device():
-    import torch.distributed as dist
-    return "cuda" if dist.get_backend() == "nccl" else "cpu"
-
-
 def broadcast_tensor(t, shape_hint=None, src: int = 0, dtype=None, device=None):
     """Broadcasts a tensor whose shape only `src` knows."""
     import torch
@@ -57,53 +60,164 @@ def broadcast_tensor(t, shape_hint=None, src: int = 0, dtype=None, device=None):
     return t
 
 
-def broadcast_scene(bvh, prims, src: int = 0, timing: dict = None):
+class Comm:
+    """An RCCL communicator owned by libbvh_amd.so (include/bvh_amd.h: bvh_amd_comm_*), bound to this process's current GPU."""
+
+    def __init__(self, handle, owner: bool = True):
+        from . import _lib
+        if not handle:
+            raise _lib.BvhAmdError(_lib.last_error())
+        self._h, self._lib, self._owner = handle, _lib.load(), owner
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._owner:
+            self._lib.bvh_amd_comm_destroy(self._h)
+        self._h = None
+
+    @property
+    def rank(self) -> int:
+        return self._lib.bvh_amd_comm_rank(self._h)
+
+    @property
+    def size(self) -> int:
+        return self._lib.bvh_amd_comm_size(self._h)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().bvh_amd_comm_unique_id(buf), "comm_unique_id")
+        return buf.raw
+
+    @staticmethod
+    def create(unique_id: bytes, n_ranks: int, rank: int) -> "Comm":
+        from . import _lib
+        assert len(unique_id) == 128
+        return Comm(_lib.load().bvh_amd_comm_create(unique_id, n_ranks, rank))
+
+    @staticmethod
+    def from_torch_distributed() -> "Comm":
+        """Every rank of the default process group calls this: rank 0 draws the RCCL unique id, torch.distributed carries its 128
+        bytes (whatever the backend), every rank joins with ncclCommInitRank on its current GPU."""
+        import torch.distributed as dist
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        box = [Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return Comm.create(box[0], world, rank)
+
+    def broadcast_(self, tensor, root: int = 0):
+        """ncclBroadcast of a contiguous CUDA tensor, in place, on the current stream."""
+        from . import _lib
+        from .api import _stream
+        assert tensor.is_cuda and tensor.is_contiguous()
+        _lib.check(self._lib.bvh_amd_comm_broadcast(self._h, tensor.data_ptr(), tensor.numel() * tensor.element_size(), root, _stream()),
+                   "comm_broadcast")
+        return tensor
+
+
+_default_comm = None
+
+
+def default_comm() -> Comm:
+    """The process-wide communicator over the default torch.distributed group (created by all ranks on first use)."""
+    global _default_comm
+    if _default_comm is None:
+        _default_comm = Comm.from_torch_distributed()
+    return _default_comm
+
+
+def _pick_transport(transport):
+    import torch.distributed as dist
+    if transport is None:
+        transport = "rccl" if (not dist.is_initialized() or dist.get_backend() == "nccl") else "staged"
+    if transport not in ("rccl", "staged"):
+        raise ValueError("transport must be 'rccl' or 'staged'")
+    return transport
+
+
+def broadcast_scene(bvh, prims, src: int = 0, timing: dict = None, comm: Comm = None, transport: str = None):
     """Rank `src` holds (Bvh, BVH-ordered primitive tensor); every rank returns its own device-resident copy.
 
-    The payload is the reference's `Bvh::serialize` byte stream (bvh.h:221-229) written into HBM by `Bvh.serialize_device`, one
-    `torch.distributed.broadcast` of that device buffer (backend nccl = RCCL over xGMI: root-to-all, no ring), and
-    `Bvh.deserialize_device` on the receivers; then the primitive array the same way. With RCCL no payload byte touches the
-    host on any rank. (gloo, CPU tests only: gloo cannot move device memory, so the same device buffers are staged through
-    host tensors around the collective.) `timing`, if given, receives {"broadcast_ms", "payload_bytes"} (wall time of the whole
-    exchange on this rank, device-synchronised)."""
+    transport "rccl" (default whenever the process group's backend is nccl, or no group exists): three RCCL broadcasts issued by
+    libbvh_amd.so on the current stream — a header, the `Bvh::serialize` stream produced and consumed on the device
+    (`bvhXX_broadcast`), the primitive array (`bvh_amd_comm_broadcast` into a torch-owned tensor) — nothing staged on a host.
+    transport "staged" (gloo groups: CPU tests, several ranks on one GPU): the same device buffers through host tensors and
+    `torch.distributed.broadcast`. `timing`, if given, receives {"broadcast_ms", "payload_bytes", "transport"} (wall time of
+    the whole exchange on this rank, device-synchronised)."""
     import time
     import torch
     import torch.distributed as dist
-    from .api import Bvh
-    rank = dist.get_rank()
-    on_device = dist.get_backend() == "nccl"
-    coll = "cuda" if on_device else "cpu"
+    from . import _lib
+    from .api import Bvh, _stream, _suffix
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    transport = _pick_transport(transport)
+    # everything that can raise on `src` alone happens before the first collective, so that the ranks cannot diverge
+    meta_h = [0] * 8                                           # ndim, shape[0..3], is_double, bvh dim, stream bytes
+    if rank == src:
+        if bvh is None or prims is None:
+            raise ValueError("broadcast_scene: the source rank passes its Bvh and primitive tensor")
+        if not (torch.is_tensor(prims) and prims.is_cuda):
+            raise TypeError("broadcast_scene: prims must be a CUDA tensor")
+        if prims.dim() < 1 or prims.dim() > 4:
+            raise ValueError("broadcast_scene: prims must have 1 to 4 dimensions")
+        want = torch.float64 if bvh.dtype == np.float64 else torch.float32
+        if prims.dtype != want:
+            raise TypeError("broadcast_scene: prims dtype must match the BVH scalar type")
+        prims = prims.contiguous()
+        meta_h[0] = prims.dim()
+        for i, s in enumerate(prims.shape):
+            meta_h[1 + i] = int(s)
+        meta_h[5], meta_h[6] = int(bvh.dtype == np.float64), bvh.dim
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    meta = torch.zeros(5, dtype=torch.int64, device=coll)      # stream bytes, is_double, dim, prims rows, prims cols
-    buf = None
-    if rank == src:
-        buf = bvh.serialize_device()
-        meta[0], meta[1], meta[2] = buf.numel(), int(bvh.dtype == np.float64), bvh.dim
-        meta[3], meta[4] = prims.shape[0], prims.shape[1]
-    dist.broadcast(meta, src)
-    m = [int(v) for v in meta.tolist()]
-    dtype = np.float64 if m[1] else np.float32
-    tdt = torch.float64 if m[1] else torch.float32
-    if on_device:
+    if transport == "rccl":
+        comm = comm or default_comm()
+        lib = _lib.load()
+        meta = torch.tensor(meta_h, dtype=torch.int64, device="cuda")
+        comm.broadcast_(meta, src)
+        m = [int(v) for v in meta.tolist()]
+        shape = tuple(m[1:1 + m[0]])
+        tdt = torch.float64 if m[5] else torch.float32
+        s = _suffix(np.dtype(np.float64 if m[5] else np.float32), m[6])
+        out_prims, out_bytes = C.c_void_p(0), C.c_size_t(0)
+        h = getattr(lib, f"bvh{s}_broadcast")(comm._h, src, bvh._h if rank == src else None, None, 0, C.byref(out_prims), C.byref(out_bytes), _stream())
+        if not h:
+            raise _lib.BvhAmdError(f"bvh{s}_broadcast: {_lib.last_error()}")
         if rank != src:
-            buf = torch.empty(m[0], dtype=torch.uint8, device="cuda")
-            prims = torch.empty((m[3], m[4]), dtype=tdt, device="cuda")
-        dist.broadcast(buf, src)
-        dist.broadcast(prims, src)
+            bvh = Bvh(h, s)
+            prims = torch.empty(shape, dtype=tdt, device="cuda")
+        elif h != bvh._h:                                      # BVH_AMD_BROADCAST_LOOPBACK=1 (test knob): the root got a received copy
+            bvh = Bvh(h, s)
+        comm.broadcast_(prims, src)
+        stream_bytes = 0                                       # (the library does not report it; recomputed below)
     else:
-        hbuf = buf.cpu() if rank == src else torch.empty(m[0], dtype=torch.uint8)
-        hprims = prims.cpu() if rank == src else torch.empty((m[3], m[4]), dtype=tdt)
+        meta = torch.tensor(meta_h, dtype=torch.int64)
+        buf = None
+        if rank == src:
+            buf = bvh.serialize_device()
+            meta[7] = buf.numel()
+        dist.broadcast(meta, src)
+        m = [int(v) for v in meta.tolist()]
+        shape = tuple(m[1:1 + m[0]])
+        tdt = torch.float64 if m[5] else torch.float32
+        hbuf = buf.cpu() if rank == src else torch.empty(m[7], dtype=torch.uint8)
+        hprims = prims.cpu() if rank == src else torch.empty(shape, dtype=tdt)
         dist.broadcast(hbuf, src)
         dist.broadcast(hprims, src)
         if rank != src:
-            buf, prims = hbuf.cuda(), hprims.cuda()
-    if rank != src:
-        bvh = Bvh.deserialize_device(buf, dtype=dtype, dim=m[2])
+            prims = hprims.cuda()
+            bvh = Bvh.deserialize_device(hbuf.cuda(), dtype=np.float64 if m[5] else np.float32, dim=m[6])
+        stream_bytes = m[7]
     torch.cuda.synchronize()
     if timing is not None:
+        if not stream_bytes:
+            idx = 8 if bvh.dtype == np.float64 else 4
+            stream_bytes = 2 * idx + bvh.node_count * (2 * bvh.dim * (8 if bvh.dtype == np.float64 else 4) + idx) + bvh.prim_count * idx
         timing["broadcast_ms"] = (time.perf_counter() - t0) * 1e3
-        timing["payload_bytes"] = m[0] + m[3] * m[4] * (8 if m[1] else 4)
+        timing["payload_bytes"] = int(stream_bytes + prims.numel() * prims.element_size())
+        timing["transport"] = ("RCCL (ncclBroadcast issued by libbvh_amd.so, device buffers end to end)" if transport == "rccl"
+                               else "torch.distributed/" + dist.get_backend() + " with host staging (functional path, not RCCL)")
     return bvh, prims
 
 

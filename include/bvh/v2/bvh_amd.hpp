@@ -301,6 +301,8 @@ template <> struct Api<float, 3> {
     static int optimize_config(Handle* h, const bvh_amd_optimize_config* c) { return bvh3f_optimize_config(h, c); }
     static void refit(Handle* h) { bvh3f_refit(h); }
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh3f_device_prim_ids(h); }
+    static Handle* broadcast(bvh_amd_comm* c, int root, Handle* h, const void* p, size_t bytes, void** p_out, size_t* bytes_out) { return bvh3f_broadcast(c, root, h, p, bytes, p_out, bytes_out, nullptr); }
+    static int replicate(Handle* h, const void* p, size_t bytes, int n, const int* devs, Handle** out, void** p_out) { return bvh3f_replicate(h, p, bytes, n, devs, out, p_out); }
     static int precompute(const void* t9, const uint32_t* perm, size_t n, void* out) { return bvh_amd_precompute_tris3f(static_cast<const float*>(t9), perm, n, static_cast<float*>(out), nullptr); }
     static int trace_tri(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3f_intersect_rays_tri(h, static_cast<const float*>(prims), static_cast<const bvh_ray3f*>(rays), n, f, static_cast<bvh_hit3f*>(hits), nullptr, nullptr); }
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3f_intersect_rays_sphere(h, static_cast<const float*>(prims), static_cast<const bvh_ray3f*>(rays), n, f, static_cast<bvh_hit3f*>(hits), nullptr, nullptr); }
@@ -327,6 +329,8 @@ template <> struct Api<double, 3> {
     static int optimize_config(Handle* h, const bvh_amd_optimize_config* c) { return bvh3d_optimize_config(h, c); }
     static void refit(Handle* h) { bvh3d_refit(h); }
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh3d_device_prim_ids(h); }
+    static Handle* broadcast(bvh_amd_comm* c, int root, Handle* h, const void* p, size_t bytes, void** p_out, size_t* bytes_out) { return bvh3d_broadcast(c, root, h, p, bytes, p_out, bytes_out, nullptr); }
+    static int replicate(Handle* h, const void* p, size_t bytes, int n, const int* devs, Handle** out, void** p_out) { return bvh3d_replicate(h, p, bytes, n, devs, out, p_out); }
     static int precompute(const void* t9, const uint32_t* perm, size_t n, void* out) { return bvh_amd_precompute_tris3d(static_cast<const double*>(t9), perm, n, static_cast<double*>(out), nullptr); }
     static int trace_tri(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3d_intersect_rays_tri(h, static_cast<const double*>(prims), static_cast<const bvh_ray3d*>(rays), n, f, static_cast<bvh_hit3d*>(hits), nullptr, nullptr); }
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh3d_intersect_rays_sphere(h, static_cast<const double*>(prims), static_cast<const bvh_ray3d*>(rays), n, f, static_cast<bvh_hit3d*>(hits), nullptr, nullptr); }
@@ -355,6 +359,8 @@ template <> struct Api<T, 2> {                                                  
     static int optimize_config(Handle* h, const bvh_amd_optimize_config* c) { return bvh##S##_optimize_config(h, c); }                    \
     static void refit(Handle* h) { bvh##S##_refit(h); }                                                                                   \
     static const uint32_t* device_prim_ids(const Handle* h) { return bvh##S##_device_prim_ids(h); }                                       \
+    static Handle* broadcast(bvh_amd_comm* c, int root, Handle* h, const void* p, size_t bytes, void** p_out, size_t* bytes_out) { return bvh##S##_broadcast(c, root, h, p, bytes, p_out, bytes_out, nullptr); } \
+    static int replicate(Handle* h, const void* p, size_t bytes, int n, const int* devs, Handle** out, void** p_out) { return bvh##S##_replicate(h, p, bytes, n, devs, out, p_out); } \
     static int trace_sphere(const Handle* h, const void* prims, const void* rays, size_t n, unsigned f, void* hits) { return bvh##S##_intersect_rays_sphere(h, static_cast<const T*>(prims), static_cast<const bvh_ray##S*>(rays), n, f, static_cast<CHit*>(hits), nullptr, nullptr); } \
     static int visit(const Handle* h, const void* ray, size_t start, unsigned f, void* user, bool (*leaf)(void*, T*, size_t, size_t), void (*inner)(void*, size_t)) { \
         const std::conditional_t<std::is_same_v<T, float>, bvh_amd_ray_visitorf, bvh_amd_ray_visitord> v{ user, leaf, inner };           \
@@ -508,6 +514,7 @@ struct Bvh {
         if (!device_) const_cast<Bvh*>(this)->push();
         return device_.get();
     }
+    void share(const Bvh& o) { nodes = o.nodes; prim_ids = o.prim_ids; device_ = o.device_; }     // the same device twin, one more owner
     void adopt(typename amd::Api<Scalar, Node::dimension>::Handle* h) {
         device_ = std::shared_ptr<typename amd::Api<Scalar, Node::dimension>::Handle>(h, [](auto* p) { amd::Api<Scalar, Node::dimension>::destroy(p); });
         pull();
@@ -720,6 +727,68 @@ void intersect_batch(const Bvh<Node>& bvh, const DeviceArray<Sphere<typename Nod
     DeviceArray<Hit<T>> d_hits(rays.size());
     check(Api<T, Node::dimension>::trace_sphere(bvh.device(), spheres.data(), d_rays.data(), rays.size(), flags, d_hits.data()), "intersect_rays_sphere");
     d_hits.download(hits);
+}
+
+// ---- multi-GPU: rays shard, the scene is broadcast once over RCCL inside the library -------------------------------
+// A device-resident scene: the BVH (host mirror filled on demand) and its BVH-ordered primitives on ONE device.
+template <typename Node, typename Prim>
+struct DeviceScene {
+    int device = 0;
+    Bvh<Node> bvh;
+    Prim* prims = nullptr;                                    // device memory of `device`
+    size_t prim_count = 0;
+    bool owns_prims = false;
+    DeviceScene() = default;
+    DeviceScene(DeviceScene&& o) noexcept : device(o.device), bvh(std::move(o.bvh)), prims(o.prims), prim_count(o.prim_count), owns_prims(o.owns_prims) { o.prims = nullptr; o.owns_prims = false; }
+    DeviceScene& operator=(DeviceScene&&) = delete;
+    ~DeviceScene() {
+        if (owns_prims && prims) { const int cur = bvh_amd_device_current(); bvh_amd_device_select(device); bvh_amd_device_free(prims); if (cur >= 0) bvh_amd_device_select(cur); }
+    }
+};
+
+// One process, several GPUs: a copy of (bvh, prims) on every device of `devices` (the BVH's own device among them); entry i
+// belongs to devices[i]. Trace shard i with `bvh_amd_device_select(devices[i])` current. (bvhXX_replicate)
+template <typename Node, typename Prim>
+std::vector<DeviceScene<Node, Prim>> replicate(const Bvh<Node>& bvh, const DeviceArray<Prim>& prims, std::span<const int> devices) {
+    using A = Api<typename Node::Scalar, Node::dimension>;
+    std::vector<typename A::Handle*> handles(devices.size(), nullptr);
+    std::vector<void*> ptrs(devices.size(), nullptr);
+    check(A::replicate(bvh.device(), prims.data(), prims.size() * sizeof(Prim), static_cast<int>(devices.size()), devices.data(), handles.data(), ptrs.data()),
+          "replicate");
+    std::vector<DeviceScene<Node, Prim>> out(devices.size());
+    const int cur = bvh_amd_device_current();
+    for (size_t i = 0; i < devices.size(); ++i) {
+        out[i].device = devices[i];
+        out[i].prims = static_cast<Prim*>(ptrs[i]);
+        out[i].prim_count = prims.size();
+        if (handles[i] == bvh.device()) { out[i].bvh.share(bvh); continue; }                 // the original, not owned twice
+        out[i].owns_prims = true;
+        bvh_amd_device_select(devices[i]);
+        out[i].bvh.adopt(handles[i]);
+    }
+    if (cur >= 0) bvh_amd_device_select(cur);
+    return out;
+}
+
+// One process per GPU: every rank calls it with the same `root`; the root passes its scene, the others empty objects.
+// `comm` from bvh_amd_comm_create (or bvh_amd_comm_adopt of an ncclComm_t the program already has). (bvhXX_broadcast)
+template <typename Node, typename Prim>
+DeviceScene<Node, Prim> broadcast(bvh_amd_comm* comm, int root, const Bvh<Node>* bvh, const DeviceArray<Prim>* prims) {
+    using A = Api<typename Node::Scalar, Node::dimension>;
+    const bool is_root = bvh_amd_comm_rank(comm) == root;
+    void* out_prims = nullptr;
+    size_t out_bytes = 0;
+    typename A::Handle* mine = is_root && bvh ? bvh->device() : nullptr;
+    typename A::Handle* h = A::broadcast(comm, root, mine, is_root && prims ? prims->data() : nullptr, is_root && prims ? prims->size() * sizeof(Prim) : 0,
+                                         &out_prims, &out_bytes);
+    if (!h) throw Error(std::string("broadcast: ") + bvh_amd_last_error());
+    DeviceScene<Node, Prim> out;
+    out.device = bvh_amd_device_current();
+    out.prims = static_cast<Prim*>(out_prims);
+    out.prim_count = out_bytes / sizeof(Prim);
+    if (h == mine) out.bvh.share(*bvh);
+    else { out.owns_prims = true; out.bvh.adopt(h); }
+    return out;
 }
 
 } // namespace amd

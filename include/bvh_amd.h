@@ -151,6 +151,48 @@ BVH_AMD_API int bvh_amd_release_cached_memory(void);
 BVH_AMD_API int bvh_amd_probe_record_walk(const void* d_table, uint32_t n_records, uint32_t steps, int blocks_per_cu, int reps,
                                           float* ms_out, unsigned long long* records_out, void* stream);
 
+/* ---- multi-GPU (the "required extension" of 8b: device select + replicate) ------------------------------------
+ * Ray batches shard embarrassingly (a const Bvh + per-ray state, reference bvh.h:160-182 touches nothing shared); the ONE
+ * exchange of the path is a root-to-all broadcast of the scene over RCCL / xGMI: the Bvh::serialize byte stream (reference
+ * bvh.h:221-229) written into HBM straight from the resident nodes, and the BVH-ordered primitive array. It runs inside this
+ * library (csrc/replicate.hip, linked against librccl); no payload byte visits the host on any rank. A BVH is bound to the device
+ * it was built / received on; bvhXX_intersect_rays_* must be called with that device current (bvh_amd_device_select).
+ *   one process per GPU: rank 0 calls bvh_amd_comm_unique_id, the 128 bytes travel by any side channel (a file, MPI, torch's
+ *     store), every rank calls bvh_amd_comm_create on ITS device, then bvhXX_broadcast; or wrap an ncclComm_t you already have
+ *     with bvh_amd_comm_adopt;
+ *   one process, N GPUs (what a C caller of the reference API would do): bvhXX_replicate.                                        */
+#define BVH_AMD_COMM_ID_BYTES 128
+struct bvh_amd_comm;                                   /* an RCCL communicator + its rank / size / device */
+BVH_AMD_API int bvh_amd_device_select(int device);     /* hipSetDevice for the calling thread: following builds / uploads live there */
+BVH_AMD_API int bvh_amd_device_current(void);          /* < 0 on HIP failure */
+BVH_AMD_API int bvh_amd_comm_unique_id(void* id_out /* BVH_AMD_COMM_ID_BYTES */);                   /* ncclGetUniqueId */
+BVH_AMD_API struct bvh_amd_comm* bvh_amd_comm_create(const void* id, int n_ranks, int rank);        /* ncclCommInitRank on the current device; NULL on failure */
+BVH_AMD_API struct bvh_amd_comm* bvh_amd_comm_adopt(void* nccl_comm /* ncclComm_t, stays yours */);
+BVH_AMD_API void bvh_amd_comm_destroy(struct bvh_amd_comm*);
+BVH_AMD_API int bvh_amd_comm_rank(const struct bvh_amd_comm*);
+BVH_AMD_API int bvh_amd_comm_size(const struct bvh_amd_comm*);
+BVH_AMD_API void* bvh_amd_comm_handle(const struct bvh_amd_comm*);                                  /* the ncclComm_t */
+/* ncclBroadcast of a raw device buffer, in place, on `stream` (e.g. the scene box the ray generators need) */
+BVH_AMD_API int bvh_amd_comm_broadcast(struct bvh_amd_comm*, void* d_buf, size_t bytes, int root, void* stream);
+/* Collective: EVERY rank of the communicator calls it. The root passes its BVH and the BVH-ordered primitive array
+ * (prim_bytes bytes of device memory); the others pass NULL / NULL / 0. Returns this rank's device-resident BVH — the root's own
+ * object on the root, a new one elsewhere (bvhXX_destroy) — and in *d_prims_out this rank's primitive array (the root's own
+ * pointer on the root, otherwise a new buffer to release with bvh_amd_device_free); *prim_bytes_out (may be NULL) its size.
+ * NULL on failure (bvh_amd_last_error; a root that has nothing valid to send tells the others through the header, so nobody
+ * hangs). When it returns, the BVH is ready on `stream`'s device and the buffers may be used from any stream.                 */
+BVH_AMD_API struct bvh3f* bvh3f_broadcast(struct bvh_amd_comm*, int root, struct bvh3f* bvh, const void* d_prims, size_t prim_bytes,
+                                          void** d_prims_out, size_t* prim_bytes_out, void* stream);
+BVH_AMD_API struct bvh3d* bvh3d_broadcast(struct bvh_amd_comm*, int root, struct bvh3d* bvh, const void* d_prims, size_t prim_bytes,
+                                          void** d_prims_out, size_t* prim_bytes_out, void* stream);
+/* One process, several GPUs: copies the scene from the BVH's own device to every other device of `devices` (NULL: 0 ..
+ * n_devices - 1; the BVH's device must be among them) with ncclCommInitAll + one grouped ncclBroadcast. bvhs_out[i] /
+ * d_prims_out[i] belong to devices[i]; the entry of the BVH's own device holds the original pointers, the others are new
+ * (bvhXX_destroy / bvh_amd_device_free with that device current). The calling thread's current device is left unchanged.      */
+BVH_AMD_API int bvh3f_replicate(struct bvh3f* bvh, const void* d_prims, size_t prim_bytes, int n_devices, const int* devices,
+                                struct bvh3f** bvhs_out, void** d_prims_out);
+BVH_AMD_API int bvh3d_replicate(struct bvh3d* bvh, const void* d_prims, size_t prim_bytes, int n_devices, const int* devices,
+                                struct bvh3d** bvhs_out, void** d_prims_out);
+
 /* ---- thread pool (c_api/bvh.h:90-91). Kept for signature compatibility; the GPU grid replaces it.
  * A non-NULL pool selects the reference's *parallel* builder semantics (mini-trees). ------------- */
 BVH_AMD_API struct bvh_thread_pool* bvh_thread_pool_create(size_t thread_count);
@@ -498,6 +540,15 @@ BVH_AMD_API int bvh2f_intersect_ray_visit(const struct bvh2f*, const struct bvh_
     const struct bvh_amd_ray_visitorf*);
 BVH_AMD_API int bvh2d_intersect_ray_visit(const struct bvh2d*, const struct bvh_ray2d*, size_t start_index, unsigned flags,
     const struct bvh_amd_ray_visitord*);
+/* multi-GPU for the 2D families: see bvh3f_broadcast / bvh3f_replicate */
+BVH_AMD_API struct bvh2f* bvh2f_broadcast(struct bvh_amd_comm*, int root, struct bvh2f* bvh, const void* d_prims, size_t prim_bytes,
+                                          void** d_prims_out, size_t* prim_bytes_out, void* stream);
+BVH_AMD_API struct bvh2d* bvh2d_broadcast(struct bvh_amd_comm*, int root, struct bvh2d* bvh, const void* d_prims, size_t prim_bytes,
+                                          void** d_prims_out, size_t* prim_bytes_out, void* stream);
+BVH_AMD_API int bvh2f_replicate(struct bvh2f* bvh, const void* d_prims, size_t prim_bytes, int n_devices, const int* devices,
+                                struct bvh2f** bvhs_out, void** d_prims_out);
+BVH_AMD_API int bvh2d_replicate(struct bvh2d* bvh, const void* d_prims, size_t prim_bytes, int n_devices, const int* devices,
+                                struct bvh2d** bvhs_out, void** d_prims_out);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ def _compile(out, src=SRC):
 def test_cpp_mirror_compiles_with_gxx(tmp_path):
     _compile(str(tmp_path / "circles_2d_amd"), os.path.join(ROOT, "tests", "cpp", "circles_2d_amd.cpp"))     # Node<T, 2>
     _compile(str(tmp_path / "serialize_amd"), os.path.join(ROOT, "tests", "cpp", "serialize_amd.cpp"))       # streams
+    _compile(str(tmp_path / "replicate_amd"), os.path.join(ROOT, "tests", "cpp", "replicate_amd.cpp"))       # multi-GPU mirror
     exe = _compile(str(tmp_path / "simple_example_amd"))
     import torch
     if not torch.cuda.is_available():                         # no GPU: the program must fail loudly, not fall back

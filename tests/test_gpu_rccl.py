@@ -1,0 +1,143 @@
+"""-m gpu: the multi-GPU entry points of the C-ABI (include/bvh_amd.h "multi-GPU", csrc/replicate.hip) — the one exchange of the
+path: an RCCL broadcast of the `Bvh::serialize` stream (reference bvh.h:221-229) + the BVH-ordered primitives.
+
+* tests/c/replicate.c, plain C against the library alone: build, `bvh3f_replicate` over every GPU of the box, one ray shard per
+  device, shards == whole batch byte for byte, every copy's stream == the original's; then `bvh_amd_comm_*` + `bvh3f_broadcast`.
+  Run once as is and once with BVH_AMD_BROADCAST_LOOPBACK=1, which makes the root run the RECEIVING side of the broadcast too
+  (RCCL refuses two ranks on one device, so on a 1-GPU box this is how the receive path executes over a real ncclBroadcast).
+* `bvh_amd.parallel.broadcast_scene(transport="rccl")` in a fresh process (communicator of size 1, loopback on).
+* with >= 2 GPUs: two ranks under torch.distributed.run, backend nccl, one GPU each — the configuration bench.py --gpus N runs."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _compile(out):
+    lib = os.path.join(ROOT, "bvh_amd", "lib")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "replicate.c"),
+           "-L", lib, "-lbvh_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+@pytest.mark.parametrize("loopback", ["0", "1"])
+def test_c_program_replicates_broadcasts_and_traces(tmp_path, loopback):
+    exe = _compile(str(tmp_path / "replicate"))
+    env = dict(os.environ, BVH_AMD_BROADCAST_LOOPBACK=loopback, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "50000", "300001"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "replicate ok" in r.stdout
+
+
+def test_cpp_mirror_replicate_and_broadcast(tmp_path):
+    """bvh::v2::amd::replicate / broadcast of the C++20 mirror (plain g++), every GPU of the box."""
+    lib = os.path.join(ROOT, "bvh_amd", "lib")
+    exe = str(tmp_path / "replicate_amd")
+    cmd = ["g++", "-std=c++20", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "replicate_amd.cpp"),
+           "-L", lib, "-lbvh_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "replicate_amd ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+PY_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+import bvh_amd
+from bvh_amd import synth
+from bvh_amd.parallel import broadcast_scene
+sph = synth.spheres(30_000)                                  # double precision + spheres: the 128-byte records travel too
+bb, cc = bvh_amd.sphere_bounds(sph)
+bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
+prims = bvh_amd.gather(torch.from_numpy(sph).cuda(), bvh.device_prim_ids())
+timing = {{}}
+got, gprims = broadcast_scene(bvh, prims, src=0, timing=timing, transport="rccl")
+assert timing["transport"].startswith("RCCL"), timing
+assert got is not bvh, "loopback: the root must hold a RECEIVED copy"
+assert got.serialize() == bvh.serialize()
+assert gprims.shape == prims.shape and gprims.dtype == prims.dtype
+assert timing["payload_bytes"] == len(bvh.serialize()) + prims.numel() * 8
+lo, hi = synth.scene_bounds(sph)
+rays = synth.rays_closest(100_000, lo, hi, dtype=np.float64)
+a = bvh_amd.intersect(bvh, prims, rays, robust=True, leaf="sphere").cpu().numpy()
+b = bvh_amd.intersect(got, gprims, rays, robust=True, leaf="sphere").cpu().numpy()
+assert a.tobytes() == b.tobytes() and (a.view(np.int64)[:, 0] & 0xFFFFFFFF != 0xFFFFFFFF).sum() > 1000
+# a 3-D primitive tensor keeps its shape (the header carries ndim + shape)
+t3 = prims.reshape(-1, 2, 2)
+_, g3 = broadcast_scene(bvh, t3, src=0, transport="rccl")
+assert g3.shape == t3.shape and torch.equal(g3, t3)
+print("rccl world-1 loopback ok", timing)
+'''
+
+
+def test_python_broadcast_scene_over_rccl_single_rank_loopback(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(PY_WORKER.format(root=ROOT))
+    env = dict(os.environ, BVH_AMD_BROADCAST_LOOPBACK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "loopback ok" in r.stdout
+
+
+NCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np, torch, torch.distributed as dist
+local = int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+rank, world = dist.get_rank(), dist.get_world_size()
+import bvh_amd
+from bvh_amd import synth
+from bvh_amd.parallel import broadcast_scene, intersect_sharded
+tris = synth.soup(60_000, seed=3, jitter=0.01)
+lo, hi = synth.scene_bounds(tris)
+rays = torch.from_numpy(synth.rays_closest(300_001, lo, hi)).cuda()
+bvh = prims = None
+if rank == 0:
+    bb, cc = bvh_amd.tri_bounds(tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
+    prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+timing = {{}}
+bvh, prims = broadcast_scene(bvh, prims, src=0, timing=timing)
+assert timing["transport"].startswith("RCCL"), timing
+b, e, hits = intersect_sharded(bvh, prims, rays, robust=True)
+np.save(os.path.join({tmp!r}, f"hits{{rank}}.npy"), hits.cpu().numpy())
+open(os.path.join({tmp!r}, f"stream{{rank}}.bin"), "wb").write(bvh.serialize())
+dist.barrier()
+if rank == 0:
+    whole = bvh_amd.intersect(bvh, prims, rays, robust=True).cpu().numpy()
+    got = np.concatenate([np.load(os.path.join({tmp!r}, f"hits{{r}}.npy")) for r in range(world)])
+    assert got.tobytes() == whole.tobytes(), "sharded hits differ from the single-GPU hits"
+    s0 = open(os.path.join({tmp!r}, "stream0.bin"), "rb").read()
+    assert all(open(os.path.join({tmp!r}, f"stream{{r}}.bin"), "rb").read() == s0 for r in range(world))
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join({tmp!r}, f"rank{{rank}}.ok"), "w").write("ok")
+'''
+
+
+def test_two_ranks_one_gpu_each_over_rccl(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device); the one-GPU box runs the loopback tests above")
+    script = tmp_path / "worker.py"
+    script.write_text(NCCL_WORKER.format(root=ROOT, tmp=str(tmp_path)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
