@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s closest-hit on a ~1M-triangle scene, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload soup_1m|sponza_262k|terrain_1m|soup_10m] [--obj mesh.obj]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload soup_1m|sponza_262k|terrain_1m|soup_10m] [--obj mesh.obj] [--strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of synthetic rays: `rays_per_gpu` uniform-random
-closest-hit rays (origin uniform in the 1.1x scene box, direction uniform on the sphere, seed 1234 + rank)
-traced through the device-resident BVH by ONE launch of the traversal kernel; rays and hit records are
-resident in HBM before/after the timed region. The BVH is built on the GPU by the product builder (rank 0),
-serialized in the reference's byte format and broadcast to the other ranks over RCCL; nothing else is
-exchanged (weak scaling: every rank traces its own `rays_per_gpu`).
+A step = one pass of the hot path over one batch of synthetic rays: `rays_per_gpu` uniform-random closest-hit rays (origin
+uniform in the 1.1x scene box, direction uniform on the sphere, seed 1234 + rank) traced through the device-resident BVH by ONE
+call of the batch entry point (ray reordering + traversal kernel); rays and hit records are resident in HBM before / after the
+timed region. The mesh reaches the builder the way the reference's benchmark gets its scene: as a Wavefront OBJ read with the
+reference loader's semantics (test/load_obj.cpp:57-96; the synthetic mesh is written out and read back, byte-identical). The BVH
+is built on the GPU by the product builder (rank 0), serialized in the reference's byte format and broadcast to the other ranks
+over RCCL by libbvh_amd.so itself (bvhXX_broadcast); nothing else is exchanged. Weak scaling by default (every rank traces its
+own `--rays`); `--strong` splits `--rays` over the ranks (BASELINE configs[3]: 100M rays / 8).
 
-Rank 0 prints ONE JSON line (metric/value/unit/... + "roofline" + "cpu_baseline").
+Rank 0 prints ONE JSON line (metric / value / unit / ... + "roofline" + "cpu_baseline").
 """
 from __future__ import annotations
 
@@ -19,6 +21,7 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,7 +36,7 @@ WORKLOADS = {
     "soup_1m": ("soup", 1_000_000, "1,000,000-triangle random soup (M3), worst-case incoherent", "1M-tri scene"),
     "terrain_1m": ("terrain", 1_000_000, "~1M-triangle height field (M2), tie-heavy", "1M-tri terrain"),
     "sponza_262k": ("sponza_proxy", 262_144, "262,144-triangle Sponza proxy (M1) — BASELINE configs[1]", "262k-tri Sponza proxy"),
-    "soup_10m": ("soup", 10_000_000, "10,000,000-triangle random soup (M3-10M) — BASELINE configs[3]; use --rays 12500000 for its 100M / 8 shards",
+    "soup_10m": ("soup", 10_000_000, "10,000,000-triangle random soup (M3-10M) — BASELINE configs[3]; --strong --rays 100000000 for its 100M rays over the ranks",
                  "10M-tri scene"),
 }
 L2_BYTES = 8 * 4 * 1024 * 1024    # MI355X_MICROARCH.md: 4 MiB of L2 per XCD, 8 XCDs
@@ -45,23 +48,48 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="soup_1m", choices=sorted(WORKLOADS))
-    ap.add_argument("--rays", type=int, default=1 << 24, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=1 << 24, help="rays per GPU per step (with --strong: rays per step over ALL GPUs)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --rays is the whole job, each rank traces ceil(rays / N) of it")
     ap.add_argument("--fast", action="store_true", help="intersect_fast instead of the robust slab test")
     ap.add_argument("--quality", default="high", choices=["low", "medium", "high"], help="DefaultBuilder quality of the traced BVH")
     ap.add_argument("--serial-builder", action="store_true", help="DefaultBuilder without a thread pool (binned/sweep) instead of mini-trees")
     ap.add_argument("--obj", default=None, help="trace this Wavefront OBJ mesh (reference loader semantics, bvh_amd/obj.py) instead of a synthetic workload")
+    ap.add_argument("--no-obj-roundtrip", action="store_true", help="feed the synthetic mesh to the builder directly instead of through an OBJ file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="rays of the CPU baseline sample (>= 1 s of work on the host cores)")
     ap.add_argument("--no-reorder", action="store_true", help="trace the rays in the order given (BVH_AMD_RAY_UNSORTED)")
-    ap.add_argument("--no-probe", action="store_true", help="skip the record-walk probe behind roofline_binding.peak")
+    ap.add_argument("--no-probe", action="store_true", help="skip the record-walk probes behind roofline.peak")
     return ap.parse_args()
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask cut by the cgroup's CPU quota (cpu.max = quota period)."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return usable, affinity, quota
 
 
 def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample, quality, serial):
     """The reference's CPU path (oracle/_ref when present, else the restatement) on a bounded sample of the same workload.
     Traversal as SURVEY.md 8(d) defines it: the ray array split by the reference's own ParallelExecutor::for_each over a
-    persistent ThreadPool of all host threads, each worker running the benchmark.cpp:277-298 loop; one untimed pass, then the
-    median of 3. Also a parity spot-check of the GPU result. Test infrastructure only."""
+    persistent ThreadPool, each worker running the benchmark.cpp:277-298 loop. The pool is sized by the CPUs this process may
+    USE (affinity cut by the cgroup quota), not by hardware_concurrency: {usable/4, usable/2, usable} threads are tried on a quarter
+    of the sample and the best count then runs one untimed pass + 3 timed ones (median). Also a parity spot-check of the GPU result.
+    Test infrastructure only."""
     import ctypes as C
     import oracle
     lib = oracle.load_ref()
@@ -69,61 +97,76 @@ def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample, quality, seria
     if lib is None:
         lib = oracle.load_oracle()
         kind = "port"
-    threads = lib.hardware_threads()
+    usable, affinity, quota = usable_cpus()
+    hw = lib.hardware_threads()
     cb = lib.from_arrays(bvh.nodes, bvh.prim_ids)
     prims = lib.precompute_tris(tris, bvh.prim_ids)
     n = len(rays_sample)
     fn = getattr(lib.dll, "ref_bench_tri3f", None) if kind == "reference" else None
     if fn is not None:
         fn.restype, fn.argtypes = None, [C.c_void_p] * 3 + [C.c_size_t] + [C.c_int] * 4 + [C.c_void_p] * 2
-        hits = np.empty(n, dtype=oracle.HITF)
-        secs = np.zeros(3)
-        fn(cb.h, prims.ctypes.data, rays_sample.ctypes.data, n, 0, int(robust), threads, 3, hits.ctypes.data, secs.ctypes.data)
-        how = "ParallelExecutor::for_each over a persistent ThreadPool"
-    else:                                                     # the restatement has no executor: std::thread chunks per pass
+
+    def passes(count, threads, reps):
+        hits = np.empty(count, dtype=oracle.HITF)
+        if fn is not None:
+            secs = np.zeros(max(reps, 1))
+            fn(cb.h, prims.ctypes.data, rays_sample.ctypes.data, count, 0, int(robust), threads, reps, hits.ctypes.data, secs.ctypes.data)
+            return hits, [float(s) for s in secs[:reps]]
         secs = []
-        cb.intersect_tri(prims, rays_sample[:65536], 0, robust, threads=threads)
-        for _ in range(3):
+        cb.intersect_tri(prims, rays_sample[:min(count, 65536)], 0, robust, threads=threads)
+        for _ in range(reps):
             t0 = time.perf_counter()
-            hits = cb.intersect_tri(prims, rays_sample, 0, robust, threads=threads)
+            hits = cb.intersect_tri(prims, rays_sample[:count], 0, robust, threads=threads)
             secs.append(time.perf_counter() - t0)
-        how = "std::thread ray chunks"
+        return hits, secs
+    how = "ParallelExecutor::for_each over a persistent ThreadPool" if fn is not None else "std::thread ray chunks"
+    candidates = sorted({max(1, usable // 4), max(1, usable // 2), usable})
+    sweep = {}
+    for th in candidates:
+        _, s = passes(max(1, n // 4), th, 1)
+        sweep[th] = (n // 4) / s[0] / 1e6
+    threads = max(sweep, key=sweep.get)
+    hits, secs = passes(n, threads, 3)
     dt = float(np.median(secs))
     parity = bool(hits.tobytes() == gpu_hits_sample.tobytes())
     _, cnt = cb.intersect_tri(prims, rays_sample[:1_000_000], 0, robust, threads=threads, counters=True)
     nc = min(n, 1_000_000)
-    # CPU build of the same tree with the reference's DefaultBuilder (thread pool = all host threads unless --serial-builder)
+    # CPU build of the same tree with the reference's DefaultBuilder (thread pool of the same size unless --serial-builder)
     bb, cc = lib.prep_tris(tris)
     q = {"low": oracle.QUALITY_LOW, "medium": oracle.QUALITY_MEDIUM, "high": oracle.QUALITY_HIGH}[quality]
     builder = oracle.BUILDER_DEFAULT_SERIAL if serial else oracle.BUILDER_DEFAULT_PARALLEL
-    lib.build(bb, cc, builder=builder, quality=q, threads=threads)              # warm-up
+    lib.build(bb, cc, builder=builder, quality=q, threads=usable)               # warm-up
     bts = []
     for _ in range(3):
         t0 = time.perf_counter()
-        cb2 = lib.build(bb, cc, builder=builder, quality=q, threads=threads)
+        cb2 = lib.build(bb, cc, builder=builder, quality=q, threads=usable)
         bts.append(time.perf_counter() - t0)
     bt = float(np.median(bts))
     same_tree = bool(cb2.serialize() == bvh.serialize())
     return {
         "value": round(n / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": kind,
-        "sample": f"first {n} rays of rank 0's batch through the same BVH, {threads} host threads ({how}); "
-                  f"median of 3 passes after a warm-up pass ({dt:.2f} s per pass)",
+        "usable_cpus": usable, "threads_used": threads, "affinity_cpus": affinity, "cgroup_cpu_quota": None if quota is None else round(quota, 2),
+        "hardware_concurrency": hw, "mrays_s_per_thread": round(n / dt / 1e6 / threads, 4),
+        "thread_sweep_mrays_s": {str(k): round(v, 3) for k, v in sweep.items()},
+        "sample": f"first {n} rays of rank 0's batch through the same BVH, {threads} host threads = the best of {candidates} on a quarter of the "
+                  f"sample ({how}; this process may use {usable} CPUs: affinity {affinity}, cgroup quota {quota}); median of 3 passes after a warm-up "
+                  f"pass ({dt:.2f} s per pass)",
         "passes_s": [round(float(x), 3) for x in secs],
-        "build_mtris_s": round(len(tris) / bt / 1e6, 3), "build_threads": 1 if serial else threads, "build_passes_s": [round(x, 3) for x in bts],
+        "build_mtris_s": round(len(tris) / bt / 1e6, 3), "build_threads": 1 if serial else usable, "build_passes_s": [round(x, 3) for x in bts],
         "gpu_matches_cpu_hits": parity, "gpu_tree_equals_cpu_tree": same_tree,
         "P": round(float(cnt[0]) / nc, 3), "T": round(float(cnt[1]) / nc, 3),
     }
 
 
-def pmc_traffic(args, robust, kernel_name, reordered):
-    """HBM-side bytes per launch of the traced kernel from SEPARATE rocprofv3 --pmc passes of this same command (FETCH_SIZE
-    and WRITE_SIZE cannot be collected inside a timed run): tools/pmc_traffic.py records them in profiles/pmc_traffic.json
-    together with a sha1 of the traced kernel's instructions. Returns (record or None, note): the counts are only quoted for a
-    library whose kernel is instruction-identical to the one that was traced."""
+def pmc_record(args, robust, kernel_name, reordered, rays):
+    """Counters of the traced kernel from SEPARATE rocprofv3 --pmc passes of this same command (they cannot be collected inside a
+    timed run): tools/pmc_traffic.py records them in profiles/pmc_traffic.json together with a sha1 of the traced kernel's
+    instructions. Returns (record or None, note): the counts are only quoted for a library whose kernel is instruction-identical
+    to the one that was traced."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None, "no profiles/pmc_traffic.json"
-    key = (f"{args.workload}|{args.quality}|{'serial' if args.serial_builder else 'pool'}|{'robust' if robust else 'fast'}|{args.rays}|"
+    key = (f"{args.workload}|{args.quality}|{'serial' if args.serial_builder else 'pool'}|{'robust' if robust else 'fast'}|{rays}|"
            f"{'reordered' if reordered else 'as_given'}")
     rec = json.load(open(path)).get(key)
     if rec is None:
@@ -134,28 +177,40 @@ def pmc_traffic(args, robust, kernel_name, reordered):
     have = kernel_isa_hash(_lib.LIB_PATH, kernel_name)
     if rec.get("kernel") != kernel_name or have is None or have != rec.get("isa_sha1"):
         note = (f"profiles/pmc_traffic.json was traced on another build of {kernel_name} (isa sha1 {rec.get('isa_sha1')} vs loaded "
-                f"{have}): traffic withheld, re-run tools/pmc_traffic.py")
+                f"{have}): counters withheld, re-run tools/pmc_traffic.py")
         print("[bench] WARNING: " + note, file=sys.stderr)
         return None, note
-    return rec, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel isa sha1 {have[:12]} (profiles/pmc_traffic.json)"
+    return rec, f"rocprofv3 --pmc passes of this command, kernel isa sha1 {have[:12]} (profiles/pmc_traffic.json)"
 
 
-def record_walk_probe(working_set_bytes):
-    """Rate (G records/s) at which the memory system serves a dependent walk over random 64-byte records of a table as large as
-    the traversal's working set (at least 2x the L2s), one record in flight per lane: csrc/probe.hip. Measured live."""
+def record_walk_probe(n_records, mode, active, steps=256):
+    """G records/s of a dependent walk over `n_records` random 64-byte records, one record in flight per chain (csrc/probe.hip);
+    mode 0 = per-lane loads, 4 = quad-cooperative loads + in-register transpose; `active` lanes of every wave own a chain."""
     import ctypes as C
     import torch
     from bvh_amd import _lib
-    n = int(max(working_set_bytes, 2 * L2_BYTES) // 64)
-    perm = torch.randperm(n, device="cuda", dtype=torch.int64)
-    table = torch.randint(0, 2 ** 31 - 1, (n, 16), dtype=torch.int32, device="cuda")
+    perm = torch.randperm(n_records, device="cuda", dtype=torch.int64)
+    table = torch.randint(0, 2 ** 31 - 1, (n_records, 16), dtype=torch.int32, device="cuda")
     table[perm, 0] = torch.roll(perm, -1).to(torch.int32)       # one cycle through all records in random order
     ms, recs = C.c_float(0), C.c_ulonglong(0)
     lib = _lib.load()
-    _lib.check(lib.bvh_amd_probe_record_walk(table.data_ptr(), n, 256, 7, 3, C.byref(ms), C.byref(recs),
-                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "probe_record_walk")
-    return {"table_mib": round(n * 64 / 2 ** 20, 1), "records_per_launch": int(recs.value), "ms": round(ms.value, 4),
-            "grec_s": round(recs.value / (ms.value * 1e-3) / 1e9, 2)}
+    _lib.check(lib.bvh_amd_probe_record_walk_ex(table.data_ptr(), n_records, steps, 7, 3, mode, active, C.byref(ms), C.byref(recs),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "probe_record_walk")
+    return recs.value / (ms.value * 1e-3) / 1e9
+
+
+def hierarchy_ceilings(working_set_bytes, coop, active):
+    """The rates the three levels of the memory system give the traversal's access pattern, measured live: L1 (a 16 KiB table),
+    L2 (2 MiB: resident in every XCD's L2), beyond the L2s (a table as large as the working set, at least 64 MiB: Infinity Cache /
+    HBM over the fabric). Records/s of the kernel's own fetch mode with as many lanes owning a chain as the kernel keeps active."""
+    mode = 4 if coop else 0
+    big = int(max(working_set_bytes, 2 * L2_BYTES) // 64)
+    return {"fetch_mode": "quad-cooperative (1 line request per record)" if coop else "per lane (4 lane requests per record)",
+            "active_lanes": active,
+            "l1_grec_s": round(record_walk_probe(256, mode, active, 512), 2),
+            "l2_grec_s": round(record_walk_probe(32768, mode, active, 512), 2),
+            "beyond_l2_grec_s": round(record_walk_probe(big, mode, active), 2),
+            "beyond_l2_table_mib": round(big * 64 / 2 ** 20, 1)}
 
 
 def mean_split_ancestors(nodes, n_prims):
@@ -173,6 +228,20 @@ def mean_split_ancestors(nodes, n_prims):
     return total / max(1, n_prims)
 
 
+def through_obj(tris):
+    """The synthetic mesh as the reference's programs would receive it: written as a Wavefront OBJ (%.9g round-trips float32) and
+    read back with the loader semantics of test/load_obj.cpp:57-96 (bvh_amd/obj.py). The bytes must not change."""
+    from bvh_amd.obj import load_obj, save_obj
+    with tempfile.TemporaryDirectory(prefix="bvh_amd_bench_") as d:
+        path = os.path.join(d, "scene.obj")
+        save_obj(path, tris)
+        size = os.path.getsize(path)
+        back = load_obj(path)
+    if back.shape != tris.shape or back.tobytes() != tris.tobytes():
+        raise SystemExit("bench: the mesh read back from its OBJ file differs from the generated one")
+    return back, size
+
+
 def main():
     args = parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs across processes on this driver
@@ -187,7 +256,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: bvh_amd has no CPU path")
     # BVH_AMD_BENCH_ONE_DEVICE=1 + BVH_AMD_BENCH_BACKEND=gloo: functional test of the N>1 path on a 1-GPU box
-    # (all ranks share cuda:0, collectives over gloo). The driver's runs use one GPU per rank and RCCL.
+    # (all ranks share cuda:0, collectives over gloo with host staging). The driver's runs use one GPU per rank and RCCL.
     one_device = os.environ.get("BVH_AMD_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("BVH_AMD_BENCH_BACKEND", "nccl")
     device_index = 0 if one_device else local_rank
@@ -202,17 +271,22 @@ def main():
 
     import bvh_amd
     from bvh_amd import synth
-    from bvh_amd.parallel import broadcast_scene
+    from bvh_amd.parallel import broadcast_scene, shard_range
 
     gen, n_tris, desc, label = WORKLOADS[args.workload]
     if args.obj:
         args.workload = "obj:" + os.path.basename(args.obj)
         gen, desc = None, f"{os.path.basename(args.obj)} (Wavefront OBJ, reference loader semantics: load_obj.cpp:57-96)"
     robust = not args.fast
+    rays_here = args.rays
+    if args.strong:
+        b, e = shard_range(args.rays, rank, world)
+        rays_here = e - b
 
     # ---- scene + build on rank 0, broadcast of the serialized BVH + BVH-ordered PrecomputedTri ------------
     tris = None
     build_ms = None
+    data = "synthetic"
     if rank == 0:
         if args.obj:
             from bvh_amd.obj import load_obj
@@ -221,11 +295,18 @@ def main():
                 raise SystemExit(f"{args.obj}: no faces")
             n_tris = len(tris)
             label = f"{n_tris}-tri OBJ mesh"
+            data = "Wavefront OBJ mesh + synthetic rays"
         else:
             tris = getattr(synth, gen)(n_tris)
+            if not args.no_obj_roundtrip and n_tris <= 2_000_000:
+                tris, obj_bytes = through_obj(tris)
+                data = (f"synthetic mesh via OBJ (written as a {obj_bytes / 1e6:.0f} MB Wavefront OBJ, read back with the reference loader's semantics, "
+                        "triangle bytes identical) + synthetic rays")
+            else:
+                data = "synthetic mesh (arrays; OBJ round trip skipped at this size) + synthetic rays"
         d_tris = torch.from_numpy(tris).cuda()
         pool = None if args.serial_builder else bvh_amd.ThreadPool()
-        builds = {}
+        builds, high_profile = {}, None
         for qname in ("low", "medium", "high"):                               # build Mtris/s of every DefaultBuilder mode
             cfg = bvh_amd.Config(quality=bvh_amd.Quality[qname.capitalize()])
             bb, cc = bvh_amd.tri_bounds(d_tris)
@@ -242,6 +323,13 @@ def main():
                 bvh_q.sync_host()                                                 # + device-to-host copy of the reference-layout Bvh
                 times.append(t1 - t0)
                 times_host.append(time.perf_counter() - t0)
+            if qname == "high":                                                   # what the ReinsertionOptimizer step of the last High build did
+                p = bvh_amd.last_optimize_profile()
+                high_profile = dict(p, us_per_replacement=None if not p["replacements"] else round(p["heap_ms"] * 1e3 / p["replacements"], 4),
+                                    heap_ms=round(p["heap_ms"], 3),
+                                    what="ReinsertionOptimizer of the last High build: iterations run, iterations that replayed the libstdc++ candidate heap "
+                                         "exactly (the heap-free fast path was refused: a tie at the top-k threshold or equal gains sharing a node), "
+                                         "pop_heap + push_heap replacements of those replays, GPU ms of the heap kernels (one sequential wave pair)")
             # B_build = 36 (tri) + 36 (bbox + center) + 76 L-bar + 28 N/n + 4 algorithmic bytes per triangle
             lbar = mean_split_ancestors(bvh_q.nodes, n_tris)
             b_build = 36.0 + 36.0 + 76.0 * lbar + 28.0 * bvh_q.node_count / n_tris + 4.0
@@ -261,9 +349,9 @@ def main():
         lo, hi = box[0].cpu().numpy(), box[1].cpu().numpy()
 
     # ---- this rank's ray shard, resident in HBM ---------------------------------------------------------------
-    rays_h = synth.rays_closest(args.rays, lo, hi, seed=1234 + rank)
+    rays_h = synth.rays_closest(rays_here, lo, hi, seed=1234 + rank)
     rays = torch.from_numpy(rays_h).cuda()
-    hits = torch.empty((args.rays, 4), dtype=torch.float32, device="cuda")
+    hits = torch.empty((rays_here, 4), dtype=torch.float32, device="cuda")
 
     sort_rays = False if args.no_reorder else None            # None: the library decides (include/bvh_amd.h: BVH_AMD_RAY_SORTED)
 
@@ -273,19 +361,29 @@ def main():
     # traversal statistics of this batch (stats variant of the kernel; equal to the oracle's counters, tests/)
     _, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, counters=True, sort_rays=sort_rays)
     cnt = cnt.cpu().numpy()
-    reordered = bool(bvh_amd._lib.load().bvh_amd_last_launch_reordered())
-    P, T = cnt[0] / args.rays, cnt[1] / args.rays
+    lib = bvh_amd._lib.load()
+    P, T = cnt[0] / rays_here, cnt[1] / rays_here
     b_ray = 32.0 + 56.0 * P + 48.0 * T + 16.0            # ray + node pairs + triangles + hit record
 
+    # set-up, like the build: the library measures how to trace large batches through THIS tree (reordered or as given, record fetch,
+    # thresholds) on its first few large batches — one whole batch per candidate plan — and keeps the fastest (csrc/traverse.hip:
+    # launch_traverse). Ten untimed passes, each waited for (the search reads a candidate's events once they have completed), let it
+    # settle before the W warm-up and K timed steps.
+    for _ in range(10):
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    import ctypes
+    plan = (ctypes.c_int * 4)()
+    lib.bvh_amd_last_launch_plan(plan)
+    reordered = bool(plan[0])
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    lib = bvh_amd._lib.load()
-    lib.bvh_amd_kernel_timing(1)                              # a pair of HIP events on the launch stream around the traversal kernel
+    lib.bvh_amd_kernel_timing(1)                              # HIP events on the launch stream: start of the call, around the traversal kernel
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(args.steps):
@@ -297,12 +395,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     pass_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))     # whole pass: reordering + kernel
-    import ctypes
-    kt = (ctypes.c_float * 256)()
+    kt, rt = (ctypes.c_float * 256)(), (ctypes.c_float * 256)()
     got = ctypes.c_size_t(0)
     bvh_amd._lib.check(lib.bvh_amd_kernel_times(kt, min(args.steps, 256), ctypes.byref(got)), "kernel_times")
-    lib.bvh_amd_kernel_timing(0)
     kernel_ms = float(np.mean(kt[:got.value])) if got.value else pass_ms                     # the traversal kernel alone
+    bvh_amd._lib.check(lib.bvh_amd_reorder_times(rt, min(args.steps, 256), ctypes.byref(got)), "reorder_times")
+    reorder_ms = float(np.mean(rt[:got.value])) if got.value else 0.0                        # ray keys + radix sort in front of it
+    lib.bvh_amd_kernel_timing(0)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if distributed:
@@ -310,73 +409,103 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        total_rays = args.rays * world * args.steps
+        total_rays = (args.rays if args.strong else args.rays * world) * args.steps
         value = total_rays / elapsed / 1e6
-        achieved = b_ray * args.rays / (kernel_ms * 1e-3) / 1e9
-        kernel_name = bvh_amd._lib.load().bvh_amd_last_kernel_name().decode()
-        rec, traffic_note = pmc_traffic(args, robust, kernel_name, reordered)
+        algorithmic = b_ray * rays_here / (kernel_ms * 1e-3) / 1e9
+        kernel_name = lib.bvh_amd_last_kernel_name().decode()
+        coop = kernel_name.rstrip(">").split(",")[-1].strip() == "true"
+        rec, pmc_note = pmc_record(args, robust, kernel_name, reordered, rays_here)
         traffic = None if rec is None else round((rec["fetch_kb"] + rec["write_kb"]) * 1024.0 / (kernel_ms * 1e-3) / 1e9, 1)
-        # The ceiling that binds this kernel (profiles/r02_traversal_experiments.md): its L2 misses against the rate at which the
-        # memory system serves a dependent walk over random 64-byte records, measured live by csrc/probe.hip.
+        # ---- the ceiling that binds: the memory hierarchy under the kernel's own access pattern ---------------------------------
+        # A ray fetches P pair records, T primitives (48 B = 3/4 of a record's requests) and itself (2 requests); each fetch is served
+        # by the L1, an L2 or the fabric side, and each level has a measured rate for dependent random 64-byte record fetches
+        # (csrc/probe.hip, live). Lower bound of the launch time: the slowest level; `sum_ms` = the no-overlap estimate.
         working_set = bvh.node_count // 2 * 64 + n_tris * 48
-        probe = None if args.no_probe else record_walk_probe(working_set)
-        miss_rate = None if rec is None else rec["fetch_kb"] * 1024.0 / 64.0 / (kernel_ms * 1e-3) / 1e9     # G 64-byte sectors/s
-        binding = {"bound": "l2_miss_path", "unit": "G 64-byte sectors/s",
-                   "achieved": None if miss_rate is None else round(miss_rate, 2), "peak": None if probe is None else probe["grec_s"],
-                   "frac": None if (miss_rate is None or probe is None) else round(miss_rate / probe["grec_s"], 4),
-                   "what": "L2 misses of the kernel (FETCH_SIZE / 64 B per launch / kernel time) over the record rate of a dependent random "
-                           "walk through a table of the working set's size, one 64-byte record in flight per lane (bvh_amd_probe_record_walk)",
-                   "probe": probe}
-        if binding["frac"] is not None:
-            binding["reading"] = ("this ceiling binds the kernel: only fewer L2 misses per ray can make it faster" if binding["frac"] >= 0.85 else
-                                  "the walk is off the miss path (rays picked up in a coherent order, one stretch of it per XCD): waves now wait for "
-                                  "the slowest lane of a step; SQ / TCP / TCC counters in profiles/r02_trace_soup1m_sorted_pmc_sq.csv")
+        lanes = 28 if rec is None or not rec.get("lane_utilisation") else max(8, min(64, int(round(64 * rec["lane_utilisation"]))))
+        probe = None if args.no_probe else hierarchy_ceilings(working_set, coop, lanes)
+        records = rays_here * (float(P) + 0.75 * float(T) + 0.5)          # record-equivalents every launch asks of the L1
+        levels = None
+        if probe is not None:
+            levels = {"l1": {"records_per_launch": round(records), "grec_s": probe["l1_grec_s"], "ms": round(records / probe["l1_grec_s"] / 1e6, 4),
+                             "what": "every record fetch passes the L1's request pipeline: rays x (P + 3/4 T + 1/2) record-equivalents at the "
+                                     "L1-resident rate of the probe"}}
+            if rec is not None and rec.get("tcp_tcc_read_req"):
+                l2_req, misses = float(rec["tcp_tcc_read_req"]), float(rec.get("tcc_miss") or rec["fetch_kb"] * 1024.0 / 64.0)
+                levels["l2"] = {"requests_per_launch": round(l2_req), "grec_s": probe["l2_grec_s"], "ms": round(l2_req / probe["l2_grec_s"] / 1e6, 4),
+                                "what": "L1 misses (TCP_TCC_READ_REQ) at the L2-resident rate of the probe"}
+                levels["fabric"] = {"requests_per_launch": round(misses), "grec_s": probe["beyond_l2_grec_s"],
+                                    "ms": round(misses / probe["beyond_l2_grec_s"] / 1e6, 4),
+                                    "what": "L2 misses (TCC_MISS; a miss of the quad-cooperative kernel fetches a 128-byte line, FETCH_SIZE = 2 x 64 B per "
+                                            "miss, where the per-lane kernel fetched 64 B) at the beyond-L2 rate of the probe, whose every record is one miss"}
+        model_ms = None if levels is None else max(v["ms"] for v in levels.values())
+        sum_ms = None if levels is None else sum(v["ms"] for v in levels.values())
+        peak_mrays = None if not model_ms else rays_here / model_ms / 1e3
+        achieved_mrays = rays_here / kernel_ms / 1e3
         out = {
             "metric": f"Mrays/s closest-hit ({label})", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": data,
             "config": {"workload": f"{args.workload}: {desc}; {'robust' if robust else 'fast'} traversal, DefaultBuilder "
                                    f"{'serial' if args.serial_builder else 'with thread pool (mini-trees)'} Quality::{args.quality.capitalize()} "
                                    f"built on the GPU (the reference's default configuration is thread pool + High)"
                                    + ("; rays reordered for coherence inside the timed pass (library default for this tree size)" if reordered else ""),
-                       "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(args.rays),
-                       "parallelism": f"rays sharded x{world}, BVH broadcast over RCCL" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_frac": None if traffic is None else round(traffic / HBM_PEAK_GBS, 4), "traffic_source": traffic_note,
-                         "achieved_is": "algorithmic bytes (SURVEY.md 8d: 32 + 56 P + 48 T + 16 per ray) / kernel time; `traffic` is what the "
-                                        "L2's fabric side actually moved. frac > 1 means L1 / L2 serve re-referenced nodes faster than HBM could "
-                                        "stream the algorithmic bytes",
-                         "kernel": kernel_name,
-                         "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
-                         "ray_reordering": ("on: 21-bit origin-cell/octant key + three radix passes inside every timed pass, "
-                                            f"{round(pass_ms - kernel_ms, 3)} ms of it" if reordered else "off"),
-                         "bytes_per_ray": round(b_ray, 1),
+                       "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(rays_here),
+                       "rays_per_step_all_gpus": int(args.rays if args.strong else args.rays * world),
+                       "parallelism": (f"rays sharded x{world} ({'strong' if args.strong else 'weak'} scaling), scene broadcast once: "
+                                       + bcast.get("transport", "?")) if world > 1 else "single GPU"},
+            "roofline": {"bound": "memory hierarchy (L1 request pipeline / L2 / fabric) under dependent random 64-byte record fetches",
+                         "achieved": round(achieved_mrays, 1), "peak": None if peak_mrays is None else round(peak_mrays, 1), "unit": "Mrays/s",
+                         "frac": None if peak_mrays is None else round(achieved_mrays / peak_mrays, 4),
+                         "binding_level": None if levels is None else max(levels, key=lambda k: levels[k]["ms"]),
+                         "model_ms": None if model_ms is None else round(model_ms, 4), "sum_of_levels_ms": None if sum_ms is None else round(sum_ms, 4),
+                         "levels": levels, "probe": probe,
+                         "what": "peak = rays per launch / the time the slowest level of the memory system needs for this launch's requests at the "
+                                 "rate measured for that level in this run; achieved = rays per launch / kernel_ms. HBM is NOT what binds this kernel: "
+                                 "see hbm_algorithmic below (SURVEY.md 8d's figure) and traffic",
+                         "traffic": traffic, "traffic_unit": "GB/s at the L2's fabric side (FETCH_SIZE + WRITE_SIZE)",
+                         "traffic_frac_of_hbm": None if traffic is None else round(traffic / HBM_PEAK_GBS, 4), "counters_source": pmc_note,
+                         "hbm_algorithmic": {"bound": "hbm", "achieved": round(algorithmic, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": round(algorithmic / HBM_PEAK_GBS, 4), "bytes_per_ray": round(b_ray, 1),
+                                             "what": "algorithmic bytes (SURVEY.md 8d: 32 + 56 P + 48 T + 16 per ray) / kernel time over the 8 TB/s HBM "
+                                                     "peak; > 1 is possible because L1 / L2 serve re-referenced nodes: not a ceiling of this kernel"},
+                         "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
+                         "pass_split_ms": {"ray_keys_and_radix_sort": round(reorder_ms, 4), "traversal_kernel": round(kernel_ms, 4),
+                                           "rest (launch gaps, counter reset)": round(max(0.0, pass_ms - reorder_ms - kernel_ms), 4)},
+                         "ray_reordering": ("on: 21-bit origin-cell/octant key + three radix passes inside every timed pass" if reordered else "off"),
+                         "record_fetch": "quad-cooperative" if coop else "per lane",
+                         "launch_plan": {"reordered": bool(plan[0]), "quad_cooperative_fetch": bool(plan[1]), "refill_threshold": int(plan[2]),
+                                         "leaf_threshold": int(plan[3]),
+                                         "how": "measured by the library on this tree's first large batches (one whole batch per candidate), then fixed"},
                          "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)},
-            "roofline_binding": binding,
             "build": {"mtris_s": round(n_tris / (build_ms * 1e-3) / 1e6, 2), "ms": round(build_ms, 3),
                       "roofline": {q: {"bound": "hbm", "achieved": round(v[4] * n_tris / (v[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(v[4] * n_tris / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_tri": round(v[4], 1),
                                        "mean_split_ancestors": round(v[3], 2)} for q, v in builds.items()},
                       "all_qualities_ms": {k: round(v[0], 3) for k, v in builds.items()},
                       "all_qualities_mtris_s": {k: round(n_tris / (v[0] * 1e-3) / 1e6, 2) for k, v in builds.items()},
+                      "high": high_profile,
                       "ms_with_host_mirror": round(build_host_ms, 3),
                       "mtris_s_with_host_mirror": round(n_tris / (build_host_ms * 1e-3) / 1e6, 2),
                       "what": "tri bounds + DefaultBuilder, triangles resident in HBM -> BVH resident in HBM; *_with_host_mirror adds "
                               "the device-to-host copy of the reference-layout Bvh; median of 5 (High: 3) after a warm-up build"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            ns = min(args.cpu_sample, args.rays)
+        if world > 1:
+            bms = bcast.get("broadcast_ms", 0.0)
+            out["broadcast"] = {"ms": round(bms, 3), "payload_bytes": int(bcast.get("payload_bytes", 0)), "transport": bcast.get("transport"),
+                                "value_including_one_broadcast_per_run": round(total_rays / (elapsed + bms * 1e-3) / 1e6, 2),
+                                "what": "Bvh::serialize stream + BVH-ordered PrecomputedTri, device buffers, one root-to-all broadcast each (outside the timed "
+                                        "steps; `value_including_one_broadcast_per_run` charges it once to the K timed steps)"}
+        if not args.no_cpu_baseline:
+            # rank 0 only, after the timed region, on a bounded sample (the other ranks wait at the final barrier)
+            ns = min(args.cpu_sample, rays_here)
             out["cpu_baseline"] = cpu_baseline(tris, bvh, rays_h[:ns], int(robust), bvh_amd.hits_to_numpy(hits[:ns]),
                                                args.quality, args.serial_builder)
         else:
             out["cpu_baseline"] = None
-        if world > 1:
-            out["broadcast"] = {"ms": round(bcast.get("broadcast_ms", 0.0), 3), "payload_bytes": int(bcast.get("payload_bytes", 0)),
-                                "what": "Bvh::serialize stream + BVH-ordered PrecomputedTri, device buffers, one root-to-all broadcast each (outside the timed steps)"}
         print(json.dumps(out), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

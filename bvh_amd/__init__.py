@@ -13,5 +13,5 @@ Everything computes in hand-written HIP kernels through the C-ABI of libbvh_amd.
 """
 from .api import (BinnedSahBuilder, MiniTreeBuilder, SplitHeuristic, Bvh, Config, DefaultBuilder, Quality, RayFlags, SweepSahBuilder, ThreadPool,  # noqa: F401
                   HITD, HITF, INVALID, NODED, NODEF, NODE2D, NODE2F, hits_to_numpy, intersect, precompute_tris, sphere_bounds,
-                  tri_bounds, gather, std_sort_ids, radix_sort_pairs, reinsertion_stats, pinhole_rays, shade_eyelight)
+                  tri_bounds, gather, std_sort_ids, radix_sort_pairs, reinsertion_stats, last_optimize_profile, pinhole_rays, shade_eyelight)
 from ._lib import BvhAmdError  # noqa: F401

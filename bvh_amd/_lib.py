@@ -55,8 +55,13 @@ _SIGS = {
     "bvh_amd_last_launch_reordered": (C.c_int, []),
     "bvh_amd_kernel_timing": (None, [C.c_int]),
     "bvh_amd_kernel_times": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bvh_amd_reorder_times": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bvh_amd_tuning": (None, [C.c_int, C.c_int, C.c_int]),
+    "bvh_amd_last_launch_plan": (None, [C.POINTER(C.c_int)]),
     "bvh_amd_reinsertion_stats": (None, [C.POINTER(C.c_uint)]),
+    "bvh_amd_last_optimize_profile": (None, [_P]),
     "bvh_amd_probe_record_walk": (_I, [_P, C.c_uint32, C.c_uint32, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
+    "bvh_amd_probe_record_walk_ex": (_I, [_P, C.c_uint32, C.c_uint32, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
     "bvh_amd_release_cached_memory": (_I, []),
     "bvh_amd_device_count": (_I, []),
     "bvh_amd_device_name": (_I, [_I, C.c_char_p, _Z]),
@@ -135,6 +140,10 @@ _SIGS_T = {
     "bvh{S}_intersect_ray_any_robust": (None, [_P, _P, _P]),
     "bvh{S}_intersect_ray_visit": (_I, [_P, _P, _Z, _U, _P]),
 }
+
+
+class OptimizeProfile(C.Structure):         # struct bvh_amd_optimize_profile
+    _fields_ = [("iterations", C.c_uint), ("replayed", C.c_uint), ("replacements", C.c_ulonglong), ("heap_ms", C.c_float)]
 
 
 class SahConfig(C.Structure):                 # struct bvh_amd_sah_config

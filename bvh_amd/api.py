@@ -468,6 +468,14 @@ def reinsertion_stats():
     return int(out[0]), int(out[1])
 
 
+def last_optimize_profile() -> dict:
+    """The calling thread's latest ReinsertionOptimizer run (a High build's optimize step included): iterations, exact heap
+    replays among them, pop + push replacements of those replays, GPU milliseconds of the heap kernels."""
+    p = _lib.OptimizeProfile()
+    _lib.load().bvh_amd_last_optimize_profile(C.byref(p))
+    return {"iterations": int(p.iterations), "replayed": int(p.replayed), "replacements": int(p.replacements), "heap_ms": float(p.heap_ms)}
+
+
 def std_sort_ids(keys):
     """ids sorted exactly like libstdc++'s std::sort(iota, by keys[i] < keys[j]) incl. tie arrangement (int32 tensor)."""
     torch = _torch()

@@ -11,6 +11,7 @@ template <typename T> int reinsertion_optimize_device(HostNode<T>* d_nodes, size
 template <typename T>
 int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim, double batch_size_ratio, size_t iterations);
 void reinsertion_stats(unsigned out[2]);
+void last_optimize_profile(bvh_amd_optimize_profile* out);
 template <typename T>
 int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config& cfg, bool prune, T ratio,
                             bool optimize, uint32_t log2_grid, hipStream_t stream);
@@ -503,6 +504,13 @@ void bvh_amd_kernel_timing(int on) { kernel_timing(on != 0); }
 int bvh_amd_kernel_times(float* ms_out, size_t capacity, size_t* count_out) {
     if (!ms_out && capacity) return fail(BVH_AMD_ERR_ARG, "bvh_amd_kernel_times: null output");
     return kernel_times(ms_out, capacity, count_out);
+}
+void bvh_amd_last_optimize_profile(struct bvh_amd_optimize_profile* out) { if (out) last_optimize_profile(out); }
+void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch) { set_tuning(refill_threshold, leaf_threshold, coop_fetch); }
+void bvh_amd_last_launch_plan(int out[4]) { if (out) last_launch_plan(out); }
+int bvh_amd_reorder_times(float* ms_out, size_t capacity, size_t* count_out) {
+    if (!ms_out && capacity) return fail(BVH_AMD_ERR_ARG, "bvh_amd_reorder_times: null output");
+    return reorder_times(ms_out, capacity, count_out);
 }
 void bvh_amd_reinsertion_stats(unsigned out[2]) { if (out) reinsertion_stats(out); }
 

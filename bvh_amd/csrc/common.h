@@ -121,15 +121,29 @@ struct BvhImpl {
     // (upload.hip: tree_depth fills it together with max_depth, before max_depth). Low for scenes a ray crosses quickly, in the
     // hundreds for a soup; decides whether reordering a ray batch is worth its fixed cost per ray (traverse.hip).
     mutable std::atomic<float> expected_visits{0.0f};
+    // How large batches are traced through THIS tree, found by measurement (traverse.hip: calibrate): index 0 closest-hit, 1 any-hit.
+    // 0 = not measured yet; otherwise 1 | reorder << 1 | coop << 2 | refill << 8 | leaf << 16. Reset whenever the tree is re-laid out.
+    mutable std::atomic<uint32_t> launch_plan[2] = {};
+    struct PlanSearch {                        // the measurement in progress: one candidate per large batch, timed by events on its stream
+        int index = 0;                         // measurements made so far (candidate = index & 3; 8 = all measured twice)
+        bool pending = false;                  // events of candidate `index` are recorded, not read yet
+        hipEvent_t start = nullptr, stop = nullptr;
+        size_t rays = 0;
+        float ns_per_ray[4] = {0, 0, 0, 0};
+    };
+    mutable PlanSearch plan_search[2];
+    mutable std::mutex plan_mutex;
     // Batch launches are re-entrant like the reference's Bvh::intersect on a const Bvh: every launch takes the next of
     // kWorkSlots {ray ticket counter, status word} slots, so launches of one BVH issued from several threads / on several streams
     // do not share a counter (up to kWorkSlots of them in flight at a time).
-    // A slot is handed out again after kWorkSlots further launches; the launch that re-uses it is ordered behind the launch
-    // that had it before (an event per slot), so a 65th launch in flight never shares a counter with a running one.
+    // A slot is claimed under work_mutex and stays busy until its launch has recorded the slot's event on its stream; the next
+    // launch that takes the slot is ordered behind that event, so launches in flight never share a counter however many host
+    // threads are between their claim and their record (a 65th concurrent claimant waits for a slot to be released).
     static constexpr uint32_t kWorkSlots = 64, kWorkStride = 128;      // slots of 1 KB: eight ticket counters 128 bytes apart
     unsigned long long* d_work = nullptr;      // kWorkSlots x kWorkStride words: the ticket counters of the launch that holds the slot
     mutable std::atomic<uint32_t> work_next{0};
     mutable hipEvent_t work_done[kWorkSlots] = {};      // recorded behind the slot's latest launch (created on first use)
+    mutable bool work_busy[kWorkSlots] = {};            // claimed by a launch that has not recorded work_done yet (under work_mutex)
     mutable std::mutex work_mutex;
     ~BvhImpl();
 };
@@ -200,10 +214,13 @@ template <typename T> int validate_resident_nodes(const HostNode<T>* d_nodes, si
 template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
                     typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream);
+void last_launch_plan(int out[4]);                            // traverse.hip: {reordered, coop, refill, leaf} of the calling thread's latest launch
+void set_tuning(int refill, int leaf, int coop);               // traverse.hip: per-thread overrides for A/B runs (< 0: default)
 const char* last_kernel_name();
 bool last_launch_reordered();
 void kernel_timing(bool on);                                  // traverse.hip
 int kernel_times(float* ms_out, size_t capacity, size_t* count_out);
+int reorder_times(float* ms_out, size_t capacity, size_t* count_out);
 template <typename T>
 int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bool any, bool robust,
                         bool (*leaf_fn)(void*, T*, size_t, size_t), void (*inner_fn)(void*, size_t), void* user);

@@ -1,9 +1,24 @@
-// Measurement aid (not on the product path; called by bench.py): the rate at which this GPU's memory system serves the
-// traversal kernel's access pattern with NOTHING else in the way — every lane walks a chain of 64-byte records through a
-// table (four global_load_dwordx4 per record, the next record's index comes out of the record just loaded, exactly one
-// record in flight per lane, like a tree walk). With a table that does not fit the L2s this is the rate of the L2-miss path;
-// bench.py prices the traversal kernel's measured L2 misses against it ("roofline_binding").
+// Measurement aids (not on the product path; called by bench.py and tools/): the rates at which this GPU's memory system
+// serves the traversal kernel's access pattern with NOTHING else in the way — every participating lane walks a chain of
+// 64-byte records through a table (the next record's index comes out of the record just loaded, exactly one record in flight
+// per chain, like a tree walk). The table's size selects the level that serves it: a few KB -> the CU's L1 (TCP), a few MB ->
+// the XCD's L2 (TCC), beyond 32 MB -> the fabric / Infinity Cache / HBM. bench.py prices the traversal kernel's measured
+// L1 accesses, L2 hits and L2 misses against these rates ("roofline": memory-hierarchy bound).
+//
+// Modes (how a record reaches its lane):
+//   0  per lane: four global_load_dwordx4 of the lane's own record (what trace_kernel does)
+//   1  quad-cooperative + LDS transpose: in instruction k the four lanes of a quad load the four 16-byte chunks of the record of
+//      the quad's lane k (one 64-byte line per quad and instruction), the chunks are parked in LDS in lane order and every lane
+//      reads its own record back with four ds_read_b128 (LDS-bound: ~90 clk per wave-step whatever the number of active lanes)
+//   2  quad-cooperative loads alone: one chain per QUAD, its four lanes load the four chunks of the chain's record with one
+//      instruction (isolates what a quad-coalesced line costs the L1)
+//   3  the same 16 chains per wave as mode 2, walked by lane 0 of each quad alone with four loads (the per-lane cost of mode 2's work)
+//   4  quad-cooperative + in-register transpose (DPP quad_perm butterflies, no LDS): trace_device.h coop_load_pair itself, what
+//      trace_kernel<..., Coop = true> does
+// `active` (1..64): lanes of a wave that own a chain (scattered over the wave: lane l is active iff (37 l mod 64) < active); the
+// others idle in mode 0 and only help loading in mode 1.
 #include "common.h"
+#include "trace_device.h"
 
 namespace bvh_amd {
 
@@ -11,8 +26,11 @@ namespace {
 
 struct WalkRec { uint32_t w[16]; };
 
-__global__ void __launch_bounds__(256) k_record_walk(const WalkRec* table, uint32_t n_rec, uint32_t steps, unsigned long long* sink) {
+__device__ inline bool lane_active(uint32_t lane, uint32_t active) { return ((lane * 37u) & 63u) < active; }
+
+__global__ void __launch_bounds__(256) k_record_walk(const WalkRec* table, uint32_t n_rec, uint32_t steps, uint32_t active, unsigned long long* sink) {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    if (!lane_active(threadIdx.x & 63u, active)) return;
     uint32_t idx = static_cast<uint32_t>((gid * 2654435761ull) % n_rec);
     uint32_t acc = 0;
     for (uint32_t it = 0; it < steps; ++it) {
@@ -24,6 +42,84 @@ __global__ void __launch_bounds__(256) k_record_walk(const WalkRec* table, uint3
     if (acc == 0x12345678u) atomicAdd(sink, 1ull);             // keeps the loads alive
 }
 
+template <int K> __device__ inline uint32_t quad_broadcast(uint32_t v) {   // value of lane K of the caller's quad (DPP quad_perm, no LDS)
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), K * 0x55, 0xF, 0xF, false));
+}
+
+__global__ void __launch_bounds__(256) k_record_walk_coop(const WalkRec* table, uint32_t n_rec, uint32_t steps, uint32_t active, unsigned long long* sink) {
+    __shared__ uint4 stage[4][4][64];                          // [wave][instruction k][loading lane]: 16 KB per block
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, j = lane & 3u, quad = lane >> 2;
+    const bool mine = lane_active(lane, active);
+    uint32_t idx = static_cast<uint32_t>((gid * 2654435761ull) % n_rec);
+    uint32_t acc = 0;
+    const uint4* base = reinterpret_cast<const uint4*>(table);
+    for (uint32_t it = 0; it < steps; ++it) {
+        const uint32_t want = mine ? idx : 0xFFFFFFFFu;
+        const uint32_t o0 = quad_broadcast<0>(want), o1 = quad_broadcast<1>(want), o2 = quad_broadcast<2>(want), o3 = quad_broadcast<3>(want);
+        // lane j loads chunk (j - k) & 3 of owner k's record: the quad covers the record's 64 bytes with one instruction, and
+        // the rotation makes the owner's four ds_read_b128 below hit four different bank groups within its quad
+        uint4 v0 = {}, v1 = {}, v2 = {}, v3 = {};
+        if (o0 != 0xFFFFFFFFu) v0 = base[4ull * o0 + ((j + 0u) & 3u)];
+        if (o1 != 0xFFFFFFFFu) v1 = base[4ull * o1 + ((j + 3u) & 3u)];
+        if (o2 != 0xFFFFFFFFu) v2 = base[4ull * o2 + ((j + 2u) & 3u)];
+        if (o3 != 0xFFFFFFFFu) v3 = base[4ull * o3 + ((j + 1u) & 3u)];
+        stage[wave][0][lane] = v0; stage[wave][1][lane] = v1; stage[wave][2][lane] = v2; stage[wave][3][lane] = v3;
+        __builtin_amdgcn_wave_barrier();                       // (one wave: its LDS operations complete in order)
+        if (mine) {
+            const uint4* rec = &stage[wave][j][4u * quad];
+            const uint4 a = rec[(0u + j) & 3u], b = rec[(1u + j) & 3u], c = rec[(2u + j) & 3u], d = rec[(3u + j) & 3u];
+            acc += a.y + b.z + c.w + d.y;
+            idx = a.x < n_rec ? a.x : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (acc == 0x12345678u) atomicAdd(sink, 1ull);
+}
+
+__global__ void __launch_bounds__(256) k_record_walk_dpp(const WalkRec* table, uint32_t n_rec, uint32_t steps, uint32_t active, unsigned long long* sink) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool mine = lane_active(lane, active);
+    uint32_t idx = static_cast<uint32_t>((gid * 2654435761ull) % n_rec);
+    float acc = 0.0f;
+    for (uint32_t it = 0; it < steps; ++it) {
+        float lb[6], rb[6];
+        uint32_t li = 0, ri = 0;
+        coop_load_pair(reinterpret_cast<const PairNode<float>*>(table), mine ? idx : 0xFFFFFFFFu, static_cast<int>(lane), lb, rb, li, ri);
+        if (mine) {
+            acc += ((lb[1] + lb[2]) + (lb[3] + lb[4])) + ((lb[5] + rb[0]) + (rb[1] + rb[2])) + ((rb[3] + rb[4]) + rb[5]);   // every word is used
+            const uint32_t next = __float_as_uint(lb[0]);     // w[0]
+            idx = next < n_rec ? next : 0u;
+            acc += __uint_as_float((li ^ ri) & 0xFFu);
+        }
+    }
+    if (acc == 1234.5f) atomicAdd(sink, 1ull);
+}
+
+template <bool Coop>
+__global__ void __launch_bounds__(256) k_record_walk_quad(const WalkRec* table, uint32_t n_rec, uint32_t steps, unsigned long long* sink) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, j = threadIdx.x & 3u;
+    uint32_t idx = static_cast<uint32_t>(((gid >> 2) * 2654435761ull) % n_rec);        // one chain per quad
+    uint32_t acc = 0;
+    const uint4* base = reinterpret_cast<const uint4*>(table);
+    if (Coop) {
+        for (uint32_t it = 0; it < steps; ++it) {
+            const uint4 v = base[4ull * idx + j];
+            acc += v.y;
+            const uint32_t next = quad_broadcast<0>(v.x);      // w[0] sits in chunk 0 = lane 0 of the quad
+            idx = next < n_rec ? next : 0u;
+        }
+    } else {
+        if (j != 0) return;
+        for (uint32_t it = 0; it < steps; ++it) {
+            const uint4* q = base + 4ull * idx;
+            const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+            acc += a.y + b.z + c.w + d.y;
+            idx = a.x < n_rec ? a.x : 0u;
+        }
+    }
+    if (acc == 0x12345678u) atomicAdd(sink, 1ull);
+}
+
 } // namespace
 
 } // namespace bvh_amd
@@ -31,41 +127,61 @@ __global__ void __launch_bounds__(256) k_record_walk(const WalkRec* table, uint3
 extern "C" {
 
 // d_table: n_records x 64 bytes, word 0 of record i = index of the next record of its chain (the caller lays out a random
-// permutation cycle). Launches blocks_per_cu x CUs blocks of 256 lanes, `steps` records per lane, `reps` times after one
-// warm-up launch; *ms_out = mean launch time. Records walked per launch = blocks x 256 x steps (returned in *records_out).
-BVH_AMD_API int bvh_amd_probe_record_walk(const void* d_table, uint32_t n_records, uint32_t steps, int blocks_per_cu, int reps,
-                                          float* ms_out, unsigned long long* records_out, void* stream_)
+// permutation cycle). Launches blocks_per_cu x CUs blocks of 256 lanes, `steps` records per chain, `reps` times after one
+// warm-up launch; *ms_out = mean launch time, *records_out = records walked per launch (chains x steps).
+BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_records, uint32_t steps, int blocks_per_cu, int reps, int mode, int active,
+                                             float* ms_out, unsigned long long* records_out, void* stream_)
 {
     using namespace bvh_amd;
-    if (!d_table || n_records == 0 || steps == 0 || reps < 1 || !ms_out) return fail(BVH_AMD_ERR_ARG, "probe_record_walk: bad argument");
+    if (!d_table || n_records == 0 || steps == 0 || reps < 1 || !ms_out || mode < 0 || mode > 4) return fail(BVH_AMD_ERR_ARG, "probe_record_walk: bad argument");
+    if (active < 1 || active > 64) active = 64;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int device = 0, cus = 0;
     BVH_HIP_TRY(hipGetDevice(&device), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device), BVH_AMD_ERR_HIP);
     if (blocks_per_cu < 1) blocks_per_cu = 7;
     const unsigned grid = static_cast<unsigned>(cus * blocks_per_cu);
+    const auto* table = static_cast<const WalkRec*>(d_table);
+    const uint32_t act = static_cast<uint32_t>(active);
     unsigned long long* sink = nullptr;
     BVH_HIP_TRY(hipMalloc(&sink, sizeof(*sink)), BVH_AMD_ERR_HIP);
+    auto launch = [&]() {
+        switch (mode) {
+        case 0: hipLaunchKernelGGL(k_record_walk, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
+        case 1: hipLaunchKernelGGL(k_record_walk_coop, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
+        case 4: hipLaunchKernelGGL(k_record_walk_dpp, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
+        case 2: hipLaunchKernelGGL(k_record_walk_quad<true>, dim3(grid), dim3(256), 0, stream, table, n_records, steps, sink); break;
+        default: hipLaunchKernelGGL(k_record_walk_quad<false>, dim3(grid), dim3(256), 0, stream, table, n_records, steps, sink); break;
+        }
+    };
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_record_walk, dim3(grid), dim3(256), 0, stream, static_cast<const WalkRec*>(d_table), n_records, steps, sink);
+        launch();
         e = hipEventRecord(e0, stream);
-        for (int r = 0; r < reps; ++r)
-            hipLaunchKernelGGL(k_record_walk, dim3(grid), dim3(256), 0, stream, static_cast<const WalkRec*>(d_table), n_records, steps, sink);
+        for (int r = 0; r < reps; ++r) launch();
         if (e == hipSuccess) e = hipEventRecord(e1, stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0;
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess) e = hipGetLastError();
         *ms_out = ms / reps;
-        if (records_out) *records_out = static_cast<unsigned long long>(grid) * 256ull * steps;
+        const unsigned long long chains_per_wave = (mode == 2 || mode == 3) ? 16ull : static_cast<unsigned long long>(active);
+        if (records_out) *records_out = static_cast<unsigned long long>(grid) * 4ull * chains_per_wave * steps;
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(sink);
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("probe_record_walk: ") + hipGetErrorString(e));
     return BVH_AMD_OK;
+}
+
+// the original entry point: every lane walks, per-lane loads
+BVH_AMD_API int bvh_amd_probe_record_walk(const void* d_table, uint32_t n_records, uint32_t steps, int blocks_per_cu, int reps,
+                                          float* ms_out, unsigned long long* records_out, void* stream)
+{
+    return bvh_amd_probe_record_walk_ex(d_table, n_records, steps, blocks_per_cu, reps, 0, 64, ms_out, records_out, stream);
 }
 
 } // extern "C"

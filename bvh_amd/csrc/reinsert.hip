@@ -46,7 +46,7 @@ template <> struct HeapLevels<double> { static constexpr int v = 13; };       //
 template <typename T> struct HeapCap { static constexpr uint32_t v = (1u << HeapLevels<T>::v) - 1; };
 
 struct Move { uint32_t from, to; };
-struct ReScalars { uint32_t n_moves, error, ambiguous, pad; };
+struct ReScalars { uint32_t n_moves, error, ambiguous, replacements; };   // replacements: pop_heap + push_heap pairs of the exact replays (statistics)
 
 template <typename T> __device__ inline T ha6(const T* b, int dim) {         // bounds = {minx,maxx,miny,maxy,minz,maxz}
     const T d0 = b[1] - b[0], d1 = b[3] - b[2], d2 = b[5] - b[4];
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(64) k_make_heap_level(Ent<T>* glob, uint32_t k
 // BelowLds: the heap has more entries than fit in LDS (k - 1 >= HeapCap); the two cases are separate kernels so that the
 // large-scene loop carries exactly one instantiation of the top phase.
 template <typename T, bool BelowLds>
-__global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_nodes, uint32_t target, Ent<T>* glob, uint32_t* out_ids) {
+__global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_nodes, uint32_t target, Ent<T>* glob, uint32_t* out_ids, ReScalars* sc) {
     extern __shared__ unsigned char heap_lds[];
     WaveHeap<T> h;
     h.lds = (typename WaveHeap<T>::LdsEnt*)heap_lds;
@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_no
         }
     };
     T root_cost = h.lds[0].cost;                              // cost of the heap minimum, tracked in a register
+    uint32_t n_replaced = 0;                                  // (wave-uniform; reported for the bench's build.high statistics)
     // pops work on positions [0, k - 1): every node above level `full_levels` has both children there
     constexpr bool below_lds = BelowLds;
     int full_levels = below_lds ? h.cap_level : 0;
@@ -491,6 +492,7 @@ __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_no
                 mask &= mask - 1;
                 const T cj = lane_value(c, j);
                 if (root_cost < cj) {
+                    ++n_replaced;
                     if (k > 1) {                                  // std::pop_heap: the value at k-1 sinks in from the root
                         Ent<T> v;
                         if (last_in_regs) { v.cost = lane_value(chain.reg.cost, 0); v.id = lane_value(chain.reg.id, 0); }
@@ -521,6 +523,7 @@ __global__ void __launch_bounds__(64) k_heap_select(const T* cost, uint32_t n_no
     resolve_tasks();
     chain.flush(h);
     for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.get(j).id;
+    if (lane == 0) atomicAdd(&sc->replacements, n_replaced);
 }
 
 // (Round 2 also built the replacement loop as a systolic pipeline on ONE wavefront — lanes = levels of the ancestor chain for the
@@ -629,6 +632,7 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
     Chain<T> chain;
     chain.init(h, k, lane);
     chain.load(h);
+    uint32_t n_replaced = 0;
     T root_cost = h.lds[0].cost;
     uint32_t sent = 0, tail_seen = 0;                         // tail_seen: B's progress as last read (only re-read when the ring looks full)
     bool failed = false;
@@ -663,6 +667,7 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                 mask &= mask - 1;
                 const T cj = lane_value(c, j);
                 if (!(root_cost < cj)) continue;
+                ++n_replaced;
                 Ent<T> v; v.cost = lane_value(chain.reg.cost, 0); v.id = lane_value(chain.reg.id, 0);      // position k-1 lives in registers
                 // levels 0 .. 5 (the subtree under the root: heap position == BFS index == lane)
                 uint32_t hand = 0;
@@ -740,6 +745,7 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
     __threadfence();
     chain.flush(h);
     for (uint32_t j = lane; j < k; j += 64) out_ids[j] = h.get(j).id;
+    if (lane == 0) atomicAdd(&sc->replacements, n_replaced);
 }
 
 // ---- fast path: top-k by cost without the heap (valid when no tie straddles the threshold) --------------------------------
@@ -967,6 +973,12 @@ static std::atomic<unsigned> g_fast_iterations{0}, g_exact_iterations{0};
 
 void reinsertion_stats(unsigned out[2]) { out[0] = g_fast_iterations.load(); out[1] = g_exact_iterations.load(); }
 
+// The calling thread's latest optimize / High build (bvh_amd_last_optimize_profile): how many iterations ran, how many of them
+// had to replay the candidate heap exactly, how many pop + push replacements those replays made and the GPU time of the
+// heap kernels (make_heap levels + replacement loop) by events on the stream.
+static thread_local bvh_amd_optimize_profile t_profile = {0, 0, 0, 0.0f};
+void last_optimize_profile(bvh_amd_optimize_profile* out) { *out = t_profile; }
+
 // ReinsertionOptimizer::optimize on device-resident nodes (reference layout), in place.
 template <typename T>
 int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, int dim, double batch_size_ratio,
@@ -1027,6 +1039,9 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
         BVH_HIP_TRY(hipMemsetAsync(&scalars.p->ambiguous, 0, 4, stream), BVH_AMD_ERR_HIP);
         return BVH_AMD_OK;
     };
+    t_profile = {static_cast<unsigned>(iterations), 0u, 0ull, 0.0f};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> heap_events;      // around the heap kernels of each exact replay
+    struct EventBin { std::vector<std::pair<hipEvent_t, hipEvent_t>>& v; ~EventBin() { for (auto& e : v) { if (e.first) (void)hipEventDestroy(e.first); if (e.second) (void)hipEventDestroy(e.second); } } } event_bin{heap_events};
     bool parents_valid = false;
     uint64_t gid_base = 0;                                    // k_apply numbers its tie groups gid_base + 1 .. gid_base + k at most
     for (size_t it = 0; it < iterations; ++it, gid_base += uint64_t{k} + 1) {
@@ -1041,6 +1056,9 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
             ReScalars hs;
             int rc;
             if (exact) {
+                heap_events.emplace_back(nullptr, nullptr);
+                if (hipEventCreate(&heap_events.back().first) == hipSuccess && hipEventCreate(&heap_events.back().second) == hipSuccess)
+                    (void)hipEventRecord(heap_events.back().first, stream);
                 hipLaunchKernelGGL(k_heap_fill<T>, dim3((k + 255) / 256), dim3(256), 0, stream, cost.p, k, heap_g.p);
                 if (k >= 2) {
                     const uint32_t last_parent = (k - 2) / 2;
@@ -1055,7 +1073,8 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
                 if (below_lds && use_pipe)
                     hipLaunchKernelGGL(k_heap_select_pipe<T>, dim3(1), dim3(128), pipe_lds, stream, cost.p, n, batch, heap_g.p, cand.p, scalars.p);
                 else
-                    hipLaunchKernelGGL(heap_kernel, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p);
+                    hipLaunchKernelGGL(heap_kernel, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p, scalars.p);
+                if (heap_events.back().second) (void)hipEventRecord(heap_events.back().second, stream);
             } else {
                 BVH_HIP_TRY(hipMemcpyAsync(backup.p, d_nodes, size_t{n} * sizeof(HostNode<T>), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
                 hipLaunchKernelGGL(k_cost_keys<T>, dim3((n + 255) / 256), dim3(256), 0, stream, cost.p, n, keys.p, ids.p);
@@ -1104,12 +1123,19 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
                 }
             }
             (exact ? g_exact_iterations : g_fast_iterations).fetch_add(1);
+            if (exact) ++t_profile.replayed;
             break;
         }
     }
     ReScalars hs;
     BVH_HIP_TRY(hipMemcpyAsync(&hs, scalars.p, sizeof(hs), hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    t_profile.replacements = hs.replacements;
+    for (auto& ev : heap_events) {
+        float ms = 0.0f;
+        if (ev.first && ev.second && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) t_profile.heap_ms += ms;
+    }
+    (void)hipGetLastError();
     if (hs.error & 2u) return fail(BVH_AMD_ERR_HIP, "optimize: the two-wave candidate-heap replay timed out (internal error; BVH_AMD_HEAP_PIPE=0 selects the one-wave loop)");
     if (hs.error) return fail(BVH_AMD_ERR_OVERFLOW, "optimize: reinsertion search stack exceeded 96 entries");
     return BVH_AMD_OK;

@@ -24,6 +24,14 @@ constexpr int kLdsDepth = 20;
 // the 1M soup) would rather have rare, full refills, and by little: 1404 Mrays/s at 54 / 8, 1382 at 36 / 12.
 constexpr int kRefillThreshold = 36;
 constexpr int kLeafThreshold = 12;
+// Quad-cooperative record fetch (coop_load_pair below) and the thresholds that go with it, by kind of launch. Measured on the
+// device (profiles/r03_traversal_experiments.md): the cooperative fetch cuts the L1's lane requests per visited record from 4 to
+// 1 but puts ~35 VALU instructions and two DPP stages on the dependent chain of every step, and wants its lanes refilled EARLY
+// (idle lanes still help loading). It pays where a step waits on memory anyway — any-hit walks (+16 % on the Sponza proxy's
+// shadow rays) and closest-hit walks through big incoherent trees (+5 % on the 1M soup) — and loses where the walk is served by
+// the L1 / L2 and the chain's length is what binds (-3 % Sponza proxy, -7 % terrain, closest-hit).
+constexpr int kCoopRefillAny = 20, kCoopLeafAny = 20;          // any-hit
+constexpr int kCoopRefillHeavy = 12, kCoopLeafHeavy = 12;      // closest-hit, trees beyond the L2s crossed by long walks
 
 
 template <typename T> struct Num;
@@ -92,6 +100,7 @@ struct TraceArgs {
     uint32_t root_index;
     int refill_threshold;                      // refill when at least this many lanes are idle
     int leaf_threshold;                        // leave the inner-node loop when this many lanes wait at a leaf
+    uint32_t coop;                             // host side only: launch the quad-cooperative variant (float, 3D, trees below 2^26 pairs)
 };
 
 __device__ inline void load_pair(const PairNode<float>* p, float (&lb)[6], float (&rb)[6], uint32_t& li, uint32_t& ri) {
@@ -111,6 +120,85 @@ __device__ inline void load_pair(const PairNode<double>* p, double (&lb)[6], dou
     uint2 d = reinterpret_cast<const uint2*>(p)[12];
     li = d.x; ri = d.y;
 }
+
+// ---- quad-cooperative record fetch (trace_kernel<..., Coop = true>) -----------------------------------------------------------
+// The L1 (TCP) charges a divergent wave-instruction per LANE request: four global_load_dwordx4 of a lane's own 64-byte record
+// cost four requests, and measured (csrc/probe.hip, tools/tcp_probe.py) a wave-instruction takes ~8.5 clk + 0.56 clk per distinct
+// line request: ~2.8 clk per record at 64 active lanes, 3.5 at 28 — while a QUAD whose four lanes read the four 16-byte chunks of
+// ONE record is a single line request (0.95 lines / clk / CU). So the four lanes of a quad fetch each other's records: in
+// instruction k every lane loads chunk (lane & 3) of the record wanted by the quad's lane k (skipped when that lane wants none),
+// and a 4 x 4 transpose inside the quad — two butterfly stages of DPP quad_perm moves, no LDS — hands every lane the four chunks
+// of its own record. Requests per visited record: 1 instead of 4. Every lane of the wave must call this (wave-uniform control flow).
+#if defined(__HIPCC__)
+template <int CTRL> __device__ inline uint32_t quad_perm(uint32_t v) {       // DPP quad_perm: lane l reads lane (l & ~3) | perm[l & 3]
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), CTRL, 0xF, 0xF, true));
+}
+// One butterfly step of the quad transpose on a register pair (a, b) of N dwords: the lower lane of each lane pair (partner =
+// lane ^ 1, or lane ^ 2 with ByTwo) keeps a and takes the partner's a into b, the upper lane keeps b and takes the partner's b into
+// a. One v_cndmask_b32 with a DPP source per dword and direction (left to the compiler the DPP move and the select stay two
+// instructions; inline asm because the select mask has to sit in VCC). The leading s_nop covers the two wait states a DPP read
+// needs after a VALU write of its source (the assembler does not see hazards across an asm statement).
+template <bool ByTwo> __device__ inline void quad_exchange4(uint32_t (&a)[4], uint32_t (&b)[4]) {
+    const uint64_t lower = ByTwo ? 0x3333333333333333ull : 0x5555555555555555ull;
+    uint32_t n0, n1, n2, n3;
+    if (ByTwo)
+        asm("s_nop 1\n\ts_mov_b64 vcc, %12\n\t"
+            "v_cndmask_b32_dpp %0, %4, %8, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %1, %5, %9, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %2, %6, %10, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %3, %7, %11, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_not_b64 vcc, vcc\n\t"
+            "v_cndmask_b32_dpp %4, %8, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %5, %9, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %6, %10, %6, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %7, %11, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+            : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(lower) : "vcc", "scc");
+    else
+        asm("s_nop 1\n\ts_mov_b64 vcc, %12\n\t"
+            "v_cndmask_b32_dpp %0, %4, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %1, %5, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %2, %6, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %3, %7, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_not_b64 vcc, vcc\n\t"
+            "v_cndmask_b32_dpp %4, %8, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %5, %9, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %6, %10, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %7, %11, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+            : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(lower) : "vcc", "scc");
+    a[0] = n0; a[1] = n1; a[2] = n2; a[3] = n3;
+}
+__device__ inline void coop_load_pair(const PairNode<float>* pairs, uint32_t want, int lane, float (&lb)[6], float (&rb)[6], uint32_t& li, uint32_t& ri) {
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    const uint32_t j = static_cast<uint32_t>(lane) & 3u;
+    const uint32_t o0 = quad_perm<0x00>(want), o1 = quad_perm<0x55>(want), o2 = quad_perm<0xAA>(want), o3 = quad_perm<0xFF>(want);
+    // (uniform base + 32-bit byte offset: the loads take the SGPR-base form and need no 64-bit address arithmetic per lane;
+    //  launch_variant only selects this kernel for trees of fewer than 2^26 pair records)
+    const char* base = reinterpret_cast<const char*>(pairs);
+    const uint32_t chunk = j * 16u;
+    uint4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+    if (o0 != kNone) c0 = *reinterpret_cast<const uint4*>(base + (o0 * 64u + chunk));
+    if (o1 != kNone) c1 = *reinterpret_cast<const uint4*>(base + (o1 * 64u + chunk));
+    if (o2 != kNone) c2 = *reinterpret_cast<const uint4*>(base + (o2 * 64u + chunk));
+    if (o3 != kNone) c3 = *reinterpret_cast<const uint4*>(base + (o3 * 64u + chunk));
+    uint32_t v0[4] = {c0.x, c0.y, c0.z, c0.w}, v1[4] = {c1.x, c1.y, c1.z, c1.w}, v2[4] = {c2.x, c2.y, c2.z, c2.w}, v3[4] = {c3.x, c3.y, c3.z, c3.w};
+    // v_k[lane j] = chunk j of the record of quad lane k  ->  v_k[lane j] = chunk k of the record of quad lane j
+    quad_exchange4<false>(v0, v1); quad_exchange4<false>(v2, v3);
+    quad_exchange4<true>(v0, v2); quad_exchange4<true>(v1, v3);
+    lb[0] = __uint_as_float(v0[0]); lb[1] = __uint_as_float(v0[1]); lb[2] = __uint_as_float(v0[2]); lb[3] = __uint_as_float(v0[3]);
+    lb[4] = __uint_as_float(v1[0]); lb[5] = __uint_as_float(v1[1]); rb[0] = __uint_as_float(v1[2]); rb[1] = __uint_as_float(v1[3]);
+    rb[2] = __uint_as_float(v2[0]); rb[3] = __uint_as_float(v2[1]); rb[4] = __uint_as_float(v2[2]); rb[5] = __uint_as_float(v2[3]);
+    li = v3[0]; ri = v3[1];
+}
+__device__ inline void coop_load_pair(const PairNode<double>* p, uint32_t want, int, double (&lb)[6], double (&rb)[6], uint32_t& li, uint32_t& ri) {
+    if (want != 0xFFFFFFFFu) load_pair(p + want, lb, rb, li, ri);          // (128-byte records: not fetched cooperatively)
+}
+#else
+template <typename T> inline void coop_load_pair(const PairNode<T>* p, uint32_t want, int, T (&lb)[6], T (&rb)[6], uint32_t& li, uint32_t& ri) {
+    if (want != 0xFFFFFFFFu) load_pair(p + want, lb, rb, li, ri);          // host harness: one emulated lane has no quad
+}
+#endif
 
 __device__ inline void load_prim12(const float* p, float (&v)[12]) {
     const float4* q = reinterpret_cast<const float4*>(p);

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -34,6 +35,7 @@ namespace {
 
 thread_local const char* g_last_kernel = "";
 thread_local bool g_last_reordered = false;
+thread_local int g_last_plan[4] = {0, 0, 0, 0};               // reordered, coop, refill, leaf of the calling thread's latest launch
 
 // Optional timing of the traversal kernel alone (bench.py's roofline: the coherence sort in front of it is not the kernel):
 // the calling thread's latest launches, a pair of events each.
@@ -42,6 +44,8 @@ struct KernelTimer {
     bool on = false;
     size_t count = 0;
     std::pair<hipEvent_t, hipEvent_t> ring[kRing] = {};
+    hipEvent_t begin[kRing] = {};                             // start of the call on its stream: ring[i].first - begin[i] = ray keys + radix sort
+    bool begin_armed = false;                                 // begin[count % kRing] was recorded by the call in progress
 };
 KernelTimer& kernel_timer() { static thread_local KernelTimer t; return t; }
 
@@ -54,9 +58,13 @@ KernelTimer& kernel_timer() { static thread_local KernelTimer t; return t; }
 // bounds are zero and never looked at): only the per-ray constants, the slab test and the leaf test run over D axes.
 // Deep = true (trees of more than 64 levels only): stack entries beyond the 64 of SmallStack spill to HBM (GrowingStack).
 // (70 VGPRs = 7 waves per SIMD; forcing 8 with amdgpu_waves_per_eu fits in 63 without spills and runs 16 % slower on soup_1m)
-template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3, bool Deep = false>
+// Coop = true (float, 3D): records are fetched quad-cooperatively (trace_device.h: coop_load_pair), one L1 line request per visited
+// record instead of four lane requests.
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3, bool Deep = false, bool Coop = false>
 __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
+#define BVH_TRACE_COOP Coop
 #include "trace_body.inc"
+#undef BVH_TRACE_COOP
 }
 
 // Coherence key of a ray: Morton code of its origin cell (64^3 grid over the root box) above the direction octant, 21 bits, three
@@ -93,6 +101,17 @@ __global__ void __launch_bounds__(256) original_ids_kernel(H* hits, size_t n, co
     if (p < prim_count) hits[i].prim = prim_ids[p];
 }
 
+// Tuning overrides of the calling thread (bvh_amd_tuning; developer A/B runs in one process): < 0 = the default / the environment
+thread_local int t_refill = -1, t_leaf = -1, t_coop = -1;
+thread_local std::pair<hipEvent_t, hipEvent_t>* t_calibration = nullptr;   // events to record around the next traversal kernel of this thread
+
+// BVH_AMD_COOP=0 / 1 (or bvh_amd_tuning) forces the per-lane / quad-cooperative record fetch of the float 3D kernels for A/B
+// runs; -1: launch_traverse decides by kind of launch (trace_device.h: kCoop*)
+int coop_fetch_forced() {
+    static const int knob = getenv("BVH_AMD_COOP") ? atoi(getenv("BVH_AMD_COOP")) : -1;
+    return t_coop >= 0 ? (t_coop != 0) : knob < 0 ? -1 : (knob != 0);
+}
+
 struct Grid { int blocks = 0; };
 
 template <typename K>
@@ -106,10 +125,10 @@ int persistent_grid(K kernel, int device, Grid& g) {
     return BVH_AMD_OK;
 }
 
-template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D, bool Deep>
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D, bool Deep, bool Coop = false>
 int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     static thread_local int cached_blocks[16] = {0};
-    auto kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D, Deep>;
+    auto kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D, Deep, Coop>;
     int& blocks = cached_blocks[b.device & 15];
     if (blocks == 0) {
         Grid g;
@@ -124,12 +143,17 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     // the symbol as rocprofv3 prints it (profiles/*_kernel_stats.csv), for bench.py's roofline.kernel
     static const std::string symbol = std::string("trace_kernel<") + (std::is_same_v<T, float> ? "float" : "double") + ", " + (Any ? "true" : "false") + ", " +
                                       (Robust ? "true" : "false") + ", " + std::to_string(Leaf) + ", " + (Stats ? "true" : "false") + ", " + std::to_string(D) +
-                                      ", " + (Deep ? "true" : "false") + ">";
+                                      ", " + (Deep ? "true" : "false") + ", " + (Coop ? "true" : "false") + ">";
     g_last_kernel = symbol.c_str();
     KernelTimer& timer = kernel_timer();
     hipEvent_t stop = nullptr;
     if (timer.on) {                                           // bvh_amd_kernel_timing: events on the launch stream around this kernel only
         std::pair<hipEvent_t, hipEvent_t>& ev = timer.ring[timer.count % KernelTimer::kRing];
+        if (!timer.begin_armed && timer.begin[timer.count % KernelTimer::kRing]) {     // no call-level start for this launch: forget a stale one
+            (void)hipEventDestroy(timer.begin[timer.count % KernelTimer::kRing]);
+            timer.begin[timer.count % KernelTimer::kRing] = nullptr;
+        }
+        timer.begin_armed = false;
         if (!ev.first) {
             BVH_HIP_TRY(hipEventCreate(&ev.first), BVH_AMD_ERR_HIP);
             BVH_HIP_TRY(hipEventCreate(&ev.second), BVH_AMD_ERR_HIP);
@@ -138,8 +162,10 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
         stop = ev.second;
         ++timer.count;
     }
+    if (t_calibration) (void)hipEventRecord(t_calibration->first, stream);     // launch_traverse is measuring candidate plans
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    if (t_calibration) (void)hipEventRecord(t_calibration->second, stream);
     if (stop) BVH_HIP_TRY(hipEventRecord(stop, stream), BVH_AMD_ERR_HIP);
     return BVH_AMD_OK;
 }
@@ -147,6 +173,9 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
 int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     if (args.deep) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, true>(b, args, stream, name);
+    if constexpr (std::is_same_v<T, float> && D == 3) {
+        if (args.coop && b.pair_count < (size_t{1} << 26)) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false, true>(b, args, stream, name);
+    }
     return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false>(b, args, stream, name);
 }
 
@@ -349,6 +378,8 @@ struct StepContextClaim {
 
 } // namespace
 
+void last_launch_plan(int out[4]) { for (int k = 0; k < 4; ++k) out[k] = g_last_plan[k]; }
+void set_tuning(int refill, int leaf, int coop) { t_refill = refill; t_leaf = leaf; t_coop = coop; }
 const char* last_kernel_name() { return g_last_kernel; }
 bool last_launch_reordered() { return g_last_reordered; }
 
@@ -370,6 +401,22 @@ int kernel_times(float* ms_out, size_t capacity, size_t* count_out) {
     return BVH_AMD_OK;
 }
 
+// Per launch of the calling thread (as kernel_times): milliseconds between the start of the call on its stream and the start of
+// the traversal kernel = the ray keys + the radix sort of the reordering (0 when the batch was traced as given).
+int reorder_times(float* ms_out, size_t capacity, size_t* count_out) {
+    KernelTimer& t = kernel_timer();
+    const size_t have = std::min<size_t>(t.count, KernelTimer::kRing), n = std::min(have, capacity);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t k = (t.count - n + i) % KernelTimer::kRing;
+        ms_out[i] = 0.0f;
+        if (!t.begin[k]) continue;
+        BVH_HIP_TRY(hipEventSynchronize(t.ring[k].first), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipEventElapsedTime(&ms_out[i], t.begin[k], t.ring[k].first), BVH_AMD_ERR_HIP);
+    }
+    if (count_out) *count_out = n;
+    return BVH_AMD_OK;
+}
+
 template <typename T>
 static int to_original_ids(const BvhImpl<T>& b, typename HitOf<T>::Type* d_hits, size_t n, hipStream_t stream) {
     if (!b.d_prim_ids) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device prim ids");
@@ -381,25 +428,46 @@ static int to_original_ids(const BvhImpl<T>& b, typename HitOf<T>::Type* d_hits,
 
 constexpr float kReorderMinVisits = 100.0f;
 
+// How one launch is traced: the batch reordered or as given, records fetched per lane or quad-cooperatively, the refill / leaf
+// thresholds of the persistent waves. Never affects results.
+struct Plan { bool reorder; bool coop; int refill, leaf; };
+
 template <typename T>
-int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
-                    typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream)
+static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
+                          typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream, const Plan* plan)
 {
     if (n == 0) return BVH_AMD_OK;
     if (!d_prims || !d_rays || !d_hits) return fail(BVH_AMD_ERR_ARG, "intersect_rays: null device pointer");
     if (b.node_count == 0 || !b.d_work) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device copy");
     if (b.pair_count && !b.d_pairs) return fail(BVH_AMD_ERR_ARG, "intersect_rays: BVH has no device nodes");
-    const uint32_t slot = b.work_next.fetch_add(1) % BvhImpl<T>::kWorkSlots;
-    unsigned long long* work = b.d_work + size_t{slot} * BvhImpl<T>::kWorkStride;
+    uint32_t slot = 0;
     hipEvent_t slot_event = nullptr;
-    {   // whoever used this slot kWorkSlots launches ago (possibly on another stream) must be done before it is zeroed again
-        std::lock_guard<std::mutex> lock(b.work_mutex);
+    {   // claim a free slot of ticket counters; whoever used it before (possibly on another stream) must be done before it is zeroed again
+        std::unique_lock<std::mutex> lock(b.work_mutex);
+        for (;;) {
+            const uint32_t from = b.work_next.load();
+            bool found = false;
+            for (uint32_t i = 0; i < BvhImpl<T>::kWorkSlots && !found; ++i) {
+                const uint32_t s = (from + i) % BvhImpl<T>::kWorkSlots;
+                if (!b.work_busy[s]) { slot = s; found = true; }
+            }
+            if (found) break;
+            lock.unlock();                                    // kWorkSlots launches are between claim and record right now
+            std::this_thread::yield();
+            lock.lock();
+        }
         if (!b.work_done[slot]) BVH_HIP_TRY(hipEventCreateWithFlags(&b.work_done[slot], hipEventDisableTiming), BVH_AMD_ERR_HIP);
         else BVH_HIP_TRY(hipStreamWaitEvent(stream, b.work_done[slot], 0), BVH_AMD_ERR_HIP);
+        b.work_busy[slot] = true;
+        b.work_next.store((slot + 1) % BvhImpl<T>::kWorkSlots);
         slot_event = b.work_done[slot];
     }
-    BVH_HIP_TRY(hipMemsetAsync(work, 0, BvhImpl<T>::kWorkStride * sizeof(unsigned long long), stream), BVH_AMD_ERR_HIP);
-    if (d_counters) BVH_HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream), BVH_AMD_ERR_HIP);
+    unsigned long long* work = b.d_work + size_t{slot} * BvhImpl<T>::kWorkStride;
+    if (KernelTimer& timer = kernel_timer(); timer.on) {     // start of the call on its stream (bvh_amd_reorder_times)
+        hipEvent_t& ev = timer.begin[timer.count % KernelTimer::kRing];
+        if (!ev) (void)hipEventCreate(&ev);
+        if (ev) timer.begin_armed = hipEventRecord(ev, stream) == hipSuccess;
+    }
     TraceArgs<T> args;
     args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
     args.n = n; args.work = work; args.counters = d_counters; args.root_index = b.root_index;
@@ -412,34 +480,55 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     args.deep = nullptr; args.deep_cap = 0;
     // Scratch that only some launches need is allocated and freed in stream order (hipMallocAsync / hipFreeAsync), so that
     // concurrent launches of one BVH never share it.
+    StreamScope scope(stream);                                // scratch_alloc / the sort's own scratch: blocks cached per (device, stream)
     void* deep_mem = nullptr;
     void* sort_mem = nullptr;
+    ScratchTag deep_tag, sort_tag;
     auto release = [&](int rc) {
         (void)hipEventRecord(slot_event, stream);             // the slot is free again once everything queued so far has run
-        if (deep_mem) (void)hipFreeAsync(deep_mem, stream);
-        if (sort_mem) (void)hipFreeAsync(sort_mem, stream);
+        { std::lock_guard<std::mutex> lock(b.work_mutex); b.work_busy[slot] = false; }
+        if (deep_mem) scratch_free(deep_mem, deep_tag);
+        if (sort_mem) scratch_free(sort_mem, sort_tag);
         return rc;
     };
+    {   // (failures before this point return without a claimed slot only above; from here on every path goes through release())
+        hipError_t e = hipMemsetAsync(work, 0, BvhImpl<T>::kWorkStride * sizeof(unsigned long long), stream);
+        if (e == hipSuccess && d_counters) e = hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream);
+        if (e != hipSuccess) return release(fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: hipMemsetAsync: ") + hipGetErrorString(e)));
+    }
     {   // SmallStack<Index, 64> covers every tree of at most 64 levels; deeper trees get the GrowingStack equivalent
         int rc = tree_depth<T>(b, stream);
-        if (rc) return rc;
+        if (rc) return release(rc);
         const int max_depth = b.max_depth.load();
         if (max_depth > 64) {
             int cus = 0;
-            BVH_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device), BVH_AMD_ERR_HIP);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess) return release(fail(BVH_AMD_ERR_HIP, "intersect_rays: hipDeviceGetAttribute"));
             const size_t lanes = size_t{8} * cus * kBlock;                   // persistent_grid launches at most 8 blocks per CU
             const size_t cap = static_cast<size_t>(max_depth - 64 + 1);
             if (lanes * cap > (size_t{1} << 32))
-                return fail(BVH_AMD_ERR_UNSUPPORTED, "intersect_rays: the tree is too deep for the traversal stack (" + std::to_string(max_depth) + " levels)");
-            BVH_HIP_TRY(hipMallocAsync(&deep_mem, lanes * cap * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
+                return release(fail(BVH_AMD_ERR_UNSUPPORTED, "intersect_rays: the tree is too deep for the traversal stack (" + std::to_string(max_depth) + " levels)"));
+            const hipError_t e = scratch_alloc(&deep_mem, lanes * cap * sizeof(uint32_t), &deep_tag);
+            if (e != hipSuccess) { deep_mem = nullptr; return release(fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: stack spill buffer: ") + hipGetErrorString(e))); }
             args.deep = static_cast<uint32_t*>(deep_mem); args.deep_cap = static_cast<uint32_t>(cap);
         }
     }
     static const int refill_env = getenv("BVH_AMD_REFILL") ? atoi(getenv("BVH_AMD_REFILL")) : 0;   // tuning knobs
     static const int leaf_env = getenv("BVH_AMD_LEAF") ? atoi(getenv("BVH_AMD_LEAF")) : 0;
-    args.refill_threshold = refill_env > 0 ? refill_env : kRefillThreshold;
-    args.leaf_threshold = leaf_env > 0 ? leaf_env : kLeafThreshold;
     const bool beyond_l2 = b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
+    const bool heavy = beyond_l2 && b.expected_visits.load() >= kReorderMinVisits;       // long walks through a tree the L2s cannot hold
+    const bool any_hit = (flags & BVH_AMD_RAY_ANY_HIT) != 0;
+    const int forced = coop_fetch_forced();
+    const bool coop_capable = std::is_same_v<T, float> && b.dim == 3;
+    if (plan) {                                               // measured for this tree (calibrate) or one of the candidates being measured
+        args.coop = coop_capable && plan->coop ? 1u : 0u;
+        args.refill_threshold = plan->refill; args.leaf_threshold = plan->leaf;
+    } else {                                                  // the predictor (+ the developer's overrides)
+        args.coop = (coop_capable && (forced >= 0 ? forced != 0 : (any_hit || heavy))) ? 1u : 0u;
+        const int refill_default = !args.coop ? kRefillThreshold : any_hit ? kCoopRefillAny : heavy ? kCoopRefillHeavy : kCoopRefillAny;
+        const int leaf_default = !args.coop ? kLeafThreshold : any_hit ? kCoopLeafAny : heavy ? kCoopLeafHeavy : kCoopLeafAny;
+        args.refill_threshold = t_refill > 0 ? t_refill : refill_env > 0 ? refill_env : refill_default;
+        args.leaf_threshold = t_leaf > 0 ? t_leaf : leaf_env > 0 ? leaf_env : leaf_default;
+    }
     if (b.dim == 2) {                                         // Node<T, 2>: circles only (tri.h has no 2D intersector)
         if (leaf_kind != LEAF_SPHERE) return release(fail(BVH_AMD_ERR_ARG, "intersect_rays: a 2D BVH traces circles (Sphere<T, 2>) only"));
         int rc2 = dispatch<T, LEAF_SPHERE, 2>(b, args, flags, d_counters != nullptr, stream);
@@ -453,13 +542,24 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     // 10M-triangle mesh 13.9 -> 9.2 ms) and costs a few per cent where it does not (262k-triangle Sponza proxy, 1M rays: 0.32 ->
     // 0.36 ms), hence the default below.
     const bool reorder = (flags & BVH_AMD_RAY_SORTED) ? n > 4096
-                       : !(flags & BVH_AMD_RAY_UNSORTED) && n >= (size_t{1} << 20) && beyond_l2 && b.expected_visits.load() >= kReorderMinVisits;
+                       : (flags & BVH_AMD_RAY_UNSORTED) ? false
+                       : plan ? plan->reorder && n > 4096
+                       : n >= (size_t{1} << 20) && beyond_l2 && b.expected_visits.load() >= kReorderMinVisits;
     g_last_reordered = reorder && n < (size_t{1} << 31);
     if (g_last_reordered) {
         const uint32_t n32 = static_cast<uint32_t>(n);
         const size_t words = 4 * n + radix_sort_hist_words(n32, 1);              // keys + tmp, indices + tmp, histogram
-        hipError_t e = hipMallocAsync(&sort_mem, words * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return release(fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: hipMallocAsync: ") + hipGetErrorString(e)));
+        // (from the per-stream block cache the builders use: a stream-ordered allocation per call cost ~20 us of every timed pass)
+        hipError_t e = scratch_alloc(&sort_mem, words * sizeof(uint32_t), &sort_tag);
+        if (e != hipSuccess) {
+            sort_mem = nullptr;
+            (void)hipGetLastError();
+            if (flags & BVH_AMD_RAY_SORTED) return release(fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: no scratch for BVH_AMD_RAY_SORTED: ") + hipGetErrorString(e)));
+            g_last_reordered = false;                         // the reordering was this library's own idea: trace the rays as given instead
+        }
+    }
+    if (g_last_reordered) {
+        const uint32_t n32 = static_cast<uint32_t>(n);
         uint32_t *keys = static_cast<uint32_t*>(sort_mem), *vals = keys + n, *kt = vals + n, *vt = kt + n, *hist = vt + n;
         T lo[3], sc[3];
         for (int k = 0; k < 3; ++k) {
@@ -474,10 +574,90 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         if (rc) return release(rc);
         args.order = order;
     }
+    g_last_plan[0] = g_last_reordered; g_last_plan[1] = static_cast<int>(args.coop); g_last_plan[2] = args.refill_threshold; g_last_plan[3] = args.leaf_threshold;
     int rc = leaf_kind == LEAF_TRIANGLE ? dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream)
                                         : dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream);
     if (rc == BVH_AMD_OK && (flags & BVH_AMD_RAY_ORIGINAL_IDS)) rc = to_original_ids<T>(b, d_hits, n, stream);
     return release(rc);
+}
+
+
+// Large batches: which way of tracing is fastest for THIS tree is MEASURED. The predictor above (tree beyond the L2s, expected
+// record fetches of a random line) was fitted on four scenes and mispredicts elsewhere — a 4M-triangle scene of clustered debris is
+// 18 % faster traced as given, per lane, than with the reordering the predictor asks for (tools/rule_check.py). So the first eight
+// batches of >= 2^20 rays through a tree (per kind: closest / any-hit) are each traced WHOLE with one of four candidate plans (each
+// twice, the better time counts), their traversal kernel timed by a pair of events on the launch stream that the NEXT such call
+// reads once they have completed (no host synchronisation is added: while a measurement is still in flight — calls issued back to
+// back without the caller waiting for results — the predictor's plan is used and the search simply takes longer; a reordering
+// candidate is charged the keys + sort at their measured rate), and every later batch uses the plan with the fewest nanoseconds
+// per ray. (Measuring stretches of ONE batch with different plans was tried first and picks wrongly: a sixteenth of
+// a batch neither fills the persistent grid the same way nor has the ray density per sort key the whole batch has.) Results never
+// depend on the plan. BVH_AMD_CALIBRATE=0 keeps the predictor.
+constexpr float kSortNsPerRay = 0.031f;                    // ray keys + three radix passes: 0.52 ms per 2^24 rays (profiles/r03_*)
+
+static uint32_t pack_plan(const Plan& p) { return 1u | (p.reorder ? 2u : 0u) | (p.coop ? 4u : 0u) | (uint32_t(p.refill) << 8) | (uint32_t(p.leaf) << 16); }
+static Plan unpack_plan(uint32_t w) { return Plan{(w & 2u) != 0, (w & 4u) != 0, int((w >> 8) & 0xFFu), int((w >> 16) & 0xFFu)}; }
+
+template <typename T>
+int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
+                    typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream)
+{
+    static const bool calibrate_on = !(getenv("BVH_AMD_CALIBRATE") && atoi(getenv("BVH_AMD_CALIBRATE")) == 0);
+    const bool any_hit = (flags & BVH_AMD_RAY_ANY_HIT) != 0;
+    const int kind = any_hit ? 1 : 0;
+    const bool free_choice = !(flags & (BVH_AMD_RAY_SORTED | BVH_AMD_RAY_UNSORTED)) && coop_fetch_forced() < 0 && t_refill <= 0 && t_leaf <= 0 &&
+                             !getenv("BVH_AMD_REFILL") && !getenv("BVH_AMD_LEAF");
+    const bool candidate = calibrate_on && free_choice && std::is_same_v<T, float> && b.dim == 3 && n >= (size_t{1} << 20) && n < (size_t{1} << 31) &&
+                           b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
+    if (!candidate) return launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, nullptr);
+    if (const uint32_t cached = b.launch_plan[kind].load()) {
+        const Plan plan = unpack_plan(cached);
+        return launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, &plan);
+    }
+    const Plan candidates[4] = {
+        {false, false, kRefillThreshold, kLeafThreshold},
+        {false, true, any_hit ? kCoopRefillAny : kCoopRefillHeavy, any_hit ? kCoopLeafAny : kCoopLeafHeavy},
+        any_hit ? Plan{false, true, kCoopRefillHeavy, kCoopLeafHeavy} : Plan{true, false, kRefillThreshold, kLeafThreshold},
+        {true, true, any_hit ? kCoopRefillAny : kCoopRefillHeavy, any_hit ? kCoopLeafAny : kCoopLeafHeavy},
+    };
+    std::pair<hipEvent_t, hipEvent_t> events{nullptr, nullptr};
+    int trying = -1;
+    Plan plan{};
+    bool have_plan = false;
+    {
+        std::lock_guard<std::mutex> lock(b.plan_mutex);
+        typename BvhImpl<T>::PlanSearch& ps = b.plan_search[kind];
+        if (ps.pending && hipEventQuery(ps.stop) == hipSuccess) {            // the previous candidate has run: note its time
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ps.start, ps.stop) == hipSuccess && ps.rays) {
+                const int c = ps.index & 3;                                  // every candidate is measured twice; the better time counts
+                const float ns = ms * 1e6f / static_cast<float>(ps.rays) + (candidates[c].reorder ? kSortNsPerRay : 0.0f);
+                ps.ns_per_ray[c] = ps.index < 4 ? ns : std::min(ps.ns_per_ray[c], ns);   // (a kernel's first launch also pays its code load)
+                ++ps.index;
+            }
+            ps.pending = false;
+        }
+        (void)hipGetLastError();
+        if (ps.index >= 8) {                                                // all four measured twice: keep the winner
+            int best = 0;
+            for (int c = 1; c < 4; ++c) if (ps.ns_per_ray[c] < ps.ns_per_ray[best]) best = c;
+            b.launch_plan[kind].store(pack_plan(candidates[best]));
+            plan = candidates[best]; have_plan = true;
+        } else if (!ps.pending && !d_counters) {                            // try the next candidate on this batch
+            if (!ps.start) (void)hipEventCreate(&ps.start);
+            if (!ps.stop) (void)hipEventCreate(&ps.stop);
+            if (ps.start && ps.stop) {
+                trying = ps.index & 3; plan = candidates[trying]; have_plan = true;
+                events = {ps.start, ps.stop};
+                ps.pending = true; ps.rays = n;
+            }
+        }
+        (void)hipGetLastError();
+    }
+    if (trying >= 0) t_calibration = &events;
+    const int rc = launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, have_plan ? &plan : nullptr);
+    t_calibration = nullptr;
+    return rc;
 }
 
 

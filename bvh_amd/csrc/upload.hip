@@ -131,6 +131,7 @@ BvhImpl<T>::~BvhImpl() {
         if (d_prim_ids) (void)hipFree(d_prim_ids);
         if (d_work) (void)hipFree(d_work);
         for (hipEvent_t& e : work_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (PlanSearch& ps : plan_search) { if (ps.start) (void)hipEventDestroy(ps.start); if (ps.stop) (void)hipEventDestroy(ps.stop); ps.start = ps.stop = nullptr; }
         if (d_nodes) (void)hipFree(d_nodes);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
@@ -160,6 +161,7 @@ template <typename T>
 int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream) {
     b.pair_count = (b.node_count - 1) / 2;
     b.max_depth = -1;
+    { std::lock_guard<std::mutex> lock(b.plan_mutex); for (int k = 0; k < 2; ++k) { b.launch_plan[k] = 0; b.plan_search[k].index = 0; b.plan_search[k].pending = false; } }
     if (b.d_pairs) { (void)hipFree(b.d_pairs); b.d_pairs = nullptr; }
     if (b.pair_count) {
         // (from the stream-ordered pool when it is on: a plain hipMalloc of the 10M-triangle scene's 0.5 GB of records costs ~2 ms;

@@ -131,8 +131,8 @@ def _pick_transport(transport):
     import torch.distributed as dist
     if transport is None:
         transport = "rccl" if (not dist.is_initialized() or dist.get_backend() == "nccl") else "staged"
-    if transport not in ("rccl", "staged"):
-        raise ValueError("transport must be 'rccl' or 'staged'")
+    if transport not in ("rccl", "staged", "torch"):
+        raise ValueError("transport must be 'rccl', 'torch' or 'staged'")
     return transport
 
 
@@ -171,8 +171,25 @@ def broadcast_scene(bvh, prims, src: int = 0, timing: dict = None, comm: Comm = 
         meta_h[5], meta_h[6] = int(bvh.dtype == np.float64), bvh.dim
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if transport == "rccl" and comm is None:
+        # the library's own communicator; should ncclCommInitRank fail on ANY rank, every rank learns it here and all of them take
+        # torch.distributed's RCCL broadcast of the same device buffers instead (still no host copy) rather than diverging
+        why = None
+        try:
+            comm = default_comm()
+        except Exception as exc:                              # noqa: BLE001
+            why = repr(exc)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                import sys
+                print(f"[bvh_amd] rank {rank}: library communicator unavailable ({why or 'on another rank'}); using torch.distributed for the scene broadcast",
+                      file=sys.stderr)
+                comm, transport = None, "torch"
+        elif why:
+            raise _lib.BvhAmdError(why)
     if transport == "rccl":
-        comm = comm or default_comm()
         lib = _lib.load()
         meta = torch.tensor(meta_h, dtype=torch.int64, device="cuda")
         comm.broadcast_(meta, src)
@@ -192,7 +209,8 @@ def broadcast_scene(bvh, prims, src: int = 0, timing: dict = None, comm: Comm = 
         comm.broadcast_(prims, src)
         stream_bytes = 0                                       # (the library does not report it; recomputed below)
     else:
-        meta = torch.tensor(meta_h, dtype=torch.int64)
+        on_device = transport == "torch" and dist.get_backend() == "nccl"     # torch's own RCCL moves the device buffers; gloo needs host staging
+        meta = torch.tensor(meta_h, dtype=torch.int64, device="cuda" if on_device else "cpu")
         buf = None
         if rank == src:
             buf = bvh.serialize_device()
@@ -201,13 +219,21 @@ def broadcast_scene(bvh, prims, src: int = 0, timing: dict = None, comm: Comm = 
         m = [int(v) for v in meta.tolist()]
         shape = tuple(m[1:1 + m[0]])
         tdt = torch.float64 if m[5] else torch.float32
-        hbuf = buf.cpu() if rank == src else torch.empty(m[7], dtype=torch.uint8)
-        hprims = prims.cpu() if rank == src else torch.empty(shape, dtype=tdt)
-        dist.broadcast(hbuf, src)
-        dist.broadcast(hprims, src)
+        if on_device:
+            if rank != src:
+                buf = torch.empty(m[7], dtype=torch.uint8, device="cuda")
+                prims = torch.empty(shape, dtype=tdt, device="cuda")
+            dist.broadcast(buf, src)
+            dist.broadcast(prims, src)
+        else:
+            hbuf = buf.cpu() if rank == src else torch.empty(m[7], dtype=torch.uint8)
+            hprims = prims.cpu() if rank == src else torch.empty(shape, dtype=tdt)
+            dist.broadcast(hbuf, src)
+            dist.broadcast(hprims, src)
+            if rank != src:
+                buf, prims = hbuf.cuda(), hprims.cuda()
         if rank != src:
-            prims = hprims.cuda()
-            bvh = Bvh.deserialize_device(hbuf.cuda(), dtype=np.float64 if m[5] else np.float32, dim=m[6])
+            bvh = Bvh.deserialize_device(buf, dtype=np.float64 if m[5] else np.float32, dim=m[6])
         stream_bytes = m[7]
     torch.cuda.synchronize()
     if timing is not None:
@@ -217,6 +243,8 @@ def broadcast_scene(bvh, prims, src: int = 0, timing: dict = None, comm: Comm = 
         timing["broadcast_ms"] = (time.perf_counter() - t0) * 1e3
         timing["payload_bytes"] = int(stream_bytes + prims.numel() * prims.element_size())
         timing["transport"] = ("RCCL (ncclBroadcast issued by libbvh_amd.so, device buffers end to end)" if transport == "rccl"
+                               else "torch.distributed/nccl = RCCL (device buffers; the library's own communicator was unavailable)"
+                               if transport == "torch" and dist.get_backend() == "nccl"
                                else "torch.distributed/" + dist.get_backend() + " with host staging (functional path, not RCCL)")
     return bvh, prims
 

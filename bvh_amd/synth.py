@@ -180,6 +180,58 @@ def rays_2d(n: int, lo=(0.0, 0.0), hi=(1.0, 1.0), seed: int = 1234, dtype=np.flo
     return out
 
 
+# the reference's own scene (test/scenes/cornell_box.obj: 18 quads = 36 triangles, light + floor + ceiling + walls + two boxes), as
+# vertex-index quads so that no file is needed at run time
+_CORNELL_QUADS = [
+    ((-0.24, 1.98, 0.16), (-0.24, 1.98, -0.22), (0.23, 1.98, -0.22), (0.23, 1.98, 0.16)),          # light
+    ((-1.01, 0.0, 0.99), (1.0, 0.0, 0.99), (1.0, 0.0, -1.04), (-0.99, 0.0, -1.04)),                # floor
+    ((-1.02, 1.99, 0.99), (-1.02, 1.99, -1.04), (1.0, 1.99, -1.04), (1.0, 1.99, 0.99)),            # ceiling
+    ((-0.99, 0.0, -1.04), (1.0, 0.0, -1.04), (1.0, 1.99, -1.04), (-1.02, 1.99, -1.04)),            # back wall
+    ((1.0, 0.0, -1.04), (1.0, 0.0, 0.99), (1.0, 1.99, 0.99), (1.0, 1.99, -1.04)),                  # right wall
+    ((-1.01, 0.0, 0.99), (-0.99, 0.0, -1.04), (-1.02, 1.99, -1.04), (-1.02, 1.99, 0.99)),          # left wall
+    ((0.53, 0.6, 0.75), (0.7, 0.6, 0.17), (0.13, 0.6, 0.0), (-0.05, 0.6, 0.57)),                   # short box
+    ((-0.05, 0.0, 0.57), (-0.05, 0.6, 0.57), (0.13, 0.6, 0.0), (0.13, 0.0, 0.0)),
+    ((0.53, 0.0, 0.75), (0.53, 0.6, 0.75), (-0.05, 0.6, 0.57), (-0.05, 0.0, 0.57)),
+    ((0.7, 0.0, 0.17), (0.7, 0.6, 0.17), (0.53, 0.6, 0.75), (0.53, 0.0, 0.75)),
+    ((0.13, 0.0, 0.0), (0.13, 0.6, 0.0), (0.7, 0.6, 0.17), (0.7, 0.0, 0.17)),
+    ((-0.53, 1.2, 0.09), (0.04, 1.2, -0.09), (-0.14, 1.2, -0.67), (-0.71, 1.2, -0.49)),            # tall box
+    ((-0.53, 0.0, 0.09), (-0.53, 1.2, 0.09), (-0.71, 1.2, -0.49), (-0.71, 0.0, -0.49)),
+    ((-0.71, 0.0, -0.49), (-0.71, 1.2, -0.49), (-0.14, 1.2, -0.67), (-0.14, 0.0, -0.67)),
+    ((-0.14, 0.0, -0.67), (-0.14, 1.2, -0.67), (0.04, 1.2, -0.09), (0.04, 0.0, -0.09)),
+    ((0.04, 0.0, -0.09), (0.04, 1.2, -0.09), (-0.53, 1.2, 0.09), (-0.53, 0.0, 0.09)),
+]
+
+
+def cornell_tessellated(n: int = 1_000_000, dtype=np.float32) -> np.ndarray:
+    """A Cornell-box-like room (the layout of the reference's test scene: light, floor, ceiling, three walls, a short and a tall
+    box) with every quad tessellated into k x k cells of two triangles, k chosen so that the total is close to n: large planar
+    regions meeting at right angles around mostly EMPTY space — structurally unlike the soup (volume-filling), the terrain (one
+    sheet) and the Sponza proxy (columns and drapes). Used to check the traversal heuristics outside the scenes they were fitted on."""
+    k = max(1, int(round(np.sqrt(n / (2.0 * len(_CORNELL_QUADS))))))
+    parts = []
+    for q in _CORNELL_QUADS:
+        p0, p1, p2, p3 = (np.asarray(v, np.float64) for v in q)
+        parts.append(_grid_patch(p0, p1 - p0, p3 - p0, k, k, height=lambda uu, vv, p0=p0, p1=p1, p2=p2, p3=p3:
+                                 (uu * vv)[..., None] * (p2 - p1 - p3 + p0)))        # bilinear: exact for the (slightly) non-planar quads
+    return np.concatenate(parts, axis=0).astype(dtype)
+
+
+def clusters(n: int = 1_000_000, seed: int = 19, n_clusters: int = 400, dtype=np.float32) -> np.ndarray:
+    """n small triangles in `n_clusters` blobs of very different size and density (cluster radius 0.002 .. 0.08, populations
+    following a power law) scattered in the unit cube: vegetation / debris-like, heavy overlap inside a blob, empty space between."""
+    u = uniform01(seed, 5 * n_clusters, 0).reshape(n_clusters, 5)
+    centre = u[:, :3]
+    radius = 0.002 * (40.0 ** u[:, 3])
+    weight = (0.02 + u[:, 4]) ** 3
+    counts = np.floor(weight / weight.sum() * n).astype(np.int64)
+    counts[0] += n - counts.sum()
+    owner = np.repeat(np.arange(n_clusters), counts)
+    g = uniform01(seed, 3 * n, 1).reshape(n, 3) + uniform01(seed, 3 * n, 2).reshape(n, 3) + uniform01(seed, 3 * n, 3).reshape(n, 3) - 1.5   # ~gaussian
+    c = centre[owner] + g * radius[owner, None]
+    d = (uniform01(seed, 9 * n, 4).reshape(n, 3, 3) * 2.0 - 1.0) * (0.15 * radius[owner])[:, None, None]
+    return (c[:, None, :] + d).astype(dtype).reshape(n, 9)
+
+
 def procedural_10m(n: int = 10_000_000, seed: int = 7, dtype=np.float32) -> np.ndarray:
     """Config 4's "10M-triangle procedural mesh" = the soup at 10M."""
     return soup(n, seed=seed, dtype=dtype)

@@ -150,6 +150,11 @@ BVH_AMD_API int bvh_amd_release_cached_memory(void);
  * pattern when nothing else is in the way. Not used by any product path. */
 BVH_AMD_API int bvh_amd_probe_record_walk(const void* d_table, uint32_t n_records, uint32_t steps, int blocks_per_cu, int reps,
                                           float* ms_out, unsigned long long* records_out, void* stream);
+/* The same walk with the way a record reaches its lane selectable (csrc/probe.hip): mode 0 per-lane loads (as above), 1 quad-
+ * cooperative loads + LDS transpose, 2 / 3 one chain per quad loaded by the quad / by its first lane; `active` = lanes of a wave
+ * that own a chain (1..64). A table of a few KB measures the L1, a few MB the L2, beyond 32 MB the fabric side. */
+BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_records, uint32_t steps, int blocks_per_cu, int reps, int mode, int active,
+                                             float* ms_out, unsigned long long* records_out, void* stream);
 
 /* ---- multi-GPU (the "required extension" of 8b: device select + replicate) ------------------------------------
  * Ray batches shard embarrassingly (a const Bvh + per-ray state, reference bvh.h:160-182 touches nothing shared); the ONE
@@ -403,10 +408,29 @@ BVH_AMD_API int bvh_amd_last_launch_reordered(void);
  * the durations (ms) of the latest min(capacity, 256) launches since timing was switched on, oldest first. */
 BVH_AMD_API void bvh_amd_kernel_timing(int on);
 BVH_AMD_API int bvh_amd_kernel_times(float* ms_out, size_t capacity, size_t* count_out);
+/* The same launches: milliseconds from the start of the call on its stream to the start of the traversal kernel = ray keys +
+ * radix sort of the optional reordering (0 for a batch traced as given). */
+BVH_AMD_API int bvh_amd_reorder_times(float* ms_out, size_t capacity, size_t* count_out);
+/* Developer knob for A/B runs inside one process: overrides, for the calling thread's following batch launches, the refill /
+ * leaf-parking thresholds of the persistent waves (lanes idle before a wave draws new rays / lanes waiting at a leaf before the
+ * leaf code runs) and the record fetch of the float 3D kernels (0 per lane, 1 quad-cooperative). < 0 restores the default. Results
+ * never depend on any of them. */
+BVH_AMD_API void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch);
+/* How the calling thread's latest batch launch was traced: out = {reordered 0/1, record fetch 0 per lane / 1 quad-cooperative, refill
+ * threshold, leaf threshold}. For trees beyond the L2s and batches of >= 2^22 rays the library MEASURES this once per tree and kind
+ * of ray (four stretches of the first such batch are traced with different candidates; csrc/traverse.hip: launch_traverse) and
+ * keeps the winner; BVH_AMD_CALIBRATE=0 in the environment keeps the static predictor. */
+BVH_AMD_API void bvh_amd_last_launch_plan(int out[4]);
 /* ReinsertionOptimizer iterations run so far in this process: out[0] = through the heap-free fast path, out[1] = through the
  * exact replay of the reference's candidate heap + std::sort (taken when ties make their layout matter).
  * Both produce the reference's result bit for bit; BVH_AMD_REINSERT=exact in the environment forces the replay. */
 BVH_AMD_API void bvh_amd_reinsertion_stats(unsigned out[2]);
+/* The calling thread's latest ReinsertionOptimizer run (bvhXX_optimize*, or the optimize step of a Quality::High build;
+ * reinsertion_optimizer.h:237-267): iterations run, how many of them had to replay the libstdc++ candidate heap of
+ * find_candidates exactly (:88-105) instead of the heap-free fast path, the pop_heap + push_heap replacements those replays
+ * made, and the GPU time of the heap kernels. */
+struct bvh_amd_optimize_profile { unsigned iterations, replayed; unsigned long long replacements; float heap_ms; };
+BVH_AMD_API void bvh_amd_last_optimize_profile(struct bvh_amd_optimize_profile* out);
 
 
 /* ---- one ray, leaves intersected by a HOST callback (c_api/bvh.h:277-295; bvh_impl.h:235-250) --------------------------------

@@ -101,8 +101,10 @@ def test_high_quality_1m_invariants_and_traversal_properties():
     for choice in (False, None):
         run = bvh_amd.intersect(bvh, prims, rays, robust=True, sort_rays=choice)
         assert bool((run.view(torch.int32) == closest.view(torch.int32)).all())
-        # (this tree — 60 MB of records, ~360 expected record fetches per line — and 4M rays are what the default rule reorders)
-        assert bvh_amd._lib.load().bvh_amd_last_launch_reordered() == (0 if choice is False else 1)
+        # (left to itself the library is still MEASURING how to trace large batches through this tree — one candidate plan per
+        #  batch, tests/test_gpu_traverse.py::test_launch_plan_search — so only the forced choice is pinned here)
+        if choice is False:
+            assert bvh_amd._lib.load().bvh_amd_last_launch_reordered() == 0
     # counters are additive over a split of the batch
     _, c_a = bvh_amd.intersect(bvh, prims, rays[: nr // 3].contiguous(), robust=True, counters=True)
     _, c_b = bvh_amd.intersect(bvh, prims, rays[nr // 3:].contiguous(), robust=True, counters=True)

@@ -310,3 +310,48 @@ def test_original_primitive_ids_flag(orc):
         assert (b["prim"][hit].astype(np.uint64) == ids[a["prim"][hit].astype(np.int64)]).all()
         assert (b["prim"][~hit] == a["prim"][~hit]).all()
         assert a["t"].tobytes() == b["t"].tobytes() and a["u"].tobytes() == b["u"].tobytes()
+
+
+def test_launch_plan_search_settles_and_never_changes_results():
+    """Large batches through a tree beyond the L2s: the library tries four candidate plans (reordered or as given, per-lane or
+    quad-cooperative record fetch, thresholds), one whole batch each, twice, and keeps the fastest (csrc/traverse.hip:
+    launch_traverse). Whatever it tries, the hit records are the same bytes; after the search the plan no longer changes; a
+    re-laid-out tree (optimize) starts a new search; forced choices bypass it."""
+    import ctypes as C
+    import torch
+    import bvh_amd
+    lib = bvh_amd._lib.load()
+    tris = synth.soup(1_200_000, seed=5)
+    d = torch.from_numpy(tris).cuda()
+    bb, cc = bvh_amd.tri_bounds(d)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+    prims = bvh_amd.precompute_tris(d, bvh.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    n = 1 << 21
+    for any_hit, rays_h in ((False, synth.rays_closest(n, lo, hi)), (True, synth.rays_shadow(n, lo, hi))):
+        rays = torch.from_numpy(rays_h).cuda()
+        want = bvh_amd.intersect(bvh, prims, rays, any_hit=any_hit, robust=True, sort_rays=False).cpu().numpy().tobytes()
+        plans = []
+        for _ in range(14):
+            got = bvh_amd.intersect(bvh, prims, rays, any_hit=any_hit, robust=True)
+            torch.cuda.synchronize()
+            assert got.cpu().numpy().tobytes() == want
+            pl = (C.c_int * 4)()
+            lib.bvh_amd_last_launch_plan(pl)
+            plans.append(tuple(pl))
+        assert len(set(plans[:8])) >= 3, plans                  # the candidates really differ ...
+        assert len(set(plans[9:])) == 1, plans                  # ... and the search ends
+        forced = bvh_amd.intersect(bvh, prims, rays, any_hit=any_hit, robust=True, sort_rays=True)
+        assert forced.cpu().numpy().tobytes() == want and lib.bvh_amd_last_launch_reordered() == 1
+    settled = plans[-1]
+    bvh.optimize()                                              # new layout: the measured plan is forgotten
+    rays = torch.from_numpy(synth.rays_shadow(n, lo, hi)).cuda()
+    prims = bvh_amd.precompute_tris(d, bvh.device_prim_ids())
+    seen = set()
+    for _ in range(4):
+        bvh_amd.intersect(bvh, prims, rays, any_hit=True, robust=True)
+        torch.cuda.synchronize()
+        pl = (C.c_int * 4)()
+        lib.bvh_amd_last_launch_plan(pl)
+        seen.add(tuple(pl))
+    assert len(seen) >= 3, (seen, settled)

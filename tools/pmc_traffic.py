@@ -1,7 +1,14 @@
-"""Regenerates profiles/pmc_traffic.json on a GPU box: the HBM-side bytes per launch of the bench's traversal kernel, from two
-SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only, with --kernel-trace — never together with a sys / hip
-trace) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-probe [bench args]`, plus the sha1 of the traced kernel's
-instructions (tools/kernel_isa.py) so that bench.py can tell whether the library it runs is the one that was traced.
+"""Regenerates profiles/pmc_traffic.json on a GPU box: counters of the bench's traversal kernel, per launch, from SEPARATE
+rocprofv3 --pmc passes (counters only, with --kernel-trace — never together with a sys / hip trace) of
+`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-probe [bench args]`:
+
+    FETCH_SIZE | WRITE_SIZE                                             bytes at the L2's fabric side (KB)
+    TCP_TOTAL_CACHE_ACCESSES, TCP_TCC_READ_REQ, TCC_HIT, TCC_MISS       L1 lane requests, L1 -> L2 requests, L2 hits / misses
+    SQ_* (waves, wave cycles, waits, VALU instructions / thread cycles) where the wave time goes, lane utilisation
+
+Only the LAST 3 dispatches of the kernel (= the timed steps: bench.py's set-up passes try other launch plans through the same
+kernel) are averaged. Stored with the sha1 of the traced kernel's instructions (tools/kernel_isa.py) so that bench.py can tell
+whether the library it runs is the one that was traced.
 
     python tools/pmc_traffic.py [--out gpurun_out/pmc_traffic.json] [-- bench args ...]        (then copy the file to profiles/)
 """
@@ -16,6 +23,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+PASSES = [
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+    ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"],
+    ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU"],
+    ["SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_FLAT", "SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES"],
+]
+STEPS = 3
+
 
 def main():
     argv = sys.argv[1:]
@@ -25,27 +41,29 @@ def main():
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     work = os.path.join(os.path.dirname(out_path), "pmc_traffic_passes")
     env = dict(os.environ, TMPDIR="/tmp")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(STEPS), "--warmup", "1", "--no-cpu-baseline", "--no-probe"] + bench_args
     # the bench line itself (kernel name, key fields) from an un-profiled run
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-probe"] + bench_args,
-                       capture_output=True, text=True, cwd=ROOT, timeout=900)
+    r = subprocess.run(base, capture_output=True, text=True, cwd=ROOT, timeout=900)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     kernel = line["roofline"]["kernel"]
     rays = line["config"]["rays_per_gpu_per_step"]
-    sums = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = os.path.join(work, counter)
-        subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-                        os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-probe"] + bench_args,
+    want = kernel.replace(" ", "")
+    values = {}
+    for i, counters in enumerate(PASSES):
+        d = os.path.join(work, f"p{i}")
+        subprocess.run(["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + base,
                        cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200, check=True)
-        vals = []
+        rows = {}
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(path)):
                 name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("bvh_amd::", "").replace("void ", "")
-                if name.split("(")[0].replace(" ", "") == kernel.replace(" ", "") and row["Counter_Name"] == counter:
-                    vals.append(float(row["Counter_Value"]))
-        if not vals:
-            raise SystemExit(f"no {counter} rows for {kernel}")
-        sums[counter] = (sum(vals) / len(vals), len(vals))
+                if name.split("(")[0].replace(" ", "") == want:
+                    rows.setdefault(row["Counter_Name"], []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+        for c in counters:
+            got = sorted(rows.get(c, []))[-STEPS:]
+            if not got:
+                raise SystemExit(f"no {c} rows for {kernel}")
+            values[c] = sum(v for _, v in got) / len(got)
     from kernel_isa import kernel_isa_hash
     from bvh_amd import _lib
     import argparse
@@ -58,13 +76,24 @@ def main():
     doc = {}
     if os.path.exists(out_path):
         doc = json.load(open(out_path))
-    doc["_doc"] = ("HBM-side traffic per launch of the bench's traversal kernel from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in KB, "
-                   "mean over the kernel's dispatches; tools/pmc_traffic.py). Requests are 64-byte record sectors, so the guide's 2x wide-stream "
-                   "correction does not apply. isa_sha1 = tools/kernel_isa.py of the traced kernel: bench.py quotes the counts only for a library "
-                   "whose kernel hashes the same. Key: workload|quality|builder|traversal|rays per launch|rays reordered by the call or traced as given.")
-    doc[key] = {"fetch_kb": round(sums["FETCH_SIZE"][0], 1), "write_kb": round(sums["WRITE_SIZE"][0], 1),
-                "dispatches": [sums["FETCH_SIZE"][1], sums["WRITE_SIZE"][1]], "kernel": kernel,
-                "isa_sha1": kernel_isa_hash(_lib.LIB_PATH, kernel), "kernel_ms_unprofiled": line["roofline"]["kernel_ms"], "round": 2}
+    doc["_doc"] = ("Counters per launch of the bench's traversal kernel from separate rocprofv3 --pmc passes (mean over the last 3 dispatches = the timed "
+                   "steps; tools/pmc_traffic.py). FETCH_SIZE / WRITE_SIZE in KB at the L2's fabric side; FETCH_SIZE was calibrated on the record walk of "
+                   "csrc/probe.hip over a 1 GiB table (a known byte count in this very access pattern): counter / known = 0.998 "
+                   "(profiles/r03_fetch_calibration.json), so no correction applies to 64-byte record fetches. isa_sha1 = tools/kernel_isa.py of the traced "
+                   "kernel: bench.py quotes the counts only for a library whose kernel hashes the same. Key: workload|quality|builder|traversal|rays per "
+                   "launch|rays reordered by the call or traced as given.")
+    v = values
+    doc[key] = {"fetch_kb": round(v["FETCH_SIZE"], 1), "write_kb": round(v["WRITE_SIZE"], 1),
+                "tcp_total_cache_accesses": round(v["TCP_TOTAL_CACHE_ACCESSES_sum"]), "tcp_tcc_read_req": round(v["TCP_TCC_READ_REQ_sum"]),
+                "tcc_hit": round(v["TCC_HIT_sum"]), "tcc_miss": round(v["TCC_MISS_sum"]),
+                "lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4),
+                "wave_time": {"waiting_at_s_waitcnt": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4), "issue_stalled": round(v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"], 4),
+                              "issuing": round(v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], 4)},
+                "wave_instructions": {"valu": round(v["SQ_INSTS_VALU"]), "salu": round(v["SQ_INSTS_SALU"]), "vmem_read": round(v["SQ_INSTS_VMEM_RD"]),
+                                      "lds": round(v["SQ_INSTS_LDS"]), "branch": round(v["SQ_INSTS_BRANCH"])},
+                "raw": {k: round(x, 1) for k, x in v.items()},
+                "kernel": kernel, "launch_plan": line["roofline"].get("launch_plan"),
+                "isa_sha1": kernel_isa_hash(_lib.LIB_PATH, kernel), "kernel_ms_unprofiled": line["roofline"]["kernel_ms"], "round": 3}
     json.dump(doc, open(out_path, "w"), indent=2)
     print(json.dumps(doc[key]))
 
