@@ -413,7 +413,7 @@ def main():
         value = total_rays / elapsed / 1e6
         algorithmic = b_ray * rays_here / (kernel_ms * 1e-3) / 1e9
         kernel_name = lib.bvh_amd_last_kernel_name().decode()
-        coop = kernel_name.rstrip(">").split(",")[-1].strip() == "true"
+        coop = kernel_name.startswith("trace_kernel_coop")
         rec, pmc_note = pmc_record(args, robust, kernel_name, reordered, rays_here)
         traffic = None if rec is None else round((rec["fetch_kb"] + rec["write_kb"]) * 1024.0 / (kernel_ms * 1e-3) / 1e9, 1)
         # ---- the ceiling that binds: the memory hierarchy under the kernel's own access pattern ---------------------------------

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libbvh_amd.so")
+LIB_PATH = os.environ.get("BVH_AMD_LIB") or os.path.join(HERE, "lib", "libbvh_amd.so")     # (BVH_AMD_LIB: a developer's A/B build)
 
 _lib = None
 

@@ -799,7 +799,10 @@ __global__ void __launch_bounds__(256) k_forest_roots(BuildCtx<T> c, const uint3
         }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { atomicMin(&slo[k], Ord<T>::enc(lo[k])); atomicMax(&shi[k], Ord<T>::enc(hi[k])); }
+    for (int k = 0; k < 3; ++k) {
+        const auto klo = wave_min_key(Ord<T>::enc(lo[k])), khi = wave_max_key(Ord<T>::enc(hi[k]));
+        if ((threadIdx.x & 63) == 0) { atomicMin(&slo[k], klo); atomicMax(&shi[k], khi); }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         ANode<T>& r = c.nodes[g];

@@ -50,6 +50,20 @@ template <> struct Ord<double> {
     __device__ static double zero(uint32_t negative) { return __longlong_as_double(static_cast<long long>(static_cast<U>(negative) << 63)); }
 };
 
+// Block-wide min / max of per-thread bounds into six LDS words: each wave folds its 64 values with xor-shuffles first and ONE lane
+// per wave touches the LDS word instead of 256 threads contending for six LDS addresses. Keys are the order-preserving integer
+// images (Ord<T>::enc), so integer min / max is the float min / max.
+template <typename U> __device__ inline U wave_min_key(U v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const U o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+template <typename U> __device__ inline U wave_max_key(U v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const U o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+
 template <typename T> __device__ inline T pick_min(T a, T b) { return a < b ? a : b; }    // utils.h:41-43
 template <typename T> __device__ inline T pick_max(T a, T b) { return a > b ? a : b; }
 
@@ -379,7 +393,10 @@ __global__ void __launch_bounds__(256) k_init_root(BuildCtx<T> c, bool init_iota
         }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { atomicMin(&slo[k], Ord<T>::enc(lo[k])); atomicMax(&shi[k], Ord<T>::enc(hi[k])); }
+    for (int k = 0; k < 3; ++k) {
+        const auto klo = wave_min_key(Ord<T>::enc(lo[k])), khi = wave_max_key(Ord<T>::enc(hi[k]));
+        if ((threadIdx.x & 63) == 0) { atomicMin(&slo[k], klo); atomicMax(&shi[k], khi); }
+    }
     __syncthreads();
     if (threadIdx.x < 3) {
         // the root's key box lives in state[0].clo[0]/chi[0] until k_make_root decodes it

@@ -61,7 +61,10 @@ __global__ void __launch_bounds__(256) k_center_bounds(const T* centers, uint32_
 #pragma unroll
         for (int k = 0; k < 3; ++k) { const T v = centers[3 * i + k]; lo[k] = pick_min(lo[k], v); hi[k] = pick_max(hi[k], v); }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { atomicMin(&slo[k], Ord<T>::enc(lo[k])); atomicMax(&shi[k], Ord<T>::enc(hi[k])); }
+    for (int k = 0; k < 3; ++k) {
+        const auto klo = wave_min_key(Ord<T>::enc(lo[k])), khi = wave_max_key(Ord<T>::enc(hi[k]));
+        if ((threadIdx.x & 63) == 0) { atomicMin(&slo[k], klo); atomicMax(&shi[k], khi); }
+    }
     __syncthreads();
     if (threadIdx.x < 3) { atomicMin(&keybox[threadIdx.x], slo[threadIdx.x]); atomicMax(&keybox[3 + threadIdx.x], shi[threadIdx.x]); }
 }

@@ -58,11 +58,21 @@ KernelTimer& kernel_timer() { static thread_local KernelTimer t; return t; }
 // bounds are zero and never looked at): only the per-ray constants, the slab test and the leaf test run over D axes.
 // Deep = true (trees of more than 64 levels only): stack entries beyond the 64 of SmallStack spill to HBM (GrowingStack).
 // (70 VGPRs = 7 waves per SIMD; forcing 8 with amdgpu_waves_per_eu fits in 63 without spills and runs 16 % slower on soup_1m)
-// Coop = true (float, 3D): records are fetched quad-cooperatively (trace_device.h: coop_load_pair), one L1 line request per visited
-// record instead of four lane requests.
-template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3, bool Deep = false, bool Coop = false>
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D = 3, bool Deep = false>
 __global__ void __launch_bounds__(kBlock) trace_kernel(TraceArgs<T> a) {
-#define BVH_TRACE_COOP Coop
+#include "trace_body.inc"
+}
+
+// The same body with the quad-cooperative record fetch (trace_device.h: coop_load_pair; float, 3D, trees of at most 64 levels and
+// fewer than 2^26 pair records): one L1 line request per visited record instead of four lane requests.
+// Waves per SIMD: the per-lane kernel runs best at the 7 its 70 VGPRs allow (forced to 8 it is 16-19 % slower on the soup: more lanes
+// asking the L1 for four requests per record), this one at 8 (64 VGPRs, no spills; +4 % on the 1M soup and the 10M mesh, +4 % on
+// the Sponza proxy: with a quarter of the L1 requests the extra wave is memory-level parallelism, not contention).
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
+__global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop(TraceArgs<T> a) {
+    constexpr int D = 3;
+    constexpr bool Deep = false;
+#define BVH_TRACE_COOP true
 #include "trace_body.inc"
 #undef BVH_TRACE_COOP
 }
@@ -128,7 +138,9 @@ int persistent_grid(K kernel, int device, Grid& g) {
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D, bool Deep, bool Coop = false>
 int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     static thread_local int cached_blocks[16] = {0};
-    auto kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D, Deep, Coop>;
+    void (*kernel)(TraceArgs<T>) = nullptr;
+    if constexpr (Coop) kernel = trace_kernel_coop<T, Any, Robust, Leaf, Stats>;
+    else kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D, Deep>;
     int& blocks = cached_blocks[b.device & 15];
     if (blocks == 0) {
         Grid g;
@@ -141,9 +153,9 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     if (grid < 1) grid = 1;
     (void)name;
     // the symbol as rocprofv3 prints it (profiles/*_kernel_stats.csv), for bench.py's roofline.kernel
-    static const std::string symbol = std::string("trace_kernel<") + (std::is_same_v<T, float> ? "float" : "double") + ", " + (Any ? "true" : "false") + ", " +
-                                      (Robust ? "true" : "false") + ", " + std::to_string(Leaf) + ", " + (Stats ? "true" : "false") + ", " + std::to_string(D) +
-                                      ", " + (Deep ? "true" : "false") + ", " + (Coop ? "true" : "false") + ">";
+    static const std::string head = std::string(Coop ? "trace_kernel_coop<" : "trace_kernel<") + (std::is_same_v<T, float> ? "float" : "double") + ", " +
+                                    (Any ? "true" : "false") + ", " + (Robust ? "true" : "false") + ", " + std::to_string(Leaf) + ", " + (Stats ? "true" : "false");
+    static const std::string symbol = Coop ? head + ">" : head + ", " + std::to_string(D) + ", " + (Deep ? "true" : "false") + ">";
     g_last_kernel = symbol.c_str();
     KernelTimer& timer = kernel_timer();
     hipEvent_t stop = nullptr;

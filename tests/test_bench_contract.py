@@ -103,7 +103,7 @@ def test_bench_json_contract(monkeypatch, orc):
 
     def fake_plan(out):
         out[0], out[1], out[2], out[3] = 1, 1, 12, 12
-    fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"fake_kernel<float, false, true, 0, false, 3, false, true>", bvh_amd_kernel_timing=lambda on: None,
+    fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"trace_kernel_coop<float, false, true, 0, false>", bvh_amd_kernel_timing=lambda on: None,
                                      bvh_amd_last_launch_reordered=lambda: 0, bvh_amd_kernel_times=fake_kernel_times, bvh_amd_reorder_times=fake_reorder_times,
                                      bvh_amd_last_launch_plan=fake_plan)
     monkeypatch.setattr(bvh_amd, "last_optimize_profile", lambda: {"iterations": 3, "replayed": 2, "replacements": 1000, "heap_ms": 0.5})

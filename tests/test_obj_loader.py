@@ -58,9 +58,9 @@ def test_kernel_isa_hash_of_the_built_library():
     from kernel_isa import kernel_isa_hash
     from bvh_amd import _lib, build
     build.build()
-    h = kernel_isa_hash(_lib.LIB_PATH, "trace_kernel<float, false, true, 0, false, 3, false, false>")
+    h = kernel_isa_hash(_lib.LIB_PATH, "trace_kernel<float, false, true, 0, false, 3, false>")
     assert h is not None and len(h) == 40
-    assert h == kernel_isa_hash(_lib.LIB_PATH, "trace_kernel<float, false, true, 0, false, 3, false, false>")
+    assert h == kernel_isa_hash(_lib.LIB_PATH, "trace_kernel<float, false, true, 0, false, 3, false>")
     assert kernel_isa_hash(_lib.LIB_PATH, "no_such_kernel<int>") is None
     import json
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# round 3, GPU call 11: final numbers — PMC passes + bench line + rocprof kernel stats of the bench command + the five BASELINE configs +
+# profiles of the config kernels + the whole GPU test-suite
+set -u
+o=gpurun_out/r03; mkdir -p $o
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 900 python tools/pmc_traffic.py --out $o/pmc_traffic.json > $o/pmc_traffic.log 2>&1; echo "pmc_traffic rc=$?"
+cp $o/pmc_traffic.json profiles/pmc_traffic.json
+timeout 600 python bench.py > $o/bench.json 2>$o/bench.err; echo "bench rc=$?"
+python -c "
+import json; d=json.load(open('$o/bench.json')); r=d['roofline']
+print('value', d['value'], 'kernel', r['kernel_ms'], 'pass', r['pass_ms'], 'roofline', r['achieved'], r['peak'], r['frac'], r['binding_level'], r['model_ms'], r['sum_of_levels_ms'], 'traffic', r['traffic'])
+print({k: (v['ms'], v['grec_s']) for k, v in r['levels'].items()}, r['probe']['active_lanes'], r['launch_plan']['refill_threshold'], r['kernel'])
+c=d['cpu_baseline']; print('cpu', c['value'], c['threads_used'], c['build_mtris_s'], c['gpu_matches_cpu_hits'], c['gpu_tree_equals_cpu_tree']); print('build', d['build']['all_qualities_ms'])"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$o/bench_stats -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$o/bench_stats.json 2>$GRAFT_REPO_ROOT/$o/bench_stats.err); echo "bench stats rc=$?"
+find $o/bench_stats -name "*kernel_stats.csv" -exec cp {} $o/bench_kernel_stats.csv \; ; find $o/bench_stats -name "*kernel_trace.csv" -delete
+head -4 $o/bench_kernel_stats.csv | cut -c1-200
+timeout 900 python tools/run_configs.py > $o/baseline_configs.jsonl 2>$o/baseline_configs.err; echo "configs rc=$?"; cat $o/baseline_configs.jsonl | cut -c1-260
+timeout 1200 bash tools/profile_configs.sh $o/configs anyhit,spheres64,shard10m 2 > $o/profile_configs.log 2>&1; echo "profile rc=$?"
+timeout 1800 python -m pytest tests -x -q -m gpu > $o/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $o/pytest_gpu.log
