@@ -435,8 +435,8 @@ def main():
                                 "what": "L1 misses (TCP_TCC_READ_REQ) at the L2-resident rate of the probe"}
                 levels["fabric"] = {"requests_per_launch": round(misses), "grec_s": probe["beyond_l2_grec_s"],
                                     "ms": round(misses / probe["beyond_l2_grec_s"] / 1e6, 4),
-                                    "what": "L2 misses (TCC_MISS; a miss of the quad-cooperative kernel fetches a 128-byte line, FETCH_SIZE = 2 x 64 B per "
-                                            "miss, where the per-lane kernel fetched 64 B) at the beyond-L2 rate of the probe, whose every record is one miss"}
+                                    "what": "L2 misses (TCC_MISS; FETCH_SIZE / 64 B agrees within 15 %, FETCH_SIZE itself calibrated at 0.998 of a known byte "
+                                            "count in this pattern: profiles/r03_fetch_calibration.json) at the beyond-L2 rate of the probe, whose every record is a miss"}
         model_ms = None if levels is None else max(v["ms"] for v in levels.values())
         sum_ms = None if levels is None else sum(v["ms"] for v in levels.values())
         peak_mrays = None if not model_ms else rays_here / model_ms / 1e3

@@ -77,6 +77,24 @@ __global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop(TraceArgs<T> a) {
 #undef BVH_TRACE_COOP
 }
 
+// Twins of the two kernels above under their own symbols, launched only while launch_traverse is MEASURING candidate plans for a tree
+// (one whole batch per candidate, see there): a profile of an application then shows the search launches apart from the settled
+// ones instead of averaging batches traced as given and batches traced reordered into one kernel's row.
+template <typename T, bool Any, bool Robust, int Leaf>
+__global__ void __launch_bounds__(kBlock) trace_kernel_plan_search(TraceArgs<T> a) {
+    constexpr int D = 3;
+    constexpr bool Deep = false, Stats = false;
+#include "trace_body.inc"
+}
+template <typename T, bool Any, bool Robust, int Leaf>
+__global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop_plan_search(TraceArgs<T> a) {
+    constexpr int D = 3;
+    constexpr bool Deep = false, Stats = false;
+#define BVH_TRACE_COOP true
+#include "trace_body.inc"
+#undef BVH_TRACE_COOP
+}
+
 // Coherence key of a ray: Morton code of its origin cell (64^3 grid over the root box) above the direction octant, 21 bits, three
 // 8-bit radix passes. Rays of one key start in the same cell and descend the same way first; any order gives the same per-ray
 // results. Measured with one ticket range per XCD on 2^24 uniform rays, rays physically permuted (tools/ray_order_probe.py,
@@ -141,6 +159,12 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     void (*kernel)(TraceArgs<T>) = nullptr;
     if constexpr (Coop) kernel = trace_kernel_coop<T, Any, Robust, Leaf, Stats>;
     else kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D, Deep>;
+    if constexpr (std::is_same_v<T, float> && D == 3 && !Deep && !Stats) {
+        if (t_calibration) {                                  // a candidate plan being measured: same code, its own symbol
+            if constexpr (Coop) kernel = trace_kernel_coop_plan_search<T, Any, Robust, Leaf>;
+            else kernel = trace_kernel_plan_search<T, Any, Robust, Leaf>;
+        }
+    }
     int& blocks = cached_blocks[b.device & 15];
     if (blocks == 0) {
         Grid g;

@@ -14,8 +14,9 @@ from bvh_amd import synth
 
 
 def timed(fn, reps):
-    fn(); fn()
-    torch.cuda.synchronize()
+    for _ in range(10):                                       # the library's launch-plan search settles on finished batches
+        fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):

@@ -12,7 +12,7 @@ lib = bvh_amd._lib.load()
 
 
 def kernel_ms(fn, reps):
-    fn(); fn()
+    fn(); fn()                                                # (forced plans: nothing to settle)
     torch.cuda.synchronize()
     lib.bvh_amd_kernel_timing(1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

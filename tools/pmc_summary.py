@@ -6,21 +6,22 @@ import sys
 from collections import defaultdict
 
 
-def main(root, match="trace_kernel"):
+def main(root, match="trace_kernel", last=0):
+    """last > 0: only the last `last` dispatches of every kernel count (the timed launches of a probe whose first launches settle
+    the library's launch plan with other plans through the same kernel)."""
     out = []
     for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
-        acc = defaultdict(lambda: [0.0, 0])
+        rows = defaultdict(list)
         for row in csv.DictReader(open(path)):
             name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-            key = (name.split("(")[0], row["Counter_Name"])
-            acc[key][0] += float(row["Counter_Value"])
-            acc[key][1] += 1
-        for (k, c), (s, n) in sorted(acc.items()):
+            rows[(name.split("(")[0], row["Counter_Name"])].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+        for (k, c), vals in sorted(rows.items()):
             if match in k:
-                out.append(f"{os.path.relpath(path, root).split(os.sep)[0]},\"{k}\",{c},{n},{s / n:.1f}")
+                vals = sorted(vals)[-last:] if last > 0 else vals
+                out.append(f"{os.path.relpath(path, root).split(os.sep)[0]},\"{k}\",{c},{len(vals)},{sum(v for _, v in vals) / len(vals):.1f}")
     print("pass,kernel,counter,dispatches,avg_per_dispatch")
     print("\n".join(out))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], *(sys.argv[2:3]))
+    main(sys.argv[1], *(sys.argv[2:3]), *(int(a) for a in sys.argv[3:4]))

@@ -16,8 +16,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WA
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$out/p$i" -- python "$here/tools/config_probe.py" "$cfgs" 2 "$q10" > "$out/p$i.log" 2>&1; echo "pass $i ($pass) rc=$?"
 done
-python "$here/tools/pmc_summary.py" "$out" trace_kernel > "$out/pmc_summary.csv" 2>&1
+python "$here/tools/pmc_summary.py" "$out" trace_kernel 2 > "$out/pmc_summary.csv" 2>&1
 find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
+python "$here/tools/last_dispatch_stats.py" "$(find "$out/stats" -name "*kernel_trace.csv" | head -1)" 5 > "$out/kernel_last5.csv" 2>&1
 # keep the merged directory small: the raw per-dispatch CSVs are summarised above
 find "$out" -name "*counter_collection.csv" -size +2M -delete; find "$out" -name "*kernel_trace.csv" -size +2M -delete
 ls "$out"

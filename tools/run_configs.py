@@ -7,10 +7,10 @@ import bvh_amd
 from bvh_amd import synth
 
 
-def timed(fn, reps=5, warm=2):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+def timed(fn, reps=5, warm=10):
+    for _ in range(warm):                                     # (the library settles its launch plan on a tree's first large batches, read
+        fn()                                                  #  back one finished batch at a time: csrc/traverse.hip launch_traverse)
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
