@@ -16,10 +16,43 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def orc():
-    """The CPU restatement of the reference (oracle/bvh_oracle.cpp); compiled on demand."""
+def _restatement():
     import oracle
     return oracle.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def _compiled_reference():
+    import oracle
+    return oracle.load_ref()
+
+
+class _PreferReference:
+    """The compiled, unmodified reference (oracle/_ref) behind the restatement's Python interface; the one entry point only the
+    restatement has (std_sort_ids: libstdc++'s std::sort on a key array) stays with it."""
+
+    def __init__(self, ref, restatement):
+        self._ref, self._restatement = ref, restatement
+
+    def __getattr__(self, name):
+        return getattr(self._restatement if name == "std_sort_ids" else self._ref, name)
+
+
+@pytest.fixture
+def restatement(_restatement):
+    """Always the restatement: for what the compiled reference's harness cannot do (it traces with the SmallStack<Index, 64> of the
+    reference's examples, so trees deeper than 64 levels need the restatement's growing stack)."""
+    return _restatement
+
+
+@pytest.fixture
+def orc(request, _restatement, _compiled_reference):
+    """The CPU checker. CPU tests: the restatement of the reference (oracle/bvh_oracle.cpp; it is what those tests pin against the
+    golden vectors). `-m gpu` tests: the compiled, unmodified reference wherever oracle/_ref loads (it does on the GPU box: the .so
+    travels with the snapshot) — the restatement only where it cannot exist."""
+    if request.node.get_closest_marker("gpu") is not None and _compiled_reference is not None:
+        return _PreferReference(_compiled_reference, _restatement)
+    return _restatement
 
 
 @pytest.fixture(scope="session")

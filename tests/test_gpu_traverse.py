@@ -202,8 +202,9 @@ def test_cornell_render_ppm_md5(orc):
 
 
 @pytest.mark.parametrize("depth", [60, 64, 65, 300, 3000])
-def test_trees_deeper_than_the_small_stack(orc, depth):
-    """The reference's examples and C API trace with SmallStack<Index, 64>; its GrowingStack (stack.h:34-46) has no limit.
+def test_trees_deeper_than_the_small_stack(restatement, depth):
+    """The reference's examples and C API trace with SmallStack<Index, 64>; its GrowingStack (stack.h:34-46) has no limit (the
+    checker here is the restatement: oracle/_ref's harness uses the SmallStack and cannot walk these trees).
     A chain-shaped tree whose inner child is always nearer than its leaf sibling fills the stack one entry per level: the
     device traversal must give the growing-stack results (LDS + scratch up to 64 entries, HBM spill beyond)."""
     import bvh_amd
@@ -212,7 +213,7 @@ def test_trees_deeper_than_the_small_stack(orc, depth):
     for k in range(n):
         x = np.float32(4000 - k)
         tris[k] = [x, -1, -1, x, 1, -1, x, 0, 1]
-    bb, _ = orc.prep_tris(tris)
+    bb, _ = restatement.prep_tris(tris)
     nodes = np.zeros(2 * n - 1, dtype=oracle.NODEF)
     suffix = bb.copy()                                        # suffix[k] = union of the boxes of leaves k..n-1
     for k in range(n - 2, -1, -1):
@@ -228,9 +229,9 @@ def test_trees_deeper_than_the_small_stack(orc, depth):
         else:
             nodes[rest]["bounds"], nodes[rest]["index"] = box(suffix[k + 1]), (2 * k + 3) << 4
     ids = np.arange(n, dtype=np.uint64)
-    ref = orc.from_arrays(nodes, ids)
+    ref = restatement.from_arrays(nodes, ids)
     gpu = bvh_amd.Bvh.from_nodes(nodes, ids)
-    prims = orc.precompute_tris(tris)
+    prims = restatement.precompute_tris(tris)
     rng = np.random.default_rng(depth)
     rays = np.zeros((70_000, 8), dtype=np.float32)
     rays[:, 0] = rng.random(len(rays)) * 100                   # origins in front of the stack of triangles

@@ -278,9 +278,9 @@ def test_python_intersect_ray_inner_callback_start_and_threads(orc):
 
 
 @pytest.mark.gpu
-def test_callback_walk_on_a_tree_deeper_than_the_small_stack(orc):
+def test_callback_walk_on_a_tree_deeper_than_the_small_stack(restatement):
     """A chain of 300 levels: the device keeps as much stack as the tree needs (the reference's GrowingStack), and a log that
-    fills up mid-walk continues from the stack the device kept."""
+    fills up mid-walk continues from the stack the device kept (checker: the restatement; oracle/_ref's harness walks with SmallStack<Index, 64>)."""
     import oracle
     import bvh_amd
     depth = 300
@@ -289,7 +289,7 @@ def test_callback_walk_on_a_tree_deeper_than_the_small_stack(orc):
     for k in range(n):
         x = np.float32(4000 - k)
         tris[k] = [x, -1, -1, x, 1, -1, x, 0, 1]
-    bb, _ = orc.prep_tris(tris)
+    bb, _ = restatement.prep_tris(tris)
     nodes = np.zeros(2 * n - 1, dtype=oracle.NODEF)
     suffix = bb.copy()
     for k in range(n - 2, -1, -1):
@@ -305,9 +305,9 @@ def test_callback_walk_on_a_tree_deeper_than_the_small_stack(orc):
         else:
             nodes[rest]["bounds"], nodes[rest]["index"] = box(suffix[k + 1]), (2 * k + 3) << 4
     ids = np.arange(n, dtype=np.uint64)
-    ref = orc.from_arrays(nodes, ids)
+    ref = restatement.from_arrays(nodes, ids)
     gpu = bvh_amd.Bvh.from_nodes(nodes, ids)
-    prims = orc.precompute_tris(tris)
+    prims = restatement.precompute_tris(tris)
     rng = np.random.default_rng(5)
     rays = np.zeros((40, 8), dtype=np.float32)
     rays[:, 0] = rng.random(len(rays)) * 100
