@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# round 3, final numbers: PMC passes + bench line + rocprof kernel stats of the bench command (plan-search launches under their own symbols) + GPU suite
+# Developer script (round 3): the final numbers: PMC passes + bench line + rocprof kernel stats of the bench command (plan-search launches under their own symbols) + GPU suite
 set -u
 o=gpurun_out/r03; mkdir -p $o
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
