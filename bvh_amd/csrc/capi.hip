@@ -506,7 +506,7 @@ int bvh_amd_kernel_times(float* ms_out, size_t capacity, size_t* count_out) {
     return kernel_times(ms_out, capacity, count_out);
 }
 void bvh_amd_last_optimize_profile(struct bvh_amd_optimize_profile* out) { if (out) last_optimize_profile(out); }
-void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch) { set_tuning(refill_threshold, leaf_threshold, coop_fetch); }
+void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch, int ticket_ranges) { set_tuning(refill_threshold, leaf_threshold, coop_fetch, ticket_ranges); }
 void bvh_amd_last_launch_plan(int out[4]) { if (out) last_launch_plan(out); }
 int bvh_amd_reorder_times(float* ms_out, size_t capacity, size_t* count_out) {
     if (!ms_out && capacity) return fail(BVH_AMD_ERR_ARG, "bvh_amd_reorder_times: null output");

@@ -139,7 +139,7 @@ struct BvhImpl {
     // A slot is claimed under work_mutex and stays busy until its launch has recorded the slot's event on its stream; the next
     // launch that takes the slot is ordered behind that event, so launches in flight never share a counter however many host
     // threads are between their claim and their record (a 65th concurrent claimant waits for a slot to be released).
-    static constexpr uint32_t kWorkSlots = 64, kWorkStride = 128;      // slots of 1 KB: eight ticket counters 128 bytes apart
+    static constexpr uint32_t kWorkSlots = 64, kWorkStride = 4096;     // slots of 32 KB: up to 256 ticket counters 128 bytes apart
     unsigned long long* d_work = nullptr;      // kWorkSlots x kWorkStride words: the ticket counters of the launch that holds the slot
     mutable std::atomic<uint32_t> work_next{0};
     mutable hipEvent_t work_done[kWorkSlots] = {};      // recorded behind the slot's latest launch (created on first use)
@@ -215,7 +215,7 @@ template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
                     typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream);
 void last_launch_plan(int out[4]);                            // traverse.hip: {reordered, coop, refill, leaf} of the calling thread's latest launch
-void set_tuning(int refill, int leaf, int coop);               // traverse.hip: per-thread overrides for A/B runs (< 0: default)
+void set_tuning(int refill, int leaf, int coop, int parts);               // traverse.hip: per-thread overrides for A/B runs (< 0: default)
 const char* last_kernel_name();
 bool last_launch_reordered();
 void kernel_timing(bool on);                                  // traverse.hip

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) original_ids_kernel(H* hits, size_t n, co
 }
 
 // Tuning overrides of the calling thread (bvh_amd_tuning; developer A/B runs in one process): < 0 = the default / the environment
-thread_local int t_refill = -1, t_leaf = -1, t_coop = -1;
+thread_local int t_refill = -1, t_leaf = -1, t_coop = -1, t_parts = -1;
 thread_local std::pair<hipEvent_t, hipEvent_t>* t_calibration = nullptr;   // events to record around the next traversal kernel of this thread
 
 // BVH_AMD_COOP=0 / 1 (or bvh_amd_tuning) forces the per-lane / quad-cooperative record fetch of the float 3D kernels for A/B
@@ -415,7 +415,7 @@ struct StepContextClaim {
 } // namespace
 
 void last_launch_plan(int out[4]) { for (int k = 0; k < 4; ++k) out[k] = g_last_plan[k]; }
-void set_tuning(int refill, int leaf, int coop) { t_refill = refill; t_leaf = leaf; t_coop = coop; }
+void set_tuning(int refill, int leaf, int coop, int parts) { t_refill = refill; t_leaf = leaf; t_coop = coop; t_parts = parts; }
 const char* last_kernel_name() { return g_last_kernel; }
 bool last_launch_reordered() { return g_last_reordered; }
 
@@ -511,7 +511,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     // one ticket range per XCD (trace_body.inc: refill): free for incoherent batches, a win for every batch whose neighbouring
     // rays are close (coherence-sorted below, or generated that way by the caller)
     static const int parts_env = getenv("BVH_AMD_PARTS") ? atoi(getenv("BVH_AMD_PARTS")) : 0;            // tuning knob
-    args.parts = parts_env > 0 ? std::min(parts_env, 8) : (n >= 65536 ? 8 : 1);
+    args.parts = t_parts > 0 ? std::min(t_parts, 256) : parts_env > 0 ? std::min(parts_env, 256) : n < 65536 ? 1 : 8;   // (refined below once the order is decided)
     args.part_size = ((n + args.parts - 1) / args.parts + 63) / 64 * 64;
     args.deep = nullptr; args.deep_cap = 0;
     // Scratch that only some launches need is allocated and freed in stream order (hipMallocAsync / hipFreeAsync), so that
@@ -582,6 +582,13 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
                        : plan ? plan->reorder && n > 4096
                        : n >= (size_t{1} << 20) && beyond_l2 && b.expected_visits.load() >= kReorderMinVisits;
     g_last_reordered = reorder && n < (size_t{1} << 31);
+    // Ticket ranges (trace_body.inc: refill). A reordered batch wants exactly one range per XCD: each L2 then serves one stretch of the
+    // order. A batch traced as given has no such locality to protect, and its waves draw tickets often (short rays, early refills):
+    // eight counters then cost measurable time in atomics on one address each — 32 ranges (four per XCD) take the 1M terrain from 1.18
+    // to 1.10 ms (per lane) and 1.31 to 1.12 ms (cooperative), the Sponza proxy's shadow rays from 1.63 to 1.52 ms; the sorted soup
+    // prefers 8 (7.24 against 7.32 ms at 32); a single counter costs 2x and more (profiles/r03_traversal_experiments.md).
+    args.parts = t_parts > 0 ? std::min(t_parts, 256) : parts_env > 0 ? std::min(parts_env, 256) : n < 65536 ? 1 : g_last_reordered ? 8 : 32;
+    args.part_size = ((n + args.parts - 1) / args.parts + 63) / 64 * 64;
     if (g_last_reordered) {
         const uint32_t n32 = static_cast<uint32_t>(n);
         const size_t words = 4 * n + radix_sort_hist_words(n32, 1);              // keys + tmp, indices + tmp, histogram

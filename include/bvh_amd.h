@@ -413,9 +413,9 @@ BVH_AMD_API int bvh_amd_kernel_times(float* ms_out, size_t capacity, size_t* cou
 BVH_AMD_API int bvh_amd_reorder_times(float* ms_out, size_t capacity, size_t* count_out);
 /* Developer knob for A/B runs inside one process: overrides, for the calling thread's following batch launches, the refill /
  * leaf-parking thresholds of the persistent waves (lanes idle before a wave draws new rays / lanes waiting at a leaf before the
- * leaf code runs) and the record fetch of the float 3D kernels (0 per lane, 1 quad-cooperative). < 0 restores the default. Results
- * never depend on any of them. */
-BVH_AMD_API void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch);
+ * leaf code runs), the record fetch of the float 3D kernels (0 per lane, 1 quad-cooperative) and the number of ticket ranges a launch
+ * is cut into (1..256; default one per XCD). < 0 restores the default. Results never depend on any of them. */
+BVH_AMD_API void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch, int ticket_ranges);
 /* How the calling thread's latest batch launch was traced: out = {reordered 0/1, record fetch 0 per lane / 1 quad-cooperative, refill
  * threshold, leaf threshold}. For trees beyond the L2s and batches of >= 2^22 rays the library MEASURES this once per tree and kind
  * of ray (four stretches of the first such batch are traced with different candidates; csrc/traverse.hip: launch_traverse) and

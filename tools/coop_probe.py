@@ -63,13 +63,13 @@ def main():
         hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
         want = None
         for coop, refill, leaf in combos:
-            lib.bvh_amd_tuning(refill, leaf, coop)
+            lib.bvh_amd_tuning(refill, leaf, coop, -1)
             k_ms, call_ms = kernel_ms(lambda: bvh_amd.intersect(bvh, prims, rays, any_hit, robust, out=hits), 5)
             sha = hashlib.sha1(hits.cpu().numpy().tobytes()).hexdigest()[:12]
             want = want or sha
             emit(f"{name:10s} coop={coop} refill={refill:2d} leaf={leaf:2d}: kernel {k_ms:7.3f} ms {n / k_ms / 1e3:8.1f} Mrays/s | call {call_ms:7.3f} ms {n / call_ms / 1e3:8.1f} Mrays/s "
                  f"| {lib.bvh_amd_last_kernel_name().decode()} hits {'==' if sha == want else '!= MISMATCH'}")
-        lib.bvh_amd_tuning(-1, -1, -1)
+        lib.bvh_amd_tuning(-1, -1, -1, -1)
         del bvh, prims, rays, hits
 
 

@@ -63,13 +63,13 @@ def main():
             for label, sort, tun in (("auto", None, (-1, -1, -1)),
                                      ("as given, per lane 36/12", False, (36, 12, 0)), ("as given, coop 20/20", False, (20, 20, 1)), ("as given, coop 12/12", False, (12, 12, 1)),
                                      ("sorted,   per lane 36/12", True, (36, 12, 0)), ("sorted,   coop 20/20", True, (20, 20, 1)), ("sorted,   coop 12/12", True, (12, 12, 1))):
-                lib.bvh_amd_tuning(*tun)
+                lib.bvh_amd_tuning(*tun, -1)
                 k_ms, c_ms = times(lambda: bvh_amd.intersect(bvh, prims, rays, any_hit, robust, out=hits, sort_rays=sort), warm=10 if label == "auto" else 2)
                 sha = hashlib.sha1(hits.cpu().numpy().tobytes()).hexdigest()[:12]
                 want = want or sha
                 pl = (C.c_int * 4)(); lib.bvh_amd_last_launch_plan(pl)
                 rows.append((label, k_ms, c_ms, bool(pl[0]), f"{pl[1]} {pl[2]}/{pl[3]}", sha == want))
-            lib.bvh_amd_tuning(-1, -1, -1)
+            lib.bvh_amd_tuning(-1, -1, -1, -1)
             best = min(r[2] for r in rows)
             emit(f"## {name} ({len(t)} tris, {bvh.node_count} nodes) {'any-hit fast' if any_hit else 'closest robust'}, {nr} rays, P = {P:.1f}")
             for label, k_ms, c_ms, reordered, coop, same in rows:
