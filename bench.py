@@ -506,6 +506,8 @@ def main():
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
+        from bvh_amd.parallel import release_default_comm
+        release_default_comm()                                # the library's own RCCL communicator, on every rank
         dist.destroy_process_group()
 
 

@@ -193,7 +193,7 @@ int replicate_scene(BvhImpl<T>* bvh, int dim, const void* d_prims, size_t prim_b
     if (r != ncclSuccess) return cleanup(fail(BVH_AMD_ERR_HIP, std::string("replicate: ncclBroadcast: ") + ncclGetErrorString(r)));
     for (int i = 0; i < n_devices; ++i) {
         if (i == root) continue;
-        BVH_HIP_TRY(hipSetDevice(devs[i]), BVH_AMD_ERR_HIP);
+        if (hipSetDevice(devs[i]) != hipSuccess) return cleanup(fail(BVH_AMD_ERR_HIP, "replicate: hipSetDevice"));
         bvhs_out[i] = deserialize_from_device<T>(bufs[i], stream_bytes, dim, streams[i]);   // synchronises streams[i]
         if (!bvhs_out[i]) return cleanup(BVH_AMD_ERR_HIP);
     }

@@ -70,8 +70,11 @@ class Comm:
         self._h, self._lib, self._owner = handle, _lib.load(), owner
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._owner:
-            self._lib.bvh_amd_comm_destroy(self._h)
+        try:                                                  # (may run during interpreter shutdown, after the library object is gone)
+            if getattr(self, "_h", None) and self._owner and self._lib is not None:
+                self._lib.bvh_amd_comm_destroy(self._h)
+        except Exception:                                     # noqa: BLE001
+            pass
         self._h = None
 
     @property
@@ -125,6 +128,14 @@ def default_comm() -> Comm:
     if _default_comm is None:
         _default_comm = Comm.from_torch_distributed()
     return _default_comm
+
+
+def release_default_comm():
+    """Destroys the process-wide communicator (ncclCommDestroy); every rank calls it, before torch's process group goes away."""
+    global _default_comm
+    c, _default_comm = _default_comm, None
+    if c is not None:
+        c.__del__()
 
 
 def _pick_transport(transport):
