@@ -356,3 +356,29 @@ def test_launch_plan_search_settles_and_never_changes_results():
         lib.bvh_amd_last_launch_plan(pl)
         seen.add(tuple(pl))
     assert len(seen) >= 3, (seen, settled)
+
+
+def test_ticket_ranges_thresholds_and_fetch_modes_never_change_results():
+    """bvh_amd_tuning: any number of ticket ranges (1..256), any refill / leaf thresholds and either record fetch give the same hit
+    records (a ragged batch size, so that the last ranges are short or empty)."""
+    import torch
+    import bvh_amd
+    lib = bvh_amd._lib.load()
+    tris = synth.sponza_proxy(40_000)
+    bb, cc = bvh_amd.tri_bounds(tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+    prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    try:
+        for any_hit, rays_h in ((False, synth.rays_closest(200_003, lo, hi)), (True, synth.rays_shadow(70_001, lo, hi))):
+            rays = torch.from_numpy(rays_h).cuda()
+            lib.bvh_amd_tuning(-1, -1, 0, 1)
+            want = bvh_amd.intersect(bvh, prims, rays, any_hit=any_hit, robust=True).cpu().numpy().tobytes()
+            for coop in (0, 1):
+                for refill, leaf, parts in ((36, 12, 8), (12, 12, 32), (1, 1, 256), (63, 40, 3), (20, 20, 200)):
+                    lib.bvh_amd_tuning(refill, leaf, coop, parts)
+                    for sort in (False, True):
+                        got = bvh_amd.intersect(bvh, prims, rays, any_hit=any_hit, robust=True, sort_rays=sort)
+                        assert got.cpu().numpy().tobytes() == want, (any_hit, coop, refill, leaf, parts, sort)
+    finally:
+        lib.bvh_amd_tuning(-1, -1, -1, -1)
