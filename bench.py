@@ -199,6 +199,34 @@ def record_walk_probe(n_records, mode, active, steps=256):
     return recs.value / (ms.value * 1e-3) / 1e9
 
 
+def walk_table(n_records):
+    import torch
+    perm = torch.randperm(n_records, device="cuda", dtype=torch.int64)
+    table = torch.randint(0, 2 ** 31 - 1, (n_records, 16), dtype=torch.int32, device="cuda")
+    table[perm, 0] = torch.roll(perm, -1).to(torch.int32)
+    return table
+
+
+def mixed_walk_probe(n_big, coop):
+    """Do the L2's and the fabric's service times add or overlap for this access pattern? One chain per lane alternating between a 2 MiB
+    and a beyond-L2 table (csrc/probe.hip: k_record_walk_mixed) against the two pure walks, all 64 lanes, G fetches/s."""
+    import ctypes as C
+    import torch
+    from bvh_amd import _lib
+    lib = _lib.load()
+    small, big = walk_table(32768), walk_table(n_big)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms, recs = C.c_float(0), C.c_ulonglong(0)
+    _lib.check(lib.bvh_amd_probe_mixed_walk(small.data_ptr(), 32768, big.data_ptr(), n_big, 256, 7, 3, int(coop), C.byref(ms), C.byref(recs), stream), "probe_mixed_walk")
+    mixed = recs.value / (ms.value * 1e-3) / 1e9
+    rates = []
+    for t, n, steps in ((small, 32768, 512), (big, n_big, 256)):
+        _lib.check(lib.bvh_amd_probe_record_walk_ex(t.data_ptr(), n, steps, 7, 3, 4 if coop else 0, 64, C.byref(ms), C.byref(recs), stream), "probe_record_walk")
+        rates.append(recs.value / (ms.value * 1e-3) / 1e9)
+    return {"alternating_l2_hit_and_miss_grec_s": round(mixed, 2), "if_times_add_grec_s": round(2.0 / (1.0 / rates[0] + 1.0 / rates[1]), 2),
+            "if_levels_overlap_grec_s": round(2.0 * min(rates), 2), "pure_l2_grec_s": round(rates[0], 2), "pure_beyond_l2_grec_s": round(rates[1], 2)}
+
+
 def hierarchy_ceilings(working_set_bytes, coop, active):
     """The rates the three levels of the memory system give the traversal's access pattern, measured live: L1 (a 16 KiB table),
     L2 (2 MiB: resident in every XCD's L2), beyond the L2s (a table as large as the working set, at least 64 MiB: Infinity Cache /
@@ -210,7 +238,8 @@ def hierarchy_ceilings(working_set_bytes, coop, active):
             "l1_grec_s": round(record_walk_probe(256, mode, active, 512), 2),
             "l2_grec_s": round(record_walk_probe(32768, mode, active, 512), 2),
             "beyond_l2_grec_s": round(record_walk_probe(big, mode, active), 2),
-            "beyond_l2_table_mib": round(big * 64 / 2 ** 20, 1)}
+            "beyond_l2_table_mib": round(big * 64 / 2 ** 20, 1),
+            "l2_and_fabric_times": mixed_walk_probe(big, coop)}
 
 
 def mean_split_ancestors(nodes, n_prims):
@@ -437,8 +466,17 @@ def main():
                                     "ms": round(misses / probe["beyond_l2_grec_s"] / 1e6, 4),
                                     "what": "L2 misses (TCC_MISS; FETCH_SIZE / 64 B agrees within 15 %, FETCH_SIZE itself calibrated at 0.998 of a known byte "
                                             "count in this pattern: profiles/r03_fetch_calibration.json) at the beyond-L2 rate of the probe, whose every record is a miss"}
+                hits = max(0.0, l2_req - misses)
+                mix = probe["l2_and_fabric_times"]                    # the ceiling takes the BEST rate this run measured for each level
+                r_l2, r_far = max(probe["l2_grec_s"], mix["pure_l2_grec_s"]), max(probe["beyond_l2_grec_s"], mix["pure_beyond_l2_grec_s"])
+                levels["beyond_l1"] = {"l2_hits_per_launch": round(hits), "l2_misses_per_launch": round(misses), "l2_grec_s": r_l2, "beyond_l2_grec_s": r_far,
+                                       "ms": round(hits / r_l2 / 1e6 + misses / r_far / 1e6, 4),
+                                       "what": "every L1 miss holds one of the CU's outstanding lines until the L2 (hit) or the fabric (miss) has served it: "
+                                               "the two service times ADD (probe.l2_and_fabric_times: a walk alternating L2 hit / L2 miss runs at the "
+                                               "add rate, not at the overlap rate), so hits / R_L2 + misses / R_beyond_L2 is the time the launch's L1 "
+                                               "misses need; the L1 request pipeline (level l1) works in parallel with it"}
         model_ms = None if levels is None else max(v["ms"] for v in levels.values())
-        sum_ms = None if levels is None else sum(v["ms"] for v in levels.values())
+        sum_ms = None if levels is None else sum(v["ms"] for k, v in levels.items() if k in ("l1", "beyond_l1"))
         peak_mrays = None if not model_ms else rays_here / model_ms / 1e3
         achieved_mrays = rays_here / kernel_ms / 1e3
         out = {
@@ -454,14 +492,15 @@ def main():
                        "rays_per_step_all_gpus": int(args.rays if args.strong else args.rays * world),
                        "parallelism": (f"rays sharded x{world} ({'strong' if args.strong else 'weak'} scaling), scene broadcast once: "
                                        + bcast.get("transport", "?")) if world > 1 else "single GPU"},
-            "roofline": {"bound": "memory hierarchy (L1 request pipeline / L2 / fabric) under dependent random 64-byte record fetches",
+            "roofline": {"bound": "memory hierarchy (L1 request pipeline | L2 hits + fabric misses behind it) under dependent random 64-byte record fetches",
                          "achieved": round(achieved_mrays, 1), "peak": None if peak_mrays is None else round(peak_mrays, 1), "unit": "Mrays/s",
                          "frac": None if peak_mrays is None else round(achieved_mrays / peak_mrays, 4),
                          "binding_level": None if levels is None else max(levels, key=lambda k: levels[k]["ms"]),
                          "model_ms": None if model_ms is None else round(model_ms, 4), "sum_of_levels_ms": None if sum_ms is None else round(sum_ms, 4),
                          "levels": levels, "probe": probe,
-                         "what": "peak = rays per launch / the time the slowest level of the memory system needs for this launch's requests at the "
-                                 "rate measured for that level in this run; achieved = rays per launch / kernel_ms. HBM is NOT what binds this kernel: "
+                         "what": "peak = rays per launch / max(time the L1 request pipeline needs for the launch's record fetches, time its L1 misses "
+                                 "need behind the L1 = L2 hits / R_L2 + L2 misses / R_beyond_L2), every rate measured in this run by a dependent-walk probe "
+                                 "in the kernel's own fetch mode; achieved = rays per launch / kernel_ms. HBM is NOT what binds this kernel: "
                                  "see hbm_algorithmic below (SURVEY.md 8d's figure) and traffic",
                          "traffic": traffic, "traffic_unit": "GB/s at the L2's fabric side (FETCH_SIZE + WRITE_SIZE)",
                          "traffic_frac_of_hbm": None if traffic is None else round(traffic / HBM_PEAK_GBS, 4), "counters_source": pmc_note,

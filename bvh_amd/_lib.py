@@ -61,6 +61,7 @@ _SIGS = {
     "bvh_amd_reinsertion_stats": (None, [C.POINTER(C.c_uint)]),
     "bvh_amd_last_optimize_profile": (None, [_P]),
     "bvh_amd_probe_record_walk": (_I, [_P, C.c_uint32, C.c_uint32, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
+    "bvh_amd_probe_mixed_walk": (_I, [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
     "bvh_amd_probe_record_walk_ex": (_I, [_P, C.c_uint32, C.c_uint32, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
     "bvh_amd_release_cached_memory": (_I, []),
     "bvh_amd_device_count": (_I, []),

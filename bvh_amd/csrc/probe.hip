@@ -120,11 +120,83 @@ __global__ void __launch_bounds__(256) k_record_walk_quad(const WalkRec* table, 
     if (acc == 0x12345678u) atomicAdd(sink, 1ull);
 }
 
+// Two dependent walks braided into ONE chain per lane: even steps fetch the next record of a SMALL table (resident in the L2s), odd
+// steps the next record of a BIG one (beyond them); each index is made to depend on the record fetched just before (a term that is
+// always zero, unknown to the compiler), so a lane has exactly one fetch in flight and alternates L2 hit, L2 miss. If the two levels
+// were independent resources the pair of steps would run at the pace of the slower one's THROUGHPUT (the fabric's 57 G misses/s -> 114 G
+// steps/s); if they share one — the CU's outstanding lines — the times add (2 / (1 / R_L2 + 1 / R_fabric)).
+template <bool Coop>
+__global__ void __launch_bounds__(256) k_record_walk_mixed(const WalkRec* small_t, uint32_t n_small, const WalkRec* big_t, uint32_t n_big, uint32_t steps,
+                                                           unsigned long long* sink) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u;
+    uint32_t is = static_cast<uint32_t>((gid * 2654435761ull) % n_small), ib = static_cast<uint32_t>((gid * 2246822519ull) % n_big);
+    float acc = 0.0f;
+    uint32_t carry = 0;
+    for (uint32_t it = 0; it < steps; ++it) {
+        const bool small_step = (it & 1u) == 0;
+        const WalkRec* t = small_step ? small_t : big_t;
+        const uint32_t idx = (small_step ? is : ib) + carry;   // carry == 0, but only the previous fetch says so
+        float lb[6], rb[6];
+        uint32_t li = 0, ri = 0;
+        if (Coop) coop_load_pair(reinterpret_cast<const PairNode<float>*>(t), idx, static_cast<int>(lane), lb, rb, li, ri);
+        else load_pair(reinterpret_cast<const PairNode<float>*>(t) + idx, lb, rb, li, ri);
+        acc += ((lb[1] + lb[2]) + (lb[3] + lb[4])) + ((lb[5] + rb[0]) + (rb[1] + rb[2])) + ((rb[3] + rb[4]) + rb[5]);
+        const uint32_t next = __float_as_uint(lb[0]);
+        carry = next >> 31;                                    // indices are below 2^31
+        if (small_step) is = next < n_small ? next : 0u; else ib = next < n_big ? next : 0u;
+        acc += __uint_as_float((li ^ ri) & 0xFFu);
+    }
+    if (acc == 1234.5f) atomicAdd(sink, 1ull);
+}
+
 } // namespace
 
 } // namespace bvh_amd
 
 extern "C" {
+
+// The braided walk above: `steps` fetches per lane, alternating between the two tables (each laid out as one random cycle, word 0 = next).
+// coop != 0: quad-cooperative fetch. *records_out = fetches per launch (both tables together).
+BVH_AMD_API int bvh_amd_probe_mixed_walk(const void* d_small, uint32_t n_small, const void* d_big, uint32_t n_big, uint32_t steps, int blocks_per_cu, int reps,
+                                         int coop, float* ms_out, unsigned long long* records_out, void* stream_)
+{
+    using namespace bvh_amd;
+    if (!d_small || !d_big || !n_small || !n_big || !steps || reps < 1 || !ms_out) return fail(BVH_AMD_ERR_ARG, "probe_mixed_walk: bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int device = 0, cus = 0;
+    BVH_HIP_TRY(hipGetDevice(&device), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device), BVH_AMD_ERR_HIP);
+    if (blocks_per_cu < 1) blocks_per_cu = 7;
+    const unsigned grid = static_cast<unsigned>(cus * blocks_per_cu);
+    unsigned long long* sink = nullptr;
+    BVH_HIP_TRY(hipMalloc(&sink, sizeof(*sink)), BVH_AMD_ERR_HIP);
+    auto launch = [&]() {
+        if (coop) hipLaunchKernelGGL(k_record_walk_mixed<true>, dim3(grid), dim3(256), 0, stream, static_cast<const WalkRec*>(d_small), n_small,
+                                     static_cast<const WalkRec*>(d_big), n_big, steps, sink);
+        else hipLaunchKernelGGL(k_record_walk_mixed<false>, dim3(grid), dim3(256), 0, stream, static_cast<const WalkRec*>(d_small), n_small,
+                                static_cast<const WalkRec*>(d_big), n_big, steps, sink);
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) {
+        launch();
+        e = hipEventRecord(e0, stream);
+        for (int r = 0; r < reps; ++r) launch();
+        if (e == hipSuccess) e = hipEventRecord(e1, stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess) e = hipGetLastError();
+        *ms_out = ms / reps;
+        if (records_out) *records_out = static_cast<unsigned long long>(grid) * 256ull * steps;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("probe_mixed_walk: ") + hipGetErrorString(e));
+    return BVH_AMD_OK;
+}
 
 // d_table: n_records x 64 bytes, word 0 of record i = index of the next record of its chain (the caller lays out a random
 // permutation cycle). Launches blocks_per_cu x CUs blocks of 256 lanes, `steps` records per chain, `reps` times after one

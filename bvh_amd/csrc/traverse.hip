@@ -174,6 +174,8 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     }
     unsigned long long need = (args.n + kBlock - 1) / kBlock;
     int grid = static_cast<int>(need < static_cast<unsigned long long>(blocks) ? need : blocks);
+    static const int grid_env = getenv("BVH_AMD_GRID_BLOCKS") ? atoi(getenv("BVH_AMD_GRID_BLOCKS")) : 0;   // developer knob: fewer resident waves (occupancy studies)
+    if (grid_env > 0 && grid > grid_env) grid = grid_env;
     if (grid < 1) grid = 1;
     (void)name;
     // the symbol as rocprofv3 prints it (profiles/*_kernel_stats.csv), for bench.py's roofline.kernel
