@@ -120,6 +120,42 @@ __global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n
     keys[i] = (code << 3) | oct;
 }
 
+// Developer experiment (BVH_AMD_RAY_KEY_DEPTH=k; profiles/r03_traversal_experiments.md §6): a TREE-ENTRY key — the ray descends the
+// top k levels of the tree the way the traversal will (nearer hit child first, plain slab test: the key only orders rays) and the
+// key is the path it took (one bit per level, left-aligned) above the direction octant: rays are ordered by the subtree they enter
+// first, i.e. by what they will fetch, instead of by the grid cell they start in.
+__global__ void __launch_bounds__(256) ray_entry_keys_kernel(const float* rays, uint32_t n, const PairNode<float>* pairs, uint32_t root_index, int depth,
+                                                             uint32_t* keys) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float r[8];
+    load_ray(rays + 8ull * i, r);
+    const float inv[3] = { 1.0f / r[3], 1.0f / r[4], 1.0f / r[5] };
+    uint32_t cur = root_index, path = 0;
+    int level = 0;
+    for (; level < depth && (cur & kCountMask) == 0; ++level) {
+        float lb[6], rb[6];
+        uint32_t li, ri;
+        load_pair(pairs + (cur >> (kCountBits + 1)), lb, rb, li, ri);
+        float t0[2] = { r[6], r[6] }, t1[2] = { r[7], r[7] };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a0 = (lb[2 * k] - r[k]) * inv[k], a1 = (lb[2 * k + 1] - r[k]) * inv[k];
+            const float b0 = (rb[2 * k] - r[k]) * inv[k], b1 = (rb[2 * k + 1] - r[k]) * inv[k];
+            t0[0] = fmaxf(t0[0], fminf(a0, a1)); t1[0] = fminf(t1[0], fmaxf(a0, a1));
+            t0[1] = fmaxf(t0[1], fminf(b0, b1)); t1[1] = fminf(t1[1], fmaxf(b0, b1));
+        }
+        const bool hl = t0[0] <= t1[0], hr = t0[1] <= t1[1];
+        if (!hl && !hr) break;
+        const bool right = hl && hr ? t0[1] < t0[0] : hr;
+        path = (path << 1) | (right ? 1u : 0u);
+        cur = right ? ri : li;
+    }
+    path <<= (depth - level);
+    const uint32_t oct = (Num<float>::sign(r[3]) ? 1u : 0u) | (Num<float>::sign(r[4]) ? 2u : 0u) | (Num<float>::sign(r[5]) ? 4u : 0u);
+    keys[i] = (path << 3) | oct;
+}
+
 // BVH_AMD_RAY_ORIGINAL_IDS: BVH-order index -> bvh.prim_ids[index] in place (misses keep BVH_AMD_INVALID)
 template <typename H>
 __global__ void __launch_bounds__(256) original_ids_kernel(H* hits, size_t n, const uint32_t* prim_ids, uint32_t prim_count) {
@@ -612,10 +648,21 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
             lo[k] = b.root_bounds[2 * k];
             sc[k] = ext > T(0) ? T(64) / ext : T(0);
         }
-        hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2],
-                           keys);
+        static const int entry_depth = getenv("BVH_AMD_RAY_KEY_DEPTH") ? std::min(29, atoi(getenv("BVH_AMD_RAY_KEY_DEPTH"))) : 0;   // developer experiment
+        int key_bits = 21;
+        bool entry_keys = false;
+        if constexpr (std::is_same_v<T, float>) entry_keys = entry_depth > 0 && b.dim == 3;
+        if constexpr (std::is_same_v<T, float>) {
+            if (entry_keys) {
+                hipLaunchKernelGGL(ray_entry_keys_kernel, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, args.pairs, args.root_index, entry_depth, keys);
+                key_bits = entry_depth + 3;
+            }
+        }
+        if (!entry_keys)
+            hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2],
+                               keys);
         uint32_t* order = nullptr;
-        int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, 21, stream, hist, /*iota_vals=*/true, /*keys_wanted=*/false, &order);
+        int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, key_bits, stream, hist, /*iota_vals=*/true, /*keys_wanted=*/false, &order);
         if (rc) return release(rc);
         args.order = order;
     }
