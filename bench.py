@@ -511,7 +511,7 @@ def main():
                          "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
                          "pass_split_ms": {"ray_keys_and_radix_sort": round(reorder_ms, 4), "traversal_kernel": round(kernel_ms, 4),
                                            "rest (launch gaps, counter reset)": round(max(0.0, pass_ms - reorder_ms - kernel_ms), 4)},
-                         "ray_reordering": ("on: 21-bit origin-cell/octant key + three radix passes inside every timed pass" if reordered else "off"),
+                         "ray_reordering": ("on: 24-bit origin-cell/octant key + three radix passes inside every timed pass" if reordered else "off"),
                          "record_fetch": "quad-cooperative" if coop else "per lane",
                          "launch_plan": {"reordered": bool(plan[0]), "quad_cooperative_fetch": bool(plan[1]), "refill_threshold": int(plan[2]),
                                          "leaf_threshold": int(plan[3]),

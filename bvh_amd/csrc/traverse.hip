@@ -95,13 +95,14 @@ __global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop_plan_search(Trace
 #undef BVH_TRACE_COOP
 }
 
-// Coherence key of a ray: Morton code of its origin cell (64^3 grid over the root box) above the direction octant, 21 bits, three
+// Coherence key of a ray: Morton code of its origin cell (128^3 grid over the root box; round 3: 7 bits per axis are 1 % better than 6
+// on the soup for the same three passes, profiles/r03_entry_key_probe.txt) above the direction octant, 24 bits, three
 // 8-bit radix passes. Rays of one key start in the same cell and descend the same way first; any order gives the same per-ray
 // results. Measured with one ticket range per XCD on 2^24 uniform rays, rays physically permuted (tools/ray_order_probe.py,
 // kernel ms): 1M-triangle soup 12.09 as given, 7.52 / 7.28 / 7.25 with 4 / 5 / 6 bits per axis + octant; 10M-triangle mesh 13.92,
 // 7.79 / 7.41 / 7.09; octant-major and direction-cube keys lose (soup 7.81, mesh 8.25). The third pass costs ~0.13 ms.
 template <typename T>
-__global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys) {
+__global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys, uint32_t cells = 64) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     T r[8];
@@ -112,8 +113,8 @@ __global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n
     for (int k = 0; k < 3; ++k) {
         T v = q[k];
         v = v > T(0) ? v : T(0);                              // (NaN origins land in cell 0)
-        uint32_t c = v >= T(63) ? 63u : static_cast<uint32_t>(v);
-        uint32_t s = (c & 1u) | ((c & 2u) << 2) | ((c & 4u) << 4) | ((c & 8u) << 6) | ((c & 16u) << 8) | ((c & 32u) << 10);
+        uint32_t c = v >= T(cells - 1) ? cells - 1 : static_cast<uint32_t>(v);
+        uint32_t s = (c & 1u) | ((c & 2u) << 2) | ((c & 4u) << 4) | ((c & 8u) << 6) | ((c & 16u) << 8) | ((c & 32u) << 10) | ((c & 64u) << 12) | ((c & 128u) << 14);
         code |= s << k;
     }
     const uint32_t oct = (Num<T>::sign(r[3]) ? 1u : 0u) | (Num<T>::sign(r[4]) ? 2u : 0u) | (Num<T>::sign(r[5]) ? 4u : 0u);
@@ -542,7 +543,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
         if (!ev) (void)hipEventCreate(&ev);
         if (ev) timer.begin_armed = hipEventRecord(ev, stream) == hipSuccess;
     }
-    TraceArgs<T> args;
+    TraceArgs<T> args{};
     args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
     args.n = n; args.work = work; args.counters = d_counters; args.root_index = b.root_index;
     args.order = nullptr;
@@ -658,9 +659,13 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
                 key_bits = entry_depth + 3;
             }
         }
-        if (!entry_keys)
-            hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2],
-                               keys);
+        if (!entry_keys) {
+            static const int cell_bits = getenv("BVH_AMD_RAY_KEY_BITS") ? std::max(1, std::min(8, atoi(getenv("BVH_AMD_RAY_KEY_BITS")))) : 7;   // developer knob
+            const T rescale = static_cast<T>(1u << cell_bits) / T(64);
+            hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0] * rescale, sc[1] * rescale,
+                               sc[2] * rescale, keys, 1u << cell_bits);
+            key_bits = 3 * cell_bits + 3;
+        }
         uint32_t* order = nullptr;
         int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, key_bits, stream, hist, /*iota_vals=*/true, /*keys_wanted=*/false, &order);
         if (rc) return release(rc);

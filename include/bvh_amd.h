@@ -111,7 +111,7 @@ struct bvh_amd_counters { unsigned long long node_pairs, prim_tests, leaves; };
 enum bvh_amd_ray_flags {
     BVH_AMD_RAY_ANY_HIT = 1u,  /* Bvh::intersect<IsAnyHit = true>: no near/far reordering, stop at first hit */
     BVH_AMD_RAY_ROBUST  = 2u,  /* Bvh::intersect<IsRobust = true>: Ize's robust slab test (node.h:68-77)      */
-    BVH_AMD_RAY_SORTED  = 4u,  /* always reorder the batch internally for coherence (a 21-bit origin-cell / direction-octant key,
+    BVH_AMD_RAY_SORTED  = 4u,  /* always reorder the batch internally for coherence (a 24-bit origin-cell / direction-octant key,
                                   three radix passes, ~0.45 ms per 16M rays); per-ray results are unchanged. With neither this
                                   flag nor BVH_AMD_RAY_UNSORTED the library decides: it reorders batches of >= 1M rays on trees
                                   whose node records exceed the 32 MB of L2 and through which a random line is expected to fetch

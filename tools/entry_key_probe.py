@@ -16,4 +16,4 @@ for coop, refill, leaf in ((1, 12, 12), (0, 36, 12)):
     lib.bvh_amd_tuning(refill, leaf, coop, -1)
     k_ms, call_ms = kernel_ms(lambda: bvh_amd.intersect(bvh, prims, rays, any_hit, robust, out=hits, sort_rays=True), 5)
     sha = hashlib.sha1(hits.cpu().numpy().tobytes()).hexdigest()[:12]
-    print(f"{name:8s} key_depth={os.environ.get('BVH_AMD_RAY_KEY_DEPTH', 'grid')} coop={coop}: kernel {k_ms:7.3f} ms | call {call_ms:7.3f} ms | hits {sha}", flush=True)
+    print(f"{name:8s} key_depth={os.environ.get('BVH_AMD_RAY_KEY_DEPTH', 'grid')} cell_bits={os.environ.get('BVH_AMD_RAY_KEY_BITS', '6')} coop={coop}: kernel {k_ms:7.3f} ms | call {call_ms:7.3f} ms | hits {sha}", flush=True)
