@@ -466,11 +466,11 @@ def main():
                                     "ms": round(misses / probe["beyond_l2_grec_s"] / 1e6, 4),
                                     "what": "L2 misses (TCC_MISS; FETCH_SIZE / 64 B agrees within 15 %, FETCH_SIZE itself calibrated at 0.998 of a known byte "
                                             "count in this pattern: profiles/r03_fetch_calibration.json) at the beyond-L2 rate of the probe, whose every record is a miss"}
-                hits = max(0.0, l2_req - misses)
+                l2_hits = max(0.0, l2_req - misses)
                 mix = probe["l2_and_fabric_times"]                    # the ceiling takes the BEST rate this run measured for each level
                 r_l2, r_far = max(probe["l2_grec_s"], mix["pure_l2_grec_s"]), max(probe["beyond_l2_grec_s"], mix["pure_beyond_l2_grec_s"])
-                levels["beyond_l1"] = {"l2_hits_per_launch": round(hits), "l2_misses_per_launch": round(misses), "l2_grec_s": r_l2, "beyond_l2_grec_s": r_far,
-                                       "ms": round(hits / r_l2 / 1e6 + misses / r_far / 1e6, 4),
+                levels["beyond_l1"] = {"l2_hits_per_launch": round(l2_hits), "l2_misses_per_launch": round(misses), "l2_grec_s": r_l2, "beyond_l2_grec_s": r_far,
+                                       "ms": round(l2_hits / r_l2 / 1e6 + misses / r_far / 1e6, 4),
                                        "what": "every L1 miss holds one of the CU's outstanding lines until the L2 (hit) or the fabric (miss) has served it: "
                                                "the two service times ADD (probe.l2_and_fabric_times: a walk alternating L2 hit / L2 miss runs at the "
                                                "add rate, not at the overlap rate), so hits / R_L2 + misses / R_beyond_L2 is the time the launch's L1 "
