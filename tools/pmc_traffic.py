@@ -48,6 +48,14 @@ def main():
     kernel = line["roofline"]["kernel"]
     rays = line["config"]["rays_per_gpu_per_step"]
     want = kernel.replace(" ", "")
+    # the profiled runs trace with the plan the un-profiled run settled on (under the counters' serialisation two close candidates can
+    # swap places in the library's search, and the rows of the kernel asked for would be missing)
+    plan = line["roofline"].get("launch_plan") or {}
+    if plan:
+        env.update(BVH_AMD_COOP=str(int(bool(plan.get("quad_cooperative_fetch")))), BVH_AMD_REFILL=str(plan.get("refill_threshold", 36)),
+                   BVH_AMD_LEAF=str(plan.get("leaf_threshold", 12)))
+        if not plan.get("reordered") and "--no-reorder" not in base:
+            base = base + ["--no-reorder"]
     values = {}
     for i, counters in enumerate(PASSES):
         d = os.path.join(work, f"p{i}")
