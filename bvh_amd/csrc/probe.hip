@@ -13,6 +13,7 @@
 //   2  quad-cooperative loads alone: one chain per QUAD, its four lanes load the four chunks of the chain's record with one
 //      instruction (isolates what a quad-coalesced line costs the L1)
 //   3  the same 16 chains per wave as mode 2, walked by lane 0 of each quad alone with four loads (the per-lane cost of mode 2's work)
+//   5 / 6  128-byte records, one chain per octet of lanes: the octet loads the line with one instruction / lane 0 alone with eight (n_records counts 128-byte records)
 //   4  quad-cooperative + in-register transpose (DPP quad_perm butterflies, no LDS): trace_device.h coop_load_pair itself, what
 //      trace_kernel<..., Coop = true> does
 // `active` (1..64): lanes of a wave that own a chain (scattered over the wave: lane l is active iff (37 l mod 64) < active); the
@@ -40,6 +41,32 @@ __global__ void __launch_bounds__(256) k_record_walk(const WalkRec* table, uint3
         idx = a.x < n_rec ? a.x : 0u;                          // w[0] = the next record of the chain
     }
     if (acc == 0x12345678u) atomicAdd(sink, 1ull);             // keeps the loads alive
+}
+
+// modes 5 / 6: 128-byte records (one full L1 / L2 line): one chain per OCTET of lanes, its 8 lanes load the record's eight 16-byte chunks
+// with one instruction (5), or lane 0 of each octet alone with eight loads (6). Does a line-granular miss cost the memory system the
+// same whether 64 or 128 of its bytes are wanted? `table` holds n_rec records of 128 bytes, word 0 = the next record.
+template <bool Coop>
+__global__ void __launch_bounds__(256) k_record_walk_wide(const uint4* table, uint32_t n_rec, uint32_t steps, unsigned long long* sink) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, j = lane & 7u;
+    uint32_t idx = static_cast<uint32_t>(((gid >> 3) * 2654435761ull) % n_rec);
+    uint32_t acc = 0;
+    if (!Coop && j != 0) return;
+    for (uint32_t it = 0; it < steps; ++it) {
+        uint32_t next;
+        if (Coop) {
+            const uint4 v = table[size_t{idx} * 8 + j];
+            acc += v.y + v.w;
+            next = static_cast<uint32_t>(__shfl(static_cast<int>(v.x), static_cast<int>(lane & ~7u)));
+        } else {
+            const uint4* q = table + size_t{idx} * 8;
+            const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6], h = q[7];
+            acc += a.y + b.z + c.w + d.y + e.z + f.w + g.y + h.z;
+            next = a.x;
+        }
+        idx = next < n_rec ? next : 0u;
+    }
+    if (acc == 0x12345678u) atomicAdd(sink, 1ull);
 }
 
 template <int K> __device__ inline uint32_t quad_broadcast(uint32_t v) {   // value of lane K of the caller's quad (DPP quad_perm, no LDS)
@@ -205,7 +232,7 @@ BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_rec
                                              float* ms_out, unsigned long long* records_out, void* stream_)
 {
     using namespace bvh_amd;
-    if (!d_table || n_records == 0 || steps == 0 || reps < 1 || !ms_out || mode < 0 || mode > 4) return fail(BVH_AMD_ERR_ARG, "probe_record_walk: bad argument");
+    if (!d_table || n_records == 0 || steps == 0 || reps < 1 || !ms_out || mode < 0 || mode > 6) return fail(BVH_AMD_ERR_ARG, "probe_record_walk: bad argument");
     if (active < 1 || active > 64) active = 64;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int device = 0, cus = 0;
@@ -222,6 +249,8 @@ BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_rec
         case 0: hipLaunchKernelGGL(k_record_walk, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
         case 1: hipLaunchKernelGGL(k_record_walk_coop, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
         case 4: hipLaunchKernelGGL(k_record_walk_dpp, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
+        case 5: hipLaunchKernelGGL(k_record_walk_wide<true>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_table), n_records, steps, sink); break;
+        case 6: hipLaunchKernelGGL(k_record_walk_wide<false>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_table), n_records, steps, sink); break;
         case 2: hipLaunchKernelGGL(k_record_walk_quad<true>, dim3(grid), dim3(256), 0, stream, table, n_records, steps, sink); break;
         default: hipLaunchKernelGGL(k_record_walk_quad<false>, dim3(grid), dim3(256), 0, stream, table, n_records, steps, sink); break;
         }
@@ -239,7 +268,7 @@ BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_rec
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
         if (e == hipSuccess) e = hipGetLastError();
         *ms_out = ms / reps;
-        const unsigned long long chains_per_wave = (mode == 2 || mode == 3) ? 16ull : static_cast<unsigned long long>(active);
+        const unsigned long long chains_per_wave = (mode == 2 || mode == 3) ? 16ull : (mode == 5 || mode == 6) ? 8ull : static_cast<unsigned long long>(active);
         if (records_out) *records_out = static_cast<unsigned long long>(grid) * 4ull * chains_per_wave * steps;
     }
     if (e0) (void)hipEventDestroy(e0);

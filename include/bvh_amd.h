@@ -152,7 +152,9 @@ BVH_AMD_API int bvh_amd_probe_record_walk(const void* d_table, uint32_t n_record
                                           float* ms_out, unsigned long long* records_out, void* stream);
 /* The same walk with the way a record reaches its lane selectable (csrc/probe.hip): mode 0 per-lane loads (as above), 1 quad-
  * cooperative loads + LDS transpose, 2 / 3 one chain per quad loaded by the quad / by its first lane; `active` = lanes of a wave
- * that own a chain (1..64). A table of a few KB measures the L1, a few MB the L2, beyond 32 MB the fabric side. */
+ * that own a chain (1..64); 4 quad-cooperative loads + in-register transpose (the shipped fetch); 5 / 6 records of 128 bytes, one chain per
+ * octet of lanes loaded by the octet / by its first lane (n_records then counts 128-byte records). A table of a few KB measures the L1,
+ * a few MB the L2, beyond 32 MB the fabric side. */
 /* One chain per lane that alternates between a small (L2-resident) and a big (beyond the L2s) table, one fetch in flight per lane:
  * do the times of the two levels add (one shared resource: the CU's outstanding lines) or overlap? (csrc/probe.hip) */
 BVH_AMD_API int bvh_amd_probe_mixed_walk(const void* d_small, uint32_t n_small, const void* d_big, uint32_t n_big, uint32_t steps, int blocks_per_cu, int reps,
