@@ -59,7 +59,25 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="rays of the CPU baseline sample (>= 1 s of work on the host cores)")
     ap.add_argument("--no-reorder", action="store_true", help="trace the rays in the order given (BVH_AMD_RAY_UNSORTED)")
     ap.add_argument("--no-probe", action="store_true", help="skip the record-walk probes behind roofline.peak")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="join the N ranks, print {n_gpus, ranks} from rank 0 and exit: checks the launch path, needs no GPU (tests/test_bench_contract.py)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: start the N ranks ourselves, one process per GPU, exactly
+    the way the driver's multi-GPU command does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 ...), and hand its exit code back. Rank 0 of the children prints the JSON line on our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, BVH_AMD_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def usable_cpus():
@@ -271,17 +289,42 @@ def through_obj(tris):
     return back, size
 
 
+def rendezvous_only(args, rank, local_rank, world):
+    """The launch path alone (no GPU needed): every rank joins the process group, rank 0 prints who took part."""
+    import torch.distributed as dist
+    who = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+    ranks = [who]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("BVH_AMD_BENCH_BACKEND", "gloo"))
+        ranks = [None] * world
+        dist.all_gather_object(ranks, who)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "ranks": ranks, "self_launched": os.environ.get("BVH_AMD_BENCH_SELF_LAUNCHED") == "1",
+                          "rendezvous_only": True}), flush=True)
+
+
 def main():
     args = parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs across processes on this driver
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # not under torchrun: N ranks are started here (one process per GPU)
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        if world > 1 and args.gpus == 1:
+            args.gpus = world                                  # torchrun ... bench.py without --gpus: the launcher's count stands
+        else:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for {args.gpus} GPUs from {world} rank(s)")
+    if args.rendezvous_only:
+        rendezvous_only(args, rank, local_rank, world)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: bvh_amd has no CPU path")
     # BVH_AMD_BENCH_ONE_DEVICE=1 + BVH_AMD_BENCH_BACKEND=gloo: functional test of the N>1 path on a 1-GPU box
@@ -377,6 +420,18 @@ def main():
     bcast = {}
     if distributed:
         bvh, prims = broadcast_scene(bvh, prims, src=0, timing=bcast)     # one device-to-device broadcast of the serialized BVH + prims
+    # who takes part: one entry per rank (device index and identity, size of the library's RCCL communicator as this rank sees it);
+    # a line for N GPUs is only printed when N ranks on N distinct devices are here
+    from bvh_amd import parallel as _par
+    props = torch.cuda.get_device_properties(device_index)
+    who = {"rank": rank, "device": device_index, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+           "rccl_ranks": _par._default_comm.size if _par._default_comm is not None else None}
+    ranks = [who]
+    if distributed:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, who)
+    if len(ranks) != world or (not one_device and len({r["device"] for r in ranks}) != world):
+        raise SystemExit(f"bench.py: {world} ranks expected on {world} distinct devices, got {ranks}")
     lo, hi = synth.scene_bounds(tris) if rank == 0 else (None, None)
     if distributed:
         box = torch.tensor(np.stack([lo, hi]) if rank == 0 else np.zeros((2, 3)), dtype=torch.float64,
@@ -498,7 +553,10 @@ def main():
                        "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(rays_here),
                        "rays_per_step_all_gpus": int(args.rays if args.strong else args.rays * world),
                        "parallelism": (f"rays sharded x{world} ({'strong' if args.strong else 'weak'} scaling), scene broadcast once: "
-                                       + bcast.get("transport", "?")) if world > 1 else "single GPU"},
+                                       + bcast.get("transport", "?")) if world > 1 else "single GPU",
+                       "ranks": ranks, "rccl_ranks": ranks[0]["rccl_ranks"],
+                       "launched_by": "bench.py itself (python -m torch.distributed.run, one process per GPU)"
+                                      if os.environ.get("BVH_AMD_BENCH_SELF_LAUNCHED") == "1" else "torchrun environment" if world > 1 else "single process"},
             "roofline": {"bound": "memory hierarchy (L1 request pipeline | L2 hits + fabric misses behind it) under dependent random 64-byte record fetches",
                          "achieved": round(achieved_mrays, 1), "peak": None if peak_mrays is None else round(peak_mrays, 1), "unit": "Mrays/s",
                          "frac": None if peak_mrays is None else round(achieved_mrays / peak_mrays, 4),

@@ -58,6 +58,7 @@ def test_bench_json_contract(monkeypatch, orc):
     monkeypatch.setattr(torch.cuda, "set_device", lambda *_: None)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *_: None)
     monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda *_: types.SimpleNamespace(name="fake MI355X", uuid="GPU-0"))
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
     real_empty = torch.empty
     monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != "device"}))
@@ -125,6 +126,7 @@ def test_bench_json_contract(monkeypatch, orc):
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["unit"] == "Mrays/s" and out["scaling"] == "weak"
     assert out["dtype"] == "f32" and out["vs_baseline"] is None and out["higher_is_better"] is True
     assert "workload" in out["config"] and "model" not in out["config"]
+    assert len(out["config"]["ranks"]) == out["n_gpus"] and out["config"]["ranks"][0]["device"] == 0 and out["config"]["launched_by"] == "single process"
     rf = out["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "levels", "hbm_algorithmic", "pass_split_ms", "launch_plan"):
         assert key in rf, key
@@ -151,3 +153,23 @@ def test_bench_json_contract(monkeypatch, orc):
         assert abs(r["bytes_per_tri"] - (76.0 + 76.0 * r["mean_split_ancestors"] + 28.0 * out["config"]["nodes"] / 3000)) < 60.0
     assert set(b["all_qualities_ms"]) == {"low", "medium", "high"} and b["ms_with_host_mirror"] >= b["ms"] > 0
     assert b["high"]["iterations"] == 3 and b["high"]["replayed"] == 2 and abs(b["high"]["us_per_replacement"] - 0.5) < 1e-6
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun (the shape of the driver's N = 1 command with another N) starts two ranks itself
+    and rank 0 reports both; a --gpus that disagrees with the launcher's WORLD_SIZE is refused instead of being printed."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["BVH_AMD_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["self_launched"] is True and sorted(x["rank"] for x in out["ranks"]) == [0, 1]
+    assert len({x["pid"] for x in out["ranks"]}) == 2
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
