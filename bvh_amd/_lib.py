@@ -76,6 +76,8 @@ _SIGS = {
     "bvh_amd_comm_size": (_I, [_P]),
     "bvh_amd_comm_handle": (_P, [_P]),
     "bvh_amd_comm_broadcast": (_I, [_P, _P, _Z, _I, _P]),
+    "bvh_amd_comm_cache_clear": (_I, []),
+    "bvh_amd_rccl_library": (C.c_char_p, []),
     "bvh_thread_pool_create": (_P, [_Z]),
     "bvh_thread_pool_destroy": (None, [_P]),
     "bvh_amd_gather": (_I, [_P, _P, _Z, _Z, _P, _P]),

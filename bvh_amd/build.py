@@ -58,8 +58,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     raise RuntimeError(f"hipcc failed on {s}")
     objs = [os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if jobs or _stale(LIB, objs):
-        # librccl: the scene broadcast of the multi-GPU path lives inside the library (csrc/replicate.hip)
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+        # (librccl — the scene broadcast of the multi-GPU path, csrc/replicate.hip — is opened with dlopen on first use: a program
+        #  that stays on one GPU loads this library without it)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             sys.stderr.write(r.stdout + r.stderr)

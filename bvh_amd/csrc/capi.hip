@@ -519,6 +519,7 @@ void bvh_amd_reinsertion_stats(unsigned out[2]) { if (out) reinsertion_stats(out
 int bvh_amd_release_cached_memory(void) {
     int dev = 0;
     BVH_HIP_TRY(hipGetDevice(&dev), BVH_AMD_ERR_HIP);
+    (void)bvh_amd_comm_cache_clear();                         // the communicators bvhXX_replicate keeps (replicate.hip)
     scratch_cache_flush();
     BVH_HIP_TRY(hipDeviceSynchronize(), BVH_AMD_ERR_HIP);
     hipMemPool_t pool = nullptr;

@@ -166,7 +166,7 @@ BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_rec
  * Ray batches shard embarrassingly (a const Bvh + per-ray state, reference bvh.h:160-182 touches nothing shared); the ONE
  * exchange of the path is a root-to-all broadcast of the scene over RCCL / xGMI: the Bvh::serialize byte stream (reference
  * bvh.h:221-229) written into HBM straight from the resident nodes, and the BVH-ordered primitive array. It runs inside this
- * library (csrc/replicate.hip, linked against librccl); no payload byte visits the host on any rank. A BVH is bound to the device
+ * library (csrc/replicate.hip; librccl is opened on first use); no payload byte visits the host on any rank. A BVH is bound to the device
  * it was built / received on; bvhXX_intersect_rays_* must be called with that device current (bvh_amd_device_select).
  *   one process per GPU: rank 0 calls bvh_amd_comm_unique_id, the 128 bytes travel by any side channel (a file, MPI, torch's
  *     store), every rank calls bvh_amd_comm_create on ITS device, then bvhXX_broadcast; or wrap an ncclComm_t you already have
@@ -185,12 +185,19 @@ BVH_AMD_API int bvh_amd_comm_size(const struct bvh_amd_comm*);
 BVH_AMD_API void* bvh_amd_comm_handle(const struct bvh_amd_comm*);                                  /* the ncclComm_t */
 /* ncclBroadcast of a raw device buffer, in place, on `stream` (e.g. the scene box the ray generators need) */
 BVH_AMD_API int bvh_amd_comm_broadcast(struct bvh_amd_comm*, void* d_buf, size_t bytes, int root, void* stream);
+/* bvhXX_replicate keeps its communicators (one set per list of devices: ncclCommInitAll is paid once, not per scene); this destroys
+ * them (also done by bvh_amd_release_cached_memory) and returns the number of sets there were.                                   */
+BVH_AMD_API int bvh_amd_comm_cache_clear(void);
+/* The path librccl was opened from ("" until the first multi-GPU call, or when it could not be opened: bvh_amd_last_error). RCCL is
+ * loaded on first use of the entry points of this section — a single-GPU program never needs it to be installed.                 */
+BVH_AMD_API const char* bvh_amd_rccl_library(void);
 /* Collective: EVERY rank of the communicator calls it. The root passes its BVH and the BVH-ordered primitive array
  * (prim_bytes bytes of device memory); the others pass NULL / NULL / 0. Returns this rank's device-resident BVH — the root's own
  * object on the root, a new one elsewhere (bvhXX_destroy) — and in *d_prims_out this rank's primitive array (the root's own
  * pointer on the root, otherwise a new buffer to release with bvh_amd_device_free); *prim_bytes_out (may be NULL) its size.
- * NULL on failure (bvh_amd_last_error; a root that has nothing valid to send tells the others through the header, so nobody
- * hangs). When it returns, the BVH is ready on `stream`'s device and the buffers may be used from any stream.                 */
+ * NULL on failure (bvh_amd_last_error). No rank is left waiting by a peer's failure: a root that has nothing valid to send says so
+ * in the header, and after the header every rank prepares its side (family check, receive buffers, the root's serialization) and
+ * the ranks agree on one status word (ncclAllReduce, min) BEFORE any payload is posted — if any rank failed, all return NULL. When it returns, the BVH is ready on `stream`'s device and the buffers may be used from any stream.                 */
 BVH_AMD_API struct bvh3f* bvh3f_broadcast(struct bvh_amd_comm*, int root, struct bvh3f* bvh, const void* d_prims, size_t prim_bytes,
                                           void** d_prims_out, size_t* prim_bytes_out, void* stream);
 BVH_AMD_API struct bvh3d* bvh3d_broadcast(struct bvh_amd_comm*, int root, struct bvh3d* bvh, const void* d_prims, size_t prim_bytes,

@@ -165,3 +165,18 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
         assert [int(x) for x in got[2:]] == [getattr(cls, f).offset for f in fields], name
     assert api.HITF.itemsize == 16 and api.HITD.itemsize == 32 and api.NODEF.itemsize == 28 and api.NODED.itemsize == 56
     assert api.NODE2F.itemsize == 20 and api.NODE2D.itemsize == 40
+
+
+def test_library_does_not_need_rccl_to_load():
+    """librccl is opened on first use of the multi-GPU entry points (csrc/replicate.hip), not linked: a single-GPU program
+    loads libbvh_amd.so on a machine without RCCL. The shared object has no NEEDED entry for it, and a process that only loads the
+    library has not mapped it."""
+    import subprocess
+    import sys
+    from bvh_amd import _lib
+    dyn = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "NEEDED" in dyn and "rccl" not in dyn
+    code = ("import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); l.bvh_amd_rccl_library.restype = ctypes.c_char_p; "
+            "maps = open('/proc/self/maps').read(); print('rccl' in maps)")
+    r = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "False", r.stdout + r.stderr
