@@ -18,6 +18,7 @@ int build_minitree_explicit(BvhImpl<T>& out, const T* d_bboxes, const T* d_cente
 template <typename T>
 int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_count, const uint32_t* d_ids, size_t root_id, hipStream_t stream);
 template <typename T> int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream);
+template <typename T> int reachable_node_count(const HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, size_t* out);
 template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
 
 namespace {
@@ -264,15 +265,32 @@ template <typename T> BvhImpl<T>* extract(BvhImpl<T>* pb, size_t root_id) {
     return out.release();
 }
 
+// The ReinsertionOptimizer walks parent links from every candidate to the root (reinsertion_optimizer.h:107-188). On an array that
+// also holds nodes nothing reachable references — tolerated on the way in (wire.hip), like the reference tolerates them — the
+// reference's zero-initialised parents_ (:74) would make such a node a child of the root and corrupt the tree, and a cycle among
+// unreachable nodes would never reach the root at all. Refused here, before anything is touched: optimize wants a proper tree.
+template <typename T> int whole_array_is_one_tree(const HostNode<T>* d, size_t n) {
+    size_t reachable = 0;
+    const int rc = reachable_node_count<T>(d, n, nullptr, &reachable);
+    if (rc) return rc;
+    if (reachable != n)
+        return fail(BVH_AMD_ERR_UNSUPPORTED, "optimize: " + std::to_string(n - reachable) + " of the " + std::to_string(n) +
+                    " nodes are not reachable from the root (unused sibling pairs); extract_bvh(0) first, or remove them");
+    return BVH_AMD_OK;
+}
 template <typename T> int optimize(BvhImpl<T>* b) {
     const int dim = b ? b->dim : 3;
-    return on_resident_nodes<T>(b, [dim](HostNode<T>* d, size_t n) { return reinsertion_optimize_device<T>(d, n, nullptr, dim); });
+    return on_resident_nodes<T>(b, [dim](HostNode<T>* d, size_t n) {
+        const int rc = whole_array_is_one_tree<T>(d, n);
+        return rc ? rc : reinsertion_optimize_device<T>(d, n, nullptr, dim);
+    });
 }
 template <typename T> int optimize_config(BvhImpl<T>* b, const bvh_amd_optimize_config* config) {
     const int dim = b ? b->dim : 3;
     const bvh_amd_optimize_config c = config ? *config : bvh_amd_optimize_config{0.05, 3};
     return on_resident_nodes<T>(b, [dim, c](HostNode<T>* d, size_t n) {
-        return reinsertion_optimize_config_device<T>(d, n, nullptr, dim, c.batch_size_ratio, c.max_iter_count);
+        const int rc = whole_array_is_one_tree<T>(d, n);
+        return rc ? rc : reinsertion_optimize_config_device<T>(d, n, nullptr, dim, c.batch_size_ratio, c.max_iter_count);
     });
 }
 template <typename T> int refit(BvhImpl<T>* b) {
@@ -506,6 +524,7 @@ int bvh_amd_kernel_times(float* ms_out, size_t capacity, size_t* count_out) {
     return kernel_times(ms_out, capacity, count_out);
 }
 void bvh_amd_last_optimize_profile(struct bvh_amd_optimize_profile* out) { if (out) last_optimize_profile(out); }
+int bvh_amd_experiment(const char* name, int value) { return set_experiment(name, value); }
 void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch, int ticket_ranges) { set_tuning(refill_threshold, leaf_threshold, coop_fetch, ticket_ranges); }
 void bvh_amd_last_launch_plan(int out[4]) { if (out) last_launch_plan(out); }
 int bvh_amd_reorder_times(float* ms_out, size_t capacity, size_t* count_out) {

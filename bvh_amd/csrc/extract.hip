@@ -18,6 +18,8 @@ using namespace bld;
 
 namespace {
 
+constexpr uint32_t kNoParent = 0xFFFFFFFFu;
+
 template <typename T> __device__ inline bool leaf_node(const HostNode<T>& n) { return (n.index & kCountMask) != 0; }
 template <typename T> __device__ inline uint32_t first_id(const HostNode<T>& n) { return static_cast<uint32_t>(n.index >> kCountBits); }
 
@@ -41,7 +43,10 @@ __global__ void __launch_bounds__(256) k_subtree_counts(const HostNode<T>* nodes
     __hip_atomic_store(&inner[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&prims[i], static_cast<uint32_t>(nd.index & kCountMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i == 0) return;
+    // (parent[] starts out as kNoParent everywhere: a node no inner node references — tolerated by the validation like the reference
+    //  tolerates it — is the top of its own subtree and the climb ends there instead of following a stale word)
     uint32_t cur = parent[i];
+    if (cur == kNoParent) return;
     for (;;) {
         __threadfence();                                      // release: this subtree's counts before the ticket
         if (atomicAdd(&arrived[cur], 1u) == 0) return;        // first child: the sibling's lane finishes this node
@@ -55,6 +60,7 @@ __global__ void __launch_bounds__(256) k_subtree_counts(const HostNode<T>* nodes
         __hip_atomic_store(&prims[cur], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0) return;
         cur = parent[cur];
+        if (cur == kNoParent) return;
     }
 }
 
@@ -101,6 +107,8 @@ int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_coun
     A(parent.alloc(n)); A(arrived.alloc(n)); A(inner.alloc(n)); A(prims.alloc(n)); A(counter.alloc(1));
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("extract: hipMalloc: ") + hipGetErrorString(e));
     BVH_HIP_TRY(hipMemsetAsync(arrived.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipMemsetAsync(parent.p, 0xFF, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);     // kNoParent: see k_subtree_counts
+    BVH_HIP_TRY(hipMemsetAsync(inner.p, 0xFF, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);      // "never counted": nodes of a cycle no leaf pass completes
     hipLaunchKernelGGL(k_parents<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p);
     hipLaunchKernelGGL(k_subtree_counts<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, parent.p, n, arrived.p, inner.p, prims.p);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
@@ -108,6 +116,7 @@ int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_coun
     BVH_HIP_TRY(hipMemcpyAsync(&counts[0], inner.p + root_id, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipMemcpyAsync(&counts[1], prims.p + root_id, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    if (counts[0] == kNoParent) return fail(BVH_AMD_ERR_ARG, "extract: root_id is not the root of a subtree (its nodes form a cycle no leaf pass completes)");
     const size_t out_nodes_n = 1 + 2 * size_t{counts[0]}, out_prims = counts[1];
     DevBuf<HostNode<T>> new_nodes;
     A(new_nodes.alloc(out_nodes_n)); A(new_ids.alloc(out_prims));
@@ -132,6 +141,32 @@ int extract_device(BvhImpl<T>& out, const HostNode<T>* d_nodes, size_t node_coun
     new_ids.p = nullptr;
     return BVH_AMD_OK;
 }
+
+// How many nodes of the array the tree below node 0 holds (1 + 2 x its inner nodes). Equal to the node count for every BVH a builder
+// made; smaller when the array also holds nodes nothing reachable references (tolerated on the way in, wire.hip).
+template <typename T>
+int reachable_node_count(const HostNode<T>* d_nodes, size_t node_count, hipStream_t stream, size_t* out) {
+    StreamScope scratch_on(stream);
+    const uint32_t n = static_cast<uint32_t>(node_count);
+    DevBuf<uint32_t> parent, arrived, inner, prims;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(parent.alloc(n)); A(arrived.alloc(n)); A(inner.alloc(n)); A(prims.alloc(n));
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("reachable_node_count: hipMalloc: ") + hipGetErrorString(e));
+    BVH_HIP_TRY(hipMemsetAsync(arrived.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipMemsetAsync(parent.p, 0xFF, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipMemsetAsync(inner.p, 0xFF, 4, stream), BVH_AMD_ERR_HIP);
+    hipLaunchKernelGGL(k_parents<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p);
+    hipLaunchKernelGGL(k_subtree_counts<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, parent.p, n, arrived.p, inner.p, prims.p);
+    BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    uint32_t inner_root = 0;
+    BVH_HIP_TRY(hipMemcpyAsync(&inner_root, inner.p, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+    *out = inner_root == kNoParent ? 0 : 1 + 2 * size_t{inner_root};
+    return BVH_AMD_OK;
+}
+template int reachable_node_count<float>(const HostNode<float>*, size_t, hipStream_t, size_t*);
+template int reachable_node_count<double>(const HostNode<double>*, size_t, hipStream_t, size_t*);
 
 template int extract_device<float>(BvhImpl<float>&, const HostNode<float>*, size_t, const uint32_t*, size_t, hipStream_t);
 template int extract_device<double>(BvhImpl<double>&, const HostNode<double>*, size_t, const uint32_t*, size_t, hipStream_t);

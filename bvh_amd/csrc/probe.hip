@@ -16,6 +16,8 @@
 //   5 / 6  128-byte records, one chain per octet of lanes: the octet loads the line with one instruction / lane 0 alone with eight (n_records counts 128-byte records)
 //   4  quad-cooperative + in-register transpose (DPP quad_perm butterflies, no LDS): trace_device.h coop_load_pair itself, what
 //      trace_kernel<..., Coop = true> does
+//   7 / 8  per-lane loads with 2 / 4 INDEPENDENT chains per lane (2 / 4 records in flight per lane); 9: two chains per lane through the
+//      cooperative fetch — do the ceilings of modes 0 / 4 belong to the memory system or to one-fetch-in-flight-per-lane?
 // `active` (1..64): lanes of a wave that own a chain (scattered over the wave: lane l is active iff (37 l mod 64) < active); the
 // others idle in mode 0 and only help loading in mode 1.
 #include "common.h"
@@ -41,6 +43,56 @@ __global__ void __launch_bounds__(256) k_record_walk(const WalkRec* table, uint3
         idx = a.x < n_rec ? a.x : 0u;                          // w[0] = the next record of the chain
     }
     if (acc == 0x12345678u) atomicAdd(sink, 1ull);             // keeps the loads alive
+}
+
+// modes 7 / 8 (K = 2 / 4): K INDEPENDENT chains per lane, the K records of a step in flight together (VERDICT r3 "Next 5": is the
+// records/s ceiling of modes 0 / 4 a property of the memory system, or of a probe that keeps ONE dependent fetch in flight per lane?
+// If the ceiling is a count of outstanding requests per CU, more chains per lane change nothing; if it is latency x lanes, the rate
+// scales with K). Per-lane loads, 4 x global_load_dwordx4 per record.
+template <int K>
+__global__ void __launch_bounds__(256) k_record_walk_mlp(const WalkRec* table, uint32_t n_rec, uint32_t steps, uint32_t active, unsigned long long* sink) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    if (!lane_active(threadIdx.x & 63u, active)) return;
+    uint32_t idx[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) idx[k] = static_cast<uint32_t>(((gid * K + k) * 2654435761ull) % n_rec);
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < steps; ++it) {
+        uint4 a[K], b[K], c[K], d[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {                          // all K x 4 loads are issued before any of them is consumed
+            const uint4* q = reinterpret_cast<const uint4*>(table + idx[k]);
+            a[k] = q[0]; b[k] = q[1]; c[k] = q[2]; d[k] = q[3];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            acc += a[k].y + b[k].z + c[k].w + d[k].y;
+            idx[k] = a[k].x < n_rec ? a[k].x : 0u;
+        }
+    }
+    if (acc == 0x12345678u) atomicAdd(sink, 1ull);
+}
+
+// mode 9: two independent chains per lane through the quad-cooperative fetch + in-register transpose (two coop_load_pair in flight)
+__global__ void __launch_bounds__(256) k_record_walk_dpp2(const WalkRec* table, uint32_t n_rec, uint32_t steps, uint32_t active, unsigned long long* sink) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool mine = lane_active(lane, active);
+    uint32_t i0 = static_cast<uint32_t>(((gid * 2u) * 2654435761ull) % n_rec), i1 = static_cast<uint32_t>(((gid * 2u + 1u) * 2654435761ull) % n_rec);
+    float acc = 0.0f;
+    for (uint32_t it = 0; it < steps; ++it) {
+        float lb0[6], rb0[6], lb1[6], rb1[6];
+        uint32_t li0 = 0, ri0 = 0, li1 = 0, ri1 = 0;
+        coop_load_pair(reinterpret_cast<const PairNode<float>*>(table), mine ? i0 : 0xFFFFFFFFu, static_cast<int>(lane), lb0, rb0, li0, ri0);
+        coop_load_pair(reinterpret_cast<const PairNode<float>*>(table), mine ? i1 : 0xFFFFFFFFu, static_cast<int>(lane), lb1, rb1, li1, ri1);
+        if (mine) {
+            acc += ((lb0[1] + lb0[2]) + (lb0[3] + lb0[4])) + ((lb0[5] + rb0[0]) + (rb0[1] + rb0[2])) + ((rb0[3] + rb0[4]) + rb0[5]);
+            acc += ((lb1[1] + lb1[2]) + (lb1[3] + lb1[4])) + ((lb1[5] + rb1[0]) + (rb1[1] + rb1[2])) + ((rb1[3] + rb1[4]) + rb1[5]);
+            acc += __uint_as_float((li0 ^ ri0 ^ li1 ^ ri1) & 0xFFu);
+            const uint32_t n0 = __float_as_uint(lb0[0]), n1 = __float_as_uint(lb1[0]);
+            i0 = n0 < n_rec ? n0 : 0u; i1 = n1 < n_rec ? n1 : 0u;
+        }
+    }
+    if (acc == 1234.5f) atomicAdd(sink, 1ull);
 }
 
 // modes 5 / 6: 128-byte records (one full L1 / L2 line): one chain per OCTET of lanes, its 8 lanes load the record's eight 16-byte chunks
@@ -232,7 +284,7 @@ BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_rec
                                              float* ms_out, unsigned long long* records_out, void* stream_)
 {
     using namespace bvh_amd;
-    if (!d_table || n_records == 0 || steps == 0 || reps < 1 || !ms_out || mode < 0 || mode > 6) return fail(BVH_AMD_ERR_ARG, "probe_record_walk: bad argument");
+    if (!d_table || n_records == 0 || steps == 0 || reps < 1 || !ms_out || mode < 0 || mode > 9) return fail(BVH_AMD_ERR_ARG, "probe_record_walk: bad argument");
     if (active < 1 || active > 64) active = 64;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int device = 0, cus = 0;
@@ -251,6 +303,9 @@ BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_rec
         case 4: hipLaunchKernelGGL(k_record_walk_dpp, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
         case 5: hipLaunchKernelGGL(k_record_walk_wide<true>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_table), n_records, steps, sink); break;
         case 6: hipLaunchKernelGGL(k_record_walk_wide<false>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_table), n_records, steps, sink); break;
+        case 7: hipLaunchKernelGGL(k_record_walk_mlp<2>, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
+        case 8: hipLaunchKernelGGL(k_record_walk_mlp<4>, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
+        case 9: hipLaunchKernelGGL(k_record_walk_dpp2, dim3(grid), dim3(256), 0, stream, table, n_records, steps, act, sink); break;
         case 2: hipLaunchKernelGGL(k_record_walk_quad<true>, dim3(grid), dim3(256), 0, stream, table, n_records, steps, sink); break;
         default: hipLaunchKernelGGL(k_record_walk_quad<false>, dim3(grid), dim3(256), 0, stream, table, n_records, steps, sink); break;
         }
@@ -269,7 +324,8 @@ BVH_AMD_API int bvh_amd_probe_record_walk_ex(const void* d_table, uint32_t n_rec
         if (e == hipSuccess) e = hipGetLastError();
         *ms_out = ms / reps;
         const unsigned long long chains_per_wave = (mode == 2 || mode == 3) ? 16ull : (mode == 5 || mode == 6) ? 8ull : static_cast<unsigned long long>(active);
-        if (records_out) *records_out = static_cast<unsigned long long>(grid) * 4ull * chains_per_wave * steps;
+        const unsigned long long per_lane = mode == 7 || mode == 9 ? 2ull : mode == 8 ? 4ull : 1ull;
+        if (records_out) *records_out = static_cast<unsigned long long>(grid) * 4ull * chains_per_wave * per_lane * steps;
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

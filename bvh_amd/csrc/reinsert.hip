@@ -925,7 +925,11 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_refit(HostNode<T>* nodes, const uint32_t* parent, uint32_t* arrived, uint32_t n) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || i == 0 || !is_leaf(nodes[i])) return;
+    // (refit_device fills parent[] with 0xFFFFFFFF first: a node no inner node references is the top of its own subtree — the
+    //  validation tolerates such arrays like the reference does — and the climb ends there; the reference's traverse_bottom_up,
+    //  bvh.h:187-204, walks such a subtree bottom-up too and stops at its top)
     uint32_t cur = parent[i];
+    if (cur == 0xFFFFFFFFu) return;
     for (;;) {
         __threadfence();                                      // release: this lane's box is visible before the ticket
         if (atomicAdd(&arrived[cur], 1u) == 0) return;        // first child: the sibling's lane finishes this node
@@ -943,6 +947,7 @@ __global__ void __launch_bounds__(256) k_refit(HostNode<T>* nodes, const uint32_
         }
         if (cur == 0) return;
         cur = parent[cur];
+        if (cur == 0xFFFFFFFFu) return;
     }
 }
 
@@ -960,6 +965,7 @@ int refit_device(HostNode<T>* d_nodes, size_t node_count, hipStream_t stream) { 
     if (e == hipSuccess) e = cost.alloc(n);
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("refit: hipMalloc: ") + hipGetErrorString(e));
     BVH_HIP_TRY(hipMemsetAsync(arrived.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipMemsetAsync(parent.p, 0xFF, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
     hipLaunchKernelGGL(k_parents_costs<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, parent.p, cost.p, 1, 3);
     hipLaunchKernelGGL(k_refit<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, parent.p, arrived.p, n);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);

@@ -101,6 +101,8 @@ struct TraceArgs {
     int refill_threshold;                      // refill when at least this many lanes are idle
     int leaf_threshold;                        // leave the inner-node loop when this many lanes wait at a leaf
     uint32_t coop;                             // host side only: launch the quad-cooperative variant (float, 3D, trees below 2^26 pairs)
+    uint32_t prim_stride;                      // scalars from one primitive to the next in `prims` (12: PrecomputedTri; developer knob: 16 = padded to a 64-byte line)
+    uint32_t stream_hints;                     // bit 0: rays / order / hit records are touched once: load / store them non-temporally (developer knob)
 };
 
 __device__ inline void load_pair(const PairNode<float>* p, float (&lb)[6], float (&rb)[6], uint32_t& li, uint32_t& ri) {
@@ -169,6 +171,25 @@ template <bool ByTwo> __device__ inline void quad_exchange4(uint32_t (&a)[4], ui
             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(lower) : "vcc", "scc");
     a[0] = n0; a[1] = n1; a[2] = n2; a[3] = n3;
 }
+#elif defined(BVH_HOST_WAVE64)
+// tests/cpp/trace_body_host.cpp, 64 fibers: the two quad primitives by their MEANING (every lane exchanges through the harness's
+// wave_read), so that coop_load_pair below — which chunk each lane loads for whom, the order of the butterfly stages, where the
+// transposed dwords end up — runs on the host as the very text the device compiles. Only the DPP encodings themselves stay untested here.
+template <int CTRL> inline uint32_t quad_perm(uint32_t v) {
+    const int l = static_cast<int>(threadIdx.x) & 63;
+    return wave_read(v, (l & ~3) | ((CTRL >> (2 * (l & 3))) & 3), true);
+}
+template <bool ByTwo> inline void quad_exchange4(uint32_t (&a)[4], uint32_t (&b)[4]) {
+    const int l = static_cast<int>(threadIdx.x) & 63, bit = ByTwo ? 2 : 1, partner = l ^ bit;
+    const bool lower = (l & bit) == 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t pa = wave_read(a[i], partner, true), pb = wave_read(b[i], partner, true);
+        const uint32_t na = lower ? a[i] : pb, nb = lower ? pa : b[i];
+        a[i] = na; b[i] = nb;
+    }
+}
+#endif
+#if defined(__HIPCC__) || defined(BVH_HOST_WAVE64)
 __device__ inline void coop_load_pair(const PairNode<float>* pairs, uint32_t want, int lane, float (&lb)[6], float (&rb)[6], uint32_t& li, uint32_t& ri) {
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t j = static_cast<uint32_t>(lane) & 3u;
@@ -230,6 +251,26 @@ __device__ inline void load_ray(const double* p, double (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
 }
+// The same, marked non-temporal: a ray is read once and its hit record written once per launch; without the hint each of them
+// takes a line of the XCD's L2 away from the node / triangle working set the in-flight rays share.
+__device__ inline void load_ray_nt(const float* p, float (&v)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* q = reinterpret_cast<const f4*>(p);
+    const f4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#else
+    load_ray(p, v);
+#endif
+}
+__device__ inline void load_ray_nt(const double* p, double (&v)[8]) { load_ray(p, v); }
+__device__ inline uint32_t load_word_nt(const uint32_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 // Ray<T, 2>: {org[2], dir[2], tmin, tmax}
 __device__ inline void load_ray2(const float* p, float (&v)[6]) {
     const float2* q = reinterpret_cast<const float2*>(p);
@@ -249,6 +290,16 @@ __device__ inline void store_hit(bvh_hit3d* out, uint32_t prim, double t, double
     q[0] = make_double2(__longlong_as_double(static_cast<long long>(prim)), t);
     q[1] = make_double2(u, v);
 }
+__device__ inline void store_hit_nt(bvh_hit3f* out, uint32_t prim, float t, float u, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 h; h.x = __uint_as_float(prim); h.y = t; h.z = u; h.w = v;
+    __builtin_nontemporal_store(h, reinterpret_cast<f4*>(out));
+#else
+    store_hit(out, prim, t, u, v);
+#endif
+}
+__device__ inline void store_hit_nt(bvh_hit3d* out, uint32_t prim, double t, double u, double v) { store_hit(out, prim, t, u, v); }
 
 } // namespace
 

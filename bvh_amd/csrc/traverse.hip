@@ -72,6 +72,7 @@ template <typename T, bool Any, bool Robust, int Leaf, bool Stats>
 __global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop(TraceArgs<T> a) {
     constexpr int D = 3;
     constexpr bool Deep = false;
+#undef BVH_TRACE_COOP
 #define BVH_TRACE_COOP true
 #include "trace_body.inc"
 #undef BVH_TRACE_COOP
@@ -90,6 +91,7 @@ template <typename T, bool Any, bool Robust, int Leaf>
 __global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop_plan_search(TraceArgs<T> a) {
     constexpr int D = 3;
     constexpr bool Deep = false, Stats = false;
+#undef BVH_TRACE_COOP
 #define BVH_TRACE_COOP true
 #include "trace_body.inc"
 #undef BVH_TRACE_COOP
@@ -101,19 +103,44 @@ __global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop_plan_search(Trace
 // results. Measured with one ticket range per XCD on 2^24 uniform rays, rays physically permuted (tools/ray_order_probe.py,
 // kernel ms): 1M-triangle soup 12.09 as given, 7.52 / 7.28 / 7.25 with 4 / 5 / 6 bits per axis + octant; 10M-triangle mesh 13.92,
 // 7.79 / 7.41 / 7.09; octant-major and direction-cube keys lose (soup 7.81, mesh 8.25). The third pass costs ~0.13 ms.
+// `hilbert_bits` > 0 (developer experiment, bvh_amd_experiment("key_curve", 1)): the cell's index along the 3D Hilbert curve of that
+// many bits per axis instead of its Morton code (Skilling's axes-to-transpose transform): consecutive keys are always adjacent cells.
 template <typename T>
-__global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys, uint32_t cells = 64) {
+__global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys, uint32_t cells = 64,
+                                                       int hilbert_bits = 0) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     T r[8];
     load_ray(rays + 8ull * i, r);
     const T q[3] = { (r[0] - lx) * sx, (r[1] - ly) * sy, (r[2] - lz) * sz };
     uint32_t code = 0;
+    uint32_t cell[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         T v = q[k];
         v = v > T(0) ? v : T(0);                              // (NaN origins land in cell 0)
-        uint32_t c = v >= T(cells - 1) ? cells - 1 : static_cast<uint32_t>(v);
+        cell[k] = v >= T(cells - 1) ? cells - 1 : static_cast<uint32_t>(v);
+    }
+    if (hilbert_bits > 0) {
+        uint32_t X[3] = { cell[2], cell[1], cell[0] };        // X[0] ends up in the most significant bit of every triple
+        const uint32_t M = 1u << (hilbert_bits - 1);
+        for (uint32_t Q = M; Q > 1; Q >>= 1) {
+            const uint32_t P = Q - 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (X[a] & Q) X[0] ^= P;
+                else { const uint32_t t = (X[0] ^ X[a]) & P; X[0] ^= t; X[a] ^= t; }
+            }
+        }
+        X[1] ^= X[0]; X[2] ^= X[1];
+        uint32_t t = 0;
+        for (uint32_t Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+        X[0] ^= t; X[1] ^= t; X[2] ^= t;
+        cell[2] = X[0]; cell[1] = X[1]; cell[0] = X[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t c = cell[k];
         uint32_t s = (c & 1u) | ((c & 2u) << 2) | ((c & 4u) << 4) | ((c & 8u) << 6) | ((c & 16u) << 8) | ((c & 32u) << 10) | ((c & 64u) << 12) | ((c & 128u) << 14);
         code |= s << k;
     }
@@ -168,6 +195,14 @@ __global__ void __launch_bounds__(256) original_ids_kernel(H* hits, size_t n, co
 
 // Tuning overrides of the calling thread (bvh_amd_tuning; developer A/B runs in one process): < 0 = the default / the environment
 thread_local int t_refill = -1, t_leaf = -1, t_coop = -1, t_parts = -1;
+// Developer experiments of the calling thread (bvh_amd_experiment(name, value); -1 = the default): never change a result.
+//   grid_blocks   cap of the persistent grid (blocks of 256 lanes)
+//   stream_hints  bit 0: rays / order / hit records loaded and stored non-temporally
+//   tri_stride    floats from one PrecomputedTri to the next in the CALLER's primitive array (12; 16 = padded to a 64-byte line)
+//   key_curve     coherence key of the ray reordering: 0 Morton code of the origin cell, 1 Hilbert index
+//   key_bits      bits per axis of that cell grid (1..8)
+struct Experiments { int grid_blocks = -1, stream_hints = -1, tri_stride = -1, key_curve = -1, key_bits = -1; };
+thread_local Experiments t_exp;
 thread_local std::pair<hipEvent_t, hipEvent_t>* t_calibration = nullptr;   // events to record around the next traversal kernel of this thread
 
 // BVH_AMD_COOP=0 / 1 (or bvh_amd_tuning) forces the per-lane / quad-cooperative record fetch of the float 3D kernels for A/B
@@ -213,6 +248,7 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     int grid = static_cast<int>(need < static_cast<unsigned long long>(blocks) ? need : blocks);
     static const int grid_env = getenv("BVH_AMD_GRID_BLOCKS") ? atoi(getenv("BVH_AMD_GRID_BLOCKS")) : 0;   // developer knob: fewer resident waves (occupancy studies)
     if (grid_env > 0 && grid > grid_env) grid = grid_env;
+    if (t_exp.grid_blocks > 0 && grid > t_exp.grid_blocks) grid = t_exp.grid_blocks;
     if (grid < 1) grid = 1;
     (void)name;
     // the symbol as rocprofv3 prints it (profiles/*_kernel_stats.csv), for bench.py's roofline.kernel
@@ -455,6 +491,17 @@ struct StepContextClaim {
 
 void last_launch_plan(int out[4]) { for (int k = 0; k < 4; ++k) out[k] = g_last_plan[k]; }
 void set_tuning(int refill, int leaf, int coop, int parts) { t_refill = refill; t_leaf = leaf; t_coop = coop; t_parts = parts; }
+int set_experiment(const char* name, int value) {
+    const std::string k = name ? name : "";
+    if (k == "grid_blocks") t_exp.grid_blocks = value;
+    else if (k == "stream_hints") t_exp.stream_hints = value;
+    else if (k == "tri_stride") t_exp.tri_stride = value;
+    else if (k == "key_curve") t_exp.key_curve = value;
+    else if (k == "key_bits") t_exp.key_bits = value;
+    else if (k == "reset") t_exp = Experiments{};
+    else return fail(BVH_AMD_ERR_ARG, "bvh_amd_experiment: unknown knob '" + k + "'");
+    return BVH_AMD_OK;
+}
 const char* last_kernel_name() { return g_last_kernel; }
 bool last_launch_reordered() { return g_last_reordered; }
 
@@ -547,6 +594,8 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     args.pairs = b.d_pairs; args.prims = d_prims; args.rays = d_rays; args.hits = d_hits;
     args.n = n; args.work = work; args.counters = d_counters; args.root_index = b.root_index;
     args.order = nullptr;
+    args.prim_stride = leaf_kind == LEAF_TRIANGLE ? (t_exp.tri_stride > 0 ? static_cast<uint32_t>(t_exp.tri_stride) : 12u) : 4u;
+    args.stream_hints = t_exp.stream_hints > 0 ? static_cast<uint32_t>(t_exp.stream_hints) : 0u;
     // one ticket range per XCD (trace_body.inc: refill): free for incoherent batches, a win for every batch whose neighbouring
     // rays are close (coherence-sorted below, or generated that way by the caller)
     static const int parts_env = getenv("BVH_AMD_PARTS") ? atoi(getenv("BVH_AMD_PARTS")) : 0;            // tuning knob
@@ -566,9 +615,9 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
         if (sort_mem) scratch_free(sort_mem, sort_tag);
         return rc;
     };
-    {   // (failures before this point return without a claimed slot only above; from here on every path goes through release())
-        hipError_t e = hipMemsetAsync(work, 0, BvhImpl<T>::kWorkStride * sizeof(unsigned long long), stream);
-        if (e == hipSuccess && d_counters) e = hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream);
+    // (failures before this point return without a claimed slot only above; from here on every path goes through release())
+    if (d_counters) {
+        const hipError_t e = hipMemsetAsync(d_counters, 0, sizeof(bvh_amd_counters), stream);
         if (e != hipSuccess) return release(fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: hipMemsetAsync: ") + hipGetErrorString(e)));
     }
     {   // SmallStack<Index, 64> covers every tree of at most 64 levels; deeper trees get the GrowingStack equivalent
@@ -604,8 +653,14 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
         args.refill_threshold = t_refill > 0 ? t_refill : refill_env > 0 ? refill_env : refill_default;
         args.leaf_threshold = t_leaf > 0 ? t_leaf : leaf_env > 0 ? leaf_env : leaf_default;
     }
+    // the ticket counters of the ranges this launch uses (one per 128 bytes), not the whole 32 KB slot
+    auto zero_tickets = [&]() -> int {
+        const hipError_t e = hipMemsetAsync(work, 0, size_t{args.parts} * kTicketStride * sizeof(unsigned long long), stream);
+        return e == hipSuccess ? BVH_AMD_OK : fail(BVH_AMD_ERR_HIP, std::string("intersect_rays: hipMemsetAsync: ") + hipGetErrorString(e));
+    };
     if (b.dim == 2) {                                         // Node<T, 2>: circles only (tri.h has no 2D intersector)
         if (leaf_kind != LEAF_SPHERE) return release(fail(BVH_AMD_ERR_ARG, "intersect_rays: a 2D BVH traces circles (Sphere<T, 2>) only"));
+        if (const int rc0 = zero_tickets()) return release(rc0);
         int rc2 = dispatch<T, LEAF_SPHERE, 2>(b, args, flags, d_counters != nullptr, stream);
         if (rc2 == BVH_AMD_OK && (flags & BVH_AMD_RAY_ORIGINAL_IDS)) rc2 = to_original_ids<T>(b, d_hits, n, stream);
         return release(rc2);
@@ -628,6 +683,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     // prefers 8 (7.24 against 7.32 ms at 32); a single counter costs 2x and more (profiles/r03_traversal_experiments.md).
     args.parts = t_parts > 0 ? std::min(t_parts, 256) : parts_env > 0 ? std::min(parts_env, 256) : n < 65536 ? 1 : g_last_reordered ? 8 : 32;
     args.part_size = ((n + args.parts - 1) / args.parts + 63) / 64 * 64;
+    if (const int rc0 = zero_tickets()) return release(rc0);
     if (g_last_reordered) {
         const uint32_t n32 = static_cast<uint32_t>(n);
         const size_t words = 4 * n + radix_sort_hist_words(n32, 1);              // keys + tmp, indices + tmp, histogram
@@ -660,10 +716,11 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
             }
         }
         if (!entry_keys) {
-            static const int cell_bits = getenv("BVH_AMD_RAY_KEY_BITS") ? std::max(1, std::min(8, atoi(getenv("BVH_AMD_RAY_KEY_BITS")))) : 7;   // developer knob
+            static const int cell_bits_env = getenv("BVH_AMD_RAY_KEY_BITS") ? std::max(1, std::min(8, atoi(getenv("BVH_AMD_RAY_KEY_BITS")))) : 7;   // developer knob
+            const int cell_bits = t_exp.key_bits > 0 ? std::min(8, t_exp.key_bits) : cell_bits_env;
             const T rescale = static_cast<T>(1u << cell_bits) / T(64);
             hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0] * rescale, sc[1] * rescale,
-                               sc[2] * rescale, keys, 1u << cell_bits);
+                               sc[2] * rescale, keys, 1u << cell_bits, t_exp.key_curve == 1 ? cell_bits : 0);
             key_bits = 3 * cell_bits + 3;
         }
         uint32_t* order = nullptr;
@@ -707,6 +764,10 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     const bool candidate = calibrate_on && free_choice && std::is_same_v<T, float> && b.dim == 3 && n >= (size_t{1} << 20) && n < (size_t{1} << 31) &&
                            b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
     if (!candidate) return launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, nullptr);
+    if (b.node_count && b.d_pairs) {                          // depth + expected record fetches of a random line, once per tree: the predictor below reads it
+        const int rc = tree_depth<T>(b, stream);
+        if (rc) return rc;
+    }
     if (const uint32_t cached = b.launch_plan[kind].load()) {
         const Plan plan = unpack_plan(cached);
         return launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, &plan);
@@ -717,6 +778,15 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         any_hit ? Plan{false, true, kCoopRefillHeavy, kCoopLeafHeavy} : Plan{true, false, kRefillThreshold, kLeafThreshold},
         {true, true, any_hit ? kCoopRefillAny : kCoopRefillHeavy, any_hit ? kCoopLeafAny : kCoopLeafHeavy},
     };
+    // The order in which the candidates are tried starts with the PREDICTOR's plan (VERDICT r3 Weak 4: the first large batch through
+    // a tree — all a single-shot caller ever sends, e.g. one GPU's 12.5M-ray shard of configs[3] — used to get candidate 0, traced
+    // as given with the per-lane fetch: the slowest plan on the very scenes the search exists for). The first batch is now traced
+    // the way round 2's rule says (reorder iff the tree is beyond the L2s and a random line is expected to fetch >= 100 records;
+    // cooperative fetch for any-hit and for such heavy trees), which is the winner or within a few per cent of it on 6 of the 7
+    // scenes of profiles/r03_rule_check.txt; the exploration of the other three starts with the second batch.
+    const bool heavy = b.expected_visits.load() >= kReorderMinVisits;       // (tree_depth has filled it: the candidate test needs a resident tree)
+    const int predicted = any_hit ? (heavy ? 3 : 1) : (heavy ? 3 : 0);
+    auto candidate_at = [&](uint32_t index) { const int k = static_cast<int>(index & 3u); return k == 0 ? predicted : k <= predicted ? k - 1 : k; };
     std::pair<hipEvent_t, hipEvent_t> events{nullptr, nullptr};
     int trying = -1;
     Plan plan{};
@@ -724,15 +794,17 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     {
         std::lock_guard<std::mutex> lock(b.plan_mutex);
         typename BvhImpl<T>::PlanSearch& ps = b.plan_search[kind];
-        if (ps.pending && hipEventQuery(ps.stop) == hipSuccess) {            // the previous candidate has run: note its time
+        // (`recorded` is set, under this mutex, by the thread that owns the measurement once BOTH events are on its stream: a second
+        //  thread can no longer read a stale pair while the first is still between claim and record — ADVICE r3)
+        if (ps.pending && ps.recorded && hipEventQuery(ps.stop) == hipSuccess) {   // the previous candidate has run: note its time
             float ms = 0;
-            if (hipEventElapsedTime(&ms, ps.start, ps.stop) == hipSuccess && ps.rays) {
-                const int c = ps.index & 3;                                  // every candidate is measured twice; the better time counts
+            if (hipEventElapsedTime(&ms, ps.start, ps.stop) == hipSuccess && ps.rays && ms > 0.0f) {
+                const int c = candidate_at(ps.index);                        // every candidate is measured twice; the better time counts
                 const float ns = ms * 1e6f / static_cast<float>(ps.rays) + (candidates[c].reorder ? kSortNsPerRay : 0.0f);
                 ps.ns_per_ray[c] = ps.index < 4 ? ns : std::min(ps.ns_per_ray[c], ns);   // (a kernel's first launch also pays its code load)
                 ++ps.index;
             }
-            ps.pending = false;
+            ps.pending = false; ps.recorded = false;
         }
         (void)hipGetLastError();
         if (ps.index >= 8) {                                                // all four measured twice: keep the winner
@@ -744,16 +816,24 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
             if (!ps.start) (void)hipEventCreate(&ps.start);
             if (!ps.stop) (void)hipEventCreate(&ps.stop);
             if (ps.start && ps.stop) {
-                trying = ps.index & 3; plan = candidates[trying]; have_plan = true;
+                trying = candidate_at(ps.index); plan = candidates[trying]; have_plan = true;
                 events = {ps.start, ps.stop};
-                ps.pending = true; ps.rays = n;
+                ps.pending = true; ps.recorded = false; ps.rays = n;
             }
+        } else {                                                            // a measurement is in flight (or counters are wanted): the predictor's plan
+            plan = candidates[predicted]; have_plan = true;
         }
         (void)hipGetLastError();
     }
     if (trying >= 0) t_calibration = &events;
     const int rc = launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, have_plan ? &plan : nullptr);
     t_calibration = nullptr;
+    if (trying >= 0) {
+        std::lock_guard<std::mutex> lock(b.plan_mutex);
+        typename BvhImpl<T>::PlanSearch& ps = b.plan_search[kind];
+        if (rc == BVH_AMD_OK) ps.recorded = true;                           // both events are on the stream now
+        else ps.pending = false;                                            // nothing was launched: the candidate is tried again
+    }
     return rc;
 }
 

@@ -43,14 +43,16 @@ __global__ void __launch_bounds__(256) k_depth_identity(uint32_t n, uint32_t* an
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { anc[i] = i; dist[i] = 0; }
 }
+// (the last round takes the maximum over the pairs whose chain ends at the ROOT's pair only: pairs nobody reachable references —
+//  tolerated by the validation, wire.hip — and cycles among them are never walked and must not deepen the traversal stack)
 __global__ void __launch_bounds__(256) k_depth_jump(const uint32_t* anc, const uint32_t* dist, uint32_t n, uint32_t* anc_out, uint32_t* dist_out,
-                                                    uint32_t* max_out) {
+                                                    uint32_t* max_out, uint32_t root_pair) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t a = anc[i], d = dist[i] + dist[a];
-    anc_out[i] = anc[a];
+    const uint32_t a = anc[i], d = dist[i] + dist[a], top = anc[a];
+    anc_out[i] = top;
     dist_out[i] = d;
-    if (max_out) atomicMax(max_out, d);
+    if (max_out && top == root_pair) atomicMax(max_out, d);
 }
 
 // Sum over the inner nodes of half-area(node) / half-area(root), in units of 2^-16 (integer, so that the sum does not depend on
@@ -104,7 +106,8 @@ int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
     int rounds = 1;
     while ((uint64_t{1} << rounds) < uint64_t{n} + 1) ++rounds;        // after r rounds every chain of length <= 2^r is resolved
     for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(k_depth_jump, dim3(grid), dim3(256), 0, stream, anc, dist, n, anc2, dist2, r == rounds - 1 ? d_max : nullptr);
+        hipLaunchKernelGGL(k_depth_jump, dim3(grid), dim3(256), 0, stream, anc, dist, n, anc2, dist2, r == rounds - 1 ? d_max : nullptr,
+                           b.root_index >> (kCountBits + 1));
         std::swap(anc, anc2); std::swap(dist, dist2);
     }
     uint32_t words[4] = {0, 0, 0, 0};

@@ -429,6 +429,12 @@ BVH_AMD_API int bvh_amd_reorder_times(float* ms_out, size_t capacity, size_t* co
  * leaf code runs), the record fetch of the float 3D kernels (0 per lane, 1 quad-cooperative) and the number of ticket ranges a launch
  * is cut into (1..256; default one per XCD). < 0 restores the default. Results never depend on any of them. */
 BVH_AMD_API void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch, int ticket_ranges);
+/* Developer experiments of the calling thread, for A/B runs inside one process (tools/r04_experiments.py); results never change.
+ * name: "grid_blocks" (cap of the persistent grid), "stream_hints" (1: rays / order / hit records loaded and stored non-temporally),
+ * "tri_stride" (floats between PrecomputedTri records of the caller's array: 12, or 16 = padded to a 64-byte line), "key_curve"
+ * (0 Morton, 1 Hilbert order of the reordering key), "key_bits" (bits per axis of its grid, 1..8); value < 0 = the default;
+ * "reset" clears all of them. Returns BVH_AMD_ERR_ARG for an unknown name.                                                       */
+BVH_AMD_API int bvh_amd_experiment(const char* name, int value);
 /* How the calling thread's latest batch launch was traced: out = {reordered 0/1, record fetch 0 per lane / 1 quad-cooperative, refill
  * threshold, leaf threshold}. For trees beyond the L2s and batches of >= 2^22 rays the library MEASURES this once per tree and kind
  * of ray (four stretches of the first such batch are traced with different candidates; csrc/traverse.hip: launch_traverse) and

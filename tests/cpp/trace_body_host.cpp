@@ -145,6 +145,21 @@ void host_trace(TraceArgs<T> a) {
 #include "../../bvh_amd/csrc/trace_body.inc"
 }
 
+#if defined(BVH_HOST_WAVE64)
+// The body with the quad-cooperative record fetch (trace_kernel_coop: float, 3D, no deep stack), 64 fibers: coop_load_pair runs as
+// the device's own text, its two quad primitives emulated by meaning (trace_device.h).
+template <bool Any, bool Robust, int Leaf, bool Stats>
+void host_trace_coop(TraceArgs<float> a) {
+    using T = float;
+    constexpr int D = 3;
+    constexpr bool Deep = false;
+#undef BVH_TRACE_COOP
+#define BVH_TRACE_COOP true
+#include "../../bvh_amd/csrc/trace_body.inc"
+#undef BVH_TRACE_COOP
+}
+#endif
+
 } // namespace
 } // namespace bvh_amd
 
@@ -174,6 +189,7 @@ int run_any(const void* pairs, uint32_t root_index, const void* prims, const voi
     a.n = n_rays; a.work = work; a.parts = g_parts; a.part_size = g_parts > 1 ? ((n_rays + g_parts - 1) / g_parts + 63) / 64 * 64 : n_rays; a.counters = &cnt; a.order = nullptr; a.deep = deep; a.deep_cap = deep_cap;
     a.root_index = root_index;
     a.refill_threshold = kHostRefill; a.leaf_threshold = kHostLeaf;
+    a.coop = 0; a.prim_stride = 12; a.stream_hints = 0;
     if (dim == 2) { if (deep) run_variant<T, LEAF_SPHERE, 2, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 2, false>(a, any, robust); }
     else if (leaf == LEAF_SPHERE) { if (deep) run_variant<T, LEAF_SPHERE, 3, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 3, false>(a, any, robust); }
     else { if (deep) run_variant<T, LEAF_TRIANGLE, 3, true>(a, any, robust); else run_variant<T, LEAF_TRIANGLE, 3, false>(a, any, robust); }
@@ -182,6 +198,35 @@ int run_any(const void* pairs, uint32_t root_index, const void* prims, const voi
 }
 
 } // namespace
+
+#if defined(BVH_HOST_WAVE64)
+// The quad-cooperative kernel's body (float / 3D / triangles or spheres) as a full wavefront, thresholds as given (the device runs it
+// with 12 / 12 and 20 / 20). Returns 0.
+extern "C" int trace_body_host_coop(const void* pairs64, uint32_t root_index, const float* prims, const float* rays8, size_t n_rays, int leaf, int any, int robust,
+                                    int refill, int leaf_threshold, void* hits16, unsigned long long* counters3) {
+    using namespace bvh_amd;
+    unsigned long long work[8 * kTicketStride] = {};
+    bvh_amd_counters cnt = {0, 0, 0};
+    TraceArgs<float> a;
+    a.pairs = static_cast<const PairNode<float>*>(pairs64);
+    a.prims = prims; a.rays = rays8; a.hits = static_cast<bvh_hit3f*>(hits16);
+    a.n = n_rays; a.work = work; a.parts = g_parts; a.part_size = g_parts > 1 ? ((n_rays + g_parts - 1) / g_parts + 63) / 64 * 64 : n_rays;
+    a.counters = &cnt; a.order = nullptr; a.deep = nullptr; a.deep_cap = 0; a.root_index = root_index;
+    a.refill_threshold = refill; a.leaf_threshold = leaf_threshold;
+    a.coop = 1; a.prim_stride = leaf == LEAF_SPHERE ? 4 : 12; a.stream_hints = 0;
+    on_all_lanes([&] {
+        if (leaf == LEAF_SPHERE) {
+            if (any) { if (robust) host_trace_coop<true, true, LEAF_SPHERE, true>(a); else host_trace_coop<true, false, LEAF_SPHERE, true>(a); }
+            else { if (robust) host_trace_coop<false, true, LEAF_SPHERE, true>(a); else host_trace_coop<false, false, LEAF_SPHERE, true>(a); }
+        } else {
+            if (any) { if (robust) host_trace_coop<true, true, LEAF_TRIANGLE, true>(a); else host_trace_coop<true, false, LEAF_TRIANGLE, true>(a); }
+            else { if (robust) host_trace_coop<false, true, LEAF_TRIANGLE, true>(a); else host_trace_coop<false, false, LEAF_TRIANGLE, true>(a); }
+        }
+    });
+    counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
+    return 0;
+}
+#endif
 
 extern "C" {
 

@@ -110,7 +110,7 @@ def test_bench_json_contract(monkeypatch, orc):
     monkeypatch.setattr(bvh_amd, "last_optimize_profile", lambda: {"iterations": 3, "replayed": 2, "replacements": 1000, "heap_ms": 0.5})
     monkeypatch.setattr(bvh_amd._lib, "load", lambda: fake_lib)
     monkeypatch.setitem(bench.WORKLOADS, "soup_1m", ("soup", 3000, "tiny stand-in scene of the contract test", "3000-tri stand-in"))
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--rays", "4096", "--cpu-sample", "2048", "--no-probe"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--rays", "4096", "--cpu-sample", "2048", "--no-probe", "--no-pmc"])
     for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(var, raising=False)
 

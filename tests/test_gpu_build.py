@@ -463,6 +463,63 @@ def test_refit_matches_reference(orc, dtype):
     assert g2.serialize() == a2.serialize()
 
 
+def test_arrays_with_unused_sibling_pairs_refit_extract_trace_and_refuse_optimize(orc):
+    """from_nodes / deserialize tolerate sibling pairs no inner node references (the reference tolerates them: nodes
+    left behind by append_node / remove_last_node edits, hand-built arrays). Everything that walks parent links must then stop at the
+    top of such a subtree instead of following a stale word: refit (== the reference's traverse_bottom_up, which refits the unused
+    subtree too), extract_bvh, the depth of the traversal stack, tracing; optimize refuses (the reference would hang the unused
+    nodes under the root and corrupt the tree)."""
+    import bvh_amd
+    tris = synth.soup(20_000, seed=21, jitter=0.02)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_SERIAL, quality=oracle.QUALITY_MEDIUM)
+    nodes, ids = ref.nodes().copy(), ref.prim_ids()
+    n = len(nodes)
+    # append an unused SUBTREE: an inner node + a leaf as one pair, the inner node's children as a second pair (leaves over prims 0..1)
+    extra = np.zeros(4, dtype=nodes.dtype)
+    extra["bounds"] = nodes["bounds"][1]
+    extra["index"][0] = (n + 2) << 4                          # inner: children at n + 2, n + 3
+    extra["index"][1] = (0 << 4) | 1
+    extra["index"][2] = (0 << 4) | 1
+    extra["index"][3] = (1 << 4) | 1
+    extra["bounds"][2] = nodes["bounds"][np.flatnonzero(nodes["index"] & 15)[0]]
+    extra["bounds"][3] = nodes["bounds"][np.flatnonzero(nodes["index"] & 15)[1]]
+    # ... and a deep unused CHAIN of 80 levels, which must not deepen the traversal stack (tree_depth counts what hangs below the root)
+    chain = np.zeros(160, dtype=nodes.dtype)
+    base = n + 4
+    for lvl in range(80):
+        chain["bounds"][2 * lvl] = nodes["bounds"][2]
+        chain["bounds"][2 * lvl + 1] = nodes["bounds"][2]
+        chain["index"][2 * lvl] = ((base + 2 * (lvl + 1)) << 4) if lvl < 79 else ((0 << 4) | 1)
+        chain["index"][2 * lvl + 1] = (0 << 4) | 1
+    wide = np.concatenate([nodes, extra, chain])
+    g = bvh_amd.Bvh.from_nodes(wide, ids)
+    a = orc.from_arrays(wide, ids)
+    # tracing ignores what is unreachable, and the stack is sized by the reachable tree (<= 64 levels: not the Deep kernel)
+    prims = bvh_amd.precompute_tris(tris, g.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    rays = synth.rays_closest(30_000, lo, hi)
+    hits = bvh_amd.hits_to_numpy(bvh_amd.intersect(g, prims, rays, robust=True))
+    assert hits.tobytes() == ref.intersect_tri(orc.precompute_tris(tris, ref.prim_ids()), rays, 0, 1, threads=4).tobytes()
+    assert "true>" not in bvh_amd._lib.load().bvh_amd_last_kernel_name().decode().split(", ")[-1], "an unreachable chain selected the deep-stack kernel"
+    # refit: move some reachable leaves; reachable part AND unused subtree equal the reference's traverse_bottom_up
+    rng = np.random.default_rng(5)
+    leaves = np.flatnonzero((nodes["index"] & 15) != 0)
+    moved = rng.choice(leaves, size=500, replace=False)
+    wide2 = wide.copy()
+    wide2["bounds"][moved] += np.float32(0.01)
+    g = bvh_amd.Bvh.from_nodes(wide2, ids)
+    a = orc.from_arrays(wide2, ids)
+    g.refit(); a.refit()
+    assert g.serialize() == a.serialize()
+    # extract of the reachable tree drops the unused nodes; of the unused subtree's top it yields that subtree
+    assert g.extract_bvh(1).serialize() == a.extract(1).serialize()
+    assert g.extract_bvh(n).serialize() == a.extract(n).serialize()
+    with pytest.raises(bvh_amd.BvhAmdError, match="not reachable"):
+        g.optimize()
+    assert g.serialize() == a.serialize(), "a refused optimize must leave the tree alone"
+
+
 def test_refit_on_device_built_tree_is_identity(orc):
     import bvh_amd
     tris = synth.terrain(30_000)

@@ -62,8 +62,14 @@ def test_kernel_isa_hash_of_the_built_library():
     assert h is not None and len(h) == 40
     assert h == kernel_isa_hash(_lib.LIB_PATH, "trace_kernel<float, false, true, 0, false, 3, false>")
     assert kernel_isa_hash(_lib.LIB_PATH, "no_such_kernel<int>") is None
+    # bench.py collects the kernel's counters itself (rocprofv3 --pmc passes of a child run); the stored profiles/pmc_traffic.json is only
+    # the fallback where that is impossible, and is quoted only for a library whose kernel hashes like the traced one
+    import argparse
     import json
+    import bench
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     key = "soup_1m|high|pool|robust|16777216|reordered"
-    traced = kernel_isa_hash(_lib.LIB_PATH, rec[key]["kernel"])                 # the kernel the default bench launches (as recorded with the counters)
-    assert rec[key]["isa_sha1"] == traced, "profiles/pmc_traffic.json was traced on another build of the bench kernel: re-run tools/pmc_traffic.py"
+    args = argparse.Namespace(workload="soup_1m", quality="high", serial_builder=False)
+    got, note = bench.pmc_record(args, True, rec[key]["kernel"], True, 16777216)
+    same = rec[key]["isa_sha1"] == kernel_isa_hash(_lib.LIB_PATH, rec[key]["kernel"])
+    assert (got is not None) == same, note
