@@ -197,9 +197,9 @@ __global__ void __launch_bounds__(256) original_ids_kernel(H* hits, size_t n, co
 thread_local int t_refill = -1, t_leaf = -1, t_coop = -1, t_parts = -1;
 // Developer experiments of the calling thread (bvh_amd_experiment(name, value); -1 = the default): never change a result.
 //   grid_blocks   cap of the persistent grid (blocks of 256 lanes)
-//   stream_hints  bit 0: rays / order / hit records loaded and stored non-temporally
+//   stream_hints  bit 0: rays / order / hit records loaded and stored non-temporally (default on; 0 = off)
 //   tri_stride    floats from one PrecomputedTri to the next in the CALLER's primitive array (12; 16 = padded to a 64-byte line)
-//   key_curve     coherence key of the ray reordering: 0 Morton code of the origin cell, 1 Hilbert index
+//   key_curve     coherence key of the ray reordering: 1 Hilbert index of the origin cell (default), 0 its Morton code
 //   key_bits      bits per axis of that cell grid (1..8)
 struct Experiments { int grid_blocks = -1, stream_hints = -1, tri_stride = -1, key_curve = -1, key_bits = -1; };
 thread_local Experiments t_exp;
@@ -595,7 +595,10 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     args.n = n; args.work = work; args.counters = d_counters; args.root_index = b.root_index;
     args.order = nullptr;
     args.prim_stride = leaf_kind == LEAF_TRIANGLE ? (t_exp.tri_stride > 0 ? static_cast<uint32_t>(t_exp.tri_stride) : 12u) : 4u;
-    args.stream_hints = t_exp.stream_hints > 0 ? static_cast<uint32_t>(t_exp.stream_hints) : 0u;
+    // rays, their order and the hit records are touched once per launch: loaded / stored non-temporally so that they do not take L2 lines
+    // from the records and triangles the in-flight rays share (round 4, 1M soup 2^24 reordered rays: cooperative kernel 7.15 -> 7.08 ms,
+    // per-lane 7.75 -> 7.56; profiles/r04_experiments_call1.txt). bvh_amd_experiment("stream_hints", 0) turns it off for A/B runs.
+    args.stream_hints = t_exp.stream_hints >= 0 ? static_cast<uint32_t>(t_exp.stream_hints) : 1u;
     // one ticket range per XCD (trace_body.inc: refill): free for incoherent batches, a win for every batch whose neighbouring
     // rays are close (coherence-sorted below, or generated that way by the caller)
     static const int parts_env = getenv("BVH_AMD_PARTS") ? atoi(getenv("BVH_AMD_PARTS")) : 0;            // tuning knob
@@ -720,7 +723,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
             const int cell_bits = t_exp.key_bits > 0 ? std::min(8, t_exp.key_bits) : cell_bits_env;
             const T rescale = static_cast<T>(1u << cell_bits) / T(64);
             hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0] * rescale, sc[1] * rescale,
-                               sc[2] * rescale, keys, 1u << cell_bits, t_exp.key_curve == 1 ? cell_bits : 0);
+                               sc[2] * rescale, keys, 1u << cell_bits, t_exp.key_curve == 0 ? 0 : cell_bits);      // Hilbert index by default (round 4); "key_curve" 0 = Morton
             key_bits = 3 * cell_bits + 3;
         }
         uint32_t* order = nullptr;

@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(256) k_depth_jump(const uint32_t* anc, const u
     anc_out[i] = top;
     dist_out[i] = d;
     if (max_out && top == root_pair) atomicMax(max_out, d);
+    if (max_out && anc[top] != top) atomicOr(max_out + 1, 1u);      // a chain longer than the rounds so far: more rounds are needed
 }
 
 // Sum over the inner nodes of half-area(node) / half-area(root), in units of 2^-16 (integer, so that the sum does not depend on
@@ -105,15 +106,25 @@ int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
     hipLaunchKernelGGL(k_depth_init<T>, dim3(grid), dim3(256), 0, stream, b.d_pairs, n, b.root_index >> (kCountBits + 1), anc, dist);
     int rounds = 1;
     while ((uint64_t{1} << rounds) < uint64_t{n} + 1) ++rounds;        // after r rounds every chain of length <= 2^r is resolved
-    for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(k_depth_jump, dim3(grid), dim3(256), 0, stream, anc, dist, n, anc2, dist2, r == rounds - 1 ? d_max : nullptr,
-                           b.root_index >> (kCountBits + 1));
-        std::swap(anc, anc2); std::swap(dist, dist2);
-    }
+    // Builders make trees of a few dozen levels: seven rounds resolve every chain of up to 128 pairs, and the last of them reports
+    // whether any chain is still unresolved (word 1); only then do the remaining rounds run (round 4: the first traversal of a tree
+    // paid ~20 launches over all pairs for nothing)
     uint32_t words[4] = {0, 0, 0, 0};
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(words, d_max, 16, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    int done = 0;
+    for (const int upto : {std::min(rounds, 7), rounds}) {
+        if (done >= upto) break;
+        if (done) e = hipMemsetAsync(d_max, 0, 8, stream);
+        for (int r = done; r < upto; ++r) {
+            hipLaunchKernelGGL(k_depth_jump, dim3(grid), dim3(256), 0, stream, anc, dist, n, anc2, dist2, r == upto - 1 ? d_max : nullptr,
+                               b.root_index >> (kCountBits + 1));
+            std::swap(anc, anc2); std::swap(dist, dist2);
+        }
+        done = upto;
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(words, d_max, 16, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess || words[1] == 0) break;                   // every chain ends at a fixed point: the depth is final
+    }
     (void)hipFree(buf);
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("tree_depth: ") + hipGetErrorString(e));
     const uint32_t deepest = words[0];

@@ -148,8 +148,76 @@ def section_first():
             print(f"first-call {scene}_{n_tris} rays={nr} call {i:2d}: {ms:8.3f} ms  plan(reorder, coop, refill, leaf)={pl} {kn}", flush=True)
 
 
+def _scene(gen, n, quality, pool=True):
+    tris = getattr(synth, gen)(n)
+    d_tris = torch.from_numpy(tris).cuda()
+    bb, cc = bvh_amd.tri_bounds(d_tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=quality), thread_pool=bvh_amd.ThreadPool() if pool else None)
+    prims = bvh_amd.precompute_tris(d_tris, bvh.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    return bvh, prims, lo, hi
+
+
+def section_grid():
+    """Resident blocks per CU of the persistent grid, per kernel, on every kind of launch; and the round-4 defaults (stream hints, Hilbert key) on / off."""
+    cases = [("terrain", 1_000_000, bvh_amd.Quality.High, True, 1 << 23, False, None),
+             ("sponza_proxy", 262_144, bvh_amd.Quality.Low, False, 10_000_000, True, None),
+             ("sponza_proxy", 262_144, bvh_amd.Quality.Low, False, 4_000_000, False, None),
+             ("soup", 1_000_000, bvh_amd.Quality.High, True, 1 << 24, False, False),
+             ("soup", 10_000_000, bvh_amd.Quality.Medium, True, 12_500_000, False, True)]
+    for gen, n, q, pool, nr, any_hit, sort in cases:
+        bvh, prims, lo, hi = _scene(gen, n, q, pool)
+        rays = torch.from_numpy(synth.rays_shadow(nr, lo, hi) if any_hit else synth.rays_closest(nr, lo, hi)).cuda()
+        out = torch.empty((nr, 4), dtype=torch.float32, device="cuda")
+        tag = f"{gen}_{n} {'any-hit' if any_hit else 'closest'} rays={nr} {'reordered' if sort else 'as given' if sort is False else 'library order'}"
+        for coop, refill, leaf in ((0, 36, 12), (1, 20 if any_hit else 12, 20 if any_hit else 12)):
+            lib.bvh_amd_tuning(refill, leaf, coop, -1)
+            cells = []
+            for per_cu in (4, 5, 6, 7, 8):
+                knob("grid_blocks", per_cu * 256)
+                k_ms, _ = kernel_ms(lambda: bvh_amd.intersect(bvh, prims, rays, any_hit, True, out=out, sort_rays=sort), reps=5, warm=2)
+                cells.append(f"{per_cu}/CU {k_ms:7.3f}")
+            knob("grid_blocks", -1)
+            print(f"grid | {tag:62s} {'coop' if coop else 'per-lane'} {refill}/{leaf}: " + "  ".join(cells) + " ms", flush=True)
+        if sort:
+            lib.bvh_amd_tuning(12, 12, 1, -1)
+            for name, knobs in (("defaults (hints on, hilbert)", {}), ("hints off", {"stream_hints": 0}), ("morton", {"key_curve": 0}), ("both off", {"stream_hints": 0, "key_curve": 0})):
+                knob("reset", 0)
+                for k, v in knobs.items():
+                    knob(k, v)
+                k_ms, p_ms = kernel_ms(lambda: bvh_amd.intersect(bvh, prims, rays, any_hit, True, out=out, sort_rays=True), reps=5, warm=2)
+                print(f"defaults | {tag:58s} coop 12/12 {name:30s}: kernel {k_ms:7.3f} pass {p_ms:7.3f} ms", flush=True)
+            knob("reset", 0)
+        else:
+            for coop, refill, leaf in ((0, 36, 12), (1, 20 if any_hit else 12, 20 if any_hit else 12)):
+                lib.bvh_amd_tuning(refill, leaf, coop, -1)
+                for hints in (1, 0):
+                    knob("stream_hints", hints)
+                    k_ms, p_ms = kernel_ms(lambda: bvh_amd.intersect(bvh, prims, rays, any_hit, True, out=out, sort_rays=sort), reps=5, warm=2)
+                    print(f"defaults | {tag:58s} {'coop' if coop else 'per-lane'} stream_hints={hints}: kernel {k_ms:7.3f} pass {p_ms:7.3f} ms", flush=True)
+            knob("reset", 0)
+        lib.bvh_amd_tuning(-1, -1, -1, -1)
+        del bvh, prims, rays, out
+
+
+def section_ramp():
+    """Kernel time against batch size on configs[1]'s tree: t(n) = t0 + n / R. t0 is what a small batch cannot amortise (first touches of
+    the tree, the longest ray's dependent chain, the drain of the persistent waves)."""
+    bvh, prims, lo, hi = _scene("sponza_proxy", 262_144, bvh_amd.Quality.Low, False)
+    for nr in (4096, 16384, 65536, 131072, 262144, 524288, 1_000_000, 2_000_000, 4_000_000, 8_000_000):
+        rays = torch.from_numpy(synth.rays_closest(nr, lo, hi)).cuda()
+        out = torch.empty((nr, 4), dtype=torch.float32, device="cuda")
+        cells = []
+        for blocks in (-1, 1280, 768):
+            knob("grid_blocks", blocks)
+            k_ms, c_ms = kernel_ms(lambda: bvh_amd.intersect(bvh, prims, rays, False, True, out=out), reps=9, warm=3)
+            cells.append(f"grid {blocks:5d}: kernel {k_ms:7.4f} call {c_ms:7.4f}")
+        knob("grid_blocks", -1)
+        print(f"ramp | sponza_262k closest rays={nr:8d} | " + " | ".join(cells), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["soup", "small", "first"]
     print(torch.cuda.get_device_name(0), flush=True)
     for w in which:
-        {"soup": section_soup, "small": section_small, "first": section_first}[w]()
+        {"soup": section_soup, "small": section_small, "first": section_first, "grid": section_grid, "ramp": section_ramp}[w]()
