@@ -212,8 +212,33 @@ __device__ inline void coop_load_pair(const PairNode<float>* pairs, uint32_t wan
     rb[2] = __uint_as_float(v2[0]); rb[3] = __uint_as_float(v2[1]); rb[4] = __uint_as_float(v2[2]); rb[5] = __uint_as_float(v2[3]);
     li = v3[0]; ri = v3[1];
 }
-__device__ inline void coop_load_pair(const PairNode<double>* p, uint32_t want, int, double (&lb)[6], double (&rb)[6], uint32_t& li, uint32_t& ri) {
-    if (want != 0xFFFFFFFFu) load_pair(p + want, lb, rb, li, ri);          // (128-byte records: not fetched cooperatively)
+// Node<double, N>: 128-byte records, fetched as two 64-byte halves by the same quad scheme (round 4): in instructions k and 4 + k the
+// quad's four lanes load the four 16-byte chunks of the first / second half of the record wanted by its lane k — two quad-coalesced
+// requests per record instead of a lane's eight — and two 4 x 4 transposes hand every lane its own 128 bytes:
+// first half = lb[0..5], rb[0..1]; second half = rb[2..5], {li, ri}, padding (common.h: PairNode<double>).
+__device__ inline void coop_load_pair(const PairNode<double>* pairs, uint32_t want, int lane, double (&lb)[6], double (&rb)[6], uint32_t& li, uint32_t& ri) {
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    const uint32_t j = static_cast<uint32_t>(lane) & 3u;
+    const uint32_t o0 = quad_perm<0x00>(want), o1 = quad_perm<0x55>(want), o2 = quad_perm<0xAA>(want), o3 = quad_perm<0xFF>(want);
+    const char* base = reinterpret_cast<const char*>(pairs);     // (launch_variant selects this kernel for fewer than 2^25 pair records only)
+    const uint32_t chunk = j * 16u;
+    uint4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0}, d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, d2 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
+    if (o0 != kNone) { c0 = *reinterpret_cast<const uint4*>(base + (o0 * 128u + chunk)); d0 = *reinterpret_cast<const uint4*>(base + (o0 * 128u + 64u + chunk)); }
+    if (o1 != kNone) { c1 = *reinterpret_cast<const uint4*>(base + (o1 * 128u + chunk)); d1 = *reinterpret_cast<const uint4*>(base + (o1 * 128u + 64u + chunk)); }
+    if (o2 != kNone) { c2 = *reinterpret_cast<const uint4*>(base + (o2 * 128u + chunk)); d2 = *reinterpret_cast<const uint4*>(base + (o2 * 128u + 64u + chunk)); }
+    if (o3 != kNone) { c3 = *reinterpret_cast<const uint4*>(base + (o3 * 128u + chunk)); d3 = *reinterpret_cast<const uint4*>(base + (o3 * 128u + 64u + chunk)); }
+    uint32_t v0[4] = {c0.x, c0.y, c0.z, c0.w}, v1[4] = {c1.x, c1.y, c1.z, c1.w}, v2[4] = {c2.x, c2.y, c2.z, c2.w}, v3[4] = {c3.x, c3.y, c3.z, c3.w};
+    uint32_t w0[4] = {d0.x, d0.y, d0.z, d0.w}, w1[4] = {d1.x, d1.y, d1.z, d1.w}, w2[4] = {d2.x, d2.y, d2.z, d2.w}, w3[4] = {d3.x, d3.y, d3.z, d3.w};
+    quad_exchange4<false>(v0, v1); quad_exchange4<false>(v2, v3);
+    quad_exchange4<true>(v0, v2); quad_exchange4<true>(v1, v3);
+    quad_exchange4<false>(w0, w1); quad_exchange4<false>(w2, w3);
+    quad_exchange4<true>(w0, w2); quad_exchange4<true>(w1, w3);
+    auto dbl = [](uint32_t lo, uint32_t hi) { return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo)); };
+    lb[0] = dbl(v0[0], v0[1]); lb[1] = dbl(v0[2], v0[3]); lb[2] = dbl(v1[0], v1[1]); lb[3] = dbl(v1[2], v1[3]);
+    lb[4] = dbl(v2[0], v2[1]); lb[5] = dbl(v2[2], v2[3]); rb[0] = dbl(v3[0], v3[1]); rb[1] = dbl(v3[2], v3[3]);
+    rb[2] = dbl(w0[0], w0[1]); rb[3] = dbl(w0[2], w0[3]); rb[4] = dbl(w1[0], w1[1]); rb[5] = dbl(w1[2], w1[3]);
+    li = w2[0]; ri = w2[1];
+    (void)w3;
 }
 #else
 template <typename T> inline void coop_load_pair(const PairNode<T>* p, uint32_t want, int, T (&lb)[6], T (&rb)[6], uint32_t& li, uint32_t& ri) {

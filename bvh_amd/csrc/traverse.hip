@@ -78,6 +78,18 @@ __global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop(TraceArgs<T> a) {
 #undef BVH_TRACE_COOP
 }
 
+// The cooperative body for the other record families (round 4): Node<double, 3> / Node<double, 2> (128-byte records as two
+// quad-coalesced halves: two L1 requests per record instead of a lane's eight) and Node<float, 2> (the same 64-byte records as 3D).
+// The transposes keep ~32 more registers live across the fetch than the per-lane loads: 4 waves per SIMD for double.
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
+__global__ void __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) trace_kernel_coop_nd(TraceArgs<T> a) {
+    constexpr bool Deep = false;
+#undef BVH_TRACE_COOP
+#define BVH_TRACE_COOP true
+#include "trace_body.inc"
+#undef BVH_TRACE_COOP
+}
+
 // Twins of the two kernels above under their own symbols, launched only while launch_traverse is MEASURING candidate plans for a tree
 // (one whole batch per candidate, see there): a profile of an application then shows the search launches apart from the settled
 // ones instead of averaging batches traced as given and batches traced reordered into one kernel's row.
@@ -229,7 +241,9 @@ template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D, bool D
 int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     static thread_local int cached_blocks[16] = {0};
     void (*kernel)(TraceArgs<T>) = nullptr;
-    if constexpr (Coop) kernel = trace_kernel_coop<T, Any, Robust, Leaf, Stats>;
+    constexpr bool CoopNd = Coop && !(std::is_same_v<T, float> && D == 3);
+    if constexpr (CoopNd) kernel = trace_kernel_coop_nd<T, Any, Robust, Leaf, Stats, D>;
+    else if constexpr (Coop) kernel = trace_kernel_coop<T, Any, Robust, Leaf, Stats>;
     else kernel = trace_kernel<T, Any, Robust, Leaf, Stats, D, Deep>;
     if constexpr (std::is_same_v<T, float> && D == 3 && !Deep && !Stats) {
         if (t_calibration) {                                  // a candidate plan being measured: same code, its own symbol
@@ -246,15 +260,26 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
     }
     unsigned long long need = (args.n + kBlock - 1) / kBlock;
     int grid = static_cast<int>(need < static_cast<unsigned long long>(blocks) ? need : blocks);
+    if constexpr (!Coop && std::is_same_v<T, float>) {
+        // The per-lane kernel runs best BELOW the 7 blocks per CU its registers allow (four L1 requests per record and lane: the
+        // seventh wave per SIMD adds contention, not throughput) — measured round 4 at 4..8 blocks per CU (profiles/r04_experiments_call2.txt):
+        // 6 is equal or better on every scene (terrain 1.079 -> 1.072 ms, Sponza any-hit 1.829 -> 1.812, 10M mesh 5.615 -> 5.598, soup as
+        // given 12.01 -> 11.95), and batches of up to 2^21 rays, whose time is mostly the dependent chain of their longest rays, want 5
+        // (configs[1], 1M rays: 0.283 -> 0.254-0.268 ms; 512k rays: 0.234 -> 0.202 ms).
+        int cus = blocks / 7 > 0 ? blocks / 7 : 1;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device);
+        const int cap = (args.n <= (1ull << 21) ? 5 : 6) * cus;
+        if (grid > cap) grid = cap;
+    }
     static const int grid_env = getenv("BVH_AMD_GRID_BLOCKS") ? atoi(getenv("BVH_AMD_GRID_BLOCKS")) : 0;   // developer knob: fewer resident waves (occupancy studies)
     if (grid_env > 0 && grid > grid_env) grid = grid_env;
     if (t_exp.grid_blocks > 0 && grid > t_exp.grid_blocks) grid = t_exp.grid_blocks;
     if (grid < 1) grid = 1;
     (void)name;
     // the symbol as rocprofv3 prints it (profiles/*_kernel_stats.csv), for bench.py's roofline.kernel
-    static const std::string head = std::string(Coop ? "trace_kernel_coop<" : "trace_kernel<") + (std::is_same_v<T, float> ? "float" : "double") + ", " +
+    static const std::string head = std::string(CoopNd ? "trace_kernel_coop_nd<" : Coop ? "trace_kernel_coop<" : "trace_kernel<") + (std::is_same_v<T, float> ? "float" : "double") + ", " +
                                     (Any ? "true" : "false") + ", " + (Robust ? "true" : "false") + ", " + std::to_string(Leaf) + ", " + (Stats ? "true" : "false");
-    static const std::string symbol = Coop ? head + ">" : head + ", " + std::to_string(D) + ", " + (Deep ? "true" : "false") + ">";
+    static const std::string symbol = CoopNd ? head + ", " + std::to_string(D) + ">" : Coop ? head + ">" : head + ", " + std::to_string(D) + ", " + (Deep ? "true" : "false") + ">";
     g_last_kernel = symbol.c_str();
     KernelTimer& timer = kernel_timer();
     hipEvent_t stop = nullptr;
@@ -284,9 +309,8 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
 template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
 int launch_variant(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t stream, const char* name) {
     if (args.deep) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, true>(b, args, stream, name);
-    if constexpr (std::is_same_v<T, float> && D == 3) {
-        if (args.coop && b.pair_count < (size_t{1} << 26)) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false, true>(b, args, stream, name);
-    }
+    // (32-bit byte offsets into the records: 64 / 128 bytes each)
+    if (args.coop && b.pair_count < (size_t{1} << (std::is_same_v<T, float> ? 26 : 25))) return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false, true>(b, args, stream, name);
     return launch_variant_d<T, Any, Robust, Leaf, Stats, D, false>(b, args, stream, name);
 }
 
@@ -595,10 +619,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     args.n = n; args.work = work; args.counters = d_counters; args.root_index = b.root_index;
     args.order = nullptr;
     args.prim_stride = leaf_kind == LEAF_TRIANGLE ? (t_exp.tri_stride > 0 ? static_cast<uint32_t>(t_exp.tri_stride) : 12u) : 4u;
-    // rays, their order and the hit records are touched once per launch: loaded / stored non-temporally so that they do not take L2 lines
-    // from the records and triangles the in-flight rays share (round 4, 1M soup 2^24 reordered rays: cooperative kernel 7.15 -> 7.08 ms,
-    // per-lane 7.75 -> 7.56; profiles/r04_experiments_call1.txt). bvh_amd_experiment("stream_hints", 0) turns it off for A/B runs.
-    args.stream_hints = t_exp.stream_hints >= 0 ? static_cast<uint32_t>(t_exp.stream_hints) : 1u;
+    args.stream_hints = 0;                                    // (decided below, with the order)
     // one ticket range per XCD (trace_body.inc: refill): free for incoherent batches, a win for every batch whose neighbouring
     // rays are close (coherence-sorted below, or generated that way by the caller)
     static const int parts_env = getenv("BVH_AMD_PARTS") ? atoi(getenv("BVH_AMD_PARTS")) : 0;            // tuning knob
@@ -645,7 +666,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     const bool heavy = beyond_l2 && b.expected_visits.load() >= kReorderMinVisits;       // long walks through a tree the L2s cannot hold
     const bool any_hit = (flags & BVH_AMD_RAY_ANY_HIT) != 0;
     const int forced = coop_fetch_forced();
-    const bool coop_capable = std::is_same_v<T, float> && b.dim == 3;
+    const bool coop_capable = true;                           // every record family since round 4 (trees of at most 64 levels: launch_variant)
     if (plan) {                                               // measured for this tree (calibrate) or one of the candidates being measured
         args.coop = coop_capable && plan->coop ? 1u : 0u;
         args.refill_threshold = plan->refill; args.leaf_threshold = plan->leaf;
@@ -679,6 +700,13 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
                        : plan ? plan->reorder && n > 4096
                        : n >= (size_t{1} << 20) && beyond_l2 && b.expected_visits.load() >= kReorderMinVisits;
     g_last_reordered = reorder && n < (size_t{1} << 31);
+    // Rays, their order and the hit records are touched once per launch. In a REORDERED launch (a tree beyond the L2s, long walks) they
+    // are loaded / stored non-temporally so that they do not take L2 lines from the records and triangles the in-flight rays share:
+    // 1M soup, 2^24 rays: cooperative kernel 7.15 -> 7.08 ms, per-lane 7.75 -> 7.56; 10M mesh: pass 5.91 -> 5.83 ms. NOT otherwise: on a
+    // tree the L2s hold (Sponza proxy, 4M closest-hit rays) the same hint COSTS 6 % (0.625 -> 0.666 ms per lane, 0.572 -> 0.605
+    // cooperative), and any-hit / terrain batches are indifferent (profiles/r04_experiments_call1.txt, _call2.txt).
+    // bvh_amd_experiment("stream_hints", 0 / 1) forces it for A/B runs.
+    args.stream_hints = t_exp.stream_hints >= 0 ? static_cast<uint32_t>(t_exp.stream_hints) : g_last_reordered ? 1u : 0u;
     // Ticket ranges (trace_body.inc: refill). A reordered batch wants exactly one range per XCD: each L2 then serves one stretch of the
     // order. A batch traced as given has no such locality to protect, and its waves draw tickets often (short rays, early refills):
     // eight counters then cost measurable time in atomics on one address each — 32 ranges (four per XCD) take the 1M terrain from 1.18
@@ -764,7 +792,7 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     const int kind = any_hit ? 1 : 0;
     const bool free_choice = !(flags & (BVH_AMD_RAY_SORTED | BVH_AMD_RAY_UNSORTED)) && coop_fetch_forced() < 0 && t_refill <= 0 && t_leaf <= 0 &&
                              !getenv("BVH_AMD_REFILL") && !getenv("BVH_AMD_LEAF");
-    const bool candidate = calibrate_on && free_choice && std::is_same_v<T, float> && b.dim == 3 && n >= (size_t{1} << 20) && n < (size_t{1} << 31) &&
+    const bool candidate = calibrate_on && free_choice && b.dim == 3 && n >= (size_t{1} << 20) && n < (size_t{1} << 31) &&
                            b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
     if (!candidate) return launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, nullptr);
     if (b.node_count && b.d_pairs) {                          // depth + expected record fetches of a random line, once per tree: the predictor below reads it

@@ -146,12 +146,10 @@ void host_trace(TraceArgs<T> a) {
 }
 
 #if defined(BVH_HOST_WAVE64)
-// The body with the quad-cooperative record fetch (trace_kernel_coop: float, 3D, no deep stack), 64 fibers: coop_load_pair runs as
-// the device's own text, its two quad primitives emulated by meaning (trace_device.h).
-template <bool Any, bool Robust, int Leaf, bool Stats>
-void host_trace_coop(TraceArgs<float> a) {
-    using T = float;
-    constexpr int D = 3;
+// The body with the quad-cooperative record fetch (trace_kernel_coop / trace_kernel_coop_nd: every record family, no deep stack), 64
+// fibers: coop_load_pair runs as the device's own text, its two quad primitives emulated by meaning (trace_device.h).
+template <typename T, bool Any, bool Robust, int Leaf, bool Stats, int D>
+void host_trace_coop(TraceArgs<T> a) {
     constexpr bool Deep = false;
 #undef BVH_TRACE_COOP
 #define BVH_TRACE_COOP true
@@ -200,31 +198,42 @@ int run_any(const void* pairs, uint32_t root_index, const void* prims, const voi
 } // namespace
 
 #if defined(BVH_HOST_WAVE64)
-// The quad-cooperative kernel's body (float / 3D / triangles or spheres) as a full wavefront, thresholds as given (the device runs it
-// with 12 / 12 and 20 / 20). Returns 0.
-extern "C" int trace_body_host_coop(const void* pairs64, uint32_t root_index, const float* prims, const float* rays8, size_t n_rays, int leaf, int any, int robust,
-                                    int refill, int leaf_threshold, void* hits16, unsigned long long* counters3) {
+namespace {
+template <typename T, int Leaf, int D>
+int run_coop(const void* pairs, uint32_t root_index, const void* prims, const void* rays, size_t n_rays, int any, int robust, int refill, int leaf_threshold,
+             void* hits, unsigned long long* counters3) {
     using namespace bvh_amd;
     unsigned long long work[8 * kTicketStride] = {};
     bvh_amd_counters cnt = {0, 0, 0};
-    TraceArgs<float> a;
-    a.pairs = static_cast<const PairNode<float>*>(pairs64);
-    a.prims = prims; a.rays = rays8; a.hits = static_cast<bvh_hit3f*>(hits16);
+    TraceArgs<T> a;
+    a.pairs = static_cast<const PairNode<T>*>(pairs);
+    a.prims = static_cast<const T*>(prims); a.rays = static_cast<const T*>(rays); a.hits = static_cast<typename HitOf<T>::Type*>(hits);
     a.n = n_rays; a.work = work; a.parts = g_parts; a.part_size = g_parts > 1 ? ((n_rays + g_parts - 1) / g_parts + 63) / 64 * 64 : n_rays;
     a.counters = &cnt; a.order = nullptr; a.deep = nullptr; a.deep_cap = 0; a.root_index = root_index;
     a.refill_threshold = refill; a.leaf_threshold = leaf_threshold;
-    a.coop = 1; a.prim_stride = leaf == LEAF_SPHERE ? 4 : 12; a.stream_hints = 0;
+    a.coop = 1; a.prim_stride = Leaf == LEAF_SPHERE ? 4 : 12; a.stream_hints = 0;
     on_all_lanes([&] {
-        if (leaf == LEAF_SPHERE) {
-            if (any) { if (robust) host_trace_coop<true, true, LEAF_SPHERE, true>(a); else host_trace_coop<true, false, LEAF_SPHERE, true>(a); }
-            else { if (robust) host_trace_coop<false, true, LEAF_SPHERE, true>(a); else host_trace_coop<false, false, LEAF_SPHERE, true>(a); }
-        } else {
-            if (any) { if (robust) host_trace_coop<true, true, LEAF_TRIANGLE, true>(a); else host_trace_coop<true, false, LEAF_TRIANGLE, true>(a); }
-            else { if (robust) host_trace_coop<false, true, LEAF_TRIANGLE, true>(a); else host_trace_coop<false, false, LEAF_TRIANGLE, true>(a); }
-        }
+        if (any) { if (robust) host_trace_coop<T, true, true, Leaf, true, D>(a); else host_trace_coop<T, true, false, Leaf, true, D>(a); }
+        else { if (robust) host_trace_coop<T, false, true, Leaf, true, D>(a); else host_trace_coop<T, false, false, Leaf, true, D>(a); }
     });
     counters3[0] = cnt.node_pairs; counters3[1] = cnt.prim_tests; counters3[2] = cnt.leaves;
     return 0;
+}
+} // namespace
+
+// The quad-cooperative kernels' body as a full wavefront, thresholds as given (the device runs it with 12 / 12 and 20 / 20): float /
+// double, dim 3 (triangles leaf = 0, spheres leaf = 1) or dim 2 (circles). Returns 0.
+extern "C" int trace_body_host_coop(int is_double, const void* pairs, uint32_t root_index, const void* prims, const void* rays, size_t n_rays, int dim, int leaf,
+                                    int any, int robust, int refill, int leaf_threshold, void* hits, unsigned long long* counters3) {
+    using namespace bvh_amd;
+    if (is_double) {
+        if (dim == 2) return run_coop<double, LEAF_SPHERE, 2>(pairs, root_index, prims, rays, n_rays, any, robust, refill, leaf_threshold, hits, counters3);
+        if (leaf == LEAF_SPHERE) return run_coop<double, LEAF_SPHERE, 3>(pairs, root_index, prims, rays, n_rays, any, robust, refill, leaf_threshold, hits, counters3);
+        return run_coop<double, LEAF_TRIANGLE, 3>(pairs, root_index, prims, rays, n_rays, any, robust, refill, leaf_threshold, hits, counters3);
+    }
+    if (dim == 2) return run_coop<float, LEAF_SPHERE, 2>(pairs, root_index, prims, rays, n_rays, any, robust, refill, leaf_threshold, hits, counters3);
+    if (leaf == LEAF_SPHERE) return run_coop<float, LEAF_SPHERE, 3>(pairs, root_index, prims, rays, n_rays, any, robust, refill, leaf_threshold, hits, counters3);
+    return run_coop<float, LEAF_TRIANGLE, 3>(pairs, root_index, prims, rays, n_rays, any, robust, refill, leaf_threshold, hits, counters3);
 }
 #endif
 

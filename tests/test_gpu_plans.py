@@ -138,3 +138,101 @@ def test_first_large_batch_uses_the_predicted_plan(soup):
     assert seen[0] == (1, 1), seen
     assert len(set(seen[:8])) == 4, seen                     # all four candidates were explored ...
     assert seen[8] == seen[9], seen                           # ... and the search has settled
+
+
+# ---- the cooperative fetch of the other record families (round 4: trace_kernel_coop_nd) --------------------------------------------
+
+def _forced(lib, coop, refill, leaf):
+    lib.bvh_amd_tuning(refill, leaf, coop, -1)
+
+
+@pytest.mark.parametrize("leaf", ["sphere", "tri"])
+def test_double_precision_cooperative_fetch_equals_the_reference(leaf):
+    """Node<double, 3> (node.h:18-45; 128-byte pair records fetched as two quad-coalesced 64-byte halves, trace_device.h): spheres
+    (sphere.h:32-49) and triangles (tri.h:56-74), closest + any, robust + fast, per-lane against cooperative fetch — hit records and
+    counters byte-equal to the compiled reference."""
+    import torch
+    import bvh_amd
+    cpu = oracle.load_ref() or oracle.load_oracle()
+    thr = max(1, min(cpu.hardware_threads(), len(os.sched_getaffinity(0))))
+    lib = bvh_amd._lib.load()
+    n = max(30_000, int(300_000 * SCALE))
+    if leaf == "sphere":
+        prim = synth.spheres(n)
+        d_bb, d_cc = bvh_amd.sphere_bounds(torch.from_numpy(prim).cuda())
+    else:
+        prim = synth.soup(n, seed=11, jitter=0.01, dtype=np.float64)
+        d_bb, d_cc = bvh_amd.tri_bounds(torch.from_numpy(prim).cuda())
+    gpu = bvh_amd.DefaultBuilder.build(d_bb, d_cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+    ref = cpu.build(d_bb.cpu().numpy(), d_cc.cpu().numpy(), builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_MEDIUM, threads=thr)
+    assert gpu.serialize() == ref.serialize()
+    if leaf == "sphere":
+        d_prims = bvh_amd.gather(torch.from_numpy(prim).cuda(), gpu.device_prim_ids())
+        oprims = np.ascontiguousarray(prim[ref.prim_ids().astype(np.int64)])
+        trace = ref.intersect_sphere
+    else:
+        d_prims = bvh_amd.precompute_tris(torch.from_numpy(prim).cuda(), gpu.device_prim_ids())
+        oprims = cpu.precompute_tris(prim, ref.prim_ids())
+        trace = ref.intersect_tri
+    lo, hi = synth.scene_bounds(prim)
+    nr = _n(1_000_000)
+    batches = {False: synth.rays_closest(nr, lo, hi, dtype=np.float64, seed=5), True: synth.rays_shadow(nr, lo, hi, dtype=np.float64, seed=6)}
+    try:
+        for any_hit, rays in batches.items():
+            d_rays = torch.from_numpy(rays).cuda()
+            for robust in (True, False):
+                want_hits, want_cnt = trace(oprims, rays, any_hit, robust, threads=thr, counters=True)
+                for coop, refill, thr_leaf in ((0, 36, 12), (1, 12, 12), (1, 20, 20)):
+                    _forced(lib, coop, refill, thr_leaf)
+                    got = bvh_amd.intersect(gpu, d_prims, d_rays, any_hit=any_hit, robust=robust, leaf=leaf, sort_rays=False)
+                    kernel = lib.bvh_amd_last_kernel_name().decode()
+                    assert kernel.startswith("trace_kernel_coop_nd<double" if coop else "trace_kernel<double"), kernel
+                    assert bvh_amd.hits_to_numpy(got).tobytes() == want_hits.tobytes(), (leaf, any_hit, robust, coop)
+                    got, cnt = bvh_amd.intersect(gpu, d_prims, d_rays, any_hit=any_hit, robust=robust, leaf=leaf, counters=True, sort_rays=False)
+                    assert bvh_amd.hits_to_numpy(got).tobytes() == want_hits.tobytes()
+                    assert (cnt.cpu().numpy().astype(np.uint64) == want_cnt).all(), (leaf, any_hit, robust, coop)
+            # a reordered batch through the cooperative kernel (the order never changes a record)
+            _forced(lib, 1, 12, 12)
+            want_hits = trace(oprims, rays, any_hit, True, threads=thr)
+            got = bvh_amd.intersect(gpu, d_prims, d_rays, any_hit=any_hit, robust=True, leaf=leaf, sort_rays=True)
+            assert bvh_amd.hits_to_numpy(got).tobytes() == want_hits.tobytes()
+    finally:
+        lib.bvh_amd_tuning(-1, -1, -1, -1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_2d_cooperative_fetch_equals_the_reference(dtype):
+    """Node<T, 2> (circles; sphere.h:32-49 over two axes): the cooperative kernels of the 2f / 2d families against the per-lane ones
+    and the compiled reference, hits and counters."""
+    import bvh_amd
+    cpu = oracle.load_ref() or oracle.load_oracle()
+    lib = bvh_amd._lib.load()
+    n = max(20_000, int(200_000 * SCALE))
+    rng = np.random.default_rng(9)
+    circ = np.ascontiguousarray(np.concatenate([rng.random((n, 2)), 0.0004 + 0.002 * rng.random((n, 1))], axis=1).astype(dtype))
+    bb, cc = cpu.sphere_bboxes(circ)
+    ref = cpu.build(bb, cc, quality=2)
+    gpu = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High))
+    assert gpu.dim == 2 and gpu.serialize() == ref.serialize()
+    ordered = circ[ref.prim_ids().astype(np.int64)]
+    d_ordered = bvh_amd.gather(circ, gpu.device_prim_ids())
+    nr = _n(500_000)
+    org = rng.random((nr, 2)) * 1.1 - 0.05
+    ang = rng.random(nr) * 2 * np.pi
+    rays = np.ascontiguousarray(np.concatenate([org, np.cos(ang)[:, None], np.sin(ang)[:, None], np.zeros((nr, 1)), np.full((nr, 1), np.finfo(dtype).max)], axis=1).astype(dtype))
+    rays[:50, 2:4] = 0
+    try:
+        for any_hit in (False, True):
+            for robust in (False, True):
+                want, cw = ref.intersect_sphere(ordered, rays, any_hit, robust, threads=8, counters=True)
+                for coop, refill, thr_leaf in ((0, 36, 12), (1, 12, 12)):
+                    _forced(lib, coop, refill, thr_leaf)
+                    got, cg = bvh_amd.intersect(gpu, d_ordered, rays, any_hit=any_hit, robust=robust, counters=True)
+                    assert bvh_amd.hits_to_numpy(got).tobytes() == want.tobytes(), (any_hit, robust, coop)
+                    assert (cg.cpu().numpy().astype(np.uint64) == cw).all()
+                    got = bvh_amd.intersect(gpu, d_ordered, rays, any_hit=any_hit, robust=robust)
+                    kernel = lib.bvh_amd_last_kernel_name().decode()
+                    assert kernel.startswith("trace_kernel_coop_nd<" if coop else "trace_kernel<") and kernel.rstrip(">").split(", ")[5 if coop else 5] == "2", kernel
+                    assert bvh_amd.hits_to_numpy(got).tobytes() == want.tobytes()
+    finally:
+        lib.bvh_amd_tuning(-1, -1, -1, -1)

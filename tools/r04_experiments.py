@@ -200,6 +200,59 @@ def section_grid():
         del bvh, prims, rays, out
 
 
+def section_double():
+    """configs[4] (1M double-precision spheres, pool-High, robust closest-hit) and its any-hit / fast twin: per-lane against the round-4
+    cooperative fetch of the 128-byte records (two quad-coalesced halves), thresholds, batch sizes; then what the library picks itself."""
+    sph = synth.spheres(1_000_000)
+    d_sph = torch.from_numpy(sph).cuda()
+    d_bb, d_cc = bvh_amd.sphere_bounds(d_sph)
+    b64 = bvh_amd.DefaultBuilder.build(d_bb, d_cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
+    sp = bvh_amd.gather(d_sph, b64.device_prim_ids())
+    lo, hi = synth.scene_bounds(sph)
+    for any_hit in (False, True):
+        for nr in (1_000_000, 4_000_000, 16_000_000):
+            rays = torch.from_numpy((synth.rays_shadow if any_hit else synth.rays_closest)(nr, lo, hi, dtype=np.float64)).cuda()
+            out = torch.empty((nr, 4), dtype=torch.float64, device="cuda")
+            ref = None
+            for coop, refill, leaf in ((0, 36, 12), (1, 12, 12), (1, 20, 20), (1, 36, 12)):
+                lib.bvh_amd_tuning(refill, leaf, coop, -1)
+                for sort in ((False, True) if nr >= 4_000_000 and not any_hit else (False,)):
+                    k_ms, c_ms = kernel_ms(lambda: bvh_amd.intersect(b64, sp, rays, any_hit, not any_hit, leaf="sphere", out=out, sort_rays=sort), reps=7, warm=2)
+                    same = True if ref is None else bool(torch.equal(out.view(torch.int64), ref.view(torch.int64)))
+                    ref = out.clone() if ref is None else ref
+                    print(f"double | spheres_f64_1m {'any-hit fast' if any_hit else 'closest robust'} rays={nr:9d} {'coop' if coop else 'per-lane'} {refill}/{leaf} "
+                          f"{'reordered' if sort else 'as given '}: kernel {k_ms:7.4f} call {c_ms:7.4f} ms  {nr / c_ms / 1e3:8.1f} Mrays/s (call) same={same} "
+                          f"{lib.bvh_amd_last_kernel_name().decode().split('<')[0]}", flush=True)
+            lib.bvh_amd_tuning(-1, -1, -1, -1)
+            plan = (C.c_int * 4)()
+            for i in range(10):
+                bvh_amd.intersect(b64, sp, rays, any_hit, not any_hit, leaf="sphere", out=out)
+                torch.cuda.synchronize()
+            k_ms, c_ms = kernel_ms(lambda: bvh_amd.intersect(b64, sp, rays, any_hit, not any_hit, leaf="sphere", out=out), reps=7, warm=2)
+            lib.bvh_amd_last_launch_plan(plan)
+            print(f"double | spheres_f64_1m {'any-hit fast' if any_hit else 'closest robust'} rays={nr:9d} LIBRARY'S OWN CHOICE plan={list(plan)}: kernel {k_ms:7.4f} "
+                  f"call {c_ms:7.4f} ms  {nr / c_ms / 1e3:8.1f} Mrays/s (call)", flush=True)
+    # Node<float, 2> / Node<double, 2>: circles
+    rng = np.random.default_rng(9)
+    for dtype in (np.float32, np.float64):
+        n = 1_000_000
+        circ = np.ascontiguousarray(np.concatenate([rng.random((n, 2)), 0.0002 + 0.0008 * rng.random((n, 1))], axis=1).astype(dtype))
+        d_bb, d_cc = bvh_amd.sphere_bounds(torch.from_numpy(circ).cuda())
+        b2 = bvh_amd.DefaultBuilder.build(d_bb, d_cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium))
+        d_ord = bvh_amd.gather(torch.from_numpy(circ).cuda(), b2.device_prim_ids())
+        nr = 4_000_000
+        org = rng.random((nr, 2)) * 1.1 - 0.05
+        ang = rng.random(nr) * 2 * np.pi
+        rays = torch.from_numpy(np.ascontiguousarray(np.concatenate([org, np.cos(ang)[:, None], np.sin(ang)[:, None], np.zeros((nr, 1)),
+                                                                     np.full((nr, 1), np.finfo(dtype).max)], axis=1).astype(dtype))).cuda()
+        for coop, refill, leaf in ((0, 36, 12), (1, 12, 12), (1, 20, 20)):
+            lib.bvh_amd_tuning(refill, leaf, coop, -1)
+            k_ms, c_ms = kernel_ms(lambda: bvh_amd.intersect(b2, d_ord, rays, False, True), reps=7, warm=2)
+            print(f"double | circles_2{'f' if dtype == np.float32 else 'd'}_1m closest rays={nr} {'coop' if coop else 'per-lane'} {refill}/{leaf}: kernel {k_ms:7.4f} "
+                  f"call {c_ms:7.4f} ms {lib.bvh_amd_last_kernel_name().decode()}", flush=True)
+        lib.bvh_amd_tuning(-1, -1, -1, -1)
+
+
 def section_ramp():
     """Kernel time against batch size on configs[1]'s tree: t(n) = t0 + n / R. t0 is what a small batch cannot amortise (first touches of
     the tree, the longest ray's dependent chain, the drain of the persistent waves)."""
@@ -220,4 +273,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["soup", "small", "first"]
     print(torch.cuda.get_device_name(0), flush=True)
     for w in which:
-        {"soup": section_soup, "small": section_small, "first": section_first, "grid": section_grid, "ramp": section_ramp}[w]()
+        {"soup": section_soup, "small": section_small, "first": section_first, "grid": section_grid, "ramp": section_ramp, "double": section_double}[w]()
