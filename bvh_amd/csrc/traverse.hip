@@ -671,7 +671,10 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
         args.coop = coop_capable && plan->coop ? 1u : 0u;
         args.refill_threshold = plan->refill; args.leaf_threshold = plan->leaf;
     } else {                                                  // the predictor (+ the developer's overrides)
-        args.coop = (coop_capable && (forced >= 0 ? forced != 0 : (any_hit || heavy))) ? 1u : 0u;
+        // (closest-hit: only batches of >= 2^21 rays — a smaller one is bound by the dependent chains of its longest rays, which the
+        //  cooperative fetch makes longer: configs[4], 1M rays: 0.60 ms per lane, 0.65 cooperative; 4M: 1.86 / 1.66; 16M: 6.68 / 5.62.
+        //  Any-hit gains at every size: 0.58 / 0.55, 1.83 / 1.41, 6.76 / 4.74 ms; profiles/r04_experiments_call3_double.txt)
+        args.coop = (coop_capable && (forced >= 0 ? forced != 0 : (any_hit || (heavy && n >= (size_t{1} << 21))))) ? 1u : 0u;
         const int refill_default = !args.coop ? kRefillThreshold : any_hit ? kCoopRefillAny : heavy ? kCoopRefillHeavy : kCoopRefillAny;
         const int leaf_default = !args.coop ? kLeafThreshold : any_hit ? kCoopLeafAny : heavy ? kCoopLeafHeavy : kCoopLeafAny;
         args.refill_threshold = t_refill > 0 ? t_refill : refill_env > 0 ? refill_env : refill_default;
