@@ -718,6 +718,347 @@ __global__ void __launch_bounds__(128, sizeof(T) == 4 ? 4 : 1) k_small_levels(Bu
     if (lane == 0) A.ic = L.nic[0];
 }
 
+// =====================================================================================================
+// Phase A', round 4: one BLOCK splits a segment of 65 .. medium_cap primitives down to subtrees of <= 64
+// =====================================================================================================
+// Phase A pays a dozen launches per level, and on segments of a few hundred to a few thousand primitives (every mini-tree of the
+// thread-pool builder, mini_tree_builder.h:160-205, starts there) each of them is a short-lived block walking a chain of dependent
+// global round trips (task -> slot -> node -> ids -> primitive data): 63 % of k_bin's wave time was waiting. Here the
+// segment's primitives (centre + box, 36 bytes each) are loaded ONCE into LDS and the block runs the same level-synchronous steps —
+// fill_bins, find_best_split, try_split's decision, std::partition as its Hoare permutation, fallback_split, compute_bbox of both
+// sides, child creation in SATO order (binned_sah_builder.h:82-156, top_down_sah_builder.h:89-121) — for ALL the segment's nodes of
+// a level at once, with block barriers instead of kernel boundaries, until every remaining piece holds <= 64 primitives (Phase B's
+// k_small_levels takes those). Only the permutation `order` moves; the primitive data stays where it was loaded. Arithmetic and
+// tie rules are Phase A's, statement by statement. The nodes it creates are appended to c.nodes (one atomicAdd per block), level by
+// level; Phase C walks them through MedInfo (build_common.h: k_medium_count / k_medium_rank).
+constexpr int kMedThreads = 512;
+constexpr int kMedNodes = 256;              // local nodes per segment (a segment whose splits are so lopsided that it needs more gives up:
+constexpr int kMedSegs = 32;                //  the build is then retried on the plain Phase A path); nodes of > 64 primitives per level
+template <typename T> constexpr uint32_t medium_cap() { return sizeof(T) == 4 ? 2048u : 1024u; }
+
+template <typename T>
+struct MediumLds {
+    static constexpr uint32_t KM = medium_cap<T>();
+    T ctr[3][KM], blo[3][KM], bhi[3][KM];   // by SLOT = position at load time
+    uint32_t order[KM];                     // order[position] = slot
+    uint32_t ltab[KM], rtab[KM];            // Hoare violator tables (positions), per segment at [begin ..)
+    uint16_t pre[KM + 2];                   // pre[p] = #primitives before position p that satisfy their node's partition predicate
+    uint8_t seg_of[KM];                     // index of the position's node among this level's active nodes, 255: settled
+    typename Ord<T>::U bin_lo[kMedSegs][3][kBins][3], bin_hi[kMedSegs][3][kBins][3];
+    uint32_t bin_cnt[kMedSegs][3][kBins];
+    T s_scale[kMedSegs][3], s_shift[kMedSegs][3], s_plane[kMedSegs];
+    T axis_cost[kMedSegs][3];
+    uint32_t axis_bin[kMedSegs][3];
+    uint32_t s_node[kMedSegs], s_begin[kMedSegs], s_end[kMedSegs], s_mode[kMedSegs], s_axis[kMedSegs], s_wide[kMedSegs], s_m[kMedSegs], s_cut[kMedSegs];
+    uint8_t s_next[kMedSegs][2];            // active index, in the next level, of the node's left / right range (255: <= 64 primitives)
+    uint32_t act_next[kMedSegs];
+    T cbox[2 * kMedSegs][6];                // {lo xyz, hi xyz} of the left / right range of every active node
+    T nbox[kMedNodes][6];
+    uint16_t nb[kMedNodes], ne[kMedNodes], nparent[kMedNodes], nchild[kMedNodes];
+    uint8_t nwhich[kMedNodes];
+    uint16_t small_nodes[kMedNodes];
+    uint32_t wave_sums[kMedThreads / 64];
+    uint32_t n_nodes, n_act, n_next, n_small, error, base, small_base, n_levels;
+    uint16_t level_start[kMedLevels + 1];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
+    __shared__ MediumLds<T> L;
+    constexpr uint32_t KM = MediumLds<T>::KM;
+    constexpr uint32_t PPT = KM / kMedThreads;                 // consecutive positions per thread
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t root_id = c.medium_list[blockIdx.x];
+    const ANode<T>& R = c.nodes[root_id];
+    const uint32_t B = R.begin, s = R.end - R.begin, tree = R.tree;
+    MedInfo* info = c.med_info + blockIdx.x;
+
+    // ---- load: one read of ids, centres and boxes per primitive for all the levels that follow
+    for (uint32_t p = tid; p < KM; p += kMedThreads) {
+        L.order[p] = p;
+        L.seg_of[p] = p < s ? 0 : 255;
+        if (p < s) {
+            const uint32_t id = c.ids[B + p];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { L.ctr[k][p] = c.centers[3ull * id + k]; L.blo[k][p] = c.bboxes[6ull * id + k]; L.bhi[k][p] = c.bboxes[6ull * id + 3 + k]; }
+        }
+    }
+    if (tid < 3) { L.nbox[0][tid] = R.lo[tid]; L.nbox[0][3 + tid] = R.hi[tid]; }
+    if (tid == 0) {
+        L.nb[0] = 0; L.ne[0] = static_cast<uint16_t>(s); L.nparent[0] = 0; L.nwhich[0] = 0; L.nchild[0] = 0;
+        L.n_nodes = 1; L.n_act = 1; L.s_node[0] = 0; L.n_small = 0; L.error = 0; L.n_levels = 1; L.level_start[0] = 0; L.level_start[1] = 1;
+    }
+    __syncthreads();
+
+    for (;;) {
+        const uint32_t n_act = L.n_act;
+        if (n_act == 0 || L.error) break;
+        // ---- the level's active nodes: range, bin scale / offset (binned_sah_builder.h:88-89), empty bins
+        if (tid < n_act) {
+            const uint32_t nd = L.s_node[tid];
+            L.s_begin[tid] = L.nb[nd]; L.s_end[tid] = L.ne[nd];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T scale = T(kBins) / (L.nbox[nd][3 + k] - L.nbox[nd][k]);
+                L.s_scale[tid][k] = scale;
+                L.s_shift[tid][k] = (-L.nbox[nd][k]) * scale;
+            }
+        }
+        {
+            const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
+            for (uint32_t q = tid; q < n_act * 3 * kBins * 3; q += kMedThreads) { (&L.bin_lo[0][0][0][0])[q] = lo0; (&L.bin_hi[0][0][0][0])[q] = hi0; }
+            for (uint32_t q = tid; q < n_act * 3 * kBins; q += kMedThreads) (&L.bin_cnt[0][0][0])[q] = 0;
+        }
+        __syncthreads();
+        // ---- fill_bins (:82-99)
+        uint32_t my_seg[PPT], my_slot[PPT];
+#pragma unroll
+        for (uint32_t i = 0; i < PPT; ++i) {
+            const uint32_t p = tid * PPT + i;
+            my_seg[i] = L.seg_of[p];
+            my_slot[i] = L.order[p];
+            if (my_seg[i] == 255) continue;
+            const uint32_t sg = my_seg[i], sl = my_slot[i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t b = bin_of(Ord<T>::fma_(L.ctr[k][sl], L.s_scale[sg][k], L.s_shift[sg][k]));   // :92-95
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { atomicMin(&L.bin_lo[sg][k][b][j], Ord<T>::enc(L.blo[j][sl])); atomicMax(&L.bin_hi[sg][k][b][j], Ord<T>::enc(L.bhi[j][sl])); }
+                atomicAdd(&L.bin_cnt[sg][k][b], 1u);
+            }
+        }
+        __syncthreads();
+        // ---- find_best_split: thread (node, axis) sweeps one axis of one node (:101-116)
+        if (tid < 3 * n_act) {
+            const uint32_t sg = tid / 3, k = tid % 3;
+            if (static_cast<int>(k) < c.dim) {
+                T cost; uint32_t bin;
+                sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
+                    for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(L.bin_lo[sg][k][i][j]); hi[j] = Ord<T>::dec(L.bin_hi[sg][k][i][j]); }
+                    n = L.bin_cnt[sg][k][i];
+                }, cost, bin, c.dim, c.sah_log);
+                L.axis_cost[sg][k] = cost;
+                L.axis_bin[sg][k] = bin;
+            }
+        }
+        __syncthreads();
+        // ---- try_split's decision, one thread per node (:128-148; k_decide)
+        if (tid < n_act) {
+            const uint32_t nd = L.s_node[tid];
+            T nlo[3], nhi[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { nlo[k] = L.nbox[nd][k]; nhi[k] = L.nbox[nd][3 + k]; }
+            const int wide = widest_axis(nlo, nhi, c.dim);
+            uint32_t best_bin = kBins / 2; T best_cost = Ord<T>::kMax; int best_axis = wide;     // :132-133
+            for (int k = 0; k < c.dim; ++k) {
+                const T cst = L.axis_cost[tid][k];
+                if (cst < best_cost) { best_cost = cst; best_bin = L.axis_bin[tid][k]; best_axis = k; }
+            }
+            const uint32_t size = L.s_end[tid] - L.s_begin[tid];
+            const T stay = half_area(nlo, nhi, c.dim) * (sah_prims<T>(size, c.sah_log) - c.sah_ratio);   // split_heuristic.h:35-37
+            L.s_wide[tid] = static_cast<uint32_t>(wide);
+            L.s_axis[tid] = static_cast<uint32_t>(best_axis);
+            if (best_cost >= stay) L.s_mode[tid] = MODE_FALLBACK;    // size > 64 > max_leaf_size: never a leaf here (:140-142)
+            else {
+                L.s_mode[tid] = MODE_PARTITION;
+                L.s_plane[tid] = Ord<T>::fma_((nhi[best_axis] - nlo[best_axis]) / T(kBins), static_cast<T>(best_bin), nlo[best_axis]);   // :145-148
+            }
+        }
+        __syncthreads();
+        // ---- the partition predicate of every primitive (:151) and its running count in position order
+        bool pred[PPT];
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < PPT; ++i) {
+            const uint32_t sg = my_seg[i];
+            pred[i] = sg != 255 && L.s_mode[sg] == MODE_PARTITION && L.ctr[L.s_axis[sg] == 0 ? 0 : (L.s_axis[sg] == 1 ? 1 : 2)][my_slot[i]] < L.s_plane[sg];
+            mine += pred[i] ? 1u : 0u;
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= static_cast<uint32_t>(d)) incl += o; }
+        if (lane == 63) L.wave_sums[wave] = incl;
+        __syncthreads();
+        {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; ++w) before += L.wave_sums[w];
+            uint32_t run = before + incl - mine;
+#pragma unroll
+            for (uint32_t i = 0; i < PPT; ++i) { L.pre[tid * PPT + i] = static_cast<uint16_t>(run); run += pred[i] ? 1u : 0u; }
+            if (tid == kMedThreads - 1) L.pre[KM] = static_cast<uint16_t>(run);
+        }
+        __syncthreads();
+        if (tid < n_act) {
+            const uint32_t m = L.pre[L.s_end[tid]] - L.pre[L.s_begin[tid]], size = L.s_end[tid] - L.s_begin[tid];
+            if (L.s_mode[tid] == MODE_PARTITION && (m == 0 || m == size)) L.s_mode[tid] = MODE_FALLBACK;   // :152-153
+            L.s_m[tid] = m;
+        }
+        __syncthreads();
+        // ---- std::partition as its Hoare permutation (k_scatter + k_swap): with m = #true, the misplaced elements left of
+        //      begin + m (ascending) are swapped pairwise with the misplaced elements right of it (descending)
+        uint32_t vkind[PPT], vrank[PPT];                       // 0: stays, 1: left violator, 2: right violator
+#pragma unroll
+        for (uint32_t i = 0; i < PPT; ++i) {
+            vkind[i] = 0; vrank[i] = 0;
+            const uint32_t sg = my_seg[i];
+            if (sg == 255 || L.s_mode[sg] != MODE_PARTITION) continue;
+            const uint32_t p = tid * PPT + i, b = L.s_begin[sg], m = L.s_m[sg];
+            const uint32_t t_before = L.pre[p] - L.pre[b];     // #true in [begin, p)
+            if (p < b + m) {
+                if (!pred[i]) { vkind[i] = 1; vrank[i] = (p - b) - t_before; L.ltab[b + vrank[i]] = p; }
+            } else if (pred[i]) { vkind[i] = 2; vrank[i] = m - t_before - 1; L.rtab[b + vrank[i]] = p; }
+        }
+        __syncthreads();
+        uint32_t moved[PPT];
+#pragma unroll
+        for (uint32_t i = 0; i < PPT; ++i) {
+            moved[i] = my_slot[i];
+            if (vkind[i] == 1) moved[i] = L.order[L.rtab[L.s_begin[my_seg[i]] + vrank[i]]];
+            else if (vkind[i] == 2) moved[i] = L.order[L.ltab[L.s_begin[my_seg[i]] + vrank[i]]];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < PPT; ++i) if (vkind[i]) L.order[tid * PPT + i] = moved[i];
+        __syncthreads();
+        // ---- fallback_split (:118-126): std::partial_sort replayed by one thread per node that needs it; the cut of every node
+        if (tid < n_act) {
+            const uint32_t b = L.s_begin[tid], e = L.s_end[tid];
+            if (L.s_mode[tid] == MODE_FALLBACK) {
+                const uint32_t mid = (B + b + B + e + 1) / 2 - B;                 // absolute indices, :119
+                const T* keys = L.ctr[L.s_wide[tid] == 0 ? 0 : (L.s_wide[tid] == 1 ? 1 : 2)];
+                partial_sort_replay(L.order + b, long(mid - b), long(e - b), [=](uint32_t slot) { return keys[slot]; });
+                L.s_cut[tid] = mid;
+            } else L.s_cut[tid] = b + L.s_m[tid];
+        }
+        __syncthreads();
+        // ---- compute_bbox of both sides (top_down_sah_builder.h:96-97, :133-139): one wave per (node, side) range, a plain
+        //      lane-strided reduction; a zero bound takes the sign of the LAST zero in position order (build_common.h: SlotState)
+        for (uint32_t r = wave; r < 2 * n_act; r += kMedThreads / 64) {
+            const uint32_t sg = r >> 1, side = r & 1u;
+            const uint32_t rb = side ? L.s_cut[sg] : L.s_begin[sg], re = side ? L.s_end[sg] : L.s_cut[sg];
+            T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+            uint32_t zl[3] = {0, 0, 0}, zh[3] = {0, 0, 0};
+            for (uint32_t p = rb + lane; p < re; p += 64) {
+                const uint32_t sl = L.order[p];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T a = L.blo[k][sl], b = L.bhi[k][sl];
+                    lo[k] = pick_min(lo[k], a); hi[k] = pick_max(hi[k], b);
+                    if (a == T(0)) zl[k] = (p << 1) | Ord<T>::sign(a);            // (p ascends within a lane: the last one stays)
+                    if (b == T(0)) zh[k] = (p << 1) | Ord<T>::sign(b);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const auto klo = wave_min_key(Ord<T>::enc(lo[k])), khi = wave_max_key(Ord<T>::enc(hi[k]));
+                const uint32_t wzl = wave_max_key(zl[k]), wzh = wave_max_key(zh[k]);
+                if (lane == 0) { L.cbox[r][k] = decode_bound<T>(klo, wzl); L.cbox[r][3 + k] = decode_bound<T>(khi, wzh); }
+            }
+        }
+        __syncthreads();
+        // ---- child creation with SATO order (:91-113; k_finalize), by the first wave: node t's children are local nodes n + 2t, n + 2t + 1
+        const uint32_t n_before = L.n_nodes;
+        if (n_before + 2 * n_act > static_cast<uint32_t>(kMedNodes) || L.n_levels + 1 > static_cast<uint32_t>(kMedLevels)) {
+            if (tid == 0) L.error = 1;
+            __syncthreads();
+            break;
+        }
+        if (wave == 0) {
+            const bool on = lane < n_act;
+            uint32_t child = 0, big[2] = {0, 0}, rbv[2] = {0, 0}, rev[2] = {0, 0};
+            int first = 0;
+            if (on) {
+                const uint32_t nd = L.s_node[lane];
+                first = half_area(&L.cbox[2 * lane][0], &L.cbox[2 * lane][3], c.dim) < half_area(&L.cbox[2 * lane + 1][0], &L.cbox[2 * lane + 1][3], c.dim) ? 1 : 0;   // :105-108
+                child = n_before + 2 * lane;
+                rbv[0] = L.s_begin[lane]; rev[0] = L.s_cut[lane]; rbv[1] = L.s_cut[lane]; rev[1] = L.s_end[lane];
+                L.nchild[nd] = static_cast<uint16_t>(child);
+                for (int w = 0; w < 2; ++w) {
+                    const int sd = w == 0 ? first : 1 - first;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) L.nbox[child + w][q] = L.cbox[2 * lane + sd][q];
+                    L.nb[child + w] = static_cast<uint16_t>(rbv[sd]); L.ne[child + w] = static_cast<uint16_t>(rev[sd]);
+                    L.nparent[child + w] = static_cast<uint16_t>(nd); L.nwhich[child + w] = static_cast<uint8_t>(w); L.nchild[child + w] = 0;
+                }
+                big[0] = rev[0] - rbv[0] > static_cast<uint32_t>(kSmall) ? 1u : 0u;
+                big[1] = rev[1] - rbv[1] > static_cast<uint32_t>(kSmall) ? 1u : 0u;
+            }
+            // next level's active nodes, in (node, side) order; the others (<= 64 primitives) go to Phase B
+            const uint64_t b0 = __ballot(on && big[0]), b1 = __ballot(on && big[1]), below = (uint64_t{1} << lane) - 1;
+            const uint64_t s0 = __ballot(on && !big[0]), s1 = __ballot(on && !big[1]);
+            if (on) {
+                const uint32_t at = __popcll(b0 & below) + __popcll(b1 & below);
+                const uint32_t sm = L.n_small + __popcll(s0 & below) + __popcll(s1 & below);
+                uint32_t a = at, q = sm;
+                for (int sd = 0; sd < 2; ++sd) {
+                    const uint32_t node = child + (sd == first ? 0u : 1u);
+                    if (big[sd]) { L.act_next[a] = node; L.s_next[lane][sd] = static_cast<uint8_t>(a); ++a; }
+                    else { L.small_nodes[q] = static_cast<uint16_t>(node); L.s_next[lane][sd] = 255; ++q; }
+                }
+            }
+            if (lane == 0) {
+                L.n_next = __popcll(b0) + __popcll(b1);
+                L.n_small += __popcll(s0) + __popcll(s1);
+                L.n_nodes = n_before + 2 * n_act;
+                L.level_start[L.n_levels + 1] = static_cast<uint16_t>(n_before + 2 * n_act);
+                L.n_levels += 1;
+            }
+        }
+        __syncthreads();
+        // ---- every position learns its node of the next level
+#pragma unroll
+        for (uint32_t i = 0; i < PPT; ++i) {
+            const uint32_t sg = my_seg[i];
+            if (sg == 255) continue;
+            const uint32_t p = tid * PPT + i;
+            L.seg_of[p] = L.s_next[sg][p >= L.s_cut[sg] ? 1 : 0];
+        }
+        if (tid < L.n_next) L.s_node[tid] = L.act_next[tid];
+        if (tid == 0) L.n_act = L.n_next;
+        __syncthreads();
+    }
+
+    if (L.error) {                                             // give up: the host retries the whole build without k_medium
+        if (tid == 0) { atomicOr(&c.counters->error, 4u); info->count = 0; info->base = 0; info->n_levels = 0; }
+        return;
+    }
+    // ---- results: the permuted ids, the nodes (appended to c.nodes), the <= 64-primitive pieces for Phase B
+    uint32_t out_id[PPT];
+#pragma unroll
+    for (uint32_t i = 0; i < PPT; ++i) { const uint32_t p = tid * PPT + i; out_id[i] = p < s ? c.ids[B + L.order[p]] : 0u; }
+    if (tid == 0) {
+        const uint32_t extra = L.n_nodes - 1;
+        L.base = atomicAdd(&c.counters->n_nodes, extra);
+        L.small_base = atomicAdd(&c.counters->n_small, L.n_small);
+        if (L.base + extra > c.node_cap || L.small_base + L.n_small > c.node_cap) { atomicOr(&c.counters->error, 2u); L.error = 1; }
+    }
+    __syncthreads();                                           // (also: every read of c.ids above precedes every write below)
+    if (L.error) { if (tid == 0) { info->count = 0; info->base = 0; info->n_levels = 0; } return; }
+#pragma unroll
+    for (uint32_t i = 0; i < PPT; ++i) { const uint32_t p = tid * PPT + i; if (p < s) c.ids[B + p] = out_id[i]; }
+    const uint32_t base = L.base, n_nodes = L.n_nodes;
+    auto global_id = [&](uint32_t t) { return t == 0 ? root_id : base + t - 1; };
+    for (uint32_t t = 1 + tid; t < n_nodes; t += kMedThreads) {
+        ANode<T> nd;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { nd.lo[k] = L.nbox[t][k]; nd.hi[k] = L.nbox[t][3 + k]; }
+        nd.begin = B + L.nb[t]; nd.end = B + L.ne[t];
+        nd.child = L.nchild[t] ? global_id(L.nchild[t]) : kNone;
+        nd.parent = global_id(L.nparent[t]) | (static_cast<uint32_t>(L.nwhich[t]) << 31);
+        nd.kind = L.nchild[t] ? KIND_INNER : KIND_SMALL;
+        nd.ic = 0; nd.rank = 0; nd.tree = tree;
+        c.nodes[global_id(t)] = nd;
+    }
+    for (uint32_t q = tid; q < L.n_small; q += kMedThreads) c.small_list[L.small_base + q] = global_id(L.small_nodes[q]);
+    if (tid == 0) {
+        ANode<T>& root = c.nodes[root_id];
+        root.child = global_id(L.nchild[0]);
+        root.kind = KIND_INNER;
+        info->base = base; info->count = n_nodes; info->n_levels = L.n_levels;
+    }
+    for (uint32_t q = tid; q <= L.n_levels; q += kMedThreads) info->level_start[q] = L.level_start[q];
+}
+
 } // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -726,7 +1067,8 @@ namespace {
 
 template <typename T>
 struct BinnedWs {
-    DevBuf<uint32_t> ids, chunk_true, ltab, rtab, small_list;
+    DevBuf<uint32_t> ids, chunk_true, ltab, rtab, small_list, medium_list;
+    DevBuf<MedInfo> med_info;
     DevBuf<ANode<T>> nodes;
     DevBuf<SlotBins<T>> bins;
     DevBuf<SlotState<T>> st_a, st_b;
@@ -745,7 +1087,14 @@ struct BinnedWs {
         A(chunk_true.alloc(task_cap)); A(ltab.alloc(n)); A(rtab.alloc(n)); A(small_list.alloc(node_cap));
         A(nodes.alloc(node_cap)); A(bins.alloc(slot_cap)); A(st_a.alloc(slot_cap)); A(st_b.alloc(slot_cap));
         A(tk_a.alloc(task_cap)); A(tk_b.alloc(task_cap)); A(stage.alloc(2 * size_t{n})); A(counters.alloc(1));
+        // segments of 65 .. medium_cap primitives go to k_medium — on the first attempt only: a retry (capacity exceeded, or a segment
+        // whose lopsided splits outgrow k_medium's local tables) takes the plain Phase A path
+        static const bool medium_off = std::getenv("BVH_AMD_MEDIUM") && std::atoi(std::getenv("BVH_AMD_MEDIUM")) == 0;   // A/B runs
+        const uint32_t medium_slots = n / (kSmall + 1) + roots + 2;
+        c.medium_cap = attempt == 0 && !medium_off ? medium_cap<T>() : 0u;
+        if (c.medium_cap) { A(medium_list.alloc(medium_slots)); A(med_info.alloc(medium_slots)); }
         if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+        c.medium_list = medium_list.p; c.med_info = med_info.p;
         if (own_ids) c.ids = ids.p;
         c.n = n; c.nodes = nodes.p; c.node_cap = node_cap; c.bins = bins.p; c.state = st_a.p; c.state_next = st_b.p;
         c.slot_cap = slot_cap; c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = chunk_true.p;
@@ -779,6 +1128,12 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
         level_start.push_back(h.n_nodes);
         n_active = h.n_active_next;
         n_tasks = h.n_tasks_next;
+    }
+    if (!overflow && h.n_medium) {
+        hipLaunchKernelGGL(k_medium<T>, dim3(h.n_medium), dim3(kMedThreads), 0, stream, c);
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        { int rb_ = readback(&h, c.counters, sizeof(h), stream); if (rb_) return rb_; }     // nodes and small pieces it added
+        overflow = h.error != 0;
     }
     if (!overflow && h.n_small) {
         static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
@@ -884,7 +1239,7 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
             if (attempt == 0) continue;
             return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
         }
-        rc = number_and_emit<T>(out, c, level_start, h.n_nodes, h.n_small, final_nodes, stream);
+        rc = number_and_emit<T>(out, c, level_start, h.n_nodes, h.n_small, final_nodes, stream, h.n_medium);
         if (rc) return rc;
         rc = finish_build<T>(out, final_nodes, ws.ids.p, n, stream, /*take_ids=*/true);
         if (rc) return rc;
@@ -926,7 +1281,7 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
             if (attempt == 0) continue;
             return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
         }
-        rc = number_nodes<T>(c, level_start, stream);
+        rc = number_nodes<T>(c, level_start, stream, h.n_medium);
         if (rc) return rc;
         BVH_HIP_TRY(tree_node_off.alloc(n_groups + 1), BVH_AMD_ERR_HIP);
         hipLaunchKernelGGL(k_forest_offsets<T>, dim3(1), dim3(1024), 0, stream, c, n_groups, tree_node_off.p);

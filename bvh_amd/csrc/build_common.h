@@ -132,7 +132,18 @@ struct SlotState {
 struct Task { uint32_t slot, begin, end; };
 
 struct Counters {
-    uint32_t n_nodes, n_active_next, n_tasks_next, n_small, error, pad[3];
+    uint32_t n_nodes, n_active_next, n_tasks_next, n_small, error, n_medium, pad[2];
+};
+
+// Round 4: segments of 65 .. medium_cap primitives leave the level-synchronous Phase A and are split down to <= 64-primitive subtrees by
+// ONE BLOCK each, primitives resident in LDS (build_binned.hip: k_medium). The nodes such a block creates are appended to c.nodes in
+// its own level order; MedInfo keeps what the numbering (Phase C) needs to walk them level by level.
+constexpr int kMedLevels = 40;
+struct MedInfo {
+    uint32_t base;                       // A id of local node 1 (local node 0 is the segment's own node)
+    uint32_t count;                      // local nodes, the segment's own node included
+    uint32_t n_levels;
+    uint16_t level_start[kMedLevels + 1];   // local ids: level l = [level_start[l], level_start[l + 1])
 };
 
 template <typename T>
@@ -164,6 +175,10 @@ struct BuildCtx {
     // tree_node_off[tree]; tree_begin[tree] = first position of the tree's primitives. Null for single trees.
     const uint32_t* tree_node_off = nullptr;
     const uint32_t* tree_begin = nullptr;
+    // segments of at most medium_cap primitives (0: none) are finished by k_medium instead of further Phase A levels
+    uint32_t medium_cap = 0;
+    uint32_t* medium_list = nullptr;
+    MedInfo* med_info = nullptr;
 };
 
 // ---- libstdc++ std::partial_sort, replayed by one lane (stl_heap.h / stl_algo.h:1912-1919)
@@ -420,7 +435,11 @@ __device__ void emit_child(const BuildCtx<T>& c, uint32_t id) {
     // registers a freshly created node either as a big segment of the next level or as a Phase B root
     ANode<T>& nd = c.nodes[id];
     const uint32_t size = nd.end - nd.begin;
-    if (size > kSmall) {
+    if (size > kSmall && size <= c.medium_cap) {              // one block finishes it in LDS (k_medium)
+        nd.kind = KIND_BIG;
+        const uint32_t m = atomicAdd(&c.counters->n_medium, 1u);
+        c.medium_list[m] = id;                                // (as many entries as small_list: a segment is in at most one of the two)
+    } else if (size > kSmall) {
         nd.kind = KIND_BIG;
         const uint32_t slot = atomicAdd(&c.counters->n_active_next, 1u);
         const uint32_t nt = (size + kChunk - 1) / kChunk;
@@ -546,10 +565,62 @@ __global__ void __launch_bounds__(64) k_finalize(BuildCtx<T> c, uint32_t n_activ
 // ---- host side shared by the builders ----------------------------------------------------------------------
 
 // Phase C: inner counts bottom-up, ranks top-down, then scatter of the Phase A nodes and the staged subtrees.
+// the medium segments' own nodes (k_medium): inner counts bottom-up / ranks top-down inside every segment, one wave each
 template <typename T>
-int number_nodes(const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, hipStream_t stream)
+__global__ void __launch_bounds__(64) k_medium_count(BuildCtx<T> c) {
+    __shared__ uint32_t ic[256];
+    __shared__ uint16_t ch[256];
+    const int lane = threadIdx.x;
+    const MedInfo mi = c.med_info[blockIdx.x];
+    const uint32_t root = c.medium_list[blockIdx.x];
+    if (mi.count == 0) return;                                // (the block gave up: the build is retried without k_medium)
+    for (uint32_t t = lane; t < mi.count; t += 64) {
+        const ANode<T>& nd = c.nodes[t == 0 ? root : mi.base + t - 1];
+        const bool inner = nd.kind == KIND_INNER;
+        ch[t] = inner ? static_cast<uint16_t>(nd.child - mi.base + 1) : uint16_t{0};
+        ic[t] = inner ? 0u : nd.ic;                           // KIND_SMALL: Phase B has counted its subtree
+    }
+    wave_sync();
+    for (uint32_t lv = mi.n_levels; lv-- > 0;) {
+        for (uint32_t t = mi.level_start[lv] + lane; t < mi.level_start[lv + 1]; t += 64)
+            if (ch[t]) ic[t] = 1 + ic[ch[t]] + ic[ch[t] + 1];
+        wave_sync();
+    }
+    for (uint32_t t = lane; t < mi.count; t += 64)
+        if (ch[t]) c.nodes[t == 0 ? root : mi.base + t - 1].ic = ic[t];
+}
+template <typename T>
+__global__ void __launch_bounds__(64) k_medium_rank(BuildCtx<T> c) {
+    __shared__ uint32_t ic[256], rank[256], size[256];
+    __shared__ uint16_t ch[256];
+    const int lane = threadIdx.x;
+    const MedInfo mi = c.med_info[blockIdx.x];
+    const uint32_t root = c.medium_list[blockIdx.x];
+    if (mi.count == 0) return;
+    for (uint32_t t = lane; t < mi.count; t += 64) {
+        const ANode<T>& nd = c.nodes[t == 0 ? root : mi.base + t - 1];
+        ch[t] = nd.kind == KIND_INNER ? static_cast<uint16_t>(nd.child - mi.base + 1) : uint16_t{0};
+        ic[t] = nd.ic; size[t] = nd.end - nd.begin; rank[t] = nd.rank;     // (rank: only the segment's own node has one yet)
+    }
+    wave_sync();
+    for (uint32_t lv = 0; lv < mi.n_levels; ++lv) {
+        for (uint32_t t = mi.level_start[lv] + lane; t < mi.level_start[lv + 1]; t += 64) {
+            const uint32_t a = ch[t];
+            if (!a) continue;
+            // the item with fewer primitives is popped first; on a tie the second child (top_down_sah_builder.h:116-121)
+            if (size[a] < size[a + 1]) { rank[a] = rank[t] + 1; rank[a + 1] = rank[t] + 1 + ic[a]; }
+            else                       { rank[a + 1] = rank[t] + 1; rank[a] = rank[t] + 1 + ic[a + 1]; }
+        }
+        wave_sync();
+    }
+    for (uint32_t t = 1 + lane; t < mi.count; t += 64) c.nodes[mi.base + t - 1].rank = rank[t];
+}
+
+template <typename T>
+int number_nodes(const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, hipStream_t stream, uint32_t n_medium = 0)
 {
     const size_t levels = level_start.size() - 1;
+    if (n_medium) hipLaunchKernelGGL(k_medium_count<T>, dim3(n_medium), dim3(64), 0, stream, c);
     for (size_t l = levels; l-- > 0;) {
         const uint32_t a = level_start[l], b = level_start[l + 1];
         if (b > a) hipLaunchKernelGGL(k_count_inner<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
@@ -558,14 +629,15 @@ int number_nodes(const BuildCtx<T>& c, const std::vector<uint32_t>& level_start,
         const uint32_t a = level_start[l], b = level_start[l + 1];
         if (b > a) hipLaunchKernelGGL(k_assign_ranks<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
     }
+    if (n_medium) hipLaunchKernelGGL(k_medium_rank<T>, dim3(n_medium), dim3(64), 0, stream, c);
     return BVH_AMD_OK;
 }
 
 template <typename T>
 int number_and_emit(BvhImpl<T>& out, const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, uint32_t n_nodes_a,
-                    uint32_t n_small, DevBuf<HostNode<T>>& final_nodes, hipStream_t stream)
+                    uint32_t n_small, DevBuf<HostNode<T>>& final_nodes, hipStream_t stream, uint32_t n_medium = 0)
 {
-    int rc = number_nodes<T>(c, level_start, stream);
+    int rc = number_nodes<T>(c, level_start, stream, n_medium);
     if (rc) return rc;
     ANode<T> root;
     { int rb_ = readback(&root, c.nodes, sizeof(root), stream); if (rb_) return rb_; }
