@@ -24,6 +24,7 @@
 
 #include "build_common.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -731,14 +732,18 @@ __global__ void __launch_bounds__(128, sizeof(T) == 4 ? 4 : 1) k_small_levels(Bu
 // k_small_levels takes those). Only the permutation `order` moves; the primitive data stays where it was loaded. Arithmetic and
 // tie rules are Phase A's, statement by statement. The nodes it creates are appended to c.nodes (one atomicAdd per block), level by
 // level; Phase C walks them through MedInfo (build_common.h: k_medium_count / k_medium_rank).
-constexpr int kMedThreads = 512;
-constexpr int kMedNodes = 256;              // local nodes per segment (a segment whose splits are so lopsided that it needs more gives up:
-constexpr int kMedSegs = 32;                //  the build is then retried on the plain Phase A path); nodes of > 64 primitives per level
+// Four size classes, KM = 256 / 512 / 1024 / 2048 primitives (double: up to 1024), KM / 2 threads each: what a block keeps in LDS
+// grows with KM (20 / 38 / 72 / 142 KB for float), so the small classes run 8 / 4 / 2 blocks per CU and hide each other's barriers —
+// Quality::Low with a pool makes 4096 mini-trees of ~n / 4096 primitives (no bin merging without pruning), the other qualities ~n / 1400.
 template <typename T> constexpr uint32_t medium_cap() { return sizeof(T) == 4 ? 2048u : 1024u; }
 
-template <typename T>
+template <typename T, uint32_t KM_>
 struct MediumLds {
-    static constexpr uint32_t KM = medium_cap<T>();
+    static constexpr uint32_t KM = KM_;
+    static constexpr int kMedThreads = KM / 2;                   // two consecutive positions per thread
+    static constexpr int kMedSegs = KM / 64;                     // nodes of > 64 primitives on one level
+    static constexpr int kMedNodes = KM >= 1024 ? 256 : KM / 4;  // local nodes (a segment whose lopsided splits need more gives up: the build
+                                                                 //  is then retried on the plain Phase A path)
     T ctr[3][KM], blo[3][KM], bhi[3][KM];   // by SLOT = position at load time
     uint32_t order[KM];                     // order[position] = slot
     uint32_t ltab[KM], rtab[KM];            // Hoare violator tables (positions), per segment at [begin ..)
@@ -752,7 +757,9 @@ struct MediumLds {
     uint32_t s_node[kMedSegs], s_begin[kMedSegs], s_end[kMedSegs], s_mode[kMedSegs], s_axis[kMedSegs], s_wide[kMedSegs], s_m[kMedSegs], s_cut[kMedSegs];
     uint8_t s_next[kMedSegs][2];            // active index, in the next level, of the node's left / right range (255: <= 64 primitives)
     uint32_t act_next[kMedSegs];
-    T cbox[2 * kMedSegs][6];                // {lo xyz, hi xyz} of the left / right range of every active node
+    typename Ord<T>::U cb_lo[2 * kMedSegs][3], cb_hi[2 * kMedSegs][3];   // key boxes of the left / right range of every active node ...
+    uint32_t cz_lo[2 * kMedSegs][3], cz_hi[2 * kMedSegs][3];             // ... and (position << 1 | sign) of their last zero-valued bound
+    T cbox[2 * kMedSegs][6];                // decoded: {lo xyz, hi xyz}
     T nbox[kMedNodes][6];
     uint16_t nb[kMedNodes], ne[kMedNodes], nparent[kMedNodes], nchild[kMedNodes];
     uint8_t nwhich[kMedNodes];
@@ -762,16 +769,21 @@ struct MediumLds {
     uint16_t level_start[kMedLevels + 1];
 };
 
-template <typename T>
-__global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
-    __shared__ MediumLds<T> L;
-    constexpr uint32_t KM = MediumLds<T>::KM;
+template <typename T, uint32_t KM_>
+__global__ void __launch_bounds__(KM_ / 2) k_medium(BuildCtx<T> c) {
+    using Lds = MediumLds<T, KM_>;
+    __shared__ Lds L;
+    constexpr uint32_t KM = Lds::KM;
+    constexpr int kMedThreads = Lds::kMedThreads, kMedSegs = Lds::kMedSegs, kMedNodes = Lds::kMedNodes;
+    (void)kMedSegs;
     constexpr uint32_t PPT = KM / kMedThreads;                 // consecutive positions per thread
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t root_id = c.medium_list[blockIdx.x];
     const ANode<T>& R = c.nodes[root_id];
     const uint32_t B = R.begin, s = R.end - R.begin, tree = R.tree;
     MedInfo* info = c.med_info + blockIdx.x;
+    unsigned long long t_mark = c.med_prof ? __builtin_readcyclecounter() : 0ull;
+    auto mark = [&](int i) { if (c.med_prof && tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); atomicAdd(&c.med_prof[i], now - t_mark); t_mark = now; } };
 
     // ---- load: one read of ids, centres and boxes per primitive for all the levels that follow
     for (uint32_t p = tid; p < KM; p += kMedThreads) {
@@ -783,12 +795,45 @@ __global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
             for (int k = 0; k < 3; ++k) { L.ctr[k][p] = c.centers[3ull * id + k]; L.blo[k][p] = c.bboxes[6ull * id + k]; L.bhi[k][p] = c.bboxes[6ull * id + 3 + k]; }
         }
     }
-    if (tid < 3) { L.nbox[0][tid] = R.lo[tid]; L.nbox[0][3 + tid] = R.hi[tid]; }
+    const bool root_box_pending = R.rank == kNone;             // a forest root whose box k_forest_roots left to this block
+    if (tid < 3 && !root_box_pending) { L.nbox[0][tid] = R.lo[tid]; L.nbox[0][3 + tid] = R.hi[tid]; }
+    if (tid < 3) { L.cb_lo[0][tid] = Ord<T>::enc(Ord<T>::kMax); L.cb_hi[0][tid] = Ord<T>::enc(-Ord<T>::kMax); L.cz_lo[0][tid] = 0; L.cz_hi[0][tid] = 0; }
     if (tid == 0) {
         L.nb[0] = 0; L.ne[0] = static_cast<uint16_t>(s); L.nparent[0] = 0; L.nwhich[0] = 0; L.nchild[0] = 0;
         L.n_nodes = 1; L.n_act = 1; L.s_node[0] = 0; L.n_small = 0; L.error = 0; L.n_levels = 1; L.level_start[0] = 0; L.level_start[1] = 1;
     }
     __syncthreads();
+    if (root_box_pending) {
+        // compute_bbox over the tree's range in position order (top_down_sah_builder.h:80, :133-139) from the data just loaded, instead of a
+        // second gather of the same boxes by k_forest_roots; a zero bound takes the sign of the last zero in position order
+        T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+        uint32_t zl[3] = {0, 0, 0}, zh[3] = {0, 0, 0};
+        for (uint32_t p = tid; p < s; p += kMedThreads) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T a = L.blo[k][p], b = L.bhi[k][p];
+                lo[k] = pick_min(lo[k], a); hi[k] = pick_max(hi[k], b);
+                if (a == T(0)) zl[k] = (p << 1) | Ord<T>::sign(a);
+                if (b == T(0)) zh[k] = (p << 1) | Ord<T>::sign(b);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const auto klo = wave_min_key(Ord<T>::enc(lo[k])), khi = wave_max_key(Ord<T>::enc(hi[k]));
+            const uint32_t wzl = wave_max_key(zl[k]), wzh = wave_max_key(zh[k]);
+            if (lane == 0) { atomicMin(&L.cb_lo[0][k], klo); atomicMax(&L.cb_hi[0][k], khi); if (wzl) atomicMax(&L.cz_lo[0][k], wzl); if (wzh) atomicMax(&L.cz_hi[0][k], wzh); }
+        }
+        __syncthreads();
+        if (tid < 3) {
+            const T a = decode_bound<T>(L.cb_lo[0][tid], L.cz_lo[0][tid]), b = decode_bound<T>(L.cb_hi[0][tid], L.cz_hi[0][tid]);
+            L.nbox[0][tid] = a; L.nbox[0][3 + tid] = b;
+            ANode<T>& root = c.nodes[root_id];
+            root.lo[tid] = a; root.hi[tid] = b;
+            if (tid == 0) root.rank = 0;
+        }
+        __syncthreads();
+    }
+    mark(0);                                                   // load
 
     for (;;) {
         const uint32_t n_act = L.n_act;
@@ -828,6 +873,7 @@ __global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
             }
         }
         __syncthreads();
+        mark(1);                                               // setup + fill_bins
         // ---- find_best_split: thread (node, axis) sweeps one axis of one node (:101-116)
         if (tid < 3 * n_act) {
             const uint32_t sg = tid / 3, k = tid % 3;
@@ -865,6 +911,7 @@ __global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
             }
         }
         __syncthreads();
+        mark(2);                                               // sweeps + decision
         // ---- the partition predicate of every primitive (:151) and its running count in position order
         bool pred[PPT];
         uint32_t mine = 0;
@@ -894,6 +941,7 @@ __global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
             L.s_m[tid] = m;
         }
         __syncthreads();
+        mark(3);                                               // predicate, scan, m
         // ---- std::partition as its Hoare permutation (k_scatter + k_swap): with m = #true, the misplaced elements left of
         //      begin + m (ascending) are swapped pairwise with the misplaced elements right of it (descending)
         uint32_t vkind[PPT], vrank[PPT];                       // 0: stays, 1: left violator, 2: right violator
@@ -920,6 +968,7 @@ __global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
 #pragma unroll
         for (uint32_t i = 0; i < PPT; ++i) if (vkind[i]) L.order[tid * PPT + i] = moved[i];
         __syncthreads();
+        mark(4);                                               // Hoare permutation
         // ---- fallback_split (:118-126): std::partial_sort replayed by one thread per node that needs it; the cut of every node
         if (tid < n_act) {
             const uint32_t b = L.s_begin[tid], e = L.s_end[tid];
@@ -931,31 +980,75 @@ __global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
             } else L.s_cut[tid] = b + L.s_m[tid];
         }
         __syncthreads();
-        // ---- compute_bbox of both sides (top_down_sah_builder.h:96-97, :133-139): one wave per (node, side) range, a plain
-        //      lane-strided reduction; a zero bound takes the sign of the LAST zero in position order (build_common.h: SlotState)
-        for (uint32_t r = wave; r < 2 * n_act; r += kMedThreads / 64) {
-            const uint32_t sg = r >> 1, side = r & 1u;
-            const uint32_t rb = side ? L.s_cut[sg] : L.s_begin[sg], re = side ? L.s_end[sg] : L.s_cut[sg];
-            T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
-            uint32_t zl[3] = {0, 0, 0}, zh[3] = {0, 0, 0};
-            for (uint32_t p = rb + lane; p < re; p += 64) {
-                const uint32_t sl = L.order[p];
+        mark(5);                                               // fallback / cut
+        // ---- compute_bbox of both sides (top_down_sah_builder.h:96-97, :133-139). Every position joins the key box of its (node, side)
+        //      range; a wave whose positions all lie in ONE range (the common case: a wave covers 64 x PPT consecutive positions) folds
+        //      them with shuffles first and touches the LDS words once. A zero bound takes the sign of the LAST zero in position order
+        //      (build_common.h: SlotState), tracked as max(position << 1 | sign).
+        for (uint32_t q = tid; q < 2 * n_act * 3; q += kMedThreads) {
+            (&L.cb_lo[0][0])[q] = Ord<T>::enc(Ord<T>::kMax); (&L.cb_hi[0][0])[q] = Ord<T>::enc(-Ord<T>::kMax); (&L.cz_lo[0][0])[q] = 0; (&L.cz_hi[0][0])[q] = 0;
+        }
+        __syncthreads();
+        {
+            uint32_t rng[PPT];
+            bool uniform = true;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T a = L.blo[k][sl], b = L.bhi[k][sl];
-                    lo[k] = pick_min(lo[k], a); hi[k] = pick_max(hi[k], b);
-                    if (a == T(0)) zl[k] = (p << 1) | Ord<T>::sign(a);            // (p ascends within a lane: the last one stays)
-                    if (b == T(0)) zh[k] = (p << 1) | Ord<T>::sign(b);
-                }
+            for (uint32_t i = 0; i < PPT; ++i) {
+                const uint32_t sg = my_seg[i], p = tid * PPT + i;
+                rng[i] = sg == 255 ? 0xFFFFu : 2 * sg + (p >= L.s_cut[sg] ? 1u : 0u);
+                uniform = uniform && rng[i] == rng[0];
             }
+            const uint32_t r0 = __shfl(rng[0], 0);
+            const bool wave_uniform = __ballot(!(uniform && rng[0] == r0)) == 0;
+            if (wave_uniform) {
+                if (r0 != 0xFFFFu) {
+                    T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+                    uint32_t zl[3] = {0, 0, 0}, zh[3] = {0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const auto klo = wave_min_key(Ord<T>::enc(lo[k])), khi = wave_max_key(Ord<T>::enc(hi[k]));
-                const uint32_t wzl = wave_max_key(zl[k]), wzh = wave_max_key(zh[k]);
-                if (lane == 0) { L.cbox[r][k] = decode_bound<T>(klo, wzl); L.cbox[r][3 + k] = decode_bound<T>(khi, wzh); }
+                    for (uint32_t i = 0; i < PPT; ++i) {
+                        const uint32_t p = tid * PPT + i, sl = L.order[p];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const T a = L.blo[k][sl], b = L.bhi[k][sl];
+                            lo[k] = pick_min(lo[k], a); hi[k] = pick_max(hi[k], b);
+                            if (a == T(0)) zl[k] = (p << 1) | Ord<T>::sign(a);
+                            if (b == T(0)) zh[k] = (p << 1) | Ord<T>::sign(b);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const auto klo = wave_min_key(Ord<T>::enc(lo[k])), khi = wave_max_key(Ord<T>::enc(hi[k]));
+                        const uint32_t wzl = wave_max_key(zl[k]), wzh = wave_max_key(zh[k]);
+                        if (lane == 0) {
+                            atomicMin(&L.cb_lo[r0][k], klo); atomicMax(&L.cb_hi[r0][k], khi);
+                            if (wzl) atomicMax(&L.cz_lo[r0][k], wzl);
+                            if (wzh) atomicMax(&L.cz_hi[r0][k], wzh);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < PPT; ++i) {
+                    if (rng[i] == 0xFFFFu) continue;
+                    const uint32_t p = tid * PPT + i, sl = L.order[p], r = rng[i];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const T a = L.blo[k][sl], b = L.bhi[k][sl];
+                        atomicMin(&L.cb_lo[r][k], Ord<T>::enc(a)); atomicMax(&L.cb_hi[r][k], Ord<T>::enc(b));
+                        if (a == T(0)) atomicMax(&L.cz_lo[r][k], (p << 1) | Ord<T>::sign(a));
+                        if (b == T(0)) atomicMax(&L.cz_hi[r][k], (p << 1) | Ord<T>::sign(b));
+                    }
+                }
             }
         }
         __syncthreads();
+        for (uint32_t q = tid; q < 2 * n_act * 3; q += kMedThreads) {
+            const uint32_t r = q / 3, k = q % 3;
+            L.cbox[r][k] = decode_bound<T>(L.cb_lo[r][k], L.cz_lo[r][k]);
+            L.cbox[r][3 + k] = decode_bound<T>(L.cb_hi[r][k], L.cz_hi[r][k]);
+        }
+        __syncthreads();
+        mark(6);                                               // child boxes
         // ---- child creation with SATO order (:91-113; k_finalize), by the first wave: node t's children are local nodes n + 2t, n + 2t + 1
         const uint32_t n_before = L.n_nodes;
         if (n_before + 2 * n_act > static_cast<uint32_t>(kMedNodes) || L.n_levels + 1 > static_cast<uint32_t>(kMedLevels)) {
@@ -1016,6 +1109,7 @@ __global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
         if (tid < L.n_next) L.s_node[tid] = L.act_next[tid];
         if (tid == 0) L.n_act = L.n_next;
         __syncthreads();
+        mark(7);                                               // children + next level
     }
 
     if (L.error) {                                             // give up: the host retries the whole build without k_medium
@@ -1057,6 +1151,8 @@ __global__ void __launch_bounds__(kMedThreads) k_medium(BuildCtx<T> c) {
         info->base = base; info->count = n_nodes; info->n_levels = L.n_levels;
     }
     for (uint32_t q = tid; q <= L.n_levels; q += kMedThreads) info->level_start[q] = L.level_start[q];
+    mark(8);                                                   // results
+    if (c.med_prof && tid == 0) atomicAdd(&c.med_prof[9], static_cast<unsigned long long>(L.n_levels));
 }
 
 } // namespace
@@ -1069,6 +1165,7 @@ template <typename T>
 struct BinnedWs {
     DevBuf<uint32_t> ids, chunk_true, ltab, rtab, small_list, medium_list;
     DevBuf<MedInfo> med_info;
+    DevBuf<unsigned long long> med_prof;
     DevBuf<ANode<T>> nodes;
     DevBuf<SlotBins<T>> bins;
     DevBuf<SlotState<T>> st_a, st_b;
@@ -1092,9 +1189,20 @@ struct BinnedWs {
         static const bool medium_off = std::getenv("BVH_AMD_MEDIUM") && std::atoi(std::getenv("BVH_AMD_MEDIUM")) == 0;   // A/B runs
         const uint32_t medium_slots = n / (kSmall + 1) + roots + 2;
         c.medium_cap = attempt == 0 && !medium_off ? medium_cap<T>() : 0u;
-        if (c.medium_cap) { A(medium_list.alloc(medium_slots)); A(med_info.alloc(medium_slots)); }
+        c.medium_slots = medium_slots;
+        // Two classes are used: segments of up to 256 primitives run as k_medium<T, 256> (128 threads, 19 KB of LDS: eight blocks per CU —
+        // Quality::Low with a pool makes 4096 mini-trees of n / 4096 primitives), everything larger as the largest class, one block of 1024
+        // threads alone on its CU. Measured round 4 (profiles/r04_build_medium_ab.txt): routing 257..1024-primitive segments to the 512 /
+        // 1024 classes instead (256 / 512 threads, 4 / 2 blocks per CU) is SLOWER everywhere they occur (1M Low serial 2.69 -> 2.78 ms,
+        // terrain 2.69 -> 2.82, Sponza proxy 1.73 -> 1.93): a block's levels are a chain of short LDS phases, and more waves on the
+        // segment shorten that chain more than a second resident block hides it. BVH_AMD_MEDIUM_CLASSES=1 routes by size (A/B runs).
+        static const bool by_size = std::getenv("BVH_AMD_MEDIUM_CLASSES") && std::atoi(std::getenv("BVH_AMD_MEDIUM_CLASSES")) != 0;
+        c.medium_min_class = by_size ? 0u : (sizeof(T) == 4 ? 3u : 2u);
+        if (c.medium_cap) { A(medium_list.alloc(4 * size_t{medium_slots})); A(med_info.alloc(4 * size_t{medium_slots})); }
         if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
         c.medium_list = medium_list.p; c.med_info = med_info.p;
+        static const bool prof = std::getenv("BVH_AMD_MED_PROF") && std::atoi(std::getenv("BVH_AMD_MED_PROF")) != 0;   // developer knob
+        if (prof && c.medium_cap && med_prof.alloc(16) == hipSuccess && hipMemset(med_prof.p, 0, 16 * sizeof(unsigned long long)) == hipSuccess) c.med_prof = med_prof.p;
         if (own_ids) c.ids = ids.p;
         c.n = n; c.nodes = nodes.p; c.node_cap = node_cap; c.bins = bins.p; c.state = st_a.p; c.state_next = st_b.p;
         c.slot_cap = slot_cap; c.tasks = tk_a.p; c.tasks_next = tk_b.p; c.task_cap = task_cap; c.chunk_true = chunk_true.p;
@@ -1129,11 +1237,35 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
         n_active = h.n_active_next;
         n_tasks = h.n_tasks_next;
     }
-    if (!overflow && h.n_medium) {
-        hipLaunchKernelGGL(k_medium<T>, dim3(h.n_medium), dim3(kMedThreads), 0, stream, c);
+    const uint32_t n_medium_all = h.n_medium[0] + h.n_medium[1] + h.n_medium[2] + h.n_medium[3];
+    if (!overflow && n_medium_all) {
+        for (uint32_t cls = 0; cls < 4; ++cls) {
+            if (!h.n_medium[cls]) continue;
+            BuildCtx<T> cc = c;
+            cc.medium_list = c.medium_list + size_t{cls} * c.medium_slots;
+            cc.med_info = c.med_info + size_t{cls} * c.medium_slots;
+            if (cls == 0) hipLaunchKernelGGL((k_medium<T, 256>), dim3(h.n_medium[cls]), dim3(128), 0, stream, cc);
+            else if (cls == 1) hipLaunchKernelGGL((k_medium<T, 512>), dim3(h.n_medium[cls]), dim3(256), 0, stream, cc);
+            else if (cls == 2) hipLaunchKernelGGL((k_medium<T, 1024>), dim3(h.n_medium[cls]), dim3(512), 0, stream, cc);
+            else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_medium<T, 2048>), dim3(h.n_medium[cls]), dim3(1024), 0, stream, cc);
+        }
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        const uint32_t n_before[4] = { h.n_medium[0], h.n_medium[1], h.n_medium[2], h.n_medium[3] };
         { int rb_ = readback(&h, c.counters, sizeof(h), stream); if (rb_) return rb_; }     // nodes and small pieces it added
         overflow = h.error != 0;
+        if (c.med_prof) {                                     // developer knob: where a block's time goes (clock ticks summed over blocks)
+            unsigned long long t[16] = {};
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(t, c.med_prof, sizeof(t), hipMemcpyDeviceToHost);
+            static const char* names[9] = {"load", "setup+fill_bins", "sweeps+decision", "predicate+scan", "hoare", "fallback/cut", "child boxes", "children+next", "results"};
+            unsigned long long sum = 0;
+            for (int i = 0; i < 9; ++i) sum += t[i];
+            fprintf(stderr, "[k_medium] blocks by class %u / %u / %u / %u, %.1f levels per block, ticks per block:", n_before[0], n_before[1], n_before[2], n_before[3],
+                    double(t[9]) / n_medium_all);
+            for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.0f (%.0f%%)", names[i], double(t[i]) / n_medium_all, 100.0 * double(t[i]) / double(sum ? sum : 1));
+            fprintf(stderr, "\n");
+            (void)hipMemset(c.med_prof, 0, sizeof(t));
+        }
     }
     if (!overflow && h.n_small) {
         static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
@@ -1150,6 +1282,16 @@ __global__ void __launch_bounds__(256) k_forest_roots(BuildCtx<T> c, const uint3
     __shared__ typename Ord<T>::U slo[3], shi[3];
     __shared__ uint32_t zlo[3], zhi[3];
     const uint32_t g = blockIdx.x, b = group_begin[g], e = group_begin[g + 1];
+    if (e - b > static_cast<uint32_t>(kSmall) && e - b <= c.medium_cap) {
+        // k_medium loads this tree's boxes anyway and computes the root box from them (rank = kNone marks it as pending)
+        if (threadIdx.x == 0) {
+            ANode<T>& r = c.nodes[g];
+            for (int k = 0; k < 3; ++k) { r.lo[k] = T(0); r.hi[k] = T(0); }
+            r.begin = b; r.end = e; r.child = kNone; r.parent = kNone; r.ic = 0; r.rank = kNone; r.tree = g;
+            emit_child(c, g);
+        }
+        return;
+    }
     if (threadIdx.x < 3) { slo[threadIdx.x] = Ord<T>::enc(Ord<T>::kMax); shi[threadIdx.x] = Ord<T>::enc(-Ord<T>::kMax); zlo[threadIdx.x] = 0; zhi[threadIdx.x] = 0; }
     __syncthreads();
     T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };

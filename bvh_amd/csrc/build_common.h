@@ -132,7 +132,8 @@ struct SlotState {
 struct Task { uint32_t slot, begin, end; };
 
 struct Counters {
-    uint32_t n_nodes, n_active_next, n_tasks_next, n_small, error, n_medium, pad[2];
+    uint32_t n_nodes, n_active_next, n_tasks_next, n_small, error, pad[3];
+    uint32_t n_medium[4];                // segments handed to k_medium, by size class (<= 256 / 512 / 1024 / 2048 primitives)
 };
 
 // Round 4: segments of 65 .. medium_cap primitives leave the level-synchronous Phase A and are split down to <= 64-primitive subtrees by
@@ -177,8 +178,11 @@ struct BuildCtx {
     const uint32_t* tree_begin = nullptr;
     // segments of at most medium_cap primitives (0: none) are finished by k_medium instead of further Phase A levels
     uint32_t medium_cap = 0;
+    uint32_t medium_slots = 0;               // entries per size class in medium_list / med_info
+    uint32_t medium_min_class = 0;           // segments of more than 256 primitives use at least this size class (default: the largest)
     uint32_t* medium_list = nullptr;
     MedInfo* med_info = nullptr;
+    unsigned long long* med_prof = nullptr;  // developer knob BVH_AMD_MED_PROF=1: reference-clock ticks per phase of k_medium, summed over blocks
 };
 
 // ---- libstdc++ std::partial_sort, replayed by one lane (stl_heap.h / stl_algo.h:1912-1919)
@@ -437,8 +441,10 @@ __device__ void emit_child(const BuildCtx<T>& c, uint32_t id) {
     const uint32_t size = nd.end - nd.begin;
     if (size > kSmall && size <= c.medium_cap) {              // one block finishes it in LDS (k_medium)
         nd.kind = KIND_BIG;
-        const uint32_t m = atomicAdd(&c.counters->n_medium, 1u);
-        c.medium_list[m] = id;                                // (as many entries as small_list: a segment is in at most one of the two)
+        uint32_t cls = size <= 256 ? 0u : size <= 512 ? 1u : size <= 1024 ? 2u : 3u;           // k_medium<T, 256 << cls>
+        if (cls > 0 && cls < c.medium_min_class) cls = c.medium_min_class;
+        const uint32_t m = atomicAdd(&c.counters->n_medium[cls], 1u);
+        c.medium_list[cls * c.medium_slots + m] = id;
     } else if (size > kSmall) {
         nd.kind = KIND_BIG;
         const uint32_t slot = atomicAdd(&c.counters->n_active_next, 1u);
@@ -617,10 +623,19 @@ __global__ void __launch_bounds__(64) k_medium_rank(BuildCtx<T> c) {
 }
 
 template <typename T>
-int number_nodes(const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, hipStream_t stream, uint32_t n_medium = 0)
+int number_nodes(const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, hipStream_t stream, const uint32_t* n_medium = nullptr)
 {
     const size_t levels = level_start.size() - 1;
-    if (n_medium) hipLaunchKernelGGL(k_medium_count<T>, dim3(n_medium), dim3(64), 0, stream, c);
+    auto per_class = [&](auto kernel) {
+        for (uint32_t cls = 0; n_medium && cls < 4; ++cls) {
+            if (!n_medium[cls]) continue;
+            BuildCtx<T> cc = c;
+            cc.medium_list = c.medium_list + size_t{cls} * c.medium_slots;
+            cc.med_info = c.med_info + size_t{cls} * c.medium_slots;
+            hipLaunchKernelGGL(kernel, dim3(n_medium[cls]), dim3(64), 0, stream, cc);
+        }
+    };
+    per_class(k_medium_count<T>);
     for (size_t l = levels; l-- > 0;) {
         const uint32_t a = level_start[l], b = level_start[l + 1];
         if (b > a) hipLaunchKernelGGL(k_count_inner<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
@@ -629,13 +644,13 @@ int number_nodes(const BuildCtx<T>& c, const std::vector<uint32_t>& level_start,
         const uint32_t a = level_start[l], b = level_start[l + 1];
         if (b > a) hipLaunchKernelGGL(k_assign_ranks<T>, dim3((b - a + 255) / 256), dim3(256), 0, stream, c, a, b);
     }
-    if (n_medium) hipLaunchKernelGGL(k_medium_rank<T>, dim3(n_medium), dim3(64), 0, stream, c);
+    per_class(k_medium_rank<T>);
     return BVH_AMD_OK;
 }
 
 template <typename T>
 int number_and_emit(BvhImpl<T>& out, const BuildCtx<T>& c, const std::vector<uint32_t>& level_start, uint32_t n_nodes_a,
-                    uint32_t n_small, DevBuf<HostNode<T>>& final_nodes, hipStream_t stream, uint32_t n_medium = 0)
+                    uint32_t n_small, DevBuf<HostNode<T>>& final_nodes, hipStream_t stream, const uint32_t* n_medium = nullptr)
 {
     int rc = number_nodes<T>(c, level_start, stream, n_medium);
     if (rc) return rc;
