@@ -1219,7 +1219,7 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
     while (n_active > 0 && !overflow) {
         std::swap(c.state, c.state_next);
         std::swap(c.tasks, c.tasks_next);
-        BVH_HIP_TRY(hipMemsetAsync(&c.counters->n_active_next, 0, 2 * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMemsetAsync(&c.counters->n_active_next, 0, 3 * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
         const unsigned slot_grid = (n_active + 63) / 64;
         hipLaunchKernelGGL(k_init_slots<T>, dim3(n_active), dim3(64), 0, stream, c);
         hipLaunchKernelGGL(k_bin<T>, dim3(n_tasks), dim3(256), 0, stream, c);

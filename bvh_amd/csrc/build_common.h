@@ -132,7 +132,7 @@ struct SlotState {
 struct Task { uint32_t slot, begin, end; };
 
 struct Counters {
-    uint32_t n_nodes, n_active_next, n_tasks_next, n_small, error, pad[3];
+    uint32_t n_nodes, n_active_next, n_tasks_next, n_big_next, n_small, error, pad[2];   // (the three *_next words are reset together per level)
     uint32_t n_medium[4];                // segments handed to k_medium, by size class (<= 256 / 512 / 1024 / 2048 primitives)
 };
 
@@ -177,6 +177,7 @@ struct BuildCtx {
     const uint32_t* tree_node_off = nullptr;
     const uint32_t* tree_begin = nullptr;
     // segments of at most medium_cap primitives (0: none) are finished by k_medium instead of further Phase A levels
+    uint32_t big_threshold = 0;              // > 0: segments of more primitives are counted in counters->n_big_next (sweep builder: multi-block scans)
     uint32_t medium_cap = 0;
     uint32_t medium_slots = 0;               // entries per size class in medium_list / med_info
     uint32_t medium_min_class = 0;           // segments of more than 256 primitives use at least this size class (default: the largest)
@@ -447,6 +448,7 @@ __device__ void emit_child(const BuildCtx<T>& c, uint32_t id) {
         c.medium_list[cls * c.medium_slots + m] = id;
     } else if (size > kSmall) {
         nd.kind = KIND_BIG;
+        if (c.big_threshold && size > c.big_threshold) atomicAdd(&c.counters->n_big_next, 1u);
         const uint32_t slot = atomicAdd(&c.counters->n_active_next, 1u);
         const uint32_t nt = (size + kChunk - 1) / kChunk;
         const uint32_t t0 = atomicAdd(&c.counters->n_tasks_next, nt);
