@@ -215,21 +215,39 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, u
     __syncthreads();
     const T pivot = key(ids[first]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // pass 1: L (key >= pivot) and R (key <= pivot) position tables over [first + 1, last), both ascending
+    // pass 1: L (key >= pivot) and R (key <= pivot) position tables over [first + 1, last), both ascending. Every thread takes kItems
+    // CONSECUTIVE positions per tile, so that a tile of 4096 positions costs one block scan (round 4: with one position per thread a
+    // multi-million-element segment of the first rounds paid two barriers per 512 positions)
+    constexpr int kItems = 8;
     uint32_t run_l = 0, run_r = 0;
-    for (uint32_t tile = first + 1; tile < last; tile += kSortThreads) {
-        const uint32_t pos = tile + threadIdx.x;
-        const bool in = pos < last;
-        const T kv = in ? key(ids[pos]) : pivot;
-        const bool fl = in && !(kv < pivot), fr = in && !(pivot < kv);
-        const uint64_t bl = __ballot(fl), br = __ballot(fr);
-        if (lane == 0) { wsum_l[wave] = __popcll(bl); wsum_r[wave] = __popcll(br); }
+    for (uint32_t tile = first + 1; tile < last; tile += kSortThreads * kItems) {
+        uint32_t ml = 0, mr = 0;
+        const uint32_t p0 = tile + threadIdx.x * kItems;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const uint32_t pos = p0 + i;
+            if (pos < last) {
+                const T kv = key(ids[pos]);
+                if (!(kv < pivot)) ml |= 1u << i;
+                if (!(pivot < kv)) mr |= 1u << i;
+            }
+        }
+        const uint32_t cl = __popc(ml), cr = __popc(mr);
+        uint32_t il = cl, ir = cr;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ol = __shfl_up(il, d), orr = __shfl_up(ir, d);
+            if (lane >= d) { il += ol; ir += orr; }
+        }
+        if (lane == 63) { wsum_l[wave] = il; wsum_r[wave] = ir; }
         __syncthreads();
-        uint32_t el = __popcll(bl & ((uint64_t{1} << lane) - 1)), er = __popcll(br & ((uint64_t{1} << lane) - 1));
-        uint32_t tl = 0, tr = 0;
+        uint32_t el = il - cl, er = ir - cr, tl = 0, tr = 0;
         for (int w = 0; w < kSortThreads / 64; ++w) { if (w < wave) { el += wsum_l[w]; er += wsum_r[w]; } tl += wsum_l[w]; tr += wsum_r[w]; }
-        if (fl) c.ltab[first + run_l + el] = pos;
-        if (fr) c.rtab[first + run_r + er] = pos;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            if (ml & (1u << i)) c.ltab[first + run_l + el + __popc(ml & ((1u << i) - 1u))] = p0 + i;
+            if (mr & (1u << i)) c.rtab[first + run_r + er + __popc(mr & ((1u << i) - 1u))] = p0 + i;
+        }
         run_l += tl; run_r += tr;
         __syncthreads();
     }

@@ -436,9 +436,12 @@ BVH_AMD_API void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int co
  * "reset" clears all of them. Returns BVH_AMD_ERR_ARG for an unknown name.                                                       */
 BVH_AMD_API int bvh_amd_experiment(const char* name, int value);
 /* How the calling thread's latest batch launch was traced: out = {reordered 0/1, record fetch 0 per lane / 1 quad-cooperative, refill
- * threshold, leaf threshold}. For trees beyond the L2s and batches of >= 2^22 rays the library MEASURES this once per tree and kind
- * of ray (four stretches of the first such batch are traced with different candidates; csrc/traverse.hip: launch_traverse) and
- * keeps the winner; BVH_AMD_CALIBRATE=0 in the environment keeps the static predictor. */
+ * threshold, leaf threshold}. For 3D trees whose traversal records exceed the 32 MB of L2 and batches of >= 2^20 rays the library
+ * MEASURES this once per tree and kind of ray (closest / any-hit): the first such batch is traced with the plan a static predictor
+ * gives the tree, the following seven WHOLE batches with the four candidate plans {as given, reordered} x {per-lane, cooperative
+ * fetch} in turn (each twice, timed by events on the launch stream; csrc/traverse.hip: launch_traverse), and the fastest is kept
+ * until the tree is re-laid out. Smaller trees and batches use the predictor. BVH_AMD_CALIBRATE=0 in the environment keeps the
+ * predictor everywhere. */
 BVH_AMD_API void bvh_amd_last_launch_plan(int out[4]);
 /* ReinsertionOptimizer iterations run so far in this process: out[0] = through the heap-free fast path, out[1] = through the
  * exact replay of the reference's candidate heap + std::sort (taken when ties make their layout matter).
