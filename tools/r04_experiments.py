@@ -253,6 +253,24 @@ def section_double():
         lib.bvh_amd_tuning(-1, -1, -1, -1)
 
 
+def section_hints():
+    """Which once-touched data to load non-temporally in a reordered launch: bit 0 = rays / order / hit records (default on); bit 1 = triangles
+    existed for the run recorded in profiles/r04_experiments_call4_hints.txt (23-35 % SLOWER: removed from the kernel again)."""
+    for gen, n, q, nr in (("soup", 1_000_000, bvh_amd.Quality.High, 1 << 24), ("soup", 10_000_000, bvh_amd.Quality.Medium, 12_500_000)):
+        bvh, prims, lo, hi = _scene(gen, n, q, True)
+        rays = torch.from_numpy(synth.rays_closest(nr, lo, hi)).cuda()
+        out = torch.empty((nr, 4), dtype=torch.float32, device="cuda")
+        for coop, refill, leaf in ((1, 12, 12), (0, 36, 12)):
+            lib.bvh_amd_tuning(refill, leaf, coop, -1)
+            for hints in (1, 3, 0, 2, 1, 3):
+                knob("stream_hints", hints)
+                k_ms, p_ms = kernel_ms(lambda: bvh_amd.intersect(bvh, prims, rays, False, True, out=out, sort_rays=True), reps=7, warm=2)
+                print(f"hints | {gen}_{n} rays={nr} {'coop' if coop else 'per-lane'} stream_hints={hints}: kernel {k_ms:7.3f} pass {p_ms:7.3f} ms", flush=True)
+        knob("reset", 0)
+        lib.bvh_amd_tuning(-1, -1, -1, -1)
+        del bvh, prims, rays, out
+
+
 def section_ramp():
     """Kernel time against batch size on configs[1]'s tree: t(n) = t0 + n / R. t0 is what a small batch cannot amortise (first touches of
     the tree, the longest ray's dependent chain, the drain of the persistent waves)."""
@@ -273,4 +291,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["soup", "small", "first"]
     print(torch.cuda.get_device_name(0), flush=True)
     for w in which:
-        {"soup": section_soup, "small": section_small, "first": section_first, "grid": section_grid, "ramp": section_ramp, "double": section_double}[w]()
+        {"soup": section_soup, "small": section_small, "first": section_first, "grid": section_grid, "ramp": section_ramp, "double": section_double, "hints": section_hints}[w]()
