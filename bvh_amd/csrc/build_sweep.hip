@@ -435,6 +435,305 @@ __global__ void __launch_bounds__(256) k_sweep_copyback(SweepCtx<T> c, uint32_t 
 }
 
 // =====================================================================================================
+// Round 4: one BLOCK builds the sweep-SAH levels of a segment of 65 .. 2048 primitives (cf. build_binned.hip: k_medium)
+// =====================================================================================================
+// The level loop above costs nine launches and a read-back per level whatever the work; the top-level BVH over a few thousand
+// mini-tree roots (mini_tree_builder.h:249-310) is all launch latency (1M triangles, Quality::Low: ~60 launches of 3-18 us for 4096
+// roots = 0.45 of the 2.25 ms). A segment of up to 2048 primitives therefore leaves the loop: its boxes and its three orders are
+// loaded into LDS once and one block runs the same steps — find_best_split as a right-to-left and a left-to-right scan per (node,
+// axis), one wave each (sweep_sah_builder.h:68-101), try_split's decision (:108-124), mark_primitives (:103-106),
+// std::stable_partition of the other two orders (:129-136), compute_bbox of both sides over the axis-0 order with the last-zero rule,
+// child creation in SATO order — for all the segment's nodes of a level, with barriers instead of kernel boundaries, until every
+// piece holds <= 64 primitives (k_small_sweep_levels takes those). Nodes are appended to the node array and numbered through
+// MedInfo like k_medium's.
+constexpr int kSwThreads = 1024;
+constexpr int kSwNodes = 256;
+template <typename T> constexpr uint32_t sweep_medium_cap() { return sizeof(T) == 4 ? 2048u : 1024u; }
+
+template <typename T>
+struct SweepMediumLds {
+    static constexpr uint32_t KS = sweep_medium_cap<T>();
+    static constexpr int kSegs = KS / 64;
+    T box[6][KS];                            // by SLOT = position in the axis-0 order at load time
+    uint32_t id_of[KS];                      // slot -> primitive id
+    uint16_t ord[3][KS], tmp[3][KS];         // ord[axis][position] = slot
+    T cost_r[3][KS];
+    uint8_t mark[KS];                        // by slot: on the left side of its node's split
+    uint8_t seg_of[KS];                      // by position: index of the position's node among the level's active nodes, 255: settled
+    T best_cost[kSegs][3];
+    uint32_t best_pos[kSegs][3];
+    uint32_t s_node[kSegs], s_begin[kSegs], s_end[kSegs], s_axis[kSegs], s_cut[kSegs];
+    uint8_t s_next[kSegs][2];
+    uint32_t act_next[kSegs];
+    T cbox[2 * kSegs][6];
+    T nbox[kSwNodes][6];
+    uint16_t nb[kSwNodes], ne[kSwNodes], nparent[kSwNodes], nchild[kSwNodes];
+    uint8_t nwhich[kSwNodes];
+    uint16_t small_nodes[kSwNodes];
+    uint32_t n_nodes, n_act, n_next, n_small, error, base, small_base, n_levels;
+    uint16_t level_start[kMedLevels + 1];
+};
+
+template <typename T> __device__ inline Box6<T> lds_box(const SweepMediumLds<T>& L, uint32_t slot) {
+    Box6<T> v;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v.lo[k] = L.box[k][slot]; v.hi[k] = L.box[3 + k][slot]; }
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kSwThreads) k_sweep_medium(SweepCtx<T> c) {
+    __shared__ SweepMediumLds<T> L;
+    constexpr uint32_t KS = SweepMediumLds<T>::KS;
+    constexpr uint32_t kWaves = kSwThreads / 64;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t root_id = c.b.medium_list[blockIdx.x];
+    const ANode<T>& R = c.b.nodes[root_id];
+    const uint32_t B = R.begin, s = R.end - R.begin, tree = R.tree;
+    MedInfo* info = c.b.med_info + blockIdx.x;
+
+    // ---- load: boxes by the axis-0 order; the other two orders as slots (through marks[], which holds the slot of every id here)
+    for (uint32_t p = tid; p < KS; p += kSwThreads) {
+        L.seg_of[p] = p < s ? 0 : 255;
+        L.ord[0][p] = static_cast<uint16_t>(p);
+        if (p < s) {
+            const uint32_t id = c.ord[0][B + p];
+            L.id_of[p] = id;
+            c.marks[id] = p;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { L.box[k][p] = c.b.bboxes[6ull * id + k]; L.box[3 + k][p] = c.b.bboxes[6ull * id + 3 + k]; }
+        }
+    }
+    if (tid < 3) { L.nbox[0][tid] = R.lo[tid]; L.nbox[0][3 + tid] = R.hi[tid]; }
+    if (tid == 0) {
+        L.nb[0] = 0; L.ne[0] = static_cast<uint16_t>(s); L.nparent[0] = 0; L.nwhich[0] = 0; L.nchild[0] = 0;
+        L.n_nodes = 1; L.n_act = 1; L.s_node[0] = 0; L.n_small = 0; L.error = 0; L.n_levels = 1; L.level_start[0] = 0; L.level_start[1] = 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t p = tid; p < s; p += kSwThreads) {
+        L.ord[1][p] = static_cast<uint16_t>(c.marks[c.ord[1][B + p]]);
+        L.ord[2][p] = static_cast<uint16_t>(c.marks[c.ord[2][B + p]]);
+    }
+    __syncthreads();
+
+    for (;;) {
+        const uint32_t n_act = L.n_act;
+        if (n_act == 0 || L.error) break;
+        if (tid < n_act) { const uint32_t nd = L.s_node[tid]; L.s_begin[tid] = L.nb[nd]; L.s_end[tid] = L.ne[nd]; }
+        __syncthreads();
+        // ---- find_best_split: one wave per (node, axis): right-to-left costs, then left-to-right costs and the arg-min (:68-101)
+        for (uint32_t task = wave; task < 3 * n_act; task += kWaves) {
+            const uint32_t sg = task / 3, axis = task % 3;
+            if (static_cast<int>(axis) >= c.b.dim) continue;
+            const uint32_t b = L.s_begin[sg], e = L.s_end[sg];
+            const uint16_t* ord = L.ord[axis];
+            T* cost_r = L.cost_r[axis];
+            Box6<T> carry = empty_box<T>();
+            for (uint32_t base = 0; base < e - b; base += 64) {
+                const uint32_t r = base + lane;
+                const bool in = r < e - b;
+                const uint32_t pos = e - 1 - (in ? r : 0);
+                Box6<T> v = in ? lds_box(L, ord[pos]) : empty_box<T>();
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { Box6<T> o = shfl_up_box(v, off); if (static_cast<int>(lane) >= off) v = join(o, v); }
+                v = join(carry, v);
+                if (in && pos > b) cost_r[pos] = half_area(v.lo, v.hi, c.b.dim) * sah_prims<T>(e - pos, c.b.sah_log);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { carry.lo[k] = __shfl(v.lo[k], 63); carry.hi[k] = __shfl(v.hi[k], 63); }
+            }
+            wave_sync();
+            carry = empty_box<T>();
+            T best = __builtin_inff();
+            uint32_t best_pos = 0xFFFFFFFFu;
+            for (uint32_t base = 0; base < e - b; base += 64) {
+                const uint32_t r = base + lane;
+                const bool in = r < e - b;
+                const uint32_t pos = b + (in ? r : 0);
+                Box6<T> v = in ? lds_box(L, ord[pos]) : empty_box<T>();
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { Box6<T> o = shfl_up_box(v, off); if (static_cast<int>(lane) >= off) v = join(o, v); }
+                v = join(carry, v);
+                if (in && pos + 1 < e) {
+                    const T cost = half_area(v.lo, v.hi, c.b.dim) * sah_prims<T>(pos + 1 - b, c.b.sah_log) + cost_r[pos + 1];
+                    if (cost < best) { best = cost; best_pos = pos + 1; }          // earlier positions win ties (strict <)
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { carry.lo[k] = __shfl(v.lo[k], 63); carry.hi[k] = __shfl(v.hi[k], 63); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const T oc = __shfl_xor(best, off);
+                const uint32_t op = __shfl_xor(best_pos, off);
+                if (oc < best || (oc == best && op < best_pos)) { best = oc; best_pos = op; }
+            }
+            if (lane == 0) { L.best_cost[sg][axis] = best; L.best_pos[sg][axis] = best_pos; }
+        }
+        __syncthreads();
+        // ---- try_split's decision (:108-124; k_sweep_decide)
+        if (tid < n_act) {
+            const uint32_t nd = L.s_node[tid], b = L.s_begin[tid], e = L.s_end[tid];
+            T nlo[3], nhi[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { nlo[k] = L.nbox[nd][k]; nhi[k] = L.nbox[nd][3 + k]; }
+            const T stay = half_area(nlo, nhi, c.b.dim) * (sah_prims<T>(e - b, c.b.sah_log) - c.b.sah_ratio);
+            uint32_t pos = (b + e + 1) / 2; T cost = stay; uint32_t axis = 0;      // :111 ((B + b + B + e + 1) / 2 - B: the same number)
+            for (int k = 0; k < c.b.dim; ++k)
+                if (L.best_cost[tid][k] < cost) { cost = L.best_cost[tid][k]; pos = L.best_pos[tid][k]; axis = static_cast<uint32_t>(k); }
+            if (cost >= stay) { pos = (b + e + 1) / 2; axis = static_cast<uint32_t>(widest_axis(nlo, nhi, c.b.dim)); }   // size > 64 > max_leaf_size (:122-123)
+            L.s_cut[tid] = pos; L.s_axis[tid] = axis;
+        }
+        __syncthreads();
+        // ---- mark_primitives (:103-106): by slot, from the split axis's order
+        for (uint32_t p = tid; p < s; p += kSwThreads) {
+            const uint32_t sg = L.seg_of[p];
+            if (sg == 255) continue;
+            L.mark[L.ord[L.s_axis[sg]][p]] = p < L.s_cut[sg] ? 1 : 0;
+        }
+        __syncthreads();
+        // ---- std::stable_partition of the other two orders (:129-136): one wave per (node, other axis)
+        for (uint32_t task = wave; task < 2 * n_act; task += kWaves) {
+            const uint32_t sg = task >> 1, axis = other_axis(L.s_axis[sg], task & 1u);
+            const uint32_t b = L.s_begin[sg], e = L.s_end[sg], cut = L.s_cut[sg];
+            uint16_t* ord = L.ord[axis];
+            uint16_t* out = L.tmp[axis];
+            uint32_t running = 0;
+            for (uint32_t base = b; base < e; base += 64) {
+                const uint32_t pos = base + lane;
+                const bool in = pos < e;
+                const uint32_t slot = in ? ord[pos] : 0u;
+                const bool flag = in && L.mark[slot] != 0;
+                const uint64_t bal = __ballot(flag);
+                const uint32_t t_before = running + __popcll(bal & ((uint64_t{1} << lane) - 1));
+                if (in) out[flag ? b + t_before : cut + (pos - b - t_before)] = static_cast<uint16_t>(slot);
+                running += __popcll(bal);
+            }
+            wave_sync();
+            for (uint32_t pos = b + lane; pos < e; pos += 64) ord[pos] = out[pos];
+        }
+        __syncthreads();
+        // ---- compute_bbox of both sides over the axis-0 order (top_down_sah_builder.h:96-97, :133-139), one wave per (node, side)
+        for (uint32_t r = wave; r < 2 * n_act; r += kWaves) {
+            const uint32_t sg = r >> 1, side = r & 1u;
+            const uint32_t rb = side ? L.s_cut[sg] : L.s_begin[sg], re = side ? L.s_end[sg] : L.s_cut[sg];
+            T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
+            uint32_t zl[3] = {0, 0, 0}, zh[3] = {0, 0, 0};
+            for (uint32_t p = rb + lane; p < re; p += 64) {
+                const uint32_t sl = L.ord[0][p];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T a = L.box[k][sl], bq = L.box[3 + k][sl];
+                    lo[k] = pick_min(lo[k], a); hi[k] = pick_max(hi[k], bq);
+                    if (a == T(0)) zl[k] = (p << 1) | Ord<T>::sign(a);            // (p ascends within a lane: the last one stays)
+                    if (bq == T(0)) zh[k] = (p << 1) | Ord<T>::sign(bq);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const auto klo = wave_min_key(Ord<T>::enc(lo[k])), khi = wave_max_key(Ord<T>::enc(hi[k]));
+                const uint32_t wzl = wave_max_key(zl[k]), wzh = wave_max_key(zh[k]);
+                if (lane == 0) { L.cbox[r][k] = decode_bound<T>(klo, wzl); L.cbox[r][3 + k] = decode_bound<T>(khi, wzh); }
+            }
+        }
+        __syncthreads();
+        // ---- child creation with SATO order (:91-113; k_finalize), by the first wave
+        const uint32_t n_before = L.n_nodes;
+        if (n_before + 2 * n_act > static_cast<uint32_t>(kSwNodes) || L.n_levels + 1 > static_cast<uint32_t>(kMedLevels)) {
+            if (tid == 0) L.error = 1;
+            __syncthreads();
+            break;
+        }
+        if (wave == 0) {
+            const bool on = lane < n_act;
+            uint32_t child = 0, big[2] = {0, 0}, rbv[2] = {0, 0}, rev[2] = {0, 0};
+            int first = 0;
+            if (on) {
+                const uint32_t nd = L.s_node[lane];
+                first = half_area(&L.cbox[2 * lane][0], &L.cbox[2 * lane][3], c.b.dim) < half_area(&L.cbox[2 * lane + 1][0], &L.cbox[2 * lane + 1][3], c.b.dim) ? 1 : 0;
+                child = n_before + 2 * lane;
+                rbv[0] = L.s_begin[lane]; rev[0] = L.s_cut[lane]; rbv[1] = L.s_cut[lane]; rev[1] = L.s_end[lane];
+                L.nchild[nd] = static_cast<uint16_t>(child);
+                for (int w = 0; w < 2; ++w) {
+                    const int sd = w == 0 ? first : 1 - first;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) L.nbox[child + w][q] = L.cbox[2 * lane + sd][q];
+                    L.nb[child + w] = static_cast<uint16_t>(rbv[sd]); L.ne[child + w] = static_cast<uint16_t>(rev[sd]);
+                    L.nparent[child + w] = static_cast<uint16_t>(nd); L.nwhich[child + w] = static_cast<uint8_t>(w); L.nchild[child + w] = 0;
+                }
+                big[0] = rev[0] - rbv[0] > static_cast<uint32_t>(kSmall) ? 1u : 0u;
+                big[1] = rev[1] - rbv[1] > static_cast<uint32_t>(kSmall) ? 1u : 0u;
+            }
+            const uint64_t b0 = __ballot(on && big[0]), b1 = __ballot(on && big[1]), below = (uint64_t{1} << lane) - 1;
+            const uint64_t s0 = __ballot(on && !big[0]), s1 = __ballot(on && !big[1]);
+            if (on) {
+                uint32_t a = __popcll(b0 & below) + __popcll(b1 & below);
+                uint32_t q = L.n_small + __popcll(s0 & below) + __popcll(s1 & below);
+                for (int sd = 0; sd < 2; ++sd) {
+                    const uint32_t node = child + (sd == first ? 0u : 1u);
+                    if (big[sd]) { L.act_next[a] = node; L.s_next[lane][sd] = static_cast<uint8_t>(a); ++a; }
+                    else { L.small_nodes[q] = static_cast<uint16_t>(node); L.s_next[lane][sd] = 255; ++q; }
+                }
+            }
+            if (lane == 0) {
+                L.n_next = __popcll(b0) + __popcll(b1);
+                L.n_small += __popcll(s0) + __popcll(s1);
+                L.n_nodes = n_before + 2 * n_act;
+                L.level_start[L.n_levels + 1] = static_cast<uint16_t>(n_before + 2 * n_act);
+                L.n_levels += 1;
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = tid; p < s; p += kSwThreads) {
+            const uint32_t sg = L.seg_of[p];
+            if (sg != 255) L.seg_of[p] = L.s_next[sg][p >= L.s_cut[sg] ? 1 : 0];
+        }
+        __syncthreads();
+        if (tid < L.n_next) L.s_node[tid] = L.act_next[tid];
+        if (tid == 0) L.n_act = L.n_next;
+        __syncthreads();
+    }
+
+    if (L.error) {                                             // give up: the host retries the whole build without k_sweep_medium
+        if (tid == 0) { atomicOr(&c.b.counters->error, 4u); info->count = 0; info->base = 0; info->n_levels = 0; }
+        return;
+    }
+    if (tid == 0) {
+        const uint32_t extra = L.n_nodes - 1;
+        L.base = atomicAdd(&c.b.counters->n_nodes, extra);
+        L.small_base = atomicAdd(&c.b.counters->n_small, L.n_small);
+        if (L.base + extra > c.b.node_cap || L.small_base + L.n_small > c.b.node_cap) { atomicOr(&c.b.counters->error, 2u); L.error = 1; }
+    }
+    __syncthreads();
+    if (L.error) { if (tid == 0) { info->count = 0; info->base = 0; info->n_levels = 0; } return; }
+    // ---- results: the three orders, the nodes (appended), the <= 64-primitive pieces
+    for (uint32_t p = tid; p < s; p += kSwThreads) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c.ord[k][B + p] = L.id_of[L.ord[k][p]];
+    }
+    const uint32_t base = L.base, n_nodes = L.n_nodes;
+    auto global_id = [&](uint32_t t) { return t == 0 ? root_id : base + t - 1; };
+    for (uint32_t t = 1 + tid; t < n_nodes; t += kSwThreads) {
+        ANode<T> nd;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { nd.lo[k] = L.nbox[t][k]; nd.hi[k] = L.nbox[t][3 + k]; }
+        nd.begin = B + L.nb[t]; nd.end = B + L.ne[t];
+        nd.child = L.nchild[t] ? global_id(L.nchild[t]) : kNone;
+        nd.parent = global_id(L.nparent[t]) | (static_cast<uint32_t>(L.nwhich[t]) << 31);
+        nd.kind = L.nchild[t] ? KIND_INNER : KIND_SMALL;
+        nd.ic = 0; nd.rank = 0; nd.tree = tree;
+        c.b.nodes[global_id(t)] = nd;
+    }
+    for (uint32_t q = tid; q < L.n_small; q += kSwThreads) c.b.small_list[L.small_base + q] = global_id(L.small_nodes[q]);
+    if (tid == 0) {
+        ANode<T>& root = c.b.nodes[root_id];
+        root.child = global_id(L.nchild[0]);
+        root.kind = KIND_INNER;
+        info->base = base; info->count = n_nodes; info->n_levels = L.n_levels;
+    }
+    for (uint32_t q = tid; q <= L.n_levels; q += kSwThreads) info->level_start[q] = L.level_start[q];
+}
+
+// =====================================================================================================
 // Segments <= 64 primitives: one wavefront, slot = lane holds a primitive, perm[k][position] = slot
 // =====================================================================================================
 
@@ -891,6 +1190,13 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         A(st_a.alloc(slot_cap)); A(st_b.alloc(slot_cap)); A(tk_a.alloc(task_cap)); A(tk_b.alloc(task_cap));
         A(stage.alloc(2 * n)); A(counters.alloc(1));
         A(chunk_box.alloc(18 * size_t{task_cap})); A(carry_l.alloc(18 * size_t{task_cap})); A(carry_r.alloc(18 * size_t{task_cap})); A(chunk_best.alloc(3 * size_t{task_cap}));
+        // segments of 65 .. 2048 primitives are finished by k_sweep_medium (first attempt only: a retry takes the plain path)
+        static const bool sw_medium_off = std::getenv("BVH_AMD_SWEEP_MEDIUM") && std::atoi(std::getenv("BVH_AMD_SWEEP_MEDIUM")) == 0;   // A/B runs
+        const uint32_t medium_slots = n32 / (kSmall + 1) + 3;
+        DevBuf<uint32_t> medium_list;
+        DevBuf<MedInfo> med_info;
+        const bool use_medium = attempt == 0 && !sw_medium_off;
+        if (use_medium) { A(medium_list.alloc(4 * size_t{medium_slots})); A(med_info.alloc(4 * size_t{medium_slots})); }
         if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
 
         SweepCtx<T> sc;
@@ -907,6 +1213,10 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         sc.chunk_box = chunk_box.p; sc.carry_l = carry_l.p; sc.carry_r = carry_r.p; sc.chunk_best = chunk_best.p; sc.multi = 0;
         static const bool multi_off = std::getenv("BVH_AMD_SWEEP_MULTI") && std::atoi(std::getenv("BVH_AMD_SWEEP_MULTI")) == 0;   // A/B runs
         c.big_threshold = multi_off ? 0u : kSweepBig;
+        if (use_medium) {
+            c.medium_cap = sweep_medium_cap<T>(); c.medium_slots = medium_slots; c.medium_min_class = 3;      // classes 0 (<= 256 primitives) and 3: one kernel serves both
+            c.medium_list = medium_list.p; c.med_info = med_info.p;
+        }
 
         hipLaunchKernelGGL(k_prepare_root<T>, dim3(1), dim3(1), 0, stream, c);
         const unsigned root_grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 2048));
@@ -952,6 +1262,22 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
             if (attempt == 0) continue;
             return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
         }
+        uint32_t n_medium[4] = { h.n_medium[0], h.n_medium[1], h.n_medium[2], h.n_medium[3] };
+        if (n_medium[0] + n_medium[3]) {
+            for (uint32_t cls : {0u, 3u}) {
+                if (!n_medium[cls]) continue;
+                SweepCtx<T> scc = sc;
+                scc.b.medium_list = c.medium_list + size_t{cls} * c.medium_slots;
+                scc.b.med_info = c.med_info + size_t{cls} * c.medium_slots;
+                hipLaunchKernelGGL(k_sweep_medium<T>, dim3(n_medium[cls]), dim3(kSwThreads), 0, stream, scc);
+            }
+            BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+            { int rb_ = readback(&h, counters.p, sizeof(h), stream); if (rb_) return rb_; }
+            if (h.error != 0) {
+                if (attempt == 0) continue;
+                return fail(BVH_AMD_ERR_OVERFLOW, "build: internal capacity exceeded");
+            }
+        }
         const uint32_t n_nodes_a = h.n_nodes, n_small = h.n_small;
         if (n_small) {
             static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
@@ -959,7 +1285,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
             else hipLaunchKernelGGL(k_small_sweep_levels<T>, dim3((n_small + 1) / 2), dim3(128), 0, stream, sc, n_small);
         }
         BvhImpl<T> sizes;                                      // only its node vector length is used
-        rc = number_and_emit<T>(sizes, c, level_start, n_nodes_a, n_small, final_nodes, stream);
+        rc = number_and_emit<T>(sizes, c, level_start, n_nodes_a, n_small, final_nodes, stream, n_medium);
         if (rc) return rc;
         total_nodes = sizes.node_count;
         if (!scratch_pool_enabled()) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // plain hipFree of the workspace on return (the pool frees in stream order)
