@@ -465,6 +465,34 @@ struct Bvh {
                                                             wants_inner ? &Visit::on_inner : nullptr), "intersect_ray_visit");
     }
 
+    // Bvh::traverse_top_down (reference bvh.h:68-70, :125-157) with a user InnerFn that STEERS the descent: inner_fn(left, right) returns
+    // {visit left, visit right, right first}; leaf_fn(begin, end) -> bool. Like traverse_bottom_up below this is a host-side utility over
+    // the mirror's nodes: user code decides every step, so there is nothing to offload — the walks the LIBRARY defines (Bvh::intersect,
+    // amd::intersect_batch) run on the device. Same visit order as the reference: the nearer (or left) child first, the other one on the
+    // caller's stack; with IsAnyHit the walk ends at the first leaf_fn that returns true.
+    template <bool IsAnyHit, typename Stack, typename LeafFn, typename InnerFn>
+    void traverse_top_down(Index start, Stack& stack, LeafFn&& leaf_fn, InnerFn&& inner_fn) const {
+        stack.push(start);
+        while (!stack.is_empty()) {
+            Index at = stack.pop();
+            bool dead_end = false;
+            while (!dead_end && at.prim_count() == 0) {
+                const Node& left = nodes[at.first_id()];
+                const Node& right = nodes[at.first_id() + 1];
+                const auto [go_left, go_right, right_first] = inner_fn(left, right);
+                if (go_left && go_right) {
+                    stack.push(right_first ? left.index : right.index);
+                    at = right_first ? right.index : left.index;
+                } else if (go_left) at = left.index;
+                else if (go_right) at = right.index;
+                else dead_end = true;
+            }
+            if (dead_end) continue;
+            [[maybe_unused]] const bool was_hit = static_cast<bool>(leaf_fn(at.first_id(), at.first_id() + at.prim_count()));
+            if constexpr (IsAnyHit) { if (was_hit) return; }
+        }
+    }
+
     // Bvh::traverse_bottom_up (reference bvh.h:76-78, :185-208) with arbitrary host functors: a host-side utility over the
     // mirror's nodes (user code runs per node, so there is nothing to offload; the library's own bottom-up pass, refit, is a
     // device kernel). Leaves are visited by descending node index; an inner node right after its second child.

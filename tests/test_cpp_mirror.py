@@ -87,3 +87,48 @@ def test_cpp_2d_circles_match_reference(tmp_path, orc):
     for line, w in zip(lines[1:], want):
         p, t, u = line.split()
         assert int(p) == int(w["prim"]) and np.float32(t) == w["t"] and np.float32(u) == w["u"]
+
+
+def test_cpp_traverse_top_down_with_a_steering_inner_fn(tmp_path):
+    """Bvh::traverse_top_down<IsAnyHit>(start, stack, leaf_fn, inner_fn) of the mirror (reference bvh.h:125-157): inner_fn returns
+    {visit left, visit right, right first}; a host-side utility over the mirror's nodes (no device involved). The expected visit orders
+    come from a restatement of the reference's loop below."""
+    exe = _compile(str(tmp_path / "top_down_amd"), os.path.join(ROOT, "tests", "cpp", "top_down_amd.cpp"))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # nodes: (x0, x1, first, count); count 0 = inner with children first, first + 1
+    nodes = [(0, 5, 1, 0), (0, 3, 3, 0), (3, 5, 5, 0), (0, 1, 0, 1), (1, 3, 1, 2), (3, 4, 3, 1), (4, 5, 4, 1)]
+
+    def walk(inner_fn, any_hit=False, hit=lambda b, e: False):
+        out, stack = [], [0]
+        while stack:                                          # bvh.h:128-156
+            top = stack.pop()
+            dead = False
+            while nodes[top][3] == 0:
+                l, rgt = nodes[top][2], nodes[top][2] + 1
+                hl, hr, swap = inner_fn(nodes[l], nodes[rgt])
+                if hl:
+                    near = l
+                    if hr:
+                        far = rgt
+                        if swap:
+                            near, far = far, near
+                        stack.append(far)
+                    top = near
+                elif hr:
+                    top = rgt
+                else:
+                    dead = True
+                    break
+            if dead:
+                continue
+            b, e = nodes[top][2], nodes[top][2] + nodes[top][3]
+            out.append(f"[{b},{e})")
+            if any_hit and hit(b, e):
+                break
+        return " ".join(out)
+    want = [walk(lambda l, r: (True, True, False)), walk(lambda l, r: (True, True, True)), walk(lambda l, r: (l[0] < 2.5, r[0] < 2.5, False)),
+            walk(lambda l, r: (True, True, False), True, lambda b, e: b <= 3 < e)]
+    got = [line.strip() for line in r.stdout.strip().splitlines()]
+    assert got == want, (got, want)
+    assert want[0] == "[0,1) [1,3) [3,4) [4,5)" and want[1] == "[4,5) [3,4) [1,3) [0,1)" and want[3] == "[0,1) [1,3) [3,4)"

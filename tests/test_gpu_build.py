@@ -520,6 +520,33 @@ def test_arrays_with_unused_sibling_pairs_refit_extract_trace_and_refuse_optimiz
     assert g.serialize() == a.serialize(), "a refused optimize must leave the tree alone"
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lopsided_segments_outgrow_the_one_block_builders_and_fall_back(orc, dtype):
+    """k_medium / k_sweep_medium (round 4) keep a segment's nodes in a local table of 256 nodes / 40 levels. Centres in geometric progression
+    make every binned split peel a handful of primitives off one end (the bins are linear in x): a chain of hundreds of levels in double
+    precision — the block gives up, the build is retried on the plain level-synchronous path, and the stream is still the reference's; in
+    float the exponent range allows ~37 levels: the same data through the one-block path itself."""
+    import bvh_amd
+    n = 1000 if dtype == np.float64 else 430
+    step = 0.5 if dtype == np.float64 else 0.2
+    ctr = np.zeros((n, 3), dtype=dtype)
+    ctr[:, 0] = np.exp(step * np.arange(n)).astype(dtype)
+    ctr[:, 1] = 1.0
+    ctr[:, 2] = -2.0
+    half = (ctr[:, :1] * dtype(1e-3)).astype(dtype)
+    bb = np.ascontiguousarray(np.concatenate([ctr - half, ctr + half], axis=1).astype(dtype))
+    cc = np.ascontiguousarray(ctr)
+    for builder, make in ((oracle.BUILDER_BINNED, lambda: bvh_amd.BinnedSahBuilder.build(bb, cc)),
+                          (oracle.BUILDER_SWEEP, lambda: bvh_amd.SweepSahBuilder.build(bb, cc)),
+                          (oracle.BUILDER_DEFAULT_SERIAL, lambda: bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Low)))):
+        ref = orc.build(bb, cc, builder=builder, quality=oracle.QUALITY_LOW)
+        gpu = make()
+        assert gpu.serialize() == ref.serialize(), (dtype, builder)
+    if dtype == np.float64:
+        nodes = orc.build(bb, cc, builder=oracle.BUILDER_BINNED).nodes()
+        assert len(nodes) > 2 * 256, "the scene no longer forces the one-block builder to give up"
+
+
 def test_refit_on_device_built_tree_is_identity(orc):
     import bvh_amd
     tris = synth.terrain(30_000)
