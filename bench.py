@@ -239,7 +239,7 @@ def pmc_live(args, robust, kernel_name, plan, rays, extra_passes=()):
             d = os.path.join(work, f"p{i}")
             try:
                 r = subprocess.run(["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
-                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
             except (OSError, subprocess.TimeoutExpired) as exc:
                 return None, f"rocprofv3 --pmc pass {counters} failed: {exc!r}"
             if r.returncode != 0:
