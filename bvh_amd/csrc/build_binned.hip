@@ -1213,7 +1213,8 @@ struct BinnedWs {
 
 // Phase A levels + Phase B. Expects the roots already registered (state_next / tasks_next / counters) and `h` read back.
 template <typename T>
-int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_start, bool& overflow, hipStream_t stream) {
+int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_start, bool& overflow, hipStream_t stream,
+                      const std::function<int()>* roots_final = nullptr) {
     uint32_t n_active = h.n_active_next, n_tasks = h.n_tasks_next;
     overflow = h.error != 0;
     while (n_active > 0 && !overflow) {
@@ -1267,6 +1268,9 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
             (void)hipMemset(c.med_prof, 0, sizeof(t));
         }
     }
+    // every root's box is final in stream order here (k_forest_roots, or k_medium for the roots it left pending): a forest caller that
+    // only needs those boxes — the mini-tree builder's top level without pruning — starts its own work beside Phase B
+    if (!overflow && roots_final) { const int rc = (*roots_final)(); if (rc) return rc; }
     if (!overflow && h.n_small) {
         static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
         if (dfs) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, stream, c, h.n_small);
@@ -1397,8 +1401,10 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
 template <typename T>
 int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* d_ids, uint32_t n, const uint32_t* d_group_begin,
                                uint32_t n_groups, const bvh_build_config& cfg, DevBuf<HostNode<T>>& trees,
-                               DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream)
+                               DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream,
+                               const std::function<int(const ANode<T>*)>& roots_ready)
 {
+    bool roots_announced = false;                             // roots_ready(first n_groups working nodes) runs once, also across a retry
     DevBuf<uint32_t> sorted_ids;                              // a retry must start from the ascending order again
     BVH_HIP_TRY(sorted_ids.alloc(n), BVH_AMD_ERR_HIP);
     BVH_HIP_TRY(hipMemcpyAsync(sorted_ids.p, d_ids, size_t{n} * 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
@@ -1417,7 +1423,12 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
         { int rb_ = readback(&h, c.counters, sizeof(h), stream); if (rb_) return rb_; }
         std::vector<uint32_t> level_start{0, n_groups};
         bool overflow = false;
-        rc = run_binned_phases(c, h, level_start, overflow, stream);
+        const std::function<int()> announce = [&]() -> int {
+            if (roots_announced || !roots_ready) return BVH_AMD_OK;
+            roots_announced = true;
+            return roots_ready(c.nodes);
+        };
+        rc = run_binned_phases(c, h, level_start, overflow, stream, &announce);
         if (rc) return rc;
         if (overflow) {
             if (attempt == 0) continue;
@@ -1443,8 +1454,8 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
 template int build_binned_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
 template int build_binned_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
 template int build_binned_forest_device<float>(const float*, const float*, uint32_t*, uint32_t, const uint32_t*, uint32_t,
-    const bvh_build_config&, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t);
+    const bvh_build_config&, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t, const std::function<int(const ANode<float>*)>&);
 template int build_binned_forest_device<double>(const double*, const double*, uint32_t*, uint32_t, const uint32_t*, uint32_t,
-    const bvh_build_config&, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t);
+    const bvh_build_config&, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t, const std::function<int(const ANode<double>*)>&);
 
 } // namespace bvh_amd

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <functional>
 #include <vector>
 
 namespace bvh_amd {

@@ -140,12 +140,38 @@ __global__ void __launch_bounds__(64) k_readback(const uint32_t* src, uint32_t w
     }
 }
 
+// Pinned words are handed from thread to thread: a thread that ends returns its words here and the next new thread of the device takes
+// them over (the mini-tree builder's top-level worker is a thread per build: a hipHostMalloc per build would cost more than the
+// worker saves). The words of the pool live as long as the process.
+struct ReadbackPool {
+    std::mutex m;
+    std::multimap<int, uint32_t*> idle;
+};
+ReadbackPool& readback_pool() { static ReadbackPool* p = new ReadbackPool; return *p; }
+
 struct ReadbackSlot {                          // one per calling thread and device
     int device = -1;
     uint32_t* pinned = nullptr;
     uint32_t seq = 0;
     bool broken = false;
-    ~ReadbackSlot() { if (pinned) (void)hipHostFree(pinned); }
+    void give_back() {
+        if (!pinned) return;
+        ReadbackPool& pool = readback_pool();
+        std::lock_guard<std::mutex> lock(pool.m);
+        pool.idle.emplace(device, pinned);
+        pinned = nullptr; device = -1;
+    }
+    bool take(int dev) {
+        ReadbackPool& pool = readback_pool();
+        std::lock_guard<std::mutex> lock(pool.m);
+        auto it = pool.idle.find(dev);
+        if (it == pool.idle.end()) return false;
+        pinned = it->second; device = dev;
+        seq = pinned[0];                        // continue the sequence its last owner left (the arrival test compares with the word)
+        pool.idle.erase(it);
+        return true;
+    }
+    ~ReadbackSlot() { give_back(); }
 };
 
 } // namespace
@@ -158,12 +184,15 @@ int readback(void* dst, const void* d_src, size_t bytes, hipStream_t stream) {
     const bool fits = bytes % 4 == 0 && bytes / 4 <= kReadbackWords && reinterpret_cast<uintptr_t>(d_src) % 4 == 0;
     if (!blocking && fits && !slot.broken) {
         if (slot.device != dev) {
-            if (slot.pinned) { (void)hipHostFree(slot.pinned); slot.pinned = nullptr; }
-            if (hipHostMalloc(reinterpret_cast<void**>(&slot.pinned), (kReadbackWords + 1) * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess) {
-                (void)hipGetLastError();
-                slot.broken = true;
-            } else {
-                slot.pinned[0] = 0; slot.seq = 0; slot.device = dev;
+            slot.give_back();
+            if (!slot.take(dev)) {
+                if (hipHostMalloc(reinterpret_cast<void**>(&slot.pinned), (kReadbackWords + 1) * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess) {
+                    (void)hipGetLastError();
+                    slot.pinned = nullptr;
+                    slot.broken = true;
+                } else {
+                    slot.pinned[0] = 0; slot.seq = 0; slot.device = dev;
+                }
             }
         }
         if (!slot.broken) {

@@ -17,6 +17,11 @@
 
 #include "build_common.h"
 
+#include <atomic>
+#include <functional>
+#include <string>
+#include <thread>
+
 namespace bvh_amd {
 
 using namespace bld;
@@ -24,7 +29,8 @@ using namespace bld;
 template <typename T>
 int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* d_ids, uint32_t n, const uint32_t* d_group_begin,
                                uint32_t n_groups, const bvh_build_config& cfg, DevBuf<HostNode<T>>& trees,
-                               DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream);
+                               DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream,
+                               const std::function<int(const ANode<T>*)>& roots_ready);
 template <typename T>
 int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_leaf, uint32_t max_leaf,
                DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& ord, size_t& total_nodes, hipStream_t stream, int dim);
@@ -338,9 +344,30 @@ __global__ void __launch_bounds__(64) k_prune_walk(const HostNode<T>* trees, con
     if (!pass) cut_count[t] = count;
 }
 
-__global__ void __launch_bounds__(256) k_whole_trees_as_cuts(uint32_t n_trees, uint2* cuts) {
+// Without pruning every mini-tree is one cut, and what the extraction's count pass and its two scans would find is known: tree t moves
+// nodes(t) - 1 nodes and all of its primitives, so the offsets are differences of the forest's own prefix sums.
+__global__ void __launch_bounds__(256) k_whole_trees_as_cuts(uint32_t n_trees, const uint32_t* tree_off, const uint32_t* group_begin, uint2* cuts,
+                                                             uint32_t* node_off, uint32_t* prim_off) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n_trees) cuts[t] = make_uint2(t, 0);
+    if (t >= n_trees) return;
+    cuts[t] = make_uint2(t, 0);
+    node_off[t] = tree_off[t] - tree_off[0] - t;
+    prim_off[t] = group_begin[t] - group_begin[0];
+}
+
+// The top-level builder's inputs (:251-256) straight from the forest's working roots (without pruning the cut roots ARE the tree roots,
+// and their boxes are final long before the trees below them are): box and (max + min) * 0.5 (bbox.h:30) per tree.
+template <typename T>
+__global__ void __launch_bounds__(256) k_top_inputs(const ANode<T>* roots, uint32_t n_trees, T* top_boxes, T* top_centers) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_trees) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T lo = roots[t].lo[k], hi = roots[t].hi[k];
+        top_boxes[6ull * t + k] = lo;
+        top_boxes[6ull * t + 3 + k] = hi;
+        top_centers[3ull * t + k] = (hi + lo) * T(0.5);
+    }
 }
 
 // extract_bvh (bvh.h:92-122) per cut. pass 0: sizes (nodes - 1, prims); pass 1: write into the final arrays.
@@ -407,6 +434,7 @@ __global__ void __launch_bounds__(64) k_extract(ExtractArgs<T> a, int pass) {
     }
     if (!pass) { a.nodes_minus1[i] = n_nodes - 1; a.prims[i] = n_prims; return; }
     a.cut_roots[i] = root_rec;
+    if (!a.top_boxes) return;                                 // (already written from the forest's working roots)
     // the top-level builder's inputs (:251-256)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -447,6 +475,75 @@ __global__ void __launch_bounds__(256) k_splice_top(const HostNode<T>* top, cons
     HostNode<T> nd = top[v];
     if (node_is_leaf(nd)) nd = cut_roots[top_ids[static_cast<uint32_t>(nd.index >> kCountBits)]];
     out[v] = nd;
+}
+
+// ---- the top-level build beside the forest (round 4) ----------------------------------------------------------------------------
+// Without pruning (Quality::Low, or MiniTreeBuilder with pruning off) the top-level BVH (:249-310) is built over the mini-trees' ROOT
+// boxes, and those are final after k_forest_roots / k_medium — a third of the way into the forest build. The top level is a chain of
+// small launches and host round trips (the std::sort replay, one sweep level, one k_sweep_medium block ...: 0.9 ms for the 4096 roots
+// of a 16^3 grid, 40 % of a 1M-triangle Low build) that leaves the chip idle, while Phase B of the forest (k_small_levels) fills it
+// without needing the host. So the top level runs on a stream of its own, driven by a worker thread (both pipelines block on
+// readbacks, one host thread cannot drive two), between two events: `roots` (recorded on the caller's stream behind the kernel that
+// writes the top-level inputs) and `done` (recorded on the worker's stream; the splice waits for it). The worker is a thread per
+// build, started while the grid / radix-sort kernels run and spinning until the roots are announced or the build gives up.
+struct TopHelper {                                            // per calling thread: stream + events of its top-level worker
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t roots = nullptr, done = nullptr, spliced = nullptr;
+    void release() {
+        if (stream) (void)hipStreamDestroy(stream);
+        for (hipEvent_t* e : { &roots, &done, &spliced }) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        stream = nullptr; device = -1;
+    }
+    int prepare(int dev) {
+        if (device == dev) return BVH_AMD_OK;
+        release();
+        // the highest priority the device offers: the worker's launches are one or a few blocks each and sit on the critical path, while
+        // Phase B on the caller's stream has thousands of blocks waiting for every slot that frees
+        int least = 0, greatest = 0;
+        BVH_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest), BVH_AMD_ERR_HIP);
+        static const bool flat = std::getenv("BVH_AMD_TOP_PRIORITY") && std::atoi(std::getenv("BVH_AMD_TOP_PRIORITY")) == 0;      // A/B runs
+        BVH_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, flat ? least : greatest), BVH_AMD_ERR_HIP);
+        for (hipEvent_t* e : { &roots, &done, &spliced }) BVH_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming), BVH_AMD_ERR_HIP);
+        device = dev;
+        return BVH_AMD_OK;
+    }
+    ~TopHelper() { release(); }
+};
+
+template <typename T>
+struct TopJob {
+    std::thread worker;
+    std::atomic<int> go{0};                                   // 0 wait, 1 the roots event is recorded, -1 not needed
+    int rc = BVH_AMD_OK;
+    std::string error;
+    DevBuf<HostNode<T>> top;
+    DevBuf<uint32_t> top_ord;
+    size_t top_count = 0;
+    bool announced = false;
+    const T* boxes = nullptr; const T* centers = nullptr; uint32_t n_roots = 0;      // set before `go`
+    void start(int dev, const TopHelper& h, SahParams sah) {
+        worker = std::thread([this, dev, &h, sah] {
+            if (hipSetDevice(dev) != hipSuccess) { rc = BVH_AMD_ERR_HIP; error = "build: hipSetDevice on the top-level worker"; return; }
+            StreamScope scratch_on(h.stream);
+            SahScope heuristic(sah);
+            int state;
+            for (uint32_t spin = 0; (state = go.load(std::memory_order_acquire)) == 0; ++spin)
+                if ((spin & 63u) == 63u) std::this_thread::yield();
+            if (state < 0) return;
+            if (hipStreamWaitEvent(h.stream, h.roots, 0) != hipSuccess) { rc = BVH_AMD_ERR_HIP; error = "build: hipStreamWaitEvent on the top-level worker"; return; }
+            rc = sweep_core<T>(boxes, centers, n_roots, 1, 1, top, top_ord, top_count, h.stream, 3);
+            if (rc) { error = current_error(); return; }
+            if (hipEventRecord(h.done, h.stream) != hipSuccess) { rc = BVH_AMD_ERR_HIP; error = "build: hipEventRecord on the top-level worker"; }
+        });
+    }
+    void finish() { if (worker.joinable()) { if (go.load() == 0) go.store(-1, std::memory_order_release); worker.join(); } }
+    ~TopJob() { finish(); }
+};
+
+bool top_beside_enabled() {
+    static const bool off = std::getenv("BVH_AMD_TOP_BESIDE") && std::atoi(std::getenv("BVH_AMD_TOP_BESIDE")) == 0;      // A/B runs
+    return !off;
 }
 
 } // namespace
@@ -497,6 +594,17 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     while (key_bits < 32 && (size_t{1} << key_bits) < max_groups) ++key_bits;
     int rc = radix_sort_pairs<uint32_t>(keys.p, ids.p, keys_tmp.p, vals_tmp.p, n32, 1, key_bits, stream);   // stable: ids ascending per group (:124)
     if (rc) return rc;
+    DevBuf<T> top_boxes, top_centers;
+    TopJob<T> job;                                            // (declared after what its worker reads: joined before those are released)
+    static thread_local TopHelper helper;
+    const bool beside = !prune && max_groups > static_cast<size_t>(kSmall) && top_beside_enabled() && scratch_pool_enabled();
+    if (beside) {                                             // the worker starts while the kernels above run (the host would only wait for them)
+        int dev = 0;
+        BVH_HIP_TRY(hipGetDevice(&dev), BVH_AMD_ERR_HIP);
+        rc = helper.prepare(dev);
+        if (rc) return rc;
+        job.start(dev, helper, ambient_sah());
+    }
     MtScalars hs;
     { int rb_ = readback(&hs, scalars.p, sizeof(hs), stream); if (rb_) return rb_; }
     const uint32_t n_trees = hs.n_groups;
@@ -504,8 +612,22 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     DevBuf<HostNode<T>> trees;
     DevBuf<uint32_t> tree_off;
     uint32_t forest_nodes = 0;
-    rc = build_binned_forest_device<T>(d_bboxes, d_centers, ids.p, n32, group_begin.p, n_trees, cfg, trees, tree_off, forest_nodes, stream);
+    std::function<int(const ANode<T>*)> roots_ready;
+    if (beside && n_trees > static_cast<uint32_t>(kSmall)) {
+        A(top_boxes.alloc(6 * size_t{n_trees})); A(top_centers.alloc(3 * size_t{n_trees}));
+        if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+        job.boxes = top_boxes.p; job.centers = top_centers.p; job.n_roots = n_trees;
+        roots_ready = [&](const ANode<T>* roots) -> int {
+            hipLaunchKernelGGL(k_top_inputs<T>, dim3((n_trees + 255) / 256), dim3(256), 0, stream, roots, n_trees, top_boxes.p, top_centers.p);
+            BVH_HIP_TRY(hipEventRecord(helper.roots, stream), BVH_AMD_ERR_HIP);
+            job.announced = true;
+            job.go.store(1, std::memory_order_release);
+            return BVH_AMD_OK;
+        };
+    }
+    rc = build_binned_forest_device<T>(d_bboxes, d_centers, ids.p, n32, group_begin.p, n_trees, cfg, trees, tree_off, forest_nodes, stream, roots_ready);
     if (rc) return rc;
+    if (!job.announced) job.finish();                         // (the forest never reached the point where it announces its roots)
 
     // ---- prune_mini_trees: the list of cuts (tree, node) in the reference's order
     DevBuf<uint2> cuts;
@@ -526,49 +648,72 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
         hipLaunchKernelGGL(k_prune_walk<T>, dim3(tg), dim3(64), 0, stream, trees.p, tree_off.p, n_trees, threshold.p, 1, cut_count.p,
                            cut_off.p, cuts.p, scalars.p);
         if (!scratch_pool_enabled()) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // plain hipFree of the workspace on return (the pool frees in stream order)
-    } else {
-        BVH_HIP_TRY(cuts.alloc(n_cuts), BVH_AMD_ERR_HIP);
-        hipLaunchKernelGGL(k_whole_trees_as_cuts, dim3((n_trees + 255) / 256), dim3(256), 0, stream, n_trees, cuts.p);
     }
 
     // ---- extract (sizes -> offsets -> write) and the top-level builder's inputs
     DevBuf<uint32_t> nm1, np, node_off, prim_off;
     DevBuf<HostNode<T>> cut_roots;
-    DevBuf<T> top_boxes, top_centers;
-    A(nm1.alloc(n_cuts)); A(np.alloc(n_cuts)); A(node_off.alloc(n_cuts)); A(prim_off.alloc(n_cuts)); A(cut_roots.alloc(n_cuts));
-    A(top_boxes.alloc(6 * size_t{n_cuts})); A(top_centers.alloc(3 * size_t{n_cuts})); A(final_ids.alloc(n));
+    if (prune) { A(nm1.alloc(n_cuts)); A(np.alloc(n_cuts)); } else A(cuts.alloc(n_cuts));
+    A(node_off.alloc(n_cuts)); A(prim_off.alloc(n_cuts)); A(cut_roots.alloc(n_cuts));
+    if (!job.announced) { A(top_boxes.alloc(6 * size_t{n_cuts})); A(top_centers.alloc(3 * size_t{n_cuts})); }
+    A(final_ids.alloc(n));
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
     ExtractArgs<T> ea;
     ea.trees = trees.p; ea.tree_off = tree_off.p; ea.group_begin = group_begin.p; ea.ids = ids.p; ea.cuts = cuts.p; ea.n_cuts = n_cuts;
     ea.nodes_minus1 = nm1.p; ea.prims = np.p; ea.node_off = node_off.p; ea.prim_off = prim_off.p;
-    ea.out_nodes = nullptr; ea.out_ids = final_ids.p; ea.cut_roots = cut_roots.p; ea.top_boxes = top_boxes.p; ea.top_centers = top_centers.p;
+    ea.out_nodes = nullptr; ea.out_ids = final_ids.p; ea.cut_roots = cut_roots.p;
+    ea.top_boxes = job.announced ? nullptr : top_boxes.p; ea.top_centers = job.announced ? nullptr : top_centers.p;
     ea.top_nodes = 2 * n_cuts - 1; ea.sc = scalars.p;
     const unsigned cg = (n_cuts + 63) / 64;
-    hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 0);
-    uint32_t below = 0, prim_total = 0;
-    rc = exclusive_scan_u32(nm1.p, node_off.p, n_cuts, &below, stream);
-    if (rc) return rc;
-    rc = exclusive_scan_u32(np.p, prim_off.p, n_cuts, &prim_total, stream);
-    if (rc) return rc;
-    if (prim_total != n32) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree extraction lost primitives (walk stack overflow?)");
+    uint32_t below = 0;
+    if (prune) {
+        uint32_t prim_total = 0;
+        hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 0);
+        rc = exclusive_scan_u32(nm1.p, node_off.p, n_cuts, &below, stream);
+        if (rc) return rc;
+        rc = exclusive_scan_u32(np.p, prim_off.p, n_cuts, &prim_total, stream);
+        if (rc) return rc;
+        if (prim_total != n32) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree extraction lost primitives (walk stack overflow?)");
+    } else {
+        // every mini-tree moves whole (:239-240): the count pass, its two scans and their host round trips have known results
+        hipLaunchKernelGGL(k_whole_trees_as_cuts, dim3((n_trees + 255) / 256), dim3(256), 0, stream, n_trees, tree_off.p, group_begin.p, cuts.p,
+                           node_off.p, prim_off.p);
+        below = forest_nodes - n_trees;
+    }
     total_nodes = size_t{ea.top_nodes} + below;
     BVH_HIP_TRY(final_nodes.alloc(total_nodes), BVH_AMD_ERR_HIP);
     ea.out_nodes = final_nodes.p;
     hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 1);
     hipLaunchKernelGGL(k_extract_whole<T>, dim3(n_cuts), dim3(256), 0, stream, ea);
-    { int rb_ = readback(&hs, scalars.p, sizeof(hs), stream); if (rb_) return rb_; }
-    if (hs.error) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree deeper than the pruning walk stack");
+    if (prune) {                                              // (only the cut walks have a stack to overflow)
+        { int rb_ = readback(&hs, scalars.p, sizeof(hs), stream); if (rb_) return rb_; }
+        if (hs.error) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree deeper than the pruning walk stack");
+    }
 
     // ---- build_top_bvh: sweep SAH with one cut root per leaf, then the splice
-    DevBuf<HostNode<T>> top;
-    DevBuf<uint32_t> top_ord;
+    DevBuf<HostNode<T>> top_here;
+    DevBuf<uint32_t> top_ord_here;
     size_t top_count = 0;
-    rc = sweep_core<T>(top_boxes.p, top_centers.p, n_cuts, 1, 1, top, top_ord, top_count, stream, 3);
-    if (rc) return rc;
+    if (job.announced) {                                      // built beside the forest: wait for the worker, then for its stream
+        job.finish();
+        if (job.rc) return fail(job.rc, job.error);
+        BVH_HIP_TRY(hipStreamWaitEvent(stream, helper.done, 0), BVH_AMD_ERR_HIP);
+        top_count = job.top_count;
+    } else {
+        rc = sweep_core<T>(top_boxes.p, top_centers.p, n_cuts, 1, 1, top_here, top_ord_here, top_count, stream, 3);
+        if (rc) return rc;
+    }
+    const DevBuf<HostNode<T>>& top = job.announced ? job.top : top_here;
+    const DevBuf<uint32_t>& top_ord = job.announced ? job.top_ord : top_ord_here;
     if (top_count != ea.top_nodes) return fail(BVH_AMD_ERR_OVERFLOW, "build: unexpected top-level node count");
     hipLaunchKernelGGL(k_splice_top<T>, dim3((ea.top_nodes + 255) / 256), dim3(256), 0, stream, top.p, top_ord.p, ea.top_nodes, cut_roots.p,
                        final_nodes.p);
     BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+    if (job.announced) {
+        // the worker's stream owns `top` / `top_ord` (they return to its cache): nothing it runs later may start before the splice has read them
+        BVH_HIP_TRY(hipEventRecord(helper.spliced, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamWaitEvent(helper.stream, helper.spliced, 0), BVH_AMD_ERR_HIP);
+    }
     if (!scratch_pool_enabled()) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // plain hipFree of the workspace on return (the pool frees in stream order)
     return BVH_AMD_OK;
 }

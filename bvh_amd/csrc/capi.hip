@@ -27,6 +27,7 @@ thread_local std::string g_error;
 
 void set_error(const std::string& msg) { g_error = msg; }
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
+std::string current_error() { return g_error; }
 
 namespace {
 

@@ -64,6 +64,7 @@ template <> struct HitOf<double> { using Type = bvh_hit3d; };
 // ---- error plumbing --------------------------------------------------------------------------------
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+std::string current_error();                   // capi.hip: the calling thread's message (a worker thread hands its own to the thread that started it)
 
 #define BVH_HIP_TRY(expr, code)                                                                     \
     do {                                                                                            \

@@ -288,6 +288,121 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, u
   }
 }
 
+// The whole of std::sort for arrays of at most kSortSmallMax ids (round 4): ONE launch, one block per array, ids and keys resident in LDS.
+// The mini-tree builder's top level without pruning sorts the roots of a 16^3 grid — three arrays of <= 4096 ids — and paid 25
+// partition rounds + a 4-pass radix sort + a host round trip for them: ~40 launches, 0.34 ms of a 2.1 ms build.
+//   * __introsort_loop (stl_algo.h:1945-1957): the same rounds as k_sort_partition, with a WAVE per segment (ballot prefix sums
+//     instead of block scans, no block barrier inside a segment) and a block barrier between rounds; segment lists in LDS (disjoint
+//     segments of more than 16 ids: at most 240).
+//   * __final_insertion_sort == the stable sort by key of the arrangement the rounds leave. Every id is then within 15 positions of
+//     its place (what is left unpartitioned is at most 16 long, and everything further left / right compares <= / >=), so an id's
+//     rank is its window's start + the ids of the window that sort before it. Keys that are NaN void that argument (std::sort
+//     itself is undefined for them): the block then ranks every id against all others — still a permutation, as the radix sort's.
+constexpr uint32_t kSortSmallMax = 4096;
+constexpr int kSortSmallThreads = 1024;
+
+template <typename T>
+__global__ void __launch_bounds__(kSortSmallThreads) k_std_sort_small(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t astride, uint32_t istride,
+                                                                      uint32_t depth0) {
+    using U = typename Ord<T>::U;
+    __shared__ T skey[kSortSmallMax];                     // by id
+    __shared__ uint32_t sid[kSortSmallMax];               // the array being sorted
+    __shared__ uint16_t ltab[kSortSmallMax], rtab[kSortSmallMax];
+    __shared__ uint32_t seg[2][256];                      // first | last << 12 | depth << 25
+    __shared__ uint32_t seg_count[2];
+    __shared__ uint32_t any_nan;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const T* kb = d_keys + size_t{blockIdx.x} * astride;
+    if (tid == 0) { seg[0][0] = 0u | (n << 12) | (depth0 << 25); seg_count[0] = n > 16 ? 1u : 0u; seg_count[1] = 0; any_nan = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kSortSmallThreads) {
+        const T v = kb[size_t{i} * istride];
+        skey[i] = v; sid[i] = i;
+        if (v != v) any_nan = 1;
+    }
+    __syncthreads();
+    auto key = [&](uint32_t id) { return skey[id]; };
+    for (uint32_t round = 0;; ++round) {
+        const uint32_t cur = round & 1u, n_active = seg_count[cur];
+        if (n_active == 0) break;
+        for (uint32_t s = wave; s < n_active; s += kSortSmallThreads / 64) {
+            const uint32_t pk = seg[cur][s];
+            const uint32_t first = pk & 0xFFFu, last = (pk >> 12) & 0x1FFFu, depth = pk >> 25, len = last - first;
+            if (depth == 0) {                             // __partial_sort(first, last, last): heap sort
+                if (lane == 0) partial_sort_replay(sid + first, long(len), long(len), key);
+                continue;
+            }
+            if (lane == 0) {                              // __move_median_to_first(first, first + 1, mid, last - 1)
+                const uint32_t a = first + 1, b = first + len / 2, cc = last - 1;
+                const T ka = key(sid[a]), kbv = key(sid[b]), kc = key(sid[cc]);
+                uint32_t pick;
+                if (ka < kbv) { if (kbv < kc) pick = b; else if (ka < kc) pick = cc; else pick = a; }
+                else if (ka < kc) pick = a;
+                else if (kbv < kc) pick = cc;
+                else pick = b;
+                const uint32_t t = sid[first]; sid[first] = sid[pick]; sid[pick] = t;
+            }
+            wave_sync();
+            const T pivot = key(sid[first]);
+            // L (key >= pivot) and R (key <= pivot) position tables over [first + 1, last), both ascending (see k_sort_partition)
+            uint32_t nl = 0, nr = 0;
+            const uint64_t below = (uint64_t{1} << lane) - 1u;
+            for (uint32_t tile = first + 1; tile < last; tile += 64) {
+                const uint32_t pos = tile + lane;
+                bool fl = false, fr = false;
+                if (pos < last) { const T kv = key(sid[pos]); fl = !(kv < pivot); fr = !(pivot < kv); }
+                const uint64_t bl = __ballot(fl), br = __ballot(fr);
+                if (fl) ltab[first + nl + __popcll(bl & below)] = static_cast<uint16_t>(pos);
+                if (fr) rtab[first + nr + __popcll(br & below)] = static_cast<uint16_t>(pos);
+                nl += __popcll(bl); nr += __popcll(br);
+            }
+            wave_sync();
+            const uint32_t lim = min(nl, nr);             // k = #{j : L_j < R_j}, R_j (descending) = rtab[nr - 1 - j]
+            uint32_t k = 0;
+            for (uint32_t j0 = 0; j0 < lim; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                k += __popcll(__ballot(j < lim && ltab[first + j] < rtab[first + nr - 1 - j]));
+            }
+            for (uint32_t j0 = 0; j0 < k; j0 += 64) {    // the swaps
+                const uint32_t j = j0 + lane;
+                if (j < k) {
+                    const uint32_t p = ltab[first + j], q = rtab[first + nr - 1 - j];
+                    const uint32_t a = sid[p], b = sid[q];
+                    sid[p] = b; sid[q] = a;
+                }
+            }
+            if (lane == 0) {
+                uint32_t cut;
+                if (k == 0) cut = ltab[first];
+                else {
+                    const uint32_t rk1 = rtab[first + nr - k];               // R_{k-1}
+                    cut = (k < nl && ltab[first + k] < rk1) ? ltab[first + k] : rk1;
+                }
+                const uint32_t cb[2] = { first, cut }, ce[2] = { cut, last };
+                for (int h = 0; h < 2; ++h)
+                    if (ce[h] - cb[h] > 16) seg[cur ^ 1u][atomicAdd(&seg_count[cur ^ 1u], 1u)] = cb[h] | (ce[h] << 12) | ((depth - 1) << 25);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) seg_count[cur] = 0;
+        __syncthreads();
+    }
+    // __final_insertion_sort
+    auto image = [&](uint32_t pos) { T v = skey[sid[pos]]; if (v == T(0)) v = T(0); return Ord<T>::enc(v); };    // -0 and +0 are EQUAL keys for operator<
+    const bool all = any_nan != 0;
+    uint32_t* out = d_ids + size_t{blockIdx.x} * n;
+    for (uint32_t p = tid; p < n; p += kSortSmallThreads) {
+        const U kp = image(p);
+        const uint32_t lo = all ? 0u : (p >= 15u ? p - 15u : 0u), hi = all ? n : min(n, p + 16u);
+        uint32_t rank = lo;
+        for (uint32_t j = lo; j < hi; ++j) {
+            const U kj = image(j);
+            rank += (kj < kp || (kj == kp && j < p)) ? 1u : 0u;
+        }
+        out[rank] = sid[p];
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_make_sort_keys(const uint32_t* ids, const T* keys, uint32_t n, uint32_t total, uint32_t astride,
                                                         uint32_t istride, typename Ord<T>::U* out) {
@@ -411,6 +526,14 @@ template <typename T>
 int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, uint32_t astride, uint32_t istride, hipStream_t stream) {
     StreamScope scratch_on(stream);
     if (n == 0 || batch == 0) return BVH_AMD_OK;
+    static const bool small_off = std::getenv("BVH_AMD_SORT_SMALL") && std::atoi(std::getenv("BVH_AMD_SORT_SMALL")) == 0;      // A/B runs
+    if (n <= kSortSmallMax && !small_off) {
+        uint32_t lg = 0;
+        while ((uint64_t{2} << lg) <= n) ++lg;            // std::__lg(n) = floor(log2 n)
+        hipLaunchKernelGGL(k_std_sort_small<T>, dim3(batch), dim3(kSortSmallThreads), 0, stream, d_ids, d_keys, n, astride, istride, 2 * lg);
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        return BVH_AMD_OK;
+    }
     const uint32_t total = n * batch;
     hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, stream, d_ids, n, total);
     using U = typename Ord<T>::U;
