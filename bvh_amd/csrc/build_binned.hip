@@ -778,10 +778,16 @@ __global__ void __launch_bounds__(KM_ / 2) k_medium(BuildCtx<T> c) {
     (void)kMedSegs;
     constexpr uint32_t PPT = KM / kMedThreads;                 // consecutive positions per thread
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t root_id = c.medium_list[blockIdx.x];
+    uint32_t slot = blockIdx.x;
+    if (c.med_cum[3]) {                                       // several class lists in one launch: which list, which entry
+        uint32_t cls = 0;
+        while (cls < 3 && slot >= c.med_cum[cls]) ++cls;
+        slot = slot - (cls ? c.med_cum[cls - 1] : 0u) + cls * c.medium_slots;
+    }
+    const uint32_t root_id = c.medium_list[slot];
     const ANode<T>& R = c.nodes[root_id];
     const uint32_t B = R.begin, s = R.end - R.begin, tree = R.tree;
-    MedInfo* info = c.med_info + blockIdx.x;
+    MedInfo* info = c.med_info + slot;
     unsigned long long t_mark = c.med_prof ? __builtin_readcyclecounter() : 0ull;
     auto mark = [&](int i) { if (c.med_prof && tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); atomicAdd(&c.med_prof[i], now - t_mark); t_mark = now; } };
 
@@ -1190,14 +1196,8 @@ struct BinnedWs {
         const uint32_t medium_slots = n / (kSmall + 1) + roots + 2;
         c.medium_cap = attempt == 0 && !medium_off ? medium_cap<T>() : 0u;
         c.medium_slots = medium_slots;
-        // Two classes are used: segments of up to 256 primitives run as k_medium<T, 256> (128 threads, 19 KB of LDS: eight blocks per CU —
-        // Quality::Low with a pool makes 4096 mini-trees of n / 4096 primitives), everything larger as the largest class, one block of 1024
-        // threads alone on its CU. Measured round 4 (profiles/r04_build_medium_ab.txt): routing 257..1024-primitive segments to the 512 /
-        // 1024 classes instead (256 / 512 threads, 4 / 2 blocks per CU) is SLOWER everywhere they occur (1M Low serial 2.69 -> 2.78 ms,
-        // terrain 2.69 -> 2.82, Sponza proxy 1.73 -> 1.93): a block's levels are a chain of short LDS phases, and more waves on the
-        // segment shorten that chain more than a second resident block hides it. BVH_AMD_MEDIUM_CLASSES=1 routes by size (A/B runs).
-        static const bool by_size = std::getenv("BVH_AMD_MEDIUM_CLASSES") && std::atoi(std::getenv("BVH_AMD_MEDIUM_CLASSES")) != 0;
-        c.medium_min_class = by_size ? 0u : (sizeof(T) == 4 ? 3u : 2u);
+        // segments are listed by size class; run_binned_phases decides which kernel serves which list
+        c.medium_min_class = 0;
         if (c.medium_cap) { A(medium_list.alloc(4 * size_t{medium_slots})); A(med_info.alloc(4 * size_t{medium_slots})); }
         if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
         c.medium_list = medium_list.p; c.med_info = med_info.p;
@@ -1214,7 +1214,7 @@ struct BinnedWs {
 // Phase A levels + Phase B. Expects the roots already registered (state_next / tasks_next / counters) and `h` read back.
 template <typename T>
 int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_start, bool& overflow, hipStream_t stream,
-                      const std::function<int()>* roots_final = nullptr) {
+                      const std::function<int(PhaseB*)>* roots_final = nullptr) {
     uint32_t n_active = h.n_active_next, n_tasks = h.n_tasks_next;
     overflow = h.error != 0;
     while (n_active > 0 && !overflow) {
@@ -1240,15 +1240,38 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
     }
     const uint32_t n_medium_all = h.n_medium[0] + h.n_medium[1] + h.n_medium[2] + h.n_medium[3];
     if (!overflow && n_medium_all) {
+        // Segments are LISTED by size class (<= 256 << cls primitives); which kernel serves a list is decided here, from the lists'
+        // lengths. A block's levels are a chain of short LDS phases, so the largest kernel (1024 threads alone on a CU) finishes a
+        // segment fastest and a smaller one only pays when there are enough segments to fill the slots it opens: the 256 class always
+        // (128 threads, eight blocks per CU), the 512 class from three blocks per CU on (Quality::Low with a pool on 1M uniformly
+        // spread triangles: 1036 mini-trees of 257..300 primitives, 0.21 -> 0.12 ms), the 1024 class never (1054 segments: no gain).
+        // Lists served by the largest kernel go into ONE launch (their tails would add up). profiles/r04_build_medium_classes_ab.txt
+        static const int policy = std::getenv("BVH_AMD_MEDIUM_CLASSES") ? std::atoi(std::getenv("BVH_AMD_MEDIUM_CLASSES")) : 0;   // A/B runs: 1 always own, 2 never
+        constexpr uint32_t largest = sizeof(T) == 4 ? 3u : 2u;
+        int cus = 256;
+        { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; }
+        uint32_t served_by[4];
         for (uint32_t cls = 0; cls < 4; ++cls) {
-            if (!h.n_medium[cls]) continue;
+            const bool own = cls == 0 || cls >= largest || policy == 1 || (policy == 0 && cls == 1 && h.n_medium[1] >= 3u * static_cast<uint32_t>(cus));
+            served_by[cls] = own ? std::min(cls, largest) : largest;
+        }
+        for (uint32_t cls = 0; cls < largest; ++cls) {
+            if (!h.n_medium[cls] || served_by[cls] != cls) continue;
             BuildCtx<T> cc = c;
             cc.medium_list = c.medium_list + size_t{cls} * c.medium_slots;
             cc.med_info = c.med_info + size_t{cls} * c.medium_slots;
             if (cls == 0) hipLaunchKernelGGL((k_medium<T, 256>), dim3(h.n_medium[cls]), dim3(128), 0, stream, cc);
             else if (cls == 1) hipLaunchKernelGGL((k_medium<T, 512>), dim3(h.n_medium[cls]), dim3(256), 0, stream, cc);
-            else if (cls == 2) hipLaunchKernelGGL((k_medium<T, 1024>), dim3(h.n_medium[cls]), dim3(512), 0, stream, cc);
-            else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_medium<T, 2048>), dim3(h.n_medium[cls]), dim3(1024), 0, stream, cc);
+            else hipLaunchKernelGGL((k_medium<T, 1024>), dim3(h.n_medium[cls]), dim3(512), 0, stream, cc);
+        }
+        {
+            BuildCtx<T> cc = c;
+            uint32_t total = 0;
+            for (uint32_t cls = 0; cls < 4; ++cls) { if (served_by[cls] == largest && cls <= largest) total += h.n_medium[cls]; cc.med_cum[cls] = total; }
+            if (total) {
+                if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_medium<T, 2048>), dim3(total), dim3(1024), 0, stream, cc);
+                else hipLaunchKernelGGL((k_medium<T, 1024>), dim3(total), dim3(512), 0, stream, cc);
+            }
         }
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
         const uint32_t n_before[4] = { h.n_medium[0], h.n_medium[1], h.n_medium[2], h.n_medium[3] };
@@ -1270,11 +1293,18 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
     }
     // every root's box is final in stream order here (k_forest_roots, or k_medium for the roots it left pending): a forest caller that
     // only needs those boxes — the mini-tree builder's top level without pruning — starts its own work beside Phase B
-    if (!overflow && roots_final) { const int rc = (*roots_final)(); if (rc) return rc; }
+    PhaseB lane;
+    if (!overflow && roots_final) { const int rc = (*roots_final)(&lane); if (rc) return rc; }
     if (!overflow && h.n_small) {
         static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
-        if (dfs) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, stream, c, h.n_small);
-        else hipLaunchKernelGGL(k_small_levels<T>, dim3((h.n_small + 1) / 2), dim3(128), 0, stream, c, h.n_small);
+        hipStream_t on = lane.stream ? lane.stream : stream;
+        if (lane.stream) BVH_HIP_TRY(hipStreamWaitEvent(lane.stream, lane.start, 0), BVH_AMD_ERR_HIP);
+        if (dfs) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, on, c, h.n_small);
+        else hipLaunchKernelGGL(k_small_levels<T>, dim3((h.n_small + 1) / 2), dim3(128), 0, on, c, h.n_small);
+        if (lane.stream) {
+            BVH_HIP_TRY(hipEventRecord(lane.done, lane.stream), BVH_AMD_ERR_HIP);
+            BVH_HIP_TRY(hipStreamWaitEvent(stream, lane.done, 0), BVH_AMD_ERR_HIP);
+        }
     }
     return BVH_AMD_OK;
 }
@@ -1402,7 +1432,7 @@ template <typename T>
 int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* d_ids, uint32_t n, const uint32_t* d_group_begin,
                                uint32_t n_groups, const bvh_build_config& cfg, DevBuf<HostNode<T>>& trees,
                                DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream,
-                               const std::function<int(const ANode<T>*)>& roots_ready)
+                               const std::function<int(const ANode<T>*, PhaseB*)>& roots_ready)
 {
     bool roots_announced = false;                             // roots_ready(first n_groups working nodes) runs once, also across a retry
     DevBuf<uint32_t> sorted_ids;                              // a retry must start from the ascending order again
@@ -1423,10 +1453,10 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
         { int rb_ = readback(&h, c.counters, sizeof(h), stream); if (rb_) return rb_; }
         std::vector<uint32_t> level_start{0, n_groups};
         bool overflow = false;
-        const std::function<int()> announce = [&]() -> int {
+        const std::function<int(PhaseB*)> announce = [&](PhaseB* lane) -> int {
             if (roots_announced || !roots_ready) return BVH_AMD_OK;
             roots_announced = true;
-            return roots_ready(c.nodes);
+            return roots_ready(c.nodes, lane);
         };
         rc = run_binned_phases(c, h, level_start, overflow, stream, &announce);
         if (rc) return rc;
@@ -1454,8 +1484,8 @@ int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* 
 template int build_binned_device<float>(BvhImpl<float>&, const float*, const float*, size_t, const bvh_build_config&, hipStream_t);
 template int build_binned_device<double>(BvhImpl<double>&, const double*, const double*, size_t, const bvh_build_config&, hipStream_t);
 template int build_binned_forest_device<float>(const float*, const float*, uint32_t*, uint32_t, const uint32_t*, uint32_t,
-    const bvh_build_config&, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t, const std::function<int(const ANode<float>*)>&);
+    const bvh_build_config&, DevBuf<HostNode<float>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t, const std::function<int(const ANode<float>*, PhaseB*)>&);
 template int build_binned_forest_device<double>(const double*, const double*, uint32_t*, uint32_t, const uint32_t*, uint32_t,
-    const bvh_build_config&, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t, const std::function<int(const ANode<double>*)>&);
+    const bvh_build_config&, DevBuf<HostNode<double>>&, DevBuf<uint32_t>&, uint32_t&, hipStream_t, const std::function<int(const ANode<double>*, PhaseB*)>&);
 
 } // namespace bvh_amd

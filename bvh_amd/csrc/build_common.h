@@ -181,7 +181,8 @@ struct BuildCtx {
     uint32_t big_threshold = 0;              // > 0: segments of more primitives are counted in counters->n_big_next (sweep builder: multi-block scans)
     uint32_t medium_cap = 0;
     uint32_t medium_slots = 0;               // entries per size class in medium_list / med_info
-    uint32_t medium_min_class = 0;           // segments of more than 256 primitives use at least this size class (default: the largest)
+    uint32_t medium_min_class = 0;           // segments of more than 256 primitives are listed under at least this size class
+    uint32_t med_cum[4] = {0, 0, 0, 0};      // a launch over several class lists at once: running block counts (all 0: one list, already offset)
     uint32_t* medium_list = nullptr;
     MedInfo* med_info = nullptr;
     unsigned long long* med_prof = nullptr;  // developer knob BVH_AMD_MED_PROF=1: reference-clock ticks per phase of k_medium, summed over blocks
@@ -372,6 +373,11 @@ __global__ void __launch_bounds__(256) k_emit_small(BuildCtx<T> c, uint32_t n_sm
 // Scratch buffer from the stream-ordered pool (common.h: scratch_alloc): allocated on, and released in the order of, the stream
 // of the operation in progress on this thread. A buffer whose pointer is taken over by a BvhImpl (p = nullptr here) is later
 // released with hipFree, which accepts pool memory.
+// A forest caller may move Phase B (k_small_levels) to a stream of its own — the mini-tree builder runs it on a stream whose CU mask
+// leaves a few CUs to the top-level build beside it: `start` is recorded on the build's stream by the caller, `done` is recorded
+// behind Phase B and the build's stream waits for it.
+struct PhaseB { hipStream_t stream = nullptr; hipEvent_t start = nullptr, done = nullptr; };
+
 template <typename T> struct DevBuf {
     T* p = nullptr;
     ScratchTag tag;

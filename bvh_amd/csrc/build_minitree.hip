@@ -20,6 +20,7 @@
 #include <atomic>
 #include <functional>
 #include <string>
+#include <system_error>
 #include <thread>
 
 namespace bvh_amd {
@@ -30,7 +31,7 @@ template <typename T>
 int build_binned_forest_device(const T* d_bboxes, const T* d_centers, uint32_t* d_ids, uint32_t n, const uint32_t* d_group_begin,
                                uint32_t n_groups, const bvh_build_config& cfg, DevBuf<HostNode<T>>& trees,
                                DevBuf<uint32_t>& tree_node_off, uint32_t& total_nodes, hipStream_t stream,
-                               const std::function<int(const ANode<T>*)>& roots_ready);
+                               const std::function<int(const ANode<T>*, PhaseB*)>& roots_ready);
 template <typename T>
 int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_leaf, uint32_t max_leaf,
                DevBuf<HostNode<T>>& final_nodes, DevBuf<uint32_t>& ord, size_t& total_nodes, hipStream_t stream, int dim);
@@ -490,10 +491,17 @@ struct TopHelper {                                            // per calling thr
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t roots = nullptr, done = nullptr, spliced = nullptr;
+    // Phase B of the forest beside the worker: a stream whose CU mask leaves `reserved` CUs alone. k_small_levels has thousands of blocks
+    // waiting for every slot that frees, and a worker launch of 1024-thread blocks (the LDS sort, the sweep's scans, k_sweep_medium)
+    // never finds a CU with room for one — measured: the worker's first such kernel sat 570 us, until Phase B had drained, whatever
+    // the stream priority. On the reserved CUs it starts at once; Phase B loses reserved / 256 of the chip.
+    hipStream_t phase_b = nullptr;
+    hipEvent_t phase_b_done = nullptr;
     void release() {
         if (stream) (void)hipStreamDestroy(stream);
-        for (hipEvent_t* e : { &roots, &done, &spliced }) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
-        stream = nullptr; device = -1;
+        if (phase_b) (void)hipStreamDestroy(phase_b);
+        for (hipEvent_t* e : { &roots, &done, &spliced, &phase_b_done }) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        stream = nullptr; phase_b = nullptr; device = -1;
     }
     int prepare(int dev) {
         if (device == dev) return BVH_AMD_OK;
@@ -504,7 +512,16 @@ struct TopHelper {                                            // per calling thr
         BVH_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest), BVH_AMD_ERR_HIP);
         static const bool flat = std::getenv("BVH_AMD_TOP_PRIORITY") && std::atoi(std::getenv("BVH_AMD_TOP_PRIORITY")) == 0;      // A/B runs
         BVH_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, flat ? least : greatest), BVH_AMD_ERR_HIP);
-        for (hipEvent_t* e : { &roots, &done, &spliced }) BVH_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming), BVH_AMD_ERR_HIP);
+        for (hipEvent_t* e : { &roots, &done, &spliced, &phase_b_done }) BVH_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming), BVH_AMD_ERR_HIP);
+        // 32 = bits 0..31 of the mask = one CU of every shader engine of every XCD (the mask's bits go round the XCDs first, then round
+        // an XCD's four engines): 8 CUs (one engine per XCD short of a CU) cost Phase B the same 8-12 % and serve the worker worse
+        static const int reserve = std::getenv("BVH_AMD_TOP_RESERVE") ? std::atoi(std::getenv("BVH_AMD_TOP_RESERVE")) : 32;            // A/B runs (0: off)
+        int cus = 0;
+        if (reserve > 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 4 * reserve) {
+            std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+            for (int cu = reserve; cu < cus; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+            if (hipExtStreamCreateWithCUMask(&phase_b, static_cast<uint32_t>(mask.size()), mask.data()) != hipSuccess) { (void)hipGetLastError(); phase_b = nullptr; }
+        }
         device = dev;
         return BVH_AMD_OK;
     }
@@ -540,6 +557,8 @@ struct TopJob {
     void finish() { if (worker.joinable()) { if (go.load() == 0) go.store(-1, std::memory_order_release); worker.join(); } }
     ~TopJob() { finish(); }
 };
+
+constexpr uint32_t kTopReserveMaxPrims = 4u << 20;
 
 bool top_beside_enabled() {
     static const bool off = std::getenv("BVH_AMD_TOP_BESIDE") && std::atoi(std::getenv("BVH_AMD_TOP_BESIDE")) == 0;      // A/B runs
@@ -603,7 +622,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
         BVH_HIP_TRY(hipGetDevice(&dev), BVH_AMD_ERR_HIP);
         rc = helper.prepare(dev);
         if (rc) return rc;
-        job.start(dev, helper, ambient_sah());
+        try { job.start(dev, helper, ambient_sah()); } catch (const std::system_error&) { /* no thread to be had: the top level follows the forest */ }
     }
     MtScalars hs;
     { int rb_ = readback(&hs, scalars.p, sizeof(hs), stream); if (rb_) return rb_; }
@@ -612,16 +631,19 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     DevBuf<HostNode<T>> trees;
     DevBuf<uint32_t> tree_off;
     uint32_t forest_nodes = 0;
-    std::function<int(const ANode<T>*)> roots_ready;
-    if (beside && n_trees > static_cast<uint32_t>(kSmall)) {
+    std::function<int(const ANode<T>*, PhaseB*)> roots_ready;
+    if (beside && job.worker.joinable() && n_trees > static_cast<uint32_t>(kSmall)) {
         A(top_boxes.alloc(6 * size_t{n_trees})); A(top_centers.alloc(3 * size_t{n_trees}));
         if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
         job.boxes = top_boxes.p; job.centers = top_centers.p; job.n_roots = n_trees;
-        roots_ready = [&](const ANode<T>* roots) -> int {
+        roots_ready = [&](const ANode<T>* roots, PhaseB* lane) -> int {
             hipLaunchKernelGGL(k_top_inputs<T>, dim3((n_trees + 255) / 256), dim3(256), 0, stream, roots, n_trees, top_boxes.p, top_centers.p);
             BVH_HIP_TRY(hipEventRecord(helper.roots, stream), BVH_AMD_ERR_HIP);
             job.announced = true;
             job.go.store(1, std::memory_order_release);
+            // (the masked stream costs Phase B ~8-12 % whatever the number of CUs left out; beyond a few million primitives that is more
+            //  than the top level's 0.5 ms, which then simply runs in the shadow of the forest's numbering / emit passes)
+            if (helper.phase_b && n32 <= kTopReserveMaxPrims) { lane->stream = helper.phase_b; lane->start = helper.roots; lane->done = helper.phase_b_done; }
             return BVH_AMD_OK;
         };
     }
