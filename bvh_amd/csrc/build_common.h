@@ -294,6 +294,15 @@ __device__ inline uint32_t pack_item(uint32_t node, uint32_t b, uint32_t e) { re
 // Lanes of one wavefront communicate through LDS without a workgroup barrier (waves of a block run
 // independent subtrees). LDS operations of a wave execute in order; this only stops the compiler from
 // moving memory operations across the hand-off.
+// Hand-off between lanes of DIFFERENT workgroups through an arrival ticket (the bottom-up climbs of refit / subtree counts): the data
+// is written and read with agent-scope relaxed atomics (sc1 accesses: coherent across the XCDs' L2s by themselves), the ticket is an
+// agent-scope atomic add, and between them only the wave's OWN accesses have to be complete — a wait, not cache maintenance.
+// __threadfence() (agent-scope fence) additionally writes back and invalidates the XCD's whole L2 on gfx950, per call: two per climbed
+// node made a 1.9M-node climb cost 6 ms instead of 0.1 (measured round 4, profiles/r04_build_extract_ab.txt). Every location
+// exchanged this way must be accessed with agent-scope atomics on both sides.
+__device__ inline void ticket_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ inline void ticket_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
 __device__ inline void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

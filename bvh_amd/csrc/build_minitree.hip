@@ -18,6 +18,9 @@
 #include "build_common.h"
 
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <system_error>
@@ -446,6 +449,127 @@ __global__ void __launch_bounds__(64) k_extract(ExtractArgs<T> a, int pass) {
     }
 }
 
+// ---- extract_bvh per cut without a walk per cut (round 4) -------------------------------------------------------------------------
+// k_extract above replays extract_bvh's explicit stack with ONE LANE per cut: a cut of a 1M-triangle Medium build has ~100 nodes, of a
+// 10M-triangle terrain ~1000 (up to 3500) — hundreds to thousands of dependent loads per lane, twice (count, then write), 0.36 ms of a
+// 3.1 ms build. The layout extract_bvh produces is a function of subtree sizes (extract.hip's header): with inner(.) / prims(.) the
+// inner nodes / primitives of a subtree, a node X processed after r(X) inner nodes and p(X) primitives puts its children at
+// 1 + 2 r(X), 2 + 2 r(X), and r(second) = r(X) + 1, p(second) = p(X), r(first) = r(X) + 1 + inner(second), p(first) = p(X) +
+// prims(second). So:
+//   k_forest_parents  parent of every node (tree-local), one lane per node;
+//   k_cut_counts      inner / prims of every node at or below a cut root: one lane per leaf climbs, the second child to arrive at a
+//                     node sums its children (arrival tickets), and the climb ends at the cut root — this also IS the count pass:
+//                     a cut holds 1 + 2 inner(root) nodes and prims(root) primitives;
+//   k_cut_assign      one lane per node climbs to its cut root adding up the r / p steps on the way (a first child, at its odd index,
+//                     adds its sibling's counts) and writes the node where that puts it; nodes above the cuts find no cut and are dropped.
+// Every lane's chain is the node's depth inside its cut (~7 for 100 nodes, ~12 for 3500), all nodes at once, no stacks to overflow.
+template <typename T>
+__global__ void __launch_bounds__(256) k_forest_parents(const HostNode<T>* trees, const uint32_t* tree_off, uint32_t* parent) {
+    const uint32_t base = tree_off[blockIdx.x], nn = tree_off[blockIdx.x + 1] - base;
+    for (uint32_t j = threadIdx.x; j < nn; j += 256) {
+        const HostNode<T> nd = trees[base + j];
+        if (node_is_leaf(nd)) continue;
+        const uint32_t f = static_cast<uint32_t>(nd.index >> kCountBits);
+        parent[base + f] = j; parent[base + f + 1] = j;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cut_flags(const uint2* cuts, uint32_t n_cuts, const uint32_t* tree_off, uint32_t* cut_of) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_cuts) cut_of[tree_off[cuts[i].x] + cuts[i].y] = i + 1;      // 0: not the root of a cut
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_cut_counts(const HostNode<T>* trees, const uint32_t* tree_off, const uint32_t* parent, const uint32_t* cut_of,
+                                                    uint32_t* arrived, uint32_t* inner, uint32_t* prims) {
+    const uint32_t base = tree_off[blockIdx.x], nn = tree_off[blockIdx.x + 1] - base;
+    const HostNode<T>* tree = trees + base;
+    // One block owns one tree, so every exchange is between waves of ONE workgroup: workgroup-scope release / acquire on the ticket is
+    // all the ordering needed — waits for the wave's own stores, no cache maintenance. (The first version used __threadfence() =
+    // agent scope, which on gfx950 writes back and invalidates the XCD's L2 per call: two per climbed node made this kernel 6 ms.)
+    auto put = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto get = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    for (uint32_t j = threadIdx.x; j < nn; j += 256) {
+        const HostNode<T> nd = tree[j];
+        if (!node_is_leaf(nd)) continue;
+        put(&inner[base + j], 0u);
+        put(&prims[base + j], static_cast<uint32_t>(nd.index & kCountMask));
+        uint32_t cur = j;
+        while (cur != 0 && cut_of[base + cur] == 0) {         // (every leaf is a cut or below one: the climb ends at a cut root)
+            const uint32_t p = parent[base + cur];
+            // release (this subtree's counts before the ticket) + acquire (the sibling's counts after it)
+            if (__hip_atomic_fetch_add(&arrived[base + p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) break;   // first to arrive: the sibling's lane finishes this node
+            const uint32_t f = static_cast<uint32_t>(tree[p].index >> kCountBits);
+            put(&inner[base + p], 1u + get(&inner[base + f]) + get(&inner[base + f + 1]));
+            put(&prims[base + p], get(&prims[base + f]) + get(&prims[base + f + 1]));
+            cur = p;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_cut_sizes(ExtractArgs<T> a, const uint32_t* inner, const uint32_t* prims) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_cuts) return;
+    const uint32_t t = a.cuts[i].x, r = a.cuts[i].y;
+    if (r == 0) {                                             // the whole mini-tree moves (:239-240)
+        a.nodes_minus1[i] = a.tree_off[t + 1] - a.tree_off[t] - 1;
+        a.prims[i] = a.group_begin[t + 1] - a.group_begin[t];
+    } else {
+        a.nodes_minus1[i] = 2 * inner[a.tree_off[t] + r];
+        a.prims[i] = prims[a.tree_off[t] + r];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_cut_assign(ExtractArgs<T> a, const uint32_t* parent, const uint32_t* cut_of, const uint32_t* inner,
+                                                    const uint32_t* prims) {
+    using I = typename IndexOf<T>::Type;
+    const uint32_t t = blockIdx.x, base = a.tree_off[t], nn = a.tree_off[t + 1] - base, gb = a.group_begin[t];
+    const HostNode<T>* tree = a.trees + base;
+    for (uint32_t j = threadIdx.x; j < nn; j += 256) {
+        uint32_t r = 0, p = 0, own_step = 0, cut = cut_of[base + j];
+        const bool is_root = cut != 0;
+        if (!is_root) {
+            uint32_t at = j;
+            while (at != 0) {
+                const bool first = (at & 1u) != 0;            // the first child of a pair sits at the odd index (bvh.h:34)
+                const uint32_t step_r = 1u + (first ? inner[base + at + 1] : 0u), step_p = first ? prims[base + at + 1] : 0u;
+                if (at == j) own_step = step_r;
+                r += step_r; p += step_p;
+                at = parent[base + at];
+                cut = cut_of[base + at];
+                if (cut) break;
+            }
+            if (!cut) continue;                               // above the cuts: the top-level build replaces these nodes
+        }
+        const uint32_t r_parent = r - own_step;               // the node's place follows from its PARENT's r: 1 + 2 r (first child), 2 + 2 r
+        const uint32_t c = cut - 1;
+        const bool whole = a.cuts[c].y == 0;
+        if (whole && !is_root) continue;                      // copied as it lies by k_extract_whole
+        const uint32_t node_base = a.top_nodes - 1 + a.node_off[c], prim_base = a.prim_off[c];
+        HostNode<T> nd = tree[j];
+        const uint32_t cnt = static_cast<uint32_t>(nd.index & kCountMask), first_id = static_cast<uint32_t>(nd.index >> kCountBits);
+        if (whole) {                                          // copy_node (:275-279) of the root of a tree that moves whole
+            nd.index = cnt ? ((static_cast<I>(prim_base + first_id) << kCountBits) | cnt) : (static_cast<I>(node_base + first_id) << kCountBits);
+        } else if (cnt) {
+            for (uint32_t q = 0; q < cnt; ++q) a.out_ids[prim_base + p + q] = a.ids[gb + first_id + q];
+            nd.index = (static_cast<I>(prim_base + p) << kCountBits) | cnt;
+        } else {
+            nd.index = static_cast<I>(node_base + 1 + 2 * r) << kCountBits;
+        }
+        if (!is_root) { a.out_nodes[node_base + ((j & 1u) ? 1u : 2u) + 2 * r_parent] = nd; continue; }
+        a.cut_roots[c] = nd;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                         // the top-level builder's inputs (:251-256)
+            const T lo = nd.bounds[2 * k], hi = nd.bounds[2 * k + 1];
+            a.top_boxes[6ull * c + k] = lo;
+            a.top_boxes[6ull * c + 3 + k] = hi;
+            a.top_centers[3ull * c + k] = (hi + lo) * T(0.5);    // bbox.h:30
+        }
+    }
+}
+
 // the copy of a cut that is a whole mini-tree (r == 0, :239-240 + copy_node :275-279), one block per cut
 template <typename T>
 __global__ void __launch_bounds__(256) k_extract_whole(ExtractArgs<T> a) {
@@ -688,14 +812,37 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     ea.top_nodes = 2 * n_cuts - 1; ea.sc = scalars.p;
     const unsigned cg = (n_cuts + 63) / 64;
     uint32_t below = 0;
+    static const bool walk_per_cut = std::getenv("BVH_AMD_EXTRACT") && std::strcmp(std::getenv("BVH_AMD_EXTRACT"), "walk") == 0;    // A/B runs
+    const bool per_node = prune && !walk_per_cut;
+    DevBuf<uint32_t> x_parent, x_cut_of, x_arrived, x_inner, x_prims;
+    if (per_node) {
+        A(x_parent.alloc(forest_nodes)); A(x_cut_of.alloc(forest_nodes)); A(x_arrived.alloc(forest_nodes)); A(x_inner.alloc(forest_nodes)); A(x_prims.alloc(forest_nodes));
+        if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
+        BVH_HIP_TRY(hipMemsetAsync(x_cut_of.p, 0, size_t{forest_nodes} * 4, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMemsetAsync(x_arrived.p, 0, size_t{forest_nodes} * 4, stream), BVH_AMD_ERR_HIP);
+        hipLaunchKernelGGL(k_forest_parents<T>, dim3(n_trees), dim3(256), 0, stream, trees.p, tree_off.p, x_parent.p);
+        hipLaunchKernelGGL(k_cut_flags, dim3((n_cuts + 255) / 256), dim3(256), 0, stream, cuts.p, n_cuts, tree_off.p, x_cut_of.p);
+        hipLaunchKernelGGL(k_cut_counts<T>, dim3(n_trees), dim3(256), 0, stream, trees.p, tree_off.p, x_parent.p, x_cut_of.p, x_arrived.p, x_inner.p, x_prims.p);
+    }
     if (prune) {
         uint32_t prim_total = 0;
-        hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 0);
+        if (per_node) hipLaunchKernelGGL(k_cut_sizes<T>, dim3((n_cuts + 255) / 256), dim3(256), 0, stream, ea, x_inner.p, x_prims.p);
+        else hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 0);
         rc = exclusive_scan_u32(nm1.p, node_off.p, n_cuts, &below, stream);
         if (rc) return rc;
         rc = exclusive_scan_u32(np.p, prim_off.p, n_cuts, &prim_total, stream);
         if (rc) return rc;
         if (prim_total != n32) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree extraction lost primitives (walk stack overflow?)");
+        if (std::getenv("BVH_AMD_CUT_STATS")) {                // developer knob: sizes of the cut subtrees
+            std::vector<uint32_t> hn(n_cuts);
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(hn.data(), nm1.p, size_t{n_cuts} * 4, hipMemcpyDeviceToHost);
+            uint32_t bins[12] = {}; uint64_t sum = 0; uint32_t mx = 0;
+            for (uint32_t v : hn) { uint32_t b = 0; while ((2u << b) <= v + 1 && b < 11) ++b; bins[b]++; sum += v + 1; mx = std::max(mx, v + 1); }
+            fprintf(stderr, "[cuts] trees %u cuts %u mean nodes %.1f max %u; by nodes <2,<4,..:", n_trees, n_cuts, double(sum) / n_cuts, mx);
+            for (int b = 0; b < 12; ++b) fprintf(stderr, " %u", bins[b]);
+            fprintf(stderr, "\n");
+        }
     } else {
         // every mini-tree moves whole (:239-240): the count pass, its two scans and their host round trips have known results
         hipLaunchKernelGGL(k_whole_trees_as_cuts, dim3((n_trees + 255) / 256), dim3(256), 0, stream, n_trees, tree_off.p, group_begin.p, cuts.p,
@@ -705,7 +852,8 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     total_nodes = size_t{ea.top_nodes} + below;
     BVH_HIP_TRY(final_nodes.alloc(total_nodes), BVH_AMD_ERR_HIP);
     ea.out_nodes = final_nodes.p;
-    hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 1);
+    if (per_node) hipLaunchKernelGGL(k_cut_assign<T>, dim3(n_trees), dim3(256), 0, stream, ea, x_parent.p, x_cut_of.p, x_inner.p, x_prims.p);
+    else hipLaunchKernelGGL(k_extract<T>, dim3(cg), dim3(64), 0, stream, ea, 1);
     hipLaunchKernelGGL(k_extract_whole<T>, dim3(n_cuts), dim3(256), 0, stream, ea);
     if (prune) {                                              // (only the cut walks have a stack to overflow)
         { int rb_ = readback(&hs, scalars.p, sizeof(hs), stream); if (rb_) return rb_; }

@@ -48,9 +48,9 @@ __global__ void __launch_bounds__(256) k_subtree_counts(const HostNode<T>* nodes
     uint32_t cur = parent[i];
     if (cur == kNoParent) return;
     for (;;) {
-        __threadfence();                                      // release: this subtree's counts before the ticket
+        ticket_release();                                     // this subtree's counts before the ticket (build_common.h)
         if (atomicAdd(&arrived[cur], 1u) == 0) return;        // first child: the sibling's lane finishes this node
-        __threadfence();                                      // acquire
+        ticket_acquire();
         const uint32_t f = first_id(nodes[cur]);
         const uint32_t in = 1u + __hip_atomic_load(&inner[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                + __hip_atomic_load(&inner[f + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -931,9 +931,9 @@ __global__ void __launch_bounds__(256) k_refit(HostNode<T>* nodes, const uint32_
     uint32_t cur = parent[i];
     if (cur == 0xFFFFFFFFu) return;
     for (;;) {
-        __threadfence();                                      // release: this lane's box is visible before the ticket
+        ticket_release();                                     // this lane's box before the ticket (build_common.h: no cache maintenance needed)
         if (atomicAdd(&arrived[cur], 1u) == 0) return;        // first child: the sibling's lane finishes this node
-        __threadfence();                                      // acquire: see the sibling's box
+        ticket_acquire();
         HostNode<T>& nd = nodes[cur];
         const uint32_t f = first_of(nd);
         const T* l = nodes[f].bounds;

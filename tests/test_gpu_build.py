@@ -463,6 +463,33 @@ def test_refit_matches_reference(orc, dtype):
     assert g2.serialize() == a2.serialize()
 
 
+def test_refit_and_extract_at_a_million_triangles(orc):
+    """The bottom-up climbs of refit / extract_bvh hand subtrees from lane to lane through arrival tickets WITHOUT cache maintenance
+    (build_common.h: ticket_release / ticket_acquire): on a 1.9M-node tree the lanes of a climb sit on all eight XCDs, and a stale box
+    or count anywhere would show in the stream. Repeated, on a tree whose leaves moved."""
+    import bvh_amd
+    tris = synth.soup(1_000_000)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_LOW)
+    nodes, ids = ref.nodes().copy(), ref.prim_ids()
+    rng = np.random.default_rng(17)
+    leaves = np.flatnonzero(nodes["index"] & 15)
+    moved = rng.choice(leaves, size=len(leaves) // 2, replace=False)
+    shift = rng.normal(0, 0.01, size=(len(moved), 3)).astype(np.float32)
+    nodes["bounds"][moved, 0::2] += shift
+    nodes["bounds"][moved, 1::2] += shift
+    a = orc.from_arrays(nodes, ids)
+    a.refit()
+    want = a.serialize()
+    for rep in range(3):
+        g = bvh_amd.Bvh.from_nodes(nodes, ids)
+        g.refit()
+        assert g.serialize() == want, rep
+    g = bvh_amd.Bvh.from_nodes(ref.nodes(), ids)
+    for root in (1, 2):
+        assert g.extract_bvh(root).serialize() == ref.extract(root).serialize(), root
+
+
 def test_arrays_with_unused_sibling_pairs_refit_extract_trace_and_refuse_optimize(orc):
     """from_nodes / deserialize tolerate sibling pairs no inner node references (the reference tolerates them: nodes
     left behind by append_node / remove_last_node edits, hand-built arrays). Everything that walks parent links must then stop at the
@@ -584,6 +611,47 @@ def test_scratch_block_cache_across_streams_and_release(orc):
         del built
         if rep == 1:
             assert lib.bvh_amd_release_cached_memory() == 0
+
+
+def test_concurrent_builds_from_host_threads(orc):
+    """Quality::Low builds run their top level on a worker thread + stream of the calling thread (build_minitree.hip) and Phase B on a
+    CU-masked stream: four host threads building at once — on the default stream and on streams of their own — get the reference's
+    trees every time, as do Medium builds mixed in (they share the scratch cache, the readback words and the pool)."""
+    import threading
+    import torch
+    import bvh_amd
+    scenes = [synth.soup(120_000, seed=1), synth.terrain(150_000), synth.sponza_proxy(100_000), synth.soup(40_000, seed=7, jitter=0.03)]
+    prepared, want = [], []
+    for tris in scenes:
+        bb, cc = orc.prep_tris(tris)
+        want.append([orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=q).serialize() for q in (0, 1)])
+        prepared.append(bvh_amd.tri_bounds(torch.from_numpy(tris).cuda()))
+    torch.cuda.synchronize()
+    failures = []
+
+    def work(t, own_stream):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+            with torch.cuda.stream(stream):
+                for rep in range(6):
+                    i = (t + rep) % len(scenes)
+                    q = 0 if rep % 3 else 1
+                    bb, cc = prepared[i]
+                    b = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality(q)), thread_pool=bvh_amd.ThreadPool())
+                    if b.serialize() != want[i][q]:
+                        failures.append((t, rep, i, q))
+        except Exception as e:                                 # noqa: BLE001 - reported by the assertion below
+            failures.append((t, repr(e)))
+
+    for own_stream in (False, True):
+        threads = [threading.Thread(target=work, args=(t, own_stream)) for t in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize()
+        assert not failures, (own_stream, failures)
 
 
 @pytest.mark.parametrize("knob", ["BVH_AMD_CACHE_MB=0", "BVH_AMD_CACHE_MB=1", "BVH_AMD_POOL=0"])
