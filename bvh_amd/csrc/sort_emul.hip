@@ -166,7 +166,9 @@ struct SortSeg { uint32_t first, last, depth; };      // indices into the batche
 // depth 2 lg n and loses one per round (stl_algo.h:1945-1957), so 2 lg n + 1 rounds always suffice; rounds that find no
 // segment cost one small launch.
 constexpr uint32_t kSortMaxRounds = 66;
-struct SortCounters { uint32_t next[kSortMaxRounds + 2]; uint32_t error; };
+struct SortCounters { uint32_t next[kSortMaxRounds + 2]; uint32_t error, n_small, nan; };
+// Segments of at most this many ids leave the rounds: a block finishes each of them in LDS (k_sort_finish below)
+constexpr uint32_t kSortSmallMax = 4096;
 
 template <typename T>
 struct SortCtx {
@@ -177,6 +179,7 @@ struct SortCtx {
     uint32_t* ltab; uint32_t* rtab;                     // batch * n scratch
     SortCounters* counters;
     uint32_t seg_cap;
+    SortSeg* small_segs;                                // segments of 17 .. kSortSmallMax ids go here instead of the next round (nullptr: off)
 };
 
 constexpr int kSortThreads = 512;
@@ -214,6 +217,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, u
     }
     __syncthreads();
     const T pivot = key(ids[first]);
+    if (round == 0 && threadIdx.x == 0 && pivot != pivot) c.counters->nan = 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // pass 1: L (key >= pivot) and R (key <= pivot) position tables over [first + 1, last), both ascending. Every thread takes kItems
     // CONSECUTIVE positions per tile, so that a tile of 4096 positions costs one block scan (round 4: with one position per thread a
@@ -230,6 +234,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, u
                 const T kv = key(ids[pos]);
                 if (!(kv < pivot)) ml |= 1u << i;
                 if (!(pivot < kv)) mr |= 1u << i;
+                if (round == 0 && kv != kv) c.counters->nan = 1u;     // (round 0 sees every key; pivots are checked by the host path's fallback too)
             }
         }
         const uint32_t cl = __popc(ml), cr = __popc(mr);
@@ -279,8 +284,9 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, u
         const uint32_t cb[2] = { first, cut }, ce[2] = { cut, last };
         for (int s = 0; s < 2; ++s) {
             if (ce[s] - cb[s] > 16) {                                    // _S_threshold
-                const uint32_t slot = atomicAdd(&c.counters->next[round + 1], 1u);
-                if (slot < c.seg_cap) segs_out[slot] = SortSeg{ cb[s], ce[s], sg.depth - 1 };
+                const bool small = c.small_segs && ce[s] - cb[s] <= kSortSmallMax;
+                const uint32_t slot = atomicAdd(small ? &c.counters->n_small : &c.counters->next[round + 1], 1u);
+                if (slot < c.seg_cap) (small ? c.small_segs : segs_out)[slot] = SortSeg{ cb[s], ce[s], sg.depth - 1 };
                 else atomicOr(&c.counters->error, 1u);
             }
         }
@@ -288,45 +294,43 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, u
   }
 }
 
-// The whole of std::sort for arrays of at most kSortSmallMax ids (round 4): ONE launch, one block per array, ids and keys resident in LDS.
-// The mini-tree builder's top level without pruning sorts the roots of a 16^3 grid — three arrays of <= 4096 ids — and paid 25
-// partition rounds + a 4-pass radix sort + a host round trip for them: ~40 launches, 0.34 ms of a 2.1 ms build.
-//   * __introsort_loop (stl_algo.h:1945-1957): the same rounds as k_sort_partition, with a WAVE per segment (ballot prefix sums
-//     instead of block scans, no block barrier inside a segment) and a block barrier between rounds; segment lists in LDS (disjoint
-//     segments of more than 16 ids: at most 240).
-//   * __final_insertion_sort == the stable sort by key of the arrangement the rounds leave. Every id is then within 15 positions of
-//     its place (what is left unpartitioned is at most 16 long, and everything further left / right compares <= / >=), so an id's
-//     rank is its window's start + the ids of the window that sort before it. Keys that are NaN void that argument (std::sort
-//     itself is undefined for them): the block then ranks every id against all others — still a permutation, as the radix sort's.
-constexpr uint32_t kSortSmallMax = 4096;
+// std::sort of what fits in LDS (round 4): ids and keys of at most kSortSmallMax positions resident in one block.
+//   * k_std_sort_small: the WHOLE of std::sort for arrays of at most kSortSmallMax ids in ONE launch, one block per array. The mini-tree
+//     builder's top level without pruning sorts the roots of a 16^3 grid — three arrays of <= 4096 ids — and paid 25 partition rounds
+//     + a 4-pass radix sort + a host round trip for them: ~40 launches, 0.34 ms of a 2.1 ms build.
+//   * k_sort_finish: longer arrays run k_sort_partition's rounds only until a segment is down to kSortSmallMax ids; one block then
+//     takes such a segment through ALL its remaining rounds (its depth budget travels with it). The rounds past that point were most of
+//     them — 2 lg n + 1 launches, the late ones grid-striding blocks of 512 threads over tens of thousands of 20..60-id segments.
+// Both: __introsort_loop (stl_algo.h:1945-1957) with a WAVE per segment (ballot prefix sums instead of block scans, no block barrier
+// inside a segment), a block barrier between rounds, segment lists in LDS (disjoint segments of more than 16 ids: at most 240).
+// __final_insertion_sort == the stable sort by key of the arrangement the rounds leave. Every id is then within 15 positions of its
+// place (what is left unpartitioned is at most 16 long, and everything further left / right compares <= / >=), so an id's rank is
+// its window's start + the ids of the window that sort before it: k_std_sort_small ranks in LDS, k_sort_rank over the whole array
+// (instead of four radix passes). Keys that are NaN void that argument (std::sort itself is undefined for them): the small kernel
+// then ranks every id against all others, the long path falls back to the radix sort — a permutation either way.
 constexpr int kSortSmallThreads = 1024;
 
 template <typename T>
-__global__ void __launch_bounds__(kSortSmallThreads) k_std_sort_small(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t astride, uint32_t istride,
-                                                                      uint32_t depth0) {
-    using U = typename Ord<T>::U;
-    __shared__ T skey[kSortSmallMax];                     // by id
-    __shared__ uint32_t sid[kSortSmallMax];               // the array being sorted
-    __shared__ uint16_t ltab[kSortSmallMax], rtab[kSortSmallMax];
-    __shared__ uint32_t seg[2][256];                      // first | last << 12 | depth << 25
-    __shared__ uint32_t seg_count[2];
-    __shared__ uint32_t any_nan;
+struct SortLds {
+    T skey[kSortSmallMax];                               // by local id
+    uint32_t sid[kSortSmallMax];                         // the positions being sorted: local ids
+    uint16_t ltab[kSortSmallMax], rtab[kSortSmallMax];
+    uint32_t seg[2][256];                                // first | last << 12 | depth << 25
+    uint32_t seg_count[2];
+    uint32_t any_nan;
+};
+
+// skey / sid are loaded, seg[0][0] / seg_count[0] describe the one starting segment; all threads of the block call this
+template <typename T>
+__device__ void lds_introsort_rounds(SortLds<T>& L) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const T* kb = d_keys + size_t{blockIdx.x} * astride;
-    if (tid == 0) { seg[0][0] = 0u | (n << 12) | (depth0 << 25); seg_count[0] = n > 16 ? 1u : 0u; seg_count[1] = 0; any_nan = 0; }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += kSortSmallThreads) {
-        const T v = kb[size_t{i} * istride];
-        skey[i] = v; sid[i] = i;
-        if (v != v) any_nan = 1;
-    }
-    __syncthreads();
-    auto key = [&](uint32_t id) { return skey[id]; };
+    auto key = [&](uint32_t id) { return L.skey[id]; };
+    uint32_t* sid = L.sid;
     for (uint32_t round = 0;; ++round) {
-        const uint32_t cur = round & 1u, n_active = seg_count[cur];
+        const uint32_t cur = round & 1u, n_active = L.seg_count[cur];
         if (n_active == 0) break;
         for (uint32_t s = wave; s < n_active; s += kSortSmallThreads / 64) {
-            const uint32_t pk = seg[cur][s];
+            const uint32_t pk = L.seg[cur][s];
             const uint32_t first = pk & 0xFFFu, last = (pk >> 12) & 0x1FFFu, depth = pk >> 25, len = last - first;
             if (depth == 0) {                             // __partial_sort(first, last, last): heap sort
                 if (lane == 0) partial_sort_replay(sid + first, long(len), long(len), key);
@@ -352,8 +356,8 @@ __global__ void __launch_bounds__(kSortSmallThreads) k_std_sort_small(uint32_t* 
                 bool fl = false, fr = false;
                 if (pos < last) { const T kv = key(sid[pos]); fl = !(kv < pivot); fr = !(pivot < kv); }
                 const uint64_t bl = __ballot(fl), br = __ballot(fr);
-                if (fl) ltab[first + nl + __popcll(bl & below)] = static_cast<uint16_t>(pos);
-                if (fr) rtab[first + nr + __popcll(br & below)] = static_cast<uint16_t>(pos);
+                if (fl) L.ltab[first + nl + __popcll(bl & below)] = static_cast<uint16_t>(pos);
+                if (fr) L.rtab[first + nr + __popcll(br & below)] = static_cast<uint16_t>(pos);
                 nl += __popcll(bl); nr += __popcll(br);
             }
             wave_sync();
@@ -361,35 +365,53 @@ __global__ void __launch_bounds__(kSortSmallThreads) k_std_sort_small(uint32_t* 
             uint32_t k = 0;
             for (uint32_t j0 = 0; j0 < lim; j0 += 64) {
                 const uint32_t j = j0 + lane;
-                k += __popcll(__ballot(j < lim && ltab[first + j] < rtab[first + nr - 1 - j]));
+                k += __popcll(__ballot(j < lim && L.ltab[first + j] < L.rtab[first + nr - 1 - j]));
             }
             for (uint32_t j0 = 0; j0 < k; j0 += 64) {    // the swaps
                 const uint32_t j = j0 + lane;
                 if (j < k) {
-                    const uint32_t p = ltab[first + j], q = rtab[first + nr - 1 - j];
+                    const uint32_t p = L.ltab[first + j], q = L.rtab[first + nr - 1 - j];
                     const uint32_t a = sid[p], b = sid[q];
                     sid[p] = b; sid[q] = a;
                 }
             }
             if (lane == 0) {
                 uint32_t cut;
-                if (k == 0) cut = ltab[first];
+                if (k == 0) cut = L.ltab[first];
                 else {
-                    const uint32_t rk1 = rtab[first + nr - k];               // R_{k-1}
-                    cut = (k < nl && ltab[first + k] < rk1) ? ltab[first + k] : rk1;
+                    const uint32_t rk1 = L.rtab[first + nr - k];             // R_{k-1}
+                    cut = (k < nl && L.ltab[first + k] < rk1) ? L.ltab[first + k] : rk1;
                 }
                 const uint32_t cb[2] = { first, cut }, ce[2] = { cut, last };
                 for (int h = 0; h < 2; ++h)
-                    if (ce[h] - cb[h] > 16) seg[cur ^ 1u][atomicAdd(&seg_count[cur ^ 1u], 1u)] = cb[h] | (ce[h] << 12) | ((depth - 1) << 25);
+                    if (ce[h] - cb[h] > 16) L.seg[cur ^ 1u][atomicAdd(&L.seg_count[cur ^ 1u], 1u)] = cb[h] | (ce[h] << 12) | ((depth - 1) << 25);
             }
         }
         __syncthreads();
-        if (tid == 0) seg_count[cur] = 0;
+        if (tid == 0) L.seg_count[cur] = 0;
         __syncthreads();
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kSortSmallThreads) k_std_sort_small(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t astride, uint32_t istride,
+                                                                      uint32_t depth0) {
+    using U = typename Ord<T>::U;
+    __shared__ SortLds<T> L;
+    const uint32_t tid = threadIdx.x;
+    const T* kb = d_keys + size_t{blockIdx.x} * astride;
+    if (tid == 0) { L.seg[0][0] = 0u | (n << 12) | (depth0 << 25); L.seg_count[0] = n > 16 ? 1u : 0u; L.seg_count[1] = 0; L.any_nan = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kSortSmallThreads) {
+        const T v = kb[size_t{i} * istride];
+        L.skey[i] = v; L.sid[i] = i;                      // local id = id
+        if (v != v) L.any_nan = 1;
+    }
+    __syncthreads();
+    lds_introsort_rounds(L);
     // __final_insertion_sort
-    auto image = [&](uint32_t pos) { T v = skey[sid[pos]]; if (v == T(0)) v = T(0); return Ord<T>::enc(v); };    // -0 and +0 are EQUAL keys for operator<
-    const bool all = any_nan != 0;
+    auto image = [&](uint32_t pos) { T v = L.skey[L.sid[pos]]; if (v == T(0)) v = T(0); return Ord<T>::enc(v); };    // -0 and +0 are EQUAL keys for operator<
+    const bool all = L.any_nan != 0;
     uint32_t* out = d_ids + size_t{blockIdx.x} * n;
     for (uint32_t p = tid; p < n; p += kSortSmallThreads) {
         const U kp = image(p);
@@ -399,8 +421,57 @@ __global__ void __launch_bounds__(kSortSmallThreads) k_std_sort_small(uint32_t* 
             const U kj = image(j);
             rank += (kj < kp || (kj == kp && j < p)) ? 1u : 0u;
         }
-        out[rank] = sid[p];
+        out[rank] = L.sid[p];
     }
+}
+
+// one block per segment that left k_sort_partition's rounds with at most kSortSmallMax ids: its remaining rounds, in place
+template <typename T>
+__global__ void __launch_bounds__(kSortSmallThreads) k_sort_finish(SortCtx<T> c) {
+    __shared__ SortLds<T> L;
+    __shared__ uint32_t orig[kSortSmallMax];              // local id -> id
+    const uint32_t tid = threadIdx.x;
+    const SortSeg sg = c.small_segs[blockIdx.x];
+    const uint32_t len = sg.last - sg.first;
+    const T* kb = c.keys + size_t{sg.first / c.n} * c.astride;
+    if (tid == 0) { L.seg[0][0] = 0u | (len << 12) | (sg.depth << 25); L.seg_count[0] = 1u; L.seg_count[1] = 0; }
+    for (uint32_t p = tid; p < len; p += kSortSmallThreads) {
+        const uint32_t id = c.ids[sg.first + p];
+        orig[p] = id; L.sid[p] = p;
+        L.skey[p] = kb[size_t{id} * c.istride];
+    }
+    __syncthreads();
+    lds_introsort_rounds(L);
+    for (uint32_t p = tid; p < len; p += kSortSmallThreads) c.ids[sg.first + p] = orig[L.sid[p]];
+}
+
+// __final_insertion_sort over whole arrays: rank of every position within its window of 31 (see above), 256 positions per block
+template <typename T>
+__global__ void __launch_bounds__(256) k_sort_rank(const uint32_t* ids, const T* keys, uint32_t n, uint32_t astride, uint32_t istride, uint32_t* out) {
+    using U = typename Ord<T>::U;
+    __shared__ U img[256 + 30];
+    const uint32_t arr = blockIdx.y, base = blockIdx.x * 256;
+    const uint32_t* a = ids + size_t{arr} * n;
+    const T* kb = keys + size_t{arr} * astride;
+    for (uint32_t q = threadIdx.x; q < 256 + 30; q += 256) {
+        const long pos = long(base) - 15 + long(q);
+        if (pos >= 0 && pos < long(n)) {
+            T v = kb[size_t{a[pos]} * istride];
+            if (v == T(0)) v = T(0);                      // -0 and +0 are EQUAL keys for operator<
+            img[q] = Ord<T>::enc(v);
+        }
+    }
+    __syncthreads();
+    const uint32_t p = base + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t lo = p >= 15u ? p - 15u : 0u, hi = min(n, p + 16u);
+    const U kp = img[threadIdx.x + 15];
+    uint32_t rank = lo;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const U kj = img[j - base + 15];
+        rank += (kj < kp || (kj == kp && j < p)) ? 1u : 0u;
+    }
+    out[size_t{arr} * n + rank] = a[p];
 }
 
 template <typename T>
@@ -537,17 +608,19 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
     const uint32_t total = n * batch;
     hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, stream, d_ids, n, total);
     using U = typename Ord<T>::U;
+    static const bool finish_off = std::getenv("BVH_AMD_SORT_FINISH") && std::atoi(std::getenv("BVH_AMD_SORT_FINISH")) == 0;   // A/B runs: every round global + radix sort
     DevBuf<uint32_t> ltab, rtab, vals_tmp;
-    DevBuf<SortSeg> seg_a, seg_b;
+    DevBuf<SortSeg> seg_a, seg_b, seg_small;
     DevBuf<SortCounters> counters;
-    DevBuf<U> skeys, skeys_tmp;
     const uint32_t seg_cap = total / 16 + batch + 2;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(ltab.alloc(total)); A(rtab.alloc(total)); A(vals_tmp.alloc(total)); A(seg_a.alloc(seg_cap)); A(seg_b.alloc(seg_cap));
-    A(counters.alloc(1)); A(skeys.alloc(total)); A(skeys_tmp.alloc(total));
+    if (!finish_off) A(seg_small.alloc(seg_cap));
+    A(counters.alloc(1));
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("std_sort_ids: hipMalloc: ") + hipGetErrorString(e));
 
+    bool ranked_by_window = false;
     if (n > 16) {
         uint32_t lg = 0;
         while ((uint64_t{2} << lg) <= n) ++lg;            // std::__lg(n) = floor(log2 n)
@@ -557,18 +630,48 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
         SortCtx<T> c;
         c.ids = d_ids; c.keys = d_keys; c.n = n; c.astride = astride; c.istride = istride;
         c.segs = seg_a.p; c.segs_next = seg_b.p; c.ltab = ltab.p; c.rtab = rtab.p; c.counters = counters.p; c.seg_cap = seg_cap;
+        c.small_segs = finish_off ? nullptr : seg_small.p;
         BVH_HIP_TRY(hipMemsetAsync(counters.p, 0, sizeof(SortCounters), stream), BVH_AMD_ERR_HIP);
         const uint32_t rounds = 2 * lg + 1;                   // <= kSortMaxRounds for any 32-bit n
         // one block per segment; disjoint segments of more than 16 ids each bound their number, a grid-stride loop covers the rest
         const uint32_t grid = std::max<uint32_t>(batch, std::min<uint32_t>(total / 17 + 1, 2048u));
-        for (uint32_t r = 0; r < rounds; ++r)
-            hipLaunchKernelGGL(k_sort_partition<T>, dim3(r == 0 ? batch : grid), dim3(kSortThreads), 0, stream, c, r, batch);
+        uint32_t r = 0;
+        auto launch_rounds = [&](uint32_t upto) {
+            for (; r < upto; ++r) hipLaunchKernelGGL(k_sort_partition<T>, dim3(r == 0 ? batch : grid), dim3(kSortThreads), 0, stream, c, r, batch);
+        };
+        if (finish_off) launch_rounds(rounds);
+        else {
+            // Rounds go on only while a segment longer than kSortSmallMax exists: lg(n / kSortSmallMax) rounds if every pivot halved its
+            // segment; medians of three do nearly that, so a few more are launched before the host looks at the list's length, then four
+            // at a time (the bound stays 2 lg n + 1: past its depth budget a segment is heap-sorted in place).
+            uint32_t expect = 3;
+            while ((uint64_t{kSortSmallMax} << (expect - 3)) < n) ++expect;
+            uint32_t big = 1;
+            while (big && r < rounds) {
+                launch_rounds(std::min(rounds, r + (r == 0 ? expect : 4u)));
+                BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+                if (r < rounds) { int rb_ = readback(&big, &counters.p->next[r], sizeof(big), stream); if (rb_) return rb_; }
+            }
+        }
         BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
-        uint32_t err = 0;
-        { int rb_ = readback(&err, &counters.p->error, sizeof(err), stream); if (rb_) return rb_; }
-        if (err) return fail(BVH_AMD_ERR_OVERFLOW, "std_sort_ids: segment capacity exceeded");
+        uint32_t tail[3] = {0, 0, 0};                         // error, n_small, nan
+        { int rb_ = readback(tail, &counters.p->error, sizeof(tail), stream); if (rb_) return rb_; }
+        if (tail[0]) return fail(BVH_AMD_ERR_OVERFLOW, "std_sort_ids: segment capacity exceeded");
+        if (tail[1]) hipLaunchKernelGGL(k_sort_finish<T>, dim3(tail[1]), dim3(kSortSmallThreads), 0, stream, c);
+        ranked_by_window = !finish_off && tail[2] == 0;
+    }
+    if (ranked_by_window) {
+        // __final_insertion_sort by window ranks (see k_sort_rank); into the scratch copy, then back
+        hipLaunchKernelGGL(k_sort_rank<T>, dim3((n + 255) / 256, batch), dim3(256), 0, stream, d_ids, d_keys, n, astride, istride, vals_tmp.p);
+        BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipMemcpyAsync(d_ids, vals_tmp.p, size_t{total} * 4, hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
+        if (!scratch_pool_enabled()) BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);   // plain hipFree of the workspace on return
+        return BVH_AMD_OK;
     }
     // __final_insertion_sort == stable sort by key of the current arrangement
+    DevBuf<U> skeys, skeys_tmp;
+    A(skeys.alloc(total)); A(skeys_tmp.alloc(total));
+    if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("std_sort_ids: hipMalloc: ") + hipGetErrorString(e));
     hipLaunchKernelGGL(k_make_sort_keys<T>, dim3((total + 255) / 256), dim3(256), 0, stream, d_ids, d_keys, n, total, astride, istride, skeys.p);
     return radix_sort_pairs<U>(skeys.p, d_ids, skeys_tmp.p, vals_tmp.p, n, batch, int(sizeof(U) * 8), stream);
 }
