@@ -180,7 +180,12 @@ struct SortCtx {
     SortCounters* counters;
     uint32_t seg_cap;
     SortSeg* small_segs;                                // segments of 17 .. kSortSmallMax ids go here instead of the next round (nullptr: off)
+    uint2* chunk_cnt;                                   // huge segments: (L, R) counts, then offsets, per kSortChunk ABSOLUTE positions
+    struct HugeState* huge;                             // per segment of the round's list
+    uint32_t skip_huge;                                 // k_sort_partition leaves segments of more than kSortHuge ids to the k_sort_huge_* kernels
 };
+struct HugeState { uint32_t nl, nr, k, pad; };
+constexpr uint32_t kSortHuge = 32768, kSortChunk = 4096;
 
 constexpr int kSortThreads = 512;
 
@@ -204,6 +209,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, u
         if (threadIdx.x == 0) partial_sort_replay(ids + first, long(len), long(len), key);
         continue;
     }
+    if (c.skip_huge && len > kSortHuge) continue;        // partitioned by many blocks (k_sort_huge_*)
     if (threadIdx.x == 0) {                              // __move_median_to_first(first, first + 1, mid, last - 1)
         const uint32_t a = first + 1, b = first + len / 2, cc = last - 1;
         const T ka = key(ids[a]), kbv = key(ids[b]), kc = key(ids[cc]);
@@ -292,6 +298,222 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_partition(SortCtx<T> c, u
         }
     }
   }
+}
+
+// ---- one partition step of a HUGE segment by many blocks (round 4) ---------------------------------------------------------------------
+// k_sort_partition gives a segment to one block: the first rounds of a long array are a few blocks walking hundreds of thousands of ids
+// each (1M ids x 3 axes: 1.7 + 1.5 + 1.0 + 0.6 + 0.4 ms for rounds 0-4, half of a serial Medium build). The same step for segments
+// of more than kSortHuge ids, cut into chunks of kSortChunk ABSOLUTE positions (so a chunk's slot in chunk_cnt needs no allocation):
+// (two slots per window of positions: a window is shared by at most two huge segments, one ending and one starting in it)
+//   median  (a lane per segment)  __move_median_to_first
+//   count   (a block per chunk)   how many L (key >= pivot) and R (key <= pivot) positions the chunk holds
+//   scan    (a block per segment) chunk counts -> chunk offsets, totals nl / nr
+//   write   (a block per chunk)   the chunk's L / R positions into ltab / rtab behind its offset, ascending
+//   k       (blocks over j)       k = #{j : L_j < R_j}
+//   swap    (blocks over j)       the k swaps; one lane computes the cut and appends the two sides to the next lists
+// — the same tables, the same k, the same swaps and cut as k_sort_partition's three passes. Blocks stride over chunks / segments, so
+// the grid only has to be roughly right; segments that are not huge (or out of depth) stay with k_sort_partition in the same round.
+template <typename T> struct SortView {
+    const SortSeg* segs_in; SortSeg* segs_out; uint32_t n_active;
+    __device__ SortView(const SortCtx<T>& c, uint32_t round, uint32_t first_count) {
+        n_active = round == 0 ? first_count : min(c.counters->next[round], c.seg_cap);
+        segs_in = (round & 1u) ? c.segs_next : c.segs;
+        segs_out = (round & 1u) ? c.segs : c.segs_next;
+    }
+};
+__device__ inline bool sort_is_huge(const SortSeg& sg) { return sg.depth != 0 && sg.last - sg.first > kSortHuge; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_sort_huge_median(SortCtx<T> c, uint32_t round, uint32_t first_count) {
+    const SortView<T> v(c, round, first_count);
+    const uint32_t seg_id = blockIdx.x * 256 + threadIdx.x;
+    if (seg_id >= v.n_active) return;
+    const SortSeg sg = v.segs_in[seg_id];
+    if (!sort_is_huge(sg)) return;
+    const T* kb = c.keys + size_t{sg.first / c.n} * c.astride;
+    auto key = [&](uint32_t id) { return kb[size_t{id} * c.istride]; };
+    uint32_t* ids = c.ids;
+    const uint32_t first = sg.first, a = first + 1, b = first + (sg.last - first) / 2, cc = sg.last - 1;
+    const T ka = key(ids[a]), kbv = key(ids[b]), kc = key(ids[cc]);
+    uint32_t pick;
+    if (ka < kbv) { if (kbv < kc) pick = b; else if (ka < kc) pick = cc; else pick = a; }
+    else if (ka < kc) pick = a;
+    else if (kbv < kc) pick = cc;
+    else pick = b;
+    const uint32_t t = ids[first]; ids[first] = ids[pick]; ids[pick] = t;
+    if (round == 0 && key(ids[first]) != key(ids[first])) c.counters->nan = 1u;
+}
+
+// flags of one chunk: thread t owns 8 consecutive positions (kSortThreads x 8 = kSortChunk)
+template <typename T, typename KeyFn>
+__device__ inline void sort_chunk_flags(const uint32_t* ids, KeyFn key, T pivot, uint32_t lo, uint32_t hi, uint32_t chunk_base, uint32_t& ml, uint32_t& mr, bool& nan) {
+    ml = 0; mr = 0;
+    const uint32_t p0 = chunk_base + threadIdx.x * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t pos = p0 + i;
+        if (pos >= lo && pos < hi) {
+            const T kv = key(ids[pos]);
+            if (!(kv < pivot)) ml |= 1u << i;
+            if (!(pivot < kv)) mr |= 1u << i;
+            nan = nan || kv != kv;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kSortThreads) k_sort_huge_count(SortCtx<T> c, uint32_t round, uint32_t first_count) {
+    static_assert(kSortThreads * 8 == kSortChunk);
+    __shared__ uint32_t wl[8], wr[8];
+    const SortView<T> v(c, round, first_count);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t seg_id = blockIdx.y; seg_id < v.n_active; seg_id += gridDim.y) {
+        const SortSeg sg = v.segs_in[seg_id];
+        if (!sort_is_huge(sg)) continue;
+        const T* kb = c.keys + size_t{sg.first / c.n} * c.astride;
+        const uint32_t istride = c.istride;
+        auto key = [=](uint32_t id) { return kb[size_t{id} * istride]; };
+        const T pivot = key(c.ids[sg.first]);
+        const uint32_t lo = sg.first + 1, hi = sg.last, g0 = lo / kSortChunk, g1 = (hi - 1) / kSortChunk;
+        for (uint32_t g = g0 + blockIdx.x; g <= g1; g += gridDim.x) {
+            uint32_t ml, mr; bool nan = false;
+            sort_chunk_flags<T>(c.ids, key, pivot, lo, hi, g * kSortChunk, ml, mr, nan);
+            if (round == 0 && nan) c.counters->nan = 1u;
+            uint32_t cl = __popc(ml), cr = __popc(mr);
+            for (int off = 32; off > 0; off >>= 1) { cl += __shfl_down(cl, off); cr += __shfl_down(cr, off); }
+            __syncthreads();
+            if (lane == 0) { wl[wave] = cl; wr[wave] = cr; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tl = 0, tr = 0;
+                for (int w = 0; w < kSortThreads / 64; ++w) { tl += wl[w]; tr += wr[w]; }
+                c.chunk_cnt[2 * g + (g != g0)] = make_uint2(tl, tr);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_sort_huge_scan(SortCtx<T> c, uint32_t round, uint32_t first_count) {
+    __shared__ uint32_t wl[4], wr[4];
+    __shared__ uint32_t run_l, run_r;
+    const SortView<T> v(c, round, first_count);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t seg_id = blockIdx.x; seg_id < v.n_active; seg_id += gridDim.x) {
+        const SortSeg sg = v.segs_in[seg_id];
+        if (!sort_is_huge(sg)) continue;
+        const uint32_t g0 = (sg.first + 1) / kSortChunk, g1 = (sg.last - 1) / kSortChunk;
+        __syncthreads();
+        if (threadIdx.x == 0) { run_l = 0; run_r = 0; }
+        __syncthreads();
+        for (uint32_t base = g0; base <= g1; base += 256) {
+            const uint32_t g = base + threadIdx.x;
+            const uint2 cnt = g <= g1 ? c.chunk_cnt[2 * g + (g != g0)] : make_uint2(0, 0);
+            uint32_t il = cnt.x, ir = cnt.y;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t ol = __shfl_up(il, d), orr = __shfl_up(ir, d);
+                if (lane >= d) { il += ol; ir += orr; }
+            }
+            if (lane == 63) { wl[wave] = il; wr[wave] = ir; }
+            __syncthreads();
+            uint32_t el = run_l + il - cnt.x, er = run_r + ir - cnt.y, tl = 0, tr = 0;
+            for (int w = 0; w < 4; ++w) { if (w < wave) { el += wl[w]; er += wr[w]; } tl += wl[w]; tr += wr[w]; }
+            if (g <= g1) c.chunk_cnt[2 * g + (g != g0)] = make_uint2(el, er);
+            __syncthreads();
+            if (threadIdx.x == 0) { run_l += tl; run_r += tr; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { HugeState hs; hs.nl = run_l; hs.nr = run_r; hs.k = 0; hs.pad = 0; c.huge[seg_id] = hs; }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kSortThreads) k_sort_huge_write(SortCtx<T> c, uint32_t round, uint32_t first_count) {
+    __shared__ uint32_t wl[8], wr[8];
+    const SortView<T> v(c, round, first_count);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t seg_id = blockIdx.y; seg_id < v.n_active; seg_id += gridDim.y) {
+        const SortSeg sg = v.segs_in[seg_id];
+        if (!sort_is_huge(sg)) continue;
+        const T* kb = c.keys + size_t{sg.first / c.n} * c.astride;
+        const uint32_t istride = c.istride;
+        auto key = [=](uint32_t id) { return kb[size_t{id} * istride]; };
+        const T pivot = key(c.ids[sg.first]);
+        const uint32_t first = sg.first, lo = first + 1, hi = sg.last, g0 = lo / kSortChunk, g1 = (hi - 1) / kSortChunk;
+        for (uint32_t g = g0 + blockIdx.x; g <= g1; g += gridDim.x) {
+            uint32_t ml, mr; bool nan = false;
+            sort_chunk_flags<T>(c.ids, key, pivot, lo, hi, g * kSortChunk, ml, mr, nan);
+            const uint32_t cl = __popc(ml), cr = __popc(mr);
+            uint32_t il = cl, ir = cr;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t ol = __shfl_up(il, d), orr = __shfl_up(ir, d);
+                if (lane >= d) { il += ol; ir += orr; }
+            }
+            __syncthreads();
+            if (lane == 63) { wl[wave] = il; wr[wave] = ir; }
+            __syncthreads();
+            const uint2 off = c.chunk_cnt[2 * g + (g != g0)];
+            uint32_t el = off.x + il - cl, er = off.y + ir - cr;
+            for (int w = 0; w < wave; ++w) { el += wl[w]; er += wr[w]; }
+            const uint32_t p0 = g * kSortChunk + threadIdx.x * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (ml & (1u << i)) c.ltab[first + el + __popc(ml & ((1u << i) - 1u))] = p0 + i;
+                if (mr & (1u << i)) c.rtab[first + er + __popc(mr & ((1u << i) - 1u))] = p0 + i;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_sort_huge_k(SortCtx<T> c, uint32_t round, uint32_t first_count) {
+    const SortView<T> v(c, round, first_count);
+    for (uint32_t seg_id = blockIdx.y; seg_id < v.n_active; seg_id += gridDim.y) {
+        const SortSeg sg = v.segs_in[seg_id];
+        if (!sort_is_huge(sg)) continue;
+        const HugeState hs = c.huge[seg_id];
+        const uint32_t lim = min(hs.nl, hs.nr), first = sg.first;
+        uint32_t mine = 0;
+        for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < lim; j += gridDim.x * 256)
+            mine += c.ltab[first + j] < c.rtab[first + hs.nr - 1 - j] ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&c.huge[seg_id].k, mine);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_sort_huge_swap(SortCtx<T> c, uint32_t round, uint32_t first_count) {
+    const SortView<T> v(c, round, first_count);
+    for (uint32_t seg_id = blockIdx.y; seg_id < v.n_active; seg_id += gridDim.y) {
+        const SortSeg sg = v.segs_in[seg_id];
+        if (!sort_is_huge(sg)) continue;
+        const HugeState hs = c.huge[seg_id];
+        const uint32_t first = sg.first, last = sg.last, k = hs.k, nl = hs.nl, nr = hs.nr;
+        for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < k; j += gridDim.x * 256) {
+            const uint32_t p = c.ltab[first + j], q = c.rtab[first + nr - 1 - j];
+            const uint32_t a = c.ids[p], b = c.ids[q];
+            c.ids[p] = b; c.ids[q] = a;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            uint32_t cut;
+            if (k == 0) cut = c.ltab[first];
+            else {
+                const uint32_t rk1 = c.rtab[first + nr - k];                 // R_{k-1}
+                cut = (k < nl && c.ltab[first + k] < rk1) ? c.ltab[first + k] : rk1;
+            }
+            const uint32_t cb[2] = { first, cut }, ce[2] = { cut, last };
+            for (int h = 0; h < 2; ++h) {
+                if (ce[h] - cb[h] > 16) {                                    // _S_threshold
+                    const bool small = c.small_segs && ce[h] - cb[h] <= kSortSmallMax;
+                    const uint32_t slot = atomicAdd(small ? &c.counters->n_small : &c.counters->next[round + 1], 1u);
+                    if (slot < c.seg_cap) (small ? c.small_segs : v.segs_out)[slot] = SortSeg{ cb[h], ce[h], sg.depth - 1 };
+                    else atomicOr(&c.counters->error, 1u);
+                }
+            }
+        }
+    }
 }
 
 // std::sort of what fits in LDS (round 4): ids and keys of at most kSortSmallMax positions resident in one block.
@@ -612,11 +834,18 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
     DevBuf<uint32_t> ltab, rtab, vals_tmp;
     DevBuf<SortSeg> seg_a, seg_b, seg_small;
     DevBuf<SortCounters> counters;
+    DevBuf<uint2> chunk_cnt;
+    DevBuf<HugeState> huge;
     const uint32_t seg_cap = total / 16 + batch + 2;
+    static const bool huge_off = std::getenv("BVH_AMD_SORT_HUGE") && std::atoi(std::getenv("BVH_AMD_SORT_HUGE")) == 0;         // A/B runs: one block per segment always
+    uint32_t huge_rounds = 0;                             // rounds that get the many-block step: until halving would have ended it, + 3
+    if (!huge_off && n > kSortHuge) { huge_rounds = 4; while ((uint64_t{kSortHuge} << (huge_rounds - 4)) < n) ++huge_rounds; }
+    const uint32_t huge_cap = static_cast<uint32_t>(std::min<uint64_t>(seg_cap, uint64_t{batch} << std::min(huge_rounds, 24u))) + 1;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(ltab.alloc(total)); A(rtab.alloc(total)); A(vals_tmp.alloc(total)); A(seg_a.alloc(seg_cap)); A(seg_b.alloc(seg_cap));
     if (!finish_off) A(seg_small.alloc(seg_cap));
+    if (huge_rounds) { A(chunk_cnt.alloc(2 * (size_t{total} / kSortChunk + 2))); A(huge.alloc(huge_cap)); }
     A(counters.alloc(1));
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("std_sort_ids: hipMalloc: ") + hipGetErrorString(e));
 
@@ -631,13 +860,29 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
         c.ids = d_ids; c.keys = d_keys; c.n = n; c.astride = astride; c.istride = istride;
         c.segs = seg_a.p; c.segs_next = seg_b.p; c.ltab = ltab.p; c.rtab = rtab.p; c.counters = counters.p; c.seg_cap = seg_cap;
         c.small_segs = finish_off ? nullptr : seg_small.p;
+        c.chunk_cnt = chunk_cnt.p; c.huge = huge.p; c.skip_huge = 0;
         BVH_HIP_TRY(hipMemsetAsync(counters.p, 0, sizeof(SortCounters), stream), BVH_AMD_ERR_HIP);
         const uint32_t rounds = 2 * lg + 1;                   // <= kSortMaxRounds for any 32-bit n
         // one block per segment; disjoint segments of more than 16 ids each bound their number, a grid-stride loop covers the rest
         const uint32_t grid = std::max<uint32_t>(batch, std::min<uint32_t>(total / 17 + 1, 2048u));
         uint32_t r = 0;
         auto launch_rounds = [&](uint32_t upto) {
-            for (; r < upto; ++r) hipLaunchKernelGGL(k_sort_partition<T>, dim3(r == 0 ? batch : grid), dim3(kSortThreads), 0, stream, c, r, batch);
+            for (; r < upto; ++r) {
+                c.skip_huge = r < huge_rounds ? 1u : 0u;
+                if (c.skip_huge) {
+                    // at most batch << r segments in round r's list; chunks per segment as if the pivots had quartered instead of halved
+                    const uint32_t segs = static_cast<uint32_t>(std::min<uint64_t>(uint64_t{batch} << r, huge_cap));
+                    const uint32_t per_seg = std::max<uint32_t>(1u, (n / kSortChunk + 1) >> (r > 2 ? r - 2 : 0));
+                    const dim3 by_chunk(per_seg, std::min<uint32_t>(segs, 4096u));
+                    hipLaunchKernelGGL(k_sort_huge_median<T>, dim3((segs + 255) / 256), dim3(256), 0, stream, c, r, batch);
+                    hipLaunchKernelGGL(k_sort_huge_count<T>, by_chunk, dim3(kSortThreads), 0, stream, c, r, batch);
+                    hipLaunchKernelGGL(k_sort_huge_scan<T>, dim3(std::min<uint32_t>(segs, 4096u)), dim3(256), 0, stream, c, r, batch);
+                    hipLaunchKernelGGL(k_sort_huge_write<T>, by_chunk, dim3(kSortThreads), 0, stream, c, r, batch);
+                    hipLaunchKernelGGL(k_sort_huge_k<T>, by_chunk, dim3(256), 0, stream, c, r, batch);
+                    hipLaunchKernelGGL(k_sort_huge_swap<T>, by_chunk, dim3(256), 0, stream, c, r, batch);
+                }
+                hipLaunchKernelGGL(k_sort_partition<T>, dim3(r == 0 ? batch : grid), dim3(kSortThreads), 0, stream, c, r, batch);
+            }
         };
         if (finish_off) launch_rounds(rounds);
         else {
