@@ -105,7 +105,9 @@ void scratch_free(void* p, const ScratchTag& tag) {
                     if (!from || it->second.age < oldest->second.age) { from = &l.second; oldest = it; on = l.first.second; }
             }
             if (!from) break;
-            if (hipFreeAsync(oldest->second.p, on) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(oldest->second.p); }   // (a stream destroyed since)
+            // (a stream destroyed since: the free is ordered on the null stream instead — any stream may free stream-ordered memory; a
+            //  plain hipFree would have the runtime look at the allocating stream again)
+            if (hipFreeAsync(oldest->second.p, on) != hipSuccess) { (void)hipGetLastError(); if (hipFreeAsync(oldest->second.p, nullptr) != hipSuccess) (void)hipGetLastError(); }
             c.cached_bytes[dev] -= oldest->first;
             from->erase(oldest);
         }
@@ -122,10 +124,27 @@ void scratch_cache_flush() {
     for (auto l = c.lists.begin(); l != c.lists.end();) {
         if (l->first.first != dev) { ++l; continue; }
         for (auto& b : l->second)
-            if (hipFreeAsync(b.second.p, l->first.second) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(b.second.p); }
+            if (hipFreeAsync(b.second.p, l->first.second) != hipSuccess) { (void)hipGetLastError(); if (hipFreeAsync(b.second.p, nullptr) != hipSuccess) (void)hipGetLastError(); }
         l = c.lists.erase(l);
     }
     if (dev >= 0 && dev < 64) c.cached_bytes[dev] = 0;
+}
+
+// A stream the library itself owns (the mini-tree builder's worker stream) is about to be destroyed: nothing may stay cached under
+// its handle — a later eviction would hand the runtime a dead stream (seen as a hang of the GPU suite, round 4: the first eviction
+// after host threads with worker streams of their own had ended).
+void scratch_cache_drop_stream(hipStream_t s) {
+    ScratchCache& c = scratch_cache();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(c.m);
+    auto l = c.lists.find({ dev, s });
+    if (l == c.lists.end()) return;
+    for (auto& b : l->second) {
+        if (hipFreeAsync(b.second.p, s) != hipSuccess) { (void)hipGetLastError(); if (hipFreeAsync(b.second.p, nullptr) != hipSuccess) (void)hipGetLastError(); }
+        if (dev >= 0 && dev < 64) c.cached_bytes[dev] -= b.first;
+    }
+    c.lists.erase(l);
 }
 
 namespace {

@@ -622,7 +622,17 @@ struct TopHelper {                                            // per calling thr
     hipStream_t phase_b = nullptr;
     hipEvent_t phase_b_done = nullptr;
     void release() {
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) {                                         // the worker's scratch is cached under this handle: hand it back first
+            int cur = -1;
+            static const bool keep = std::getenv("BVH_AMD_DROP_ON_DESTROY") && std::atoi(std::getenv("BVH_AMD_DROP_ON_DESTROY")) == 0;   // developer knob (reproduces the hang)
+            if (!keep && hipGetDevice(&cur) == hipSuccess) {
+                if (cur != device) (void)hipSetDevice(device);
+                scratch_cache_drop_stream(stream);
+                (void)hipStreamSynchronize(stream);
+                if (cur != device) (void)hipSetDevice(cur);
+            }
+            (void)hipStreamDestroy(stream);
+        }
         if (phase_b) (void)hipStreamDestroy(phase_b);
         for (hipEvent_t* e : { &roots, &done, &spliced, &phase_b_done }) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
         stream = nullptr; phase_b = nullptr; device = -1;

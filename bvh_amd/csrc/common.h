@@ -191,6 +191,7 @@ struct ScratchTag {                            // what scratch_free needs to kno
 hipError_t scratch_alloc(void** p, size_t bytes, ScratchTag* tag);
 void scratch_free(void* p, const ScratchTag& tag);
 void scratch_cache_flush();                    // hands every cached block of the current device back to the pool (hipFreeAsync)
+void scratch_cache_drop_stream(hipStream_t s); // the same for the blocks cached under one stream of the current device: call BEFORE destroying a stream the library owns
 
 // A few bytes (<= 256, 4-byte aligned) from device memory to the host, in stream order, WITHOUT a stream synchronisation: a
 // one-lane kernel copies them into coherent pinned host memory and publishes a sequence number, the host spins on it (falls back to
