@@ -300,7 +300,16 @@ __device__ inline uint32_t pack_item(uint32_t node, uint32_t b, uint32_t e) { re
 // __threadfence() (agent-scope fence) additionally writes back and invalidates the XCD's whole L2 on gfx950, per call: two per climbed
 // node made a 1.9M-node climb cost 6 ms instead of 0.1 (measured round 4, profiles/r04_build_extract_ab.txt). Every location
 // exchanged this way must be accessed with agent-scope atomics on both sides.
-__device__ inline void ticket_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// The wait is written out (round 5): a workgroup-scope release fence emits NO s_waitcnt on gfx950, so the sc1 stores were
+// ordered before the ticket only by an unrelated dependent load that happened to sit between them. `s_waitcnt vmcnt(0)` = every
+// store / load this wave has issued has been acknowledged at its scope (sc1 stores: past the XCD's L2); the fences around it keep
+// the compiler from moving accesses across. tests/test_host_logic.py greps the ISA of the climbing kernels for the wait.
+__device__ inline void ticket_release() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 __device__ inline void ticket_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
 __device__ inline void wave_sync() {

@@ -180,3 +180,27 @@ def test_library_does_not_need_rccl_to_load():
             "maps = open('/proc/self/maps').read(); print('rccl' in maps)")
     r = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "False", r.stdout + r.stderr
+
+
+def test_arrival_tickets_wait_for_the_waves_own_stores():
+    """the bottom-up climbs of `refit` and `extract_bvh` hand data to a lane of ANOTHER workgroup through an
+    arrival ticket; the sc1 stores must have been acknowledged before the ticket's atomic add is issued. A workgroup-scope fence
+    emits no wait on gfx950, so build_common.h `ticket_release()` writes `s_waitcnt vmcnt(0)` out — and this test reads the ISA:
+    walking back from every returning `global_atomic_add` of the climbing kernels, the wait comes before any global store / load."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_isa import kernel_isa_lines
+    from bvh_amd import _lib
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    for kernel in ("k_refit<float>", "k_refit<double>", "k_subtree_counts<float>", "k_subtree_counts<double>"):
+        body = kernel_isa_lines(_lib.LIB_PATH, kernel)
+        assert body, kernel
+        tickets = [i for i, t in enumerate(body) if t.startswith("global_atomic_add") and " sc0" in t]
+        assert tickets, (kernel, "no returning atomic add")
+        for i in tickets:
+            j = i - 1
+            while j >= 0 and not body[j].startswith(("global_store", "global_load", "flat_", "buffer_")):
+                if re.match(r"s_waitcnt\s+vmcnt\(0\)", body[j]):
+                    break
+                j -= 1
+            assert j >= 0 and body[j].startswith("s_waitcnt"), (kernel, body[max(0, i - 8):i + 1])

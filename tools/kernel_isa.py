@@ -17,6 +17,12 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 def kernel_isa_hash(lib_path: str, kernel: str):
     """None when the tools or the kernel are missing (never raises: measurement plumbing must not take the bench down)."""
+    body = kernel_isa_lines(lib_path, kernel)
+    return None if not body else hashlib.sha1("\n".join(body).encode()).hexdigest()
+
+
+def kernel_isa_lines(lib_path: str, kernel: str):
+    """The kernel's instructions, one per line (branch targets replaced by X), or None."""
     objdump = os.path.join(LLVM, "llvm-objdump")
     if not (os.path.exists(objdump) and os.path.exists(lib_path)):
         return None
@@ -45,7 +51,7 @@ def kernel_isa_hash(lib_path: str, kernel: str):
                 if t:
                     body.append(re.sub(r"(s_c?branch\S*)\s+\S+", r"\1 X", t))
             if cur is not None and body:
-                return hashlib.sha1("\n".join(body).encode()).hexdigest()
+                return body
         return None
     except Exception:
         return None
