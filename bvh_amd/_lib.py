@@ -65,6 +65,8 @@ _SIGS = {
     "bvh_amd_probe_mixed_walk": (_I, [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
     "bvh_amd_probe_record_walk_ex": (_I, [_P, C.c_uint32, C.c_uint32, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong), _P]),
     "bvh_amd_release_cached_memory": (_I, []),
+    "bvh_amd_cached_scratch_bytes": (_Z, []),
+    "bvh_amd_scratch_cache_limit": (_Z, []),
     "bvh_amd_device_count": (_I, []),
     "bvh_amd_device_name": (_I, [_I, C.c_char_p, _Z]),
     "bvh_amd_device_select": (_I, [_I]),

@@ -1192,7 +1192,7 @@ struct BinnedWs {
         A(tk_a.alloc(task_cap)); A(tk_b.alloc(task_cap)); A(stage.alloc(2 * size_t{n})); A(counters.alloc(1));
         // segments of 65 .. medium_cap primitives go to k_medium — on the first attempt only: a retry (capacity exceeded, or a segment
         // whose lopsided splits outgrow k_medium's local tables) takes the plain Phase A path
-        static const bool medium_off = std::getenv("BVH_AMD_MEDIUM") && std::atoi(std::getenv("BVH_AMD_MEDIUM")) == 0;   // A/B runs
+        static const bool medium_off = BVH_DEV_INT("BVH_AMD_MEDIUM", 1) == 0;   // A/B runs
         const uint32_t medium_slots = n / (kSmall + 1) + roots + 2;
         c.medium_cap = attempt == 0 && !medium_off ? medium_cap<T>() : 0u;
         c.medium_slots = medium_slots;
@@ -1201,7 +1201,7 @@ struct BinnedWs {
         if (c.medium_cap) { A(medium_list.alloc(4 * size_t{medium_slots})); A(med_info.alloc(4 * size_t{medium_slots})); }
         if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
         c.medium_list = medium_list.p; c.med_info = med_info.p;
-        static const bool prof = std::getenv("BVH_AMD_MED_PROF") && std::atoi(std::getenv("BVH_AMD_MED_PROF")) != 0;   // developer knob
+        static const bool prof = BVH_DEV_INT("BVH_AMD_MED_PROF", 0) != 0;   // developer knob
         if (prof && c.medium_cap && med_prof.alloc(16) == hipSuccess && hipMemset(med_prof.p, 0, 16 * sizeof(unsigned long long)) == hipSuccess) c.med_prof = med_prof.p;
         if (own_ids) c.ids = ids.p;
         c.n = n; c.nodes = nodes.p; c.node_cap = node_cap; c.bins = bins.p; c.state = st_a.p; c.state_next = st_b.p;
@@ -1246,7 +1246,7 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
         // (128 threads, eight blocks per CU), the 512 class from three blocks per CU on (Quality::Low with a pool on 1M uniformly
         // spread triangles: 1036 mini-trees of 257..300 primitives, 0.21 -> 0.12 ms), the 1024 class never (1054 segments: no gain).
         // Lists served by the largest kernel go into ONE launch (their tails would add up). profiles/r04_build_medium_classes_ab.txt
-        static const int policy = std::getenv("BVH_AMD_MEDIUM_CLASSES") ? std::atoi(std::getenv("BVH_AMD_MEDIUM_CLASSES")) : 0;   // A/B runs: 1 always own, 2 never
+        static const int policy = BVH_DEV_INT("BVH_AMD_MEDIUM_CLASSES", 0);   // A/B runs: 1 always own, 2 never
         constexpr uint32_t largest = sizeof(T) == 4 ? 3u : 2u;
         int cus = 256;
         { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; }
@@ -1296,7 +1296,7 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
     PhaseB lane;
     if (!overflow && roots_final) { const int rc = (*roots_final)(&lane); if (rc) return rc; }
     if (!overflow && h.n_small) {
-        static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
+        static const bool dfs = BVH_DEV_IS("BVH_AMD_SMALL", "dfs");   // the node-by-node walk (A/B runs)
         hipStream_t on = lane.stream ? lane.stream : stream;
         if (lane.stream) BVH_HIP_TRY(hipStreamWaitEvent(lane.stream, lane.start, 0), BVH_AMD_ERR_HIP);
         if (dfs) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, on, c, h.n_small);

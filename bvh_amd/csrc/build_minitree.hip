@@ -24,6 +24,7 @@
 #include <functional>
 #include <string>
 #include <system_error>
+#include <condition_variable>
 #include <thread>
 
 namespace bvh_amd {
@@ -609,8 +610,12 @@ __global__ void __launch_bounds__(256) k_splice_top(const HostNode<T>* top, cons
 // of a 16^3 grid, 40 % of a 1M-triangle Low build) that leaves the chip idle, while Phase B of the forest (k_small_levels) fills it
 // without needing the host. So the top level runs on a stream of its own, driven by a worker thread (both pipelines block on
 // readbacks, one host thread cannot drive two), between two events: `roots` (recorded on the caller's stream behind the kernel that
-// writes the top-level inputs) and `done` (recorded on the worker's stream; the splice waits for it). The worker is a thread per
-// build, started while the grid / radix-sort kernels run and spinning until the roots are announced or the build gives up.
+// writes the top-level inputs) and `done` (recorded on the worker's stream; the splice waits for it). The worker is ONE persistent
+// thread per calling thread (round 5; rounds 4's builds spawned a std::thread each and that thread spun until the roots were
+// announced): idle it sleeps on a condition variable; handed a job while the grid / radix-sort kernels run, it sets its device and
+// scopes up and waits for the roots — a bounded spin first (the announcement is ~0.3 ms away and a futex wake-up costs 30-60 us of a
+// 1.5 ms build), then the condition variable — so a build that takes long to reach its roots, or eight host threads building at
+// once, do not burn a core each.
 struct TopHelper {                                            // per calling thread: stream + events of its top-level worker
     int device = -1;
     hipStream_t stream = nullptr;
@@ -621,16 +626,50 @@ struct TopHelper {                                            // per calling thr
     // the stream priority. On the reserved CUs it starts at once; Phase B loses reserved / 256 of the chip.
     hipStream_t phase_b = nullptr;
     hipEvent_t phase_b_done = nullptr;
+    // the persistent worker: `work` is the posted job (empty when idle)
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> work;
+    bool busy = false, quit = false;
+    bool post(std::function<void()> fn) {                     // false: no thread to be had (the top level then follows the forest)
+        std::unique_lock<std::mutex> lock(m);
+        if (!worker.joinable()) {
+            try {
+                worker = std::thread([this] {
+                    std::unique_lock<std::mutex> l(m);
+                    for (;;) {
+                        cv.wait(l, [this] { return quit || static_cast<bool>(work); });
+                        if (quit) return;
+                        std::function<void()> fn = std::move(work);
+                        work = nullptr;
+                        l.unlock();
+                        fn();
+                        l.lock();
+                        busy = false;
+                        cv.notify_all();
+                    }
+                });
+            } catch (const std::system_error&) { return false; }
+        }
+        cv.wait(lock, [this] { return !busy; });
+        work = std::move(fn);
+        busy = true;
+        cv.notify_all();
+        return true;
+    }
+    void wait_idle() { std::unique_lock<std::mutex> lock(m); cv.wait(lock, [this] { return !busy; }); }
+    void stop_worker() {
+        if (!worker.joinable()) return;
+        { std::lock_guard<std::mutex> lock(m); quit = true; }
+        cv.notify_all();
+        worker.join();
+        quit = false;
+    }
     void release() {
-        if (stream) {                                         // the worker's scratch is cached under this handle: hand it back first
-            int cur = -1;
-            static const bool keep = std::getenv("BVH_AMD_DROP_ON_DESTROY") && std::atoi(std::getenv("BVH_AMD_DROP_ON_DESTROY")) == 0;   // developer knob (reproduces the hang)
-            if (!keep && hipGetDevice(&cur) == hipSuccess) {
-                if (cur != device) (void)hipSetDevice(device);
-                scratch_cache_drop_stream(stream);
-                (void)hipStreamSynchronize(stream);
-                if (cur != device) (void)hipSetDevice(cur);
-            }
+        wait_idle();
+        if (stream) {                                         // (scratch cached by the worker hangs on fences, not on this handle: build_device.hip)
+            (void)hipStreamSynchronize(stream);
             (void)hipStreamDestroy(stream);
         }
         if (phase_b) (void)hipStreamDestroy(phase_b);
@@ -644,12 +683,12 @@ struct TopHelper {                                            // per calling thr
         // Phase B on the caller's stream has thousands of blocks waiting for every slot that frees
         int least = 0, greatest = 0;
         BVH_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest), BVH_AMD_ERR_HIP);
-        static const bool flat = std::getenv("BVH_AMD_TOP_PRIORITY") && std::atoi(std::getenv("BVH_AMD_TOP_PRIORITY")) == 0;      // A/B runs
+        static const bool flat = BVH_DEV_INT("BVH_AMD_TOP_PRIORITY", 1) == 0;      // A/B runs
         BVH_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, flat ? least : greatest), BVH_AMD_ERR_HIP);
         for (hipEvent_t* e : { &roots, &done, &spliced, &phase_b_done }) BVH_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming), BVH_AMD_ERR_HIP);
         // 32 = bits 0..31 of the mask = one CU of every shader engine of every XCD (the mask's bits go round the XCDs first, then round
         // an XCD's four engines): 8 CUs (one engine per XCD short of a CU) cost Phase B the same 8-12 % and serve the worker worse
-        static const int reserve = std::getenv("BVH_AMD_TOP_RESERVE") ? std::atoi(std::getenv("BVH_AMD_TOP_RESERVE")) : 32;            // A/B runs (0: off)
+        static const int reserve = BVH_DEV_INT("BVH_AMD_TOP_RESERVE", 32);            // A/B runs (0: off)
         int cus = 0;
         if (reserve > 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 4 * reserve) {
             std::vector<uint32_t> mask((cus + 31) / 32, 0u);
@@ -659,43 +698,68 @@ struct TopHelper {                                            // per calling thr
         device = dev;
         return BVH_AMD_OK;
     }
-    ~TopHelper() { release(); }
+    ~TopHelper() { stop_worker(); release(); }
 };
 
 template <typename T>
 struct TopJob {
-    std::thread worker;
+    TopHelper* helper = nullptr;                              // set by start(): the job was posted to this helper's worker
     std::atomic<int> go{0};                                   // 0 wait, 1 the roots event is recorded, -1 not needed
+    std::mutex go_m;
+    std::condition_variable go_cv;
     int rc = BVH_AMD_OK;
     std::string error;
     DevBuf<HostNode<T>> top;
     DevBuf<uint32_t> top_ord;
     size_t top_count = 0;
     bool announced = false;
+    bool joined = false;                                      // the caller's stream waits for (or the host has waited for) the worker's stream
     const T* boxes = nullptr; const T* centers = nullptr; uint32_t n_roots = 0;      // set before `go`
-    void start(int dev, const TopHelper& h, SahParams sah) {
-        worker = std::thread([this, dev, &h, sah] {
+    bool started() const { return helper != nullptr; }
+    void start(int dev, TopHelper& h, SahParams sah) {
+        const bool posted = h.post([this, dev, &h, sah] {
             if (hipSetDevice(dev) != hipSuccess) { rc = BVH_AMD_ERR_HIP; error = "build: hipSetDevice on the top-level worker"; return; }
             StreamScope scratch_on(h.stream);
             SahScope heuristic(sah);
-            int state;
-            for (uint32_t spin = 0; (state = go.load(std::memory_order_acquire)) == 0; ++spin)
+            int state = 0;
+            for (uint32_t spin = 0; spin < 200000u && (state = go.load(std::memory_order_acquire)) == 0; ++spin)      // ~0.5 ms
                 if ((spin & 63u) == 63u) std::this_thread::yield();
+            if (state == 0) {
+                std::unique_lock<std::mutex> lock(go_m);
+                go_cv.wait(lock, [this] { return go.load(std::memory_order_acquire) != 0; });
+                state = go.load(std::memory_order_acquire);
+            }
             if (state < 0) return;
             if (hipStreamWaitEvent(h.stream, h.roots, 0) != hipSuccess) { rc = BVH_AMD_ERR_HIP; error = "build: hipStreamWaitEvent on the top-level worker"; return; }
             rc = sweep_core<T>(boxes, centers, n_roots, 1, 1, top, top_ord, top_count, h.stream, 3);
             if (rc) { error = current_error(); return; }
             if (hipEventRecord(h.done, h.stream) != hipSuccess) { rc = BVH_AMD_ERR_HIP; error = "build: hipEventRecord on the top-level worker"; }
         });
+        if (posted) helper = &h;
     }
-    void finish() { if (worker.joinable()) { if (go.load() == 0) go.store(-1, std::memory_order_release); worker.join(); } }
-    ~TopJob() { finish(); }
+    void signal(int state) {
+        { std::lock_guard<std::mutex> lock(go_m); go.store(state, std::memory_order_release); }
+        go_cv.notify_all();
+    }
+    // the worker is through with this job (its host side); a job whose roots were never announced is called off
+    void finish() {
+        if (!helper) return;
+        if (go.load(std::memory_order_acquire) == 0) signal(-1);
+        helper->wait_idle();
+    }
+    // Every exit: the worker's KERNELS may still be reading the inputs (top_boxes / top_centers) and writing `top` when the buffers
+    // are released in the order of the caller's stream. The success path makes the caller's stream wait for `done`
+    // (joined = true); any other exit after the announcement waits for the worker's stream here.
+    ~TopJob() {
+        finish();
+        if (helper && announced && !joined) (void)hipStreamSynchronize(helper->stream);
+    }
 };
 
 constexpr uint32_t kTopReserveMaxPrims = 4u << 20;
 
 bool top_beside_enabled() {
-    static const bool off = std::getenv("BVH_AMD_TOP_BESIDE") && std::atoi(std::getenv("BVH_AMD_TOP_BESIDE")) == 0;      // A/B runs
+    static const bool off = BVH_DEV_INT("BVH_AMD_TOP_BESIDE", 1) == 0;      // A/B runs
     return !off;
 }
 
@@ -756,7 +820,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
         BVH_HIP_TRY(hipGetDevice(&dev), BVH_AMD_ERR_HIP);
         rc = helper.prepare(dev);
         if (rc) return rc;
-        try { job.start(dev, helper, ambient_sah()); } catch (const std::system_error&) { /* no thread to be had: the top level follows the forest */ }
+        job.start(dev, helper, ambient_sah());             // (no thread to be had: the top level follows the forest)
     }
     MtScalars hs;
     { int rb_ = readback(&hs, scalars.p, sizeof(hs), stream); if (rb_) return rb_; }
@@ -766,7 +830,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     DevBuf<uint32_t> tree_off;
     uint32_t forest_nodes = 0;
     std::function<int(const ANode<T>*, PhaseB*)> roots_ready;
-    if (beside && job.worker.joinable() && n_trees > static_cast<uint32_t>(kSmall)) {
+    if (beside && job.started() && n_trees > static_cast<uint32_t>(kSmall)) {
         A(top_boxes.alloc(6 * size_t{n_trees})); A(top_centers.alloc(3 * size_t{n_trees}));
         if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("build: hipMalloc: ") + hipGetErrorString(e));
         job.boxes = top_boxes.p; job.centers = top_centers.p; job.n_roots = n_trees;
@@ -774,7 +838,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
             hipLaunchKernelGGL(k_top_inputs<T>, dim3((n_trees + 255) / 256), dim3(256), 0, stream, roots, n_trees, top_boxes.p, top_centers.p);
             BVH_HIP_TRY(hipEventRecord(helper.roots, stream), BVH_AMD_ERR_HIP);
             job.announced = true;
-            job.go.store(1, std::memory_order_release);
+            job.signal(1);
             // (the masked stream costs Phase B ~8-12 % whatever the number of CUs left out; beyond a few million primitives that is more
             //  than the top level's 0.5 ms, which then simply runs in the shadow of the forest's numbering / emit passes)
             if (helper.phase_b && n32 <= kTopReserveMaxPrims) { lane->stream = helper.phase_b; lane->start = helper.roots; lane->done = helper.phase_b_done; }
@@ -822,7 +886,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
     ea.top_nodes = 2 * n_cuts - 1; ea.sc = scalars.p;
     const unsigned cg = (n_cuts + 63) / 64;
     uint32_t below = 0;
-    static const bool walk_per_cut = std::getenv("BVH_AMD_EXTRACT") && std::strcmp(std::getenv("BVH_AMD_EXTRACT"), "walk") == 0;    // A/B runs
+    static const bool walk_per_cut = BVH_DEV_IS("BVH_AMD_EXTRACT", "walk");    // A/B runs
     const bool per_node = prune && !walk_per_cut;
     DevBuf<uint32_t> x_parent, x_cut_of, x_arrived, x_inner, x_prims;
     if (per_node) {
@@ -843,7 +907,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
         rc = exclusive_scan_u32(np.p, prim_off.p, n_cuts, &prim_total, stream);
         if (rc) return rc;
         if (prim_total != n32) return fail(BVH_AMD_ERR_OVERFLOW, "build: mini-tree extraction lost primitives (walk stack overflow?)");
-        if (std::getenv("BVH_AMD_CUT_STATS")) {                // developer knob: sizes of the cut subtrees
+        if (BVH_DEV_STR("BVH_AMD_CUT_STATS")) {                // developer knob: sizes of the cut subtrees
             std::vector<uint32_t> hn(n_cuts);
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpy(hn.data(), nm1.p, size_t{n_cuts} * 4, hipMemcpyDeviceToHost);
@@ -878,6 +942,7 @@ int minitree_core(const T* d_bboxes, const T* d_centers, size_t n, const bvh_bui
         job.finish();
         if (job.rc) return fail(job.rc, job.error);
         BVH_HIP_TRY(hipStreamWaitEvent(stream, helper.done, 0), BVH_AMD_ERR_HIP);
+        job.joined = true;
         top_count = job.top_count;
     } else {
         rc = sweep_core<T>(top_boxes.p, top_centers.p, n_cuts, 1, 1, top_here, top_ord_here, top_count, stream, 3);

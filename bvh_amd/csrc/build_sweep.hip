@@ -1191,7 +1191,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         A(stage.alloc(2 * n)); A(counters.alloc(1));
         A(chunk_box.alloc(18 * size_t{task_cap})); A(carry_l.alloc(18 * size_t{task_cap})); A(carry_r.alloc(18 * size_t{task_cap})); A(chunk_best.alloc(3 * size_t{task_cap}));
         // segments of 65 .. 2048 primitives are finished by k_sweep_medium (first attempt only: a retry takes the plain path)
-        static const bool sw_medium_off = std::getenv("BVH_AMD_SWEEP_MEDIUM") && std::atoi(std::getenv("BVH_AMD_SWEEP_MEDIUM")) == 0;   // A/B runs
+        static const bool sw_medium_off = BVH_DEV_INT("BVH_AMD_SWEEP_MEDIUM", 1) == 0;   // A/B runs
         const uint32_t medium_slots = n32 / (kSmall + 1) + 3;
         DevBuf<uint32_t> medium_list;
         DevBuf<MedInfo> med_info;
@@ -1211,7 +1211,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         for (int k = 0; k < 3; ++k) sc.ord[k] = ord.p + size_t{n} * k;
         sc.ord_tmp = ord_tmp.p; sc.marks = marks.p; sc.cost_r = cost_r.p; sc.axis_best = axis_best.p; sc.chunk_true2 = chunk_true2.p;
         sc.chunk_box = chunk_box.p; sc.carry_l = carry_l.p; sc.carry_r = carry_r.p; sc.chunk_best = chunk_best.p; sc.multi = 0;
-        static const bool multi_off = std::getenv("BVH_AMD_SWEEP_MULTI") && std::atoi(std::getenv("BVH_AMD_SWEEP_MULTI")) == 0;   // A/B runs
+        static const bool multi_off = BVH_DEV_INT("BVH_AMD_SWEEP_MULTI", 1) == 0;   // A/B runs
         c.big_threshold = multi_off ? 0u : kSweepBig;
         if (use_medium) {
             c.medium_cap = sweep_medium_cap<T>(); c.medium_slots = medium_slots; c.medium_min_class = 3;      // classes 0 (<= 256 primitives) and 3: one kernel serves both
@@ -1280,7 +1280,7 @@ int sweep_core(const T* d_bboxes, const T* d_centers, size_t n, uint32_t min_lea
         }
         const uint32_t n_nodes_a = h.n_nodes, n_small = h.n_small;
         if (n_small) {
-            static const bool dfs = std::getenv("BVH_AMD_SMALL") && std::strcmp(std::getenv("BVH_AMD_SMALL"), "dfs") == 0;   // the node-by-node walk (A/B runs)
+            static const bool dfs = BVH_DEV_IS("BVH_AMD_SMALL", "dfs");   // the node-by-node walk (A/B runs)
             if (dfs) hipLaunchKernelGGL(k_small_sweep<T>, dim3((n_small + 3) / 4), dim3(256), 0, stream, sc, n_small);
             else hipLaunchKernelGGL(k_small_sweep_levels<T>, dim3((n_small + 1) / 2), dim3(128), 0, stream, sc, n_small);
         }

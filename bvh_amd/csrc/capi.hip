@@ -548,6 +548,9 @@ int bvh_amd_release_cached_memory(void) {
     return BVH_AMD_OK;
 }
 
+size_t bvh_amd_cached_scratch_bytes(void) { return scratch_cache_bytes(); }
+size_t bvh_amd_scratch_cache_limit(void) { return scratch_cache_limit(); }
+
 int bvh_amd_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -150,6 +150,23 @@ struct BvhImpl {
     ~BvhImpl();
 };
 
+// Environment switches. A RELEASE library reads exactly the variables documented in include/bvh_amd.h ("Environment": BVH_AMD_CACHE_MB,
+// BVH_AMD_POOL, BVH_AMD_CALIBRATE, BVH_AMD_REINSERT, BVH_AMD_RCCL_LIB and the platform's ROCM_PATH). A/B switches, profiling aids and
+// fault injection exist only in a library compiled with -DBVH_AMD_DEVELOPER (`python -m bvh_amd.build --developer` ->
+// bvh_amd/lib/libbvh_amd_dev.so, what the fault-injection tests load): in a release build the macros below drop the variable's name
+// at preprocessing time, so that neither the switch nor its string exists in the product.
+#if defined(BVH_AMD_DEVELOPER)
+inline int dev_env_int_(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
+inline bool dev_env_is_(const char* name, const char* value) { const char* v = std::getenv(name); return v && std::strcmp(v, value) == 0; }
+#define BVH_DEV_INT(name, dflt) (::bvh_amd::dev_env_int_(name, dflt))
+#define BVH_DEV_STR(name) (static_cast<const char*>(std::getenv(name)))
+#define BVH_DEV_IS(name, value) (::bvh_amd::dev_env_is_(name, value))
+#else
+#define BVH_DEV_INT(name, dflt) (dflt)
+#define BVH_DEV_STR(name) (static_cast<const char*>(nullptr))
+#define BVH_DEV_IS(name, value) (false)
+#endif
+
 // The SplitHeuristic (reference split_heuristic.h:17-23) of the build in progress on the calling thread. The reference's C
 // struct bvh_build_config has no room for it, so the C-ABI entry points that accept one (bvh_amd_sah_config) set it for the
 // duration of the call and the builders read it where they fill their kernel arguments; the default is the reference's {0, 1}.
@@ -169,29 +186,34 @@ struct SahScope {
 // synchronises the device (measured: ~2.4 ms of a 10.9 ms 1M-triangle build). bvh_amd_release_cached_memory() trims the pool;
 // BVH_AMD_POOL=0 restores plain hipMalloc / hipFree.
 hipStream_t& ambient_stream();                 // build_device.hip
+// The stream of the API call in progress on this thread. The OUTERMOST scope of a call on its stream is also what the scratch cache
+// hangs its bookkeeping on: if the call freed scratch, one event (the scope's fence) is recorded on the stream when the scope ends.
+struct ScratchScope;                           // build_device.hip
 struct StreamScope {
     hipStream_t saved;
-    explicit StreamScope(hipStream_t s) : saved(ambient_stream()) { ambient_stream() = s; }
-    ~StreamScope() { ambient_stream() = saved; }
+    ScratchScope* scope;                       // nullptr: shares the enclosing scope's (same stream)
+    explicit StreamScope(hipStream_t s);
+    ~StreamScope();
     StreamScope(const StreamScope&) = delete;
     StreamScope& operator=(const StreamScope&) = delete;
 };
 bool scratch_pool_enabled();                   // build_device.hip: configures the current device's default pool on first use
-// On top of the pool sits a small block cache (build_device.hip): hipMallocAsync / hipFreeAsync still cost ~5 / ~13 us of host
-// time per call (measured, tools/src/alloc_bench.hip), ~1 ms over the ~60 scratch buffers of a build, so a freed block is kept
-// per (device, stream) and handed to the next request of about the same size ON THE SAME STREAM (stream order makes that safe
-// without any synchronisation, exactly like the pool's own reuse). A block whose pointer is taken over by a BvhImpl simply never
-// comes back to the cache; the BvhImpl releases it with hipFree, which accepts pool memory. BVH_AMD_CACHE_MB bounds the cached
-// bytes per device (default 8192; 0 turns the cache off).
+// Scratch comes from the runtime's stream-ordered pool, but only ever through ONE library-owned stream per device — the pool never
+// sees a caller's stream, so nothing the library caches or a Bvh owns can outlive a handle it depends on (build_device.hip, round 5).
+// On top of the pool sits a small block cache: hipMallocAsync / hipFreeAsync still cost ~5 / ~13 us of host time per call (measured,
+// tools/src/alloc_bench.hip), ~1 ms over the ~60 scratch buffers of a build, so a freed block is kept together with the fence of the
+// API call that freed it and handed to the next request of about the same size, behind that fence. A block whose pointer is taken
+// over by a BvhImpl simply never comes back to the cache; the BvhImpl releases it with hipFree, which accepts pool memory.
+// BVH_AMD_CACHE_MB bounds the cached bytes per device (default min(1024, 5 % of the free HBM); 0 turns the cache off).
 struct ScratchTag {                            // what scratch_free needs to know about a block
-    hipStream_t stream = nullptr;
     size_t capacity = 0;                       // bytes actually behind the pointer (>= the request)
     bool pooled = false;
 };
 hipError_t scratch_alloc(void** p, size_t bytes, ScratchTag* tag);
 void scratch_free(void* p, const ScratchTag& tag);
-void scratch_cache_flush();                    // hands every cached block of the current device back to the pool (hipFreeAsync)
-void scratch_cache_drop_stream(hipStream_t s); // the same for the blocks cached under one stream of the current device: call BEFORE destroying a stream the library owns
+void scratch_cache_flush();                    // hands every cached block of the current device back to the pool
+size_t scratch_cache_bytes();                  // bytes the cache holds on the current device / its bound
+size_t scratch_cache_limit();
 
 // A few bytes (<= 256, 4-byte aligned) from device memory to the host, in stream order, WITHOUT a stream synchronisation: a
 // one-lane kernel copies them into coherent pinned host memory and publishes a sequence number, the host spins on it (falls back to

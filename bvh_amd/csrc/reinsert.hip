@@ -1027,7 +1027,7 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
 
     const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>) + kStreamChunk * sizeof(T);
     const bool below_lds = k >= 1 && k - 1 >= HeapCap<T>::v;
-    const char* pipe_knob = std::getenv("BVH_AMD_HEAP_PIPE");                      // 0: the one-wave replacement loop
+    const char* pipe_knob = BVH_DEV_STR("BVH_AMD_HEAP_PIPE");                      // 0: the one-wave replacement loop
     const bool use_pipe = !(pipe_knob && std::atoi(pipe_knob) == 0);
     const size_t pipe_lds = heap_lds + kQueueCap * sizeof(PipeToken<T>) + sizeof(PipeCtrl);
     if (below_lds && use_pipe)
@@ -1098,7 +1098,7 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
             if (!exact) {
                 if ((rc = read_scalars(hs))) return rc;
                 if (hs.ambiguous) {                           // nothing was modified yet
-                    if (std::getenv("BVH_AMD_REINSERT_DEBUG")) std::fprintf(stderr, "[bvh_amd] reinsertion iteration %zu: tie at the top-k threshold -> exact replay\n", it);
+                    if (BVH_DEV_STR("BVH_AMD_REINSERT_DEBUG")) std::fprintf(stderr, "[bvh_amd] reinsertion iteration %zu: tie at the top-k threshold -> exact replay\n", it);
                     if ((rc = clear_ambiguous())) return rc;
                     exact = true;
                     continue;
@@ -1119,7 +1119,7 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
                 if (!exact) {
                     if ((rc = read_scalars(hs))) return rc;
                     if (hs.ambiguous) {                       // roll the iteration back and replay it exactly
-                        if (std::getenv("BVH_AMD_REINSERT_DEBUG")) std::fprintf(stderr, "[bvh_amd] reinsertion iteration %zu: equal gains with shared nodes -> exact replay\n", it);
+                        if (BVH_DEV_STR("BVH_AMD_REINSERT_DEBUG")) std::fprintf(stderr, "[bvh_amd] reinsertion iteration %zu: equal gains with shared nodes -> exact replay\n", it);
                         BVH_HIP_TRY(hipMemcpyAsync(d_nodes, backup.p, size_t{n} * sizeof(HostNode<T>), hipMemcpyDeviceToDevice, stream), BVH_AMD_ERR_HIP);
                         if ((rc = clear_ambiguous())) return rc;
                         parents_valid = false;
@@ -1142,7 +1142,7 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
         if (ev.first && ev.second && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) t_profile.heap_ms += ms;
     }
     (void)hipGetLastError();
-    if (hs.error & 2u) return fail(BVH_AMD_ERR_HIP, "optimize: the two-wave candidate-heap replay timed out (internal error; BVH_AMD_HEAP_PIPE=0 selects the one-wave loop)");
+    if (hs.error & 2u) return fail(BVH_AMD_ERR_HIP, "optimize: the two-wave candidate-heap replay timed out (internal error)");
     if (hs.error) return fail(BVH_AMD_ERR_OVERFLOW, "optimize: reinsertion search stack exceeded 96 entries");
     return BVH_AMD_OK;
 }

@@ -138,10 +138,10 @@ BvhImpl<T>* broadcast_scene(bvh_amd_comm* c, int root, BvhImpl<T>* bvh, int dim,
     const bool is_root = c->rank == root;
     // a test knob: the root ALSO runs the receiving side on the broadcast buffers and returns that copy (exercises the whole
     // non-root path on a single GPU, where RCCL refuses two ranks on one device)
-    static const bool loopback = getenv("BVH_AMD_BROADCAST_LOOPBACK") && atoi(getenv("BVH_AMD_BROADCAST_LOOPBACK")) != 0;
+    static const bool loopback = BVH_DEV_INT("BVH_AMD_BROADCAST_LOOPBACK", 0) != 0;
     // test knob: this rank pretends its local step 2 failed (BVH_AMD_BROADCAST_FAIL_RANK = a rank number): the status round must
     // make every rank return instead of hanging
-    static const int fail_rank = getenv("BVH_AMD_BROADCAST_FAIL_RANK") ? atoi(getenv("BVH_AMD_BROADCAST_FAIL_RANK")) : -1;
+    static const int fail_rank = BVH_DEV_INT("BVH_AMD_BROADCAST_FAIL_RANK", -1);
     // 1. header. Every check that can fail on the root alone comes before it and is reported THROUGH it.
     SceneMeta meta = {0, 0, 0, 0};
     if (is_root) {
@@ -163,25 +163,26 @@ BvhImpl<T>* broadcast_scene(bvh_amd_comm* c, int root, BvhImpl<T>* bvh, int dim,
     bool header_ok = true;
     if (is_root) header_ok = hipMemcpyAsync(d_meta, &meta, sizeof(meta), hipMemcpyHostToDevice, stream) == hipSuccess;
     if (is_root && !header_ok) (void)hipMemsetAsync(d_meta, 0, sizeof(SceneMeta), stream);
-    ncclResult_t r = nccl.Broadcast(d_meta, d_meta, sizeof(SceneMeta), ncclUint8, root, c->comm, stream);
-    if (r != ncclSuccess) { set_error(std::string("broadcast: ncclBroadcast(header): ") + nccl.GetErrorString(r)); return nullptr; }
-    SceneMeta got = {0, 0, 0, 0};
-    const bool read_ok = hipMemcpyAsync(&got, d_meta, sizeof(got), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
-    if (read_ok && got.dim == 0) {                             // the root refused (its message is in ITS last_error)
-        if (!is_root) set_error("broadcast: the root rank had nothing valid to send");
-        else if (!header_ok) set_error("broadcast: copying the header to the device failed");
-        return nullptr;
-    }
-    // 2. local preparation; from here on a rank that fails still goes through the status round
+    // From the header on EVERY rank leaves through the status round, whatever happened to it (round 5): a rank whose header
+    // call failed used to return while its peers went on to the all-reduce, and a rank that could not read the header back went on
+    // alone while the others returned on "the root has nothing to send" (dim == 0). All of these are status 0 now.
     std::string why;
+    ncclResult_t r = nccl.Broadcast(d_meta, d_meta, sizeof(SceneMeta), ncclUint8, root, c->comm, stream);
+    if (r != ncclSuccess) why = std::string("broadcast: ncclBroadcast(header): ") + nccl.GetErrorString(r);
+    SceneMeta got = {0, 0, 0, 0};
+    const bool read_ok = why.empty() && hipMemcpyAsync(&got, d_meta, sizeof(got), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+    // 2. local preparation
     void* d_stream = nullptr;
     void* d_recv_prims = nullptr;
     auto drop = [&]() { if (d_stream) (void)hipFree(d_stream); if (d_recv_prims) (void)hipFree(d_recv_prims); d_stream = d_recv_prims = nullptr; };
     const bool receives = !is_root || loopback;
-    if (!read_ok) why = "broadcast: reading the header failed";
+    if (!why.empty()) {}
+    else if (!read_ok) why = "broadcast: reading the header failed";
+    else if (got.dim == 0)                                     // the root refused (its message is in ITS last_error)
+        why = !is_root ? "broadcast: the root rank had nothing valid to send" : !header_ok ? "broadcast: copying the header to the device failed" : bvh_amd_last_error();
     else if (got.dim != static_cast<unsigned long long>(dim) || got.is_double != (sizeof(T) == 8 ? 1ull : 0ull))
         why = "broadcast: the root sends another BVH family (scalar type / dimension) than this entry point receives";
-    else if (fail_rank == c->rank) why = "broadcast: BVH_AMD_BROADCAST_FAIL_RANK (test knob) made this rank fail its preparation";
+    else if (fail_rank == c->rank) why = "broadcast: fault injection (developer build) made this rank fail its preparation";
     else if (hipMalloc(&d_stream, got.stream_bytes) != hipSuccess) { d_stream = nullptr; why = "broadcast: out of device memory for the serialized BVH"; }
     else if (is_root && serialize_to_device<T>(*bvh, d_stream, got.stream_bytes, stream) != got.stream_bytes) why = std::string("broadcast: ") + bvh_amd_last_error();
     else if (receives && got.prim_bytes && hipMalloc(&d_recv_prims, got.prim_bytes) != hipSuccess) { d_recv_prims = nullptr; why = "broadcast: out of device memory for the primitives"; }

@@ -819,7 +819,7 @@ template <typename T>
 int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, uint32_t astride, uint32_t istride, hipStream_t stream) {
     StreamScope scratch_on(stream);
     if (n == 0 || batch == 0) return BVH_AMD_OK;
-    static const bool small_off = std::getenv("BVH_AMD_SORT_SMALL") && std::atoi(std::getenv("BVH_AMD_SORT_SMALL")) == 0;      // A/B runs
+    static const bool small_off = BVH_DEV_INT("BVH_AMD_SORT_SMALL", 1) == 0;      // A/B runs
     if (n <= kSortSmallMax && !small_off) {
         uint32_t lg = 0;
         while ((uint64_t{2} << lg) <= n) ++lg;            // std::__lg(n) = floor(log2 n)
@@ -830,14 +830,14 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
     const uint32_t total = n * batch;
     hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, stream, d_ids, n, total);
     using U = typename Ord<T>::U;
-    static const bool finish_off = std::getenv("BVH_AMD_SORT_FINISH") && std::atoi(std::getenv("BVH_AMD_SORT_FINISH")) == 0;   // A/B runs: every round global + radix sort
+    static const bool finish_off = BVH_DEV_INT("BVH_AMD_SORT_FINISH", 1) == 0;   // A/B runs: every round global + radix sort
     DevBuf<uint32_t> ltab, rtab, vals_tmp;
     DevBuf<SortSeg> seg_a, seg_b, seg_small;
     DevBuf<SortCounters> counters;
     DevBuf<uint2> chunk_cnt;
     DevBuf<HugeState> huge;
     const uint32_t seg_cap = total / 16 + batch + 2;
-    static const bool huge_off = std::getenv("BVH_AMD_SORT_HUGE") && std::atoi(std::getenv("BVH_AMD_SORT_HUGE")) == 0;         // A/B runs: one block per segment always
+    static const bool huge_off = BVH_DEV_INT("BVH_AMD_SORT_HUGE", 1) == 0;         // A/B runs: one block per segment always
     uint32_t huge_rounds = 0;                             // rounds that get the many-block step: until halving would have ended it, + 3
     if (!huge_off && n > kSortHuge) { huge_rounds = 4; while ((uint64_t{kSortHuge} << (huge_rounds - 4)) < n) ++huge_rounds; }
     const uint32_t huge_cap = static_cast<uint32_t>(std::min<uint64_t>(seg_cap, uint64_t{batch} << std::min(huge_rounds, 24u))) + 1;

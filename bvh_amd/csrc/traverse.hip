@@ -213,14 +213,14 @@ thread_local int t_refill = -1, t_leaf = -1, t_coop = -1, t_parts = -1;
 //   tri_stride    floats from one PrecomputedTri to the next in the CALLER's primitive array (12; 16 = padded to a 64-byte line)
 //   key_curve     coherence key of the ray reordering: 1 Hilbert index of the origin cell (default), 0 its Morton code
 //   key_bits      bits per axis of that cell grid (1..8)
-struct Experiments { int grid_blocks = -1, stream_hints = -1, tri_stride = -1, key_curve = -1, key_bits = -1; };
+struct Experiments { int grid_blocks = -1, stream_hints = -1, tri_stride = -1, key_curve = -1, key_bits = -1, step_events = -1; };
 thread_local Experiments t_exp;
 thread_local std::pair<hipEvent_t, hipEvent_t>* t_calibration = nullptr;   // events to record around the next traversal kernel of this thread
 
 // BVH_AMD_COOP=0 / 1 (or bvh_amd_tuning) forces the per-lane / quad-cooperative record fetch of the float 3D kernels for A/B
 // runs; -1: launch_traverse decides by kind of launch (trace_device.h: kCoop*)
 int coop_fetch_forced() {
-    static const int knob = getenv("BVH_AMD_COOP") ? atoi(getenv("BVH_AMD_COOP")) : -1;
+    static const int knob = BVH_DEV_INT("BVH_AMD_COOP", -1);
     return t_coop >= 0 ? (t_coop != 0) : knob < 0 ? -1 : (knob != 0);
 }
 
@@ -271,7 +271,7 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
         const int cap = (args.n <= (1ull << 21) ? 5 : 6) * cus;
         if (grid > cap) grid = cap;
     }
-    static const int grid_env = getenv("BVH_AMD_GRID_BLOCKS") ? atoi(getenv("BVH_AMD_GRID_BLOCKS")) : 0;   // developer knob: fewer resident waves (occupancy studies)
+    static const int grid_env = BVH_DEV_INT("BVH_AMD_GRID_BLOCKS", 0);   // developer knob: fewer resident waves (occupancy studies)
     if (grid_env > 0 && grid > grid_env) grid = grid_env;
     if (t_exp.grid_blocks > 0 && grid > t_exp.grid_blocks) grid = t_exp.grid_blocks;
     if (grid < 1) grid = 1;
@@ -522,6 +522,7 @@ int set_experiment(const char* name, int value) {
     else if (k == "tri_stride") t_exp.tri_stride = value;
     else if (k == "key_curve") t_exp.key_curve = value;
     else if (k == "key_bits") t_exp.key_bits = value;
+    else if (k == "step_events") t_exp.step_events = value;
     else if (k == "reset") t_exp = Experiments{};
     else return fail(BVH_AMD_ERR_ARG, "bvh_amd_experiment: unknown knob '" + k + "'");
     return BVH_AMD_OK;
@@ -622,7 +623,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     args.stream_hints = 0;                                    // (decided below, with the order)
     // one ticket range per XCD (trace_body.inc: refill): free for incoherent batches, a win for every batch whose neighbouring
     // rays are close (coherence-sorted below, or generated that way by the caller)
-    static const int parts_env = getenv("BVH_AMD_PARTS") ? atoi(getenv("BVH_AMD_PARTS")) : 0;            // tuning knob
+    static const int parts_env = BVH_DEV_INT("BVH_AMD_PARTS", 0);            // tuning knob
     args.parts = t_parts > 0 ? std::min(t_parts, 256) : parts_env > 0 ? std::min(parts_env, 256) : n < 65536 ? 1 : 8;   // (refined below once the order is decided)
     args.part_size = ((n + args.parts - 1) / args.parts + 63) / 64 * 64;
     args.deep = nullptr; args.deep_cap = 0;
@@ -660,8 +661,8 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
             args.deep = static_cast<uint32_t*>(deep_mem); args.deep_cap = static_cast<uint32_t>(cap);
         }
     }
-    static const int refill_env = getenv("BVH_AMD_REFILL") ? atoi(getenv("BVH_AMD_REFILL")) : 0;   // tuning knobs
-    static const int leaf_env = getenv("BVH_AMD_LEAF") ? atoi(getenv("BVH_AMD_LEAF")) : 0;
+    static const int refill_env = BVH_DEV_INT("BVH_AMD_REFILL", 0);   // tuning knobs
+    static const int leaf_env = BVH_DEV_INT("BVH_AMD_LEAF", 0);
     const bool beyond_l2 = b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
     const bool heavy = beyond_l2 && b.expected_visits.load() >= kReorderMinVisits;       // long walks through a tree the L2s cannot hold
     const bool any_hit = (flags & BVH_AMD_RAY_ANY_HIT) != 0;
@@ -739,7 +740,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
             lo[k] = b.root_bounds[2 * k];
             sc[k] = ext > T(0) ? T(64) / ext : T(0);
         }
-        static const int entry_depth = getenv("BVH_AMD_RAY_KEY_DEPTH") ? std::min(29, atoi(getenv("BVH_AMD_RAY_KEY_DEPTH"))) : 0;   // developer experiment
+        static const int entry_depth = std::min(29, BVH_DEV_INT("BVH_AMD_RAY_KEY_DEPTH", 0));   // developer experiment
         int key_bits = 21;
         bool entry_keys = false;
         if constexpr (std::is_same_v<T, float>) entry_keys = entry_depth > 0 && b.dim == 3;
@@ -750,7 +751,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
             }
         }
         if (!entry_keys) {
-            static const int cell_bits_env = getenv("BVH_AMD_RAY_KEY_BITS") ? std::max(1, std::min(8, atoi(getenv("BVH_AMD_RAY_KEY_BITS")))) : 7;   // developer knob
+            static const int cell_bits_env = std::max(1, std::min(8, BVH_DEV_INT("BVH_AMD_RAY_KEY_BITS", 7)));   // developer knob
             const int cell_bits = t_exp.key_bits > 0 ? std::min(8, t_exp.key_bits) : cell_bits_env;
             const T rescale = static_cast<T>(1u << cell_bits) / T(64);
             hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0] * rescale, sc[1] * rescale,
@@ -794,7 +795,7 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     const bool any_hit = (flags & BVH_AMD_RAY_ANY_HIT) != 0;
     const int kind = any_hit ? 1 : 0;
     const bool free_choice = !(flags & (BVH_AMD_RAY_SORTED | BVH_AMD_RAY_UNSORTED)) && coop_fetch_forced() < 0 && t_refill <= 0 && t_leaf <= 0 &&
-                             !getenv("BVH_AMD_REFILL") && !getenv("BVH_AMD_LEAF");
+                             !BVH_DEV_STR("BVH_AMD_REFILL") && !BVH_DEV_STR("BVH_AMD_LEAF");
     const bool candidate = calibrate_on && free_choice && b.dim == 3 && n >= (size_t{1} << 20) && n < (size_t{1} << 31) &&
                            b.pair_count * sizeof(PairNode<T>) > (size_t{32} << 20);
     if (!candidate) return launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, nullptr);
@@ -901,12 +902,10 @@ int trace_ray_callbacks(const BvhImpl<T>& b, const T ray8[8], uint32_t start, bo
     a.any = any ? 1u : 0u; a.record_pairs = inner_fn ? 1u : 0u;
     a.max_events = kStepEvents;
     a.max_steps = static_cast<uint32_t>(std::min<size_t>(b.pair_count + 1, 0xFFFFFFFFu));
-    if (const char* cap = getenv("BVH_AMD_STEP_EVENTS")) {    // test knob: a short log exercises the continue-from-device path
-        const long v = atol(cap);
-        if (v >= 1 && v < static_cast<long>(kStepEvents)) a.max_events = static_cast<uint32_t>(v);
-    }
+    // (bvh_amd_experiment("step_events", n): a short log exercises the continue-from-device path in the tests)
+    if (t_exp.step_events >= 1 && t_exp.step_events < static_cast<int>(kStepEvents)) a.max_events = static_cast<uint32_t>(t_exp.step_events);
     for (int k = 0; k < 8; ++k) a.ray[k] = ray8[k];
-    static const bool poll = !(getenv("BVH_AMD_STEP_POLL") && atoi(getenv("BVH_AMD_STEP_POLL")) == 0);
+    static const bool poll = !(BVH_DEV_INT("BVH_AMD_STEP_POLL", 1) == 0);
     T tmax = ray8[7];
     in[0] = 1; in[1] = start;
     for (;;) {

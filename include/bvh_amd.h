@@ -141,10 +141,24 @@ BVH_AMD_API void bvh_amd_device_free(void* d_ptr);
 BVH_AMD_API int bvh_amd_copy_to_device(void* d_dst, const void* h_src, size_t bytes);
 BVH_AMD_API int bvh_amd_copy_to_host(void* h_dst, const void* d_src, size_t bytes);
 BVH_AMD_API int bvh_amd_synchronize(void* stream);
-/* Builds, optimize and the sorts take their scratch from the device's stream-ordered memory pool and leave it cached there for
- * the next call (a 10M-triangle build uses a few GB); this returns the cached blocks to the driver. BVH_AMD_POOL=0 in the
- * environment disables the caching altogether (plain hipMalloc / hipFree). */
+/* Builds, optimize, the sorts and reordered ray batches take their scratch from the device's stream-ordered memory pool — always
+ * through a stream the LIBRARY owns, never the caller's — and keep freed blocks in a small cache for the next call, each with an
+ * event that marks the end of the call that freed it. Consequences a caller can rely on (round 5; c_api/bvh.h:129-132 has no
+ * lifetime rule beyond _destroy, and neither has this library): a `stream` argument is only used during the call it is passed to;
+ * it may be destroyed afterwards, whatever was built or cached while it lived (tests/c/stream_lifetime.c).
+ * The cache holds at most BVH_AMD_CACHE_MB megabytes per device (default: min(1024, 5 % of the HBM free at first use); 0 = no
+ * cache) and the pool keeps as much again of freed memory; a 10M-triangle build cycles ~3 GB of scratch, so a program that
+ * rebuilds scenes of that size in a loop wants BVH_AMD_CACHE_MB=8192. bvh_amd_release_cached_memory() returns everything to the
+ * driver (waits for the device). BVH_AMD_POOL=0 disables pool and cache (plain hipMalloc / hipFree).
+ *
+ * Environment variables a release library reads — all of them: BVH_AMD_CACHE_MB, BVH_AMD_POOL (above); BVH_AMD_CALIBRATE=0 (no
+ * measured launch-plan search, the predictor's plan always); BVH_AMD_REINSERT=exact (ReinsertionOptimizer: replay the reference's
+ * candidate heap in every iteration instead of only where the heap-free path cannot prove the same result); BVH_AMD_RCCL_LIB (path of librccl for the multi-GPU
+ * entry points; else the loader's search path, $ROCM_PATH/lib, /opt/rocm/lib). A/B switches, profiling aids and fault injection
+ * exist only in the developer build (python -m bvh_amd.build --developer -> libbvh_amd_dev.so, -DBVH_AMD_DEVELOPER).          */
 BVH_AMD_API int bvh_amd_release_cached_memory(void);
+BVH_AMD_API size_t bvh_amd_cached_scratch_bytes(void);     /* bytes the block cache holds on the current device right now */
+BVH_AMD_API size_t bvh_amd_scratch_cache_limit(void);      /* its bound on the current device */
 /* Measurement aid for bench.py (csrc/probe.hip): mean launch time of a dependent walk over a table of 64-byte records (word 0 of
  * a record = index of the next one), one record in flight per lane — the rate the memory system gives the traversal's access
  * pattern when nothing else is in the way. Not used by any product path. */
@@ -432,7 +446,8 @@ BVH_AMD_API void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int co
 /* Developer experiments of the calling thread, for A/B runs inside one process (tools/r04_experiments.py); results never change.
  * name: "grid_blocks" (cap of the persistent grid), "stream_hints" (1: rays / order / hit records loaded and stored non-temporally),
  * "tri_stride" (floats between PrecomputedTri records of the caller's array: 12, or 16 = padded to a 64-byte line), "key_curve"
- * (0 Morton, 1 Hilbert order of the reordering key), "key_bits" (bits per axis of its grid, 1..8); value < 0 = the default;
+ * (0 Morton, 1 Hilbert order of the reordering key), "key_bits" (bits per axis of its grid, 1..8), "step_events" (events the device
+ * logs per launch of the per-ray callback walk: a short log makes the tests continue a walk from the device's stack); value < 0 = the default;
  * "reset" clears all of them. Returns BVH_AMD_ERR_ARG for an unknown name.                                                       */
 BVH_AMD_API int bvh_amd_experiment(const char* name, int value);
 /* How the calling thread's latest batch launch was traced: out = {reordered 0/1, record fetch 0 per lane / 1 quad-cooperative, refill

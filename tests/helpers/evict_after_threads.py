@@ -1,7 +1,7 @@
 """Developer probe (round 4): host threads that build Quality::Low trees end (their worker streams are destroyed), then the main thread's
-builds push the scratch cache over a small bound so that the blocks those workers left are evicted.   BVH_AMD_CACHE_MB=64 python tools/diag_evict.py"""
+builds push the scratch cache over a small bound so that the blocks those workers left are evicted.   BVH_AMD_CACHE_MB=64 python tests/helpers/evict_after_threads.py"""
 import os, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bvh_amd
 from bvh_amd import synth

@@ -679,10 +679,10 @@ def test_scratch_block_cache_off_and_tiny(knob):
 def test_worker_streams_leave_nothing_cached_when_their_thread_ends():
     """A host thread that builds Quality::Low trees owns a worker stream (build_minitree.hip); when the thread ends the stream is destroyed,
     and scratch cached under its handle must be gone by then: the first eviction that met such a block crashed inside the runtime (a hang
-    of this suite in round 4). tools/diag_evict.py: three threads build and end, then the main thread's 1M-triangle builds evict under a
+    of this suite in round 4). tests/helpers/evict_after_threads.py: three threads build and end, then the main thread's 1M-triangle builds evict under a
     64 MB bound. Own process: the bound is read once."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_evict.py")], cwd=root, env=dict(os.environ, BVH_AMD_CACHE_MB="64"),
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "evict_after_threads.py")], cwd=root, env=dict(os.environ, BVH_AMD_CACHE_MB="64"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "] done" in r.stdout, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])

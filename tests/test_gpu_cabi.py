@@ -8,7 +8,7 @@ import pytest
 
 import oracle
 from bvh_amd import synth
-from conftest import load_golden
+from conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -101,3 +101,25 @@ def test_errors_are_reported_not_swallowed():
     assert dll.bvh3f_intersect_rays_tri(None, None, None, 10, 0, None, None, None) != 0
     assert not dll.bvh3f_deserialize(b"\x01\x00", 2)
     assert "truncated" in L.last_error()
+
+
+def test_a_callers_stream_may_die_after_the_call(tmp_path):
+    """VERDICT r4 item 3 / ADVICE r4: scratch is allocated and freed through a stream the library owns and cached blocks hang on events,
+    so a stream handed to build / intersect calls may be destroyed afterwards — evictions, the flush and the destruction of a BVH built
+    on the dead stream must all work (tests/c/stream_lifetime.c; BVH_AMD_CACHE_MB=8 makes every later build evict). The reference's
+    contract has no lifetime rule beyond _destroy (c_api/bvh.h:129-132)."""
+    import subprocess
+    lib = os.path.join(ROOT, "bvh_amd", "lib")
+    exe = str(tmp_path / "stream_lifetime")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "stream_lifetime.c"),
+           "-L", lib, "-lbvh_amd", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for mb in ("8", "0", None):                                    # evicting on every free / no cache at all / the default bound
+        env = dict(os.environ)
+        env.pop("BVH_AMD_CACHE_MB", None)
+        if mb is not None:
+            env["BVH_AMD_CACHE_MB"] = mb
+        r = subprocess.run([exe, "300000", "1048576"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "stream lifetime ok" in r.stdout, (mb, r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+

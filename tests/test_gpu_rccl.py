@@ -17,12 +17,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the loopback and fault-injection knobs exist only in the developer build of the library (csrc/common.h: BVH_DEV_*; built by
+# __graft_entry__.build() next to the release library, same sources + -DBVH_AMD_DEVELOPER)
+DEV_LIB = os.path.join(ROOT, "bvh_amd", "lib", "libbvh_amd_dev.so")
 
 
-def _compile(out):
+def _dev_env(**knobs):
+    assert os.path.exists(DEV_LIB), "bvh_amd/lib/libbvh_amd_dev.so missing: python -m bvh_amd.build --developer"
+    return dict(os.environ, BVH_AMD_LIB=DEV_LIB, HSA_ENABLE_IPC_MODE_LEGACY="0", **knobs)
+
+
+def _compile(out, developer=False):
     lib = os.path.join(ROOT, "bvh_amd", "lib")
     cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "replicate.c"),
-           "-L", lib, "-lbvh_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+           "-L", lib, "-lbvh_amd_dev" if developer else "-lbvh_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out
@@ -30,8 +38,8 @@ def _compile(out):
 
 @pytest.mark.parametrize("loopback", ["0", "1"])
 def test_c_program_replicates_broadcasts_and_traces(tmp_path, loopback):
-    exe = _compile(str(tmp_path / "replicate"))
-    env = dict(os.environ, BVH_AMD_BROADCAST_LOOPBACK=loopback, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    exe = _compile(str(tmp_path / "replicate"), developer=loopback == "1")
+    env = _dev_env(BVH_AMD_BROADCAST_LOOPBACK="1") if loopback == "1" else dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([exe, "50000", "300001"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "replicate ok" in r.stdout
@@ -83,7 +91,7 @@ print("rccl world-1 loopback ok", timing)
 def test_python_broadcast_scene_over_rccl_single_rank_loopback(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(PY_WORKER.format(root=ROOT))
-    env = dict(os.environ, BVH_AMD_BROADCAST_LOOPBACK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = _dev_env(BVH_AMD_BROADCAST_LOOPBACK="1")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "loopback ok" in r.stdout
@@ -157,7 +165,7 @@ prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
 try:
     broadcast_scene(bvh, prims, src=0, transport="rccl")
 except _lib.BvhAmdError as e:
-    assert "BVH_AMD_BROADCAST_FAIL_RANK" in str(e), str(e)
+    assert "fault injection" in str(e), str(e)
     print("status round ok:", e)
 else:
     raise SystemExit("the failing rank's broadcast returned a scene")
@@ -171,7 +179,7 @@ def test_failed_preparation_is_agreed_on_before_any_payload(tmp_path):
     knob BVH_AMD_BROADCAST_FAIL_RANK makes a rank fail its preparation: the call returns an error instead of posting the payload."""
     script = tmp_path / "f.py"
     script.write_text(FAIL_WORKER.format(root=ROOT))
-    env = dict(os.environ, BVH_AMD_BROADCAST_FAIL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = _dev_env(BVH_AMD_BROADCAST_FAIL_RANK="0")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "status round ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
@@ -216,6 +224,6 @@ def test_two_ranks_receiver_failure_reaches_the_root(tmp_path):
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            str(script)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, BVH_AMD_BROADCAST_FAIL_RANK="1"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_dev_env(BVH_AMD_BROADCAST_FAIL_RANK="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "test knob" in (tmp_path / "failed1.txt").read_text() and "another rank" in (tmp_path / "failed0.txt").read_text()
+    assert "fault injection" in (tmp_path / "failed1.txt").read_text() and "another rank" in (tmp_path / "failed0.txt").read_text()

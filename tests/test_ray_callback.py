@@ -318,10 +318,8 @@ def test_callback_walk_on_a_tree_deeper_than_the_small_stack(restatement):
     for any_hit, log_cap in ((False, None), (True, None), (False, "7"), (False, "1")):
         want, cnt = ref.intersect_tri(prims, rays, any_hit, True, counters=True)
         pairs = leaves = 0
-        if log_cap:
-            os.environ["BVH_AMD_STEP_EVENTS"] = log_cap        # a log of 7 (or 1) events per launch
-        else:
-            os.environ.pop("BVH_AMD_STEP_EVENTS", None)
+        lib = bvh_amd._lib.load()
+        lib.bvh_amd_experiment(b"step_events", int(log_cap) if log_cap else -1)   # a log of 7 (or 1) events per launch
         for j, ray in enumerate(rays):
             leaf, state = _tri_leaf(prims, ray, np.float32)
             seen, calls = [], [0]
@@ -333,7 +331,7 @@ def test_callback_walk_on_a_tree_deeper_than_the_small_stack(restatement):
                 gpu.intersect_ray(ray, counted, any_hit=any_hit, robust=True, inner_fn=seen.append)
             finally:
                 if j == len(rays) - 1:
-                    os.environ.pop("BVH_AMD_STEP_EVENTS", None)
+                    lib.bvh_amd_experiment(b"step_events", -1)
             pairs += len(seen)
             leaves += calls[0]
             assert state["prim"] == (int(want["prim"][j]) if want["prim"][j] != oracle.INVALID else -1)
