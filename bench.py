@@ -50,6 +50,13 @@ def parse_args():
     ap.add_argument("--workload", default="soup_1m", choices=sorted(WORKLOADS))
     ap.add_argument("--rays", type=int, default=1 << 24, help="rays per GPU per step (with --strong: rays per step over ALL GPUs)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --rays is the whole job, each rank traces ceil(rays / N) of it")
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE.json configs[3] exactly: the 10M-triangle procedural mesh (soup_10m), DefaultBuilder with thread pool + Quality::High "
+                         "(mini-trees + reinsertion), 100M closest-hit rays per step over ALL ranks (--strong): = --workload soup_10m --quality high "
+                         "--strong --rays 100000000. `python bench.py --gpus 8 --config3` is THE configs[3] line.")
+    ap.add_argument("--one-process", action="store_true",
+                    help="N > 1 without torch.distributed: ONE process, bvh3f_replicate (the library's ncclCommInitAll + grouped ncclBroadcast) "
+                         "and one host thread + stream per device — what a C caller of the reference API would write (tests/c/replicate.c)")
     ap.add_argument("--fast", action="store_true", help="intersect_fast instead of the robust slab test")
     ap.add_argument("--quality", default="high", choices=["low", "medium", "high"], help="DefaultBuilder quality of the traced BVH")
     ap.add_argument("--serial-builder", action="store_true", help="DefaultBuilder without a thread pool (binned/sweep) instead of mini-trees")
@@ -60,24 +67,26 @@ def parse_args():
     ap.add_argument("--no-reorder", action="store_true", help="trace the rays in the order given (BVH_AMD_RAY_UNSORTED)")
     ap.add_argument("--no-probe", action="store_true", help="skip the record-walk probes behind roofline.peak")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect the traversal kernel's L1 / L2 / fabric counters with rocprofv3 --pmc passes of a child run")
+    ap.add_argument("--pmc-budget", type=float, default=240.0, help="seconds the rocprofv3 --pmc child passes may take in total")
     ap.add_argument("--pmc-child", default=None, metavar="R,C,REFILL,LEAF",
                     help="(internal) the child of a --pmc pass: build the scene, trace 1 + 3 batches with this launch plan, print nothing")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="join the N ranks, print {n_gpus, ranks} from rank 0 and exit: checks the launch path, needs no GPU (tests/test_bench_contract.py)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config3:
+        args.workload, args.quality, args.strong, args.rays, args.serial_builder = "soup_10m", "high", True, 100_000_000, False
+    return args
 
 
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) outside a torchrun environment: start the N ranks ourselves, one process per GPU, exactly
-    the way the driver's multi-GPU command does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
-    127.0.0.1 ...), and hand its exit code back. Rank 0 of the children prints the JSON line on our stdout."""
-    import socket
+    the way the driver's multi-GPU command does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...; the rendezvous
+    is torchrun's --standalone one instead of --master-addr/--master-port), and hand its exit code back. Rank 0 of the children prints the JSON line on our stdout."""
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous on a port IT binds (a port probed here first could be taken again before
+    # torchrun binds it — ADVICE r4); --local-addr 127.0.0.1 because the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, BVH_AMD_BENCH_SELF_LAUNCHED="1")
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.call(cmd, env=env)
@@ -113,11 +122,8 @@ def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample, quality, seria
     Test infrastructure only."""
     import ctypes as C
     import oracle
-    lib = oracle.load_ref()
-    kind = "reference"
-    if lib is None:
-        lib = oracle.load_oracle()
-        kind = "port"
+    lib = oracle.gpu_checker()                                # oracle/_ref wherever it is in the tree (it must load then), else the restatement
+    kind = "reference" if lib.prefix == "ref" else "port"
     usable, affinity, quota = usable_cpus()
     hw = lib.hardware_threads()
     cb = lib.from_arrays(bvh.nodes, bvh.prim_ids)
@@ -179,42 +185,19 @@ def cpu_baseline(tris, bvh, rays_sample, robust, gpu_hits_sample, quality, seria
     }
 
 
-def pmc_record(args, robust, kernel_name, reordered, rays):
-    """Counters of the traced kernel from SEPARATE rocprofv3 --pmc passes of this same command (they cannot be collected inside a
-    timed run): tools/pmc_traffic.py records them in profiles/pmc_traffic.json together with a sha1 of the traced kernel's
-    instructions. Returns (record or None, note): the counts are only quoted for a library whose kernel is instruction-identical
-    to the one that was traced."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None, "no profiles/pmc_traffic.json"
-    key = (f"{args.workload}|{args.quality}|{'serial' if args.serial_builder else 'pool'}|{'robust' if robust else 'fast'}|{rays}|"
-           f"{'reordered' if reordered else 'as_given'}")
-    rec = json.load(open(path)).get(key)
-    if rec is None:
-        return None, f"no --pmc pass recorded for {key}"
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from kernel_isa import kernel_isa_hash
-    from bvh_amd import _lib
-    have = kernel_isa_hash(_lib.LIB_PATH, kernel_name)
-    if rec.get("kernel") != kernel_name or have is None or have != rec.get("isa_sha1"):
-        note = (f"profiles/pmc_traffic.json was traced on another build of {kernel_name} (isa sha1 {rec.get('isa_sha1')} vs loaded "
-                f"{have}): counters withheld, re-run tools/pmc_traffic.py")
-        print("[bench] WARNING: " + note, file=sys.stderr)
-        return None, note
-    return rec, f"rocprofv3 --pmc passes of this command, kernel isa sha1 {have[:12]} (profiles/pmc_traffic.json)"
-
-
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"],
               ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]]
 PMC_CHILD_STEPS = 3
 
 
-def pmc_live(args, robust, kernel_name, plan, rays, extra_passes=()):
+def pmc_live(args, robust, kernel_name, plan, rays, extra_passes=(), device_index=0):
     """The traversal kernel's counters, per launch, collected NOW: one child run of this script per counter group under
     `rocprofv3 --pmc <group> --kernel-trace` (counters only — never together with a sys / hip trace), each child building the same
     scene and tracing 1 + 3 batches with the launch plan the timed run settled on; the mean over the kernel's last 3 dispatches is kept.
     Returns (record or None, note). FETCH_SIZE / WRITE_SIZE are KB at the L2's fabric side (calibrated at 0.998 of a known byte count in
-    this access pattern, profiles/r03_fetch_calibration.json)."""
+    this access pattern, profiles/r03_fetch_calibration.json). The passes share ONE time budget (--pmc-budget seconds, default 240:
+    every child rebuilds the scene); a pass that cannot start within it is not started and the line says so. With N > 1
+    ranks, rank 0 runs this after the final device barrier while the other ranks wait on the host (gloo), on rank 0's own device."""
     import csv
     import glob
     import shutil
@@ -229,17 +212,25 @@ def pmc_live(args, robust, kernel_name, plan, rays, extra_passes=()):
         child.append("--serial-builder")
     if args.fast:
         child.append("--fast")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "BVH_AMD_BENCH_SELF_LAUNCHED", "BVH_AMD_BENCH_ONE_DEVICE", "BVH_AMD_BENCH_BACKEND")}
     env["TMPDIR"] = "/tmp"
+    if device_index:                                          # the child sees only this rank's GPU (as its device 0)
+        env["HIP_VISIBLE_DEVICES"] = str(device_index)
+    deadline = time.perf_counter() + float(args.pmc_budget)
     want = kernel_name.replace(" ", "")
     values = {}
     t0 = time.perf_counter()
     with tempfile.TemporaryDirectory(prefix="bvh_amd_pmc_") as work:
         for i, counters in enumerate(list(PMC_PASSES) + [list(p) for p in extra_passes]):
             d = os.path.join(work, f"p{i}")
+            left = deadline - time.perf_counter()
+            if left < 20.0:
+                return None, f"--pmc-budget of {args.pmc_budget:.0f} s spent before pass {i + 1} ({counters}): counters withheld rather than quoted in part"
             try:
                 r = subprocess.run(["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
-                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=min(180.0, left))
             except (OSError, subprocess.TimeoutExpired) as exc:
                 return None, f"rocprofv3 --pmc pass {counters} failed: {exc!r}"
             if r.returncode != 0:
@@ -326,6 +317,99 @@ def hierarchy_ceilings(working_set_bytes, coop, active):
             "l2_and_fabric_times": mixed_walk_probe(big, coop)}
 
 
+def roofline_section(args, lib, *, robust, rays_here, kernel_ms, pass_ms, reorder_ms, P, T, b_ray, node_count, n_tris, plan, first_plan,
+                     first_call_ms, device_index, reordered):
+    """The `roofline` object of the line for ONE device's launches (rank 0 / device 0): algorithmic bytes, the kernel's counters collected
+    now by child passes (pmc_live), the probe-measured ceilings of every level of the memory hierarchy, the data-sheet pricing."""
+    algorithmic = b_ray * rays_here / (kernel_ms * 1e-3) / 1e9
+    kernel_name = lib.bvh_amd_last_kernel_name().decode()
+    coop = kernel_name.startswith("trace_kernel_coop")
+    # counters of THIS kernel on THIS workload, whatever N: rank 0 collects them now, on its own device, while the other ranks wait
+    # on the host at the final (gloo) barrier — every N's line carries the same roofline fields (VERDICT r4 Weak 6); there is no
+    # stored fallback any more (profiles/pmc_traffic.json went stale with every kernel change)
+    rec, pmc_note = (None, "--no-pmc") if args.no_pmc else pmc_live(args, robust, kernel_name, [plan[0], plan[1], plan[2], plan[3]], rays_here,
+                                                                     device_index=device_index)
+    if rec is None:
+        print("[bench] WARNING: no counters on this line: " + pmc_note, file=sys.stderr)
+    traffic = None if rec is None else round((rec["fetch_kb"] + rec["write_kb"]) * 1024.0 / (kernel_ms * 1e-3) / 1e9, 1)
+    # ---- the ceiling that binds: the memory hierarchy under the kernel's own access pattern ---------------------------------
+    # A ray fetches P pair records, T primitives (48 B = 3/4 of a record's requests) and itself (2 requests); each fetch is served
+    # by the L1, an L2 or the fabric side, and each level has a measured rate for dependent random 64-byte record fetches
+    # (csrc/probe.hip, live). Lower bound of the launch time: the slowest level; `sum_ms` = the no-overlap estimate.
+    working_set = node_count // 2 * 64 + n_tris * 48
+    lanes = 28 if rec is None or not rec.get("lane_utilisation") else max(8, min(64, int(round(64 * rec["lane_utilisation"]))))
+    probe = None if args.no_probe else hierarchy_ceilings(working_set, coop, lanes)
+    records = rays_here * (float(P) + 0.75 * float(T) + 0.5)          # record-equivalents every launch asks of the L1
+    levels = None
+    if probe is not None:
+        levels = {"l1": {"records_per_launch": round(records), "grec_s": probe["l1_grec_s"], "ms": round(records / probe["l1_grec_s"] / 1e6, 4),
+                         "what": "every record fetch passes the L1's request pipeline: rays x (P + 3/4 T + 1/2) record-equivalents at the "
+                                 "L1-resident rate of the probe"}}
+        if rec is not None and rec.get("tcp_tcc_read_req"):
+            l2_req, misses = float(rec["tcp_tcc_read_req"]), float(rec.get("tcc_miss") or rec["fetch_kb"] * 1024.0 / 64.0)
+            levels["l2"] = {"requests_per_launch": round(l2_req), "grec_s": probe["l2_grec_s"], "ms": round(l2_req / probe["l2_grec_s"] / 1e6, 4),
+                            "what": "L1 misses (TCP_TCC_READ_REQ) at the L2-resident rate of the probe"}
+            levels["fabric"] = {"requests_per_launch": round(misses), "grec_s": probe["beyond_l2_grec_s"],
+                                "ms": round(misses / probe["beyond_l2_grec_s"] / 1e6, 4),
+                                "what": "L2 misses (TCC_MISS; FETCH_SIZE / 64 B agrees within 15 %, FETCH_SIZE itself calibrated at 0.998 of a known byte "
+                                        "count in this pattern: profiles/r03_fetch_calibration.json) at the beyond-L2 rate of the probe, whose every record is a miss"}
+            l2_hits = max(0.0, l2_req - misses)
+            mix = probe["l2_and_fabric_times"]                    # the ceiling takes the BEST rate this run measured for each level
+            r_l2, r_far = max(probe["l2_grec_s"], mix["pure_l2_grec_s"]), max(probe["beyond_l2_grec_s"], mix["pure_beyond_l2_grec_s"])
+            levels["beyond_l1"] = {"l2_hits_per_launch": round(l2_hits), "l2_misses_per_launch": round(misses), "l2_grec_s": r_l2, "beyond_l2_grec_s": r_far,
+                                   "ms": round(l2_hits / r_l2 / 1e6 + misses / r_far / 1e6, 4),
+                                   "what": "every L1 miss holds one of the CU's outstanding lines until the L2 (hit) or the fabric (miss) has served it: "
+                                           "the two service times ADD (probe.l2_and_fabric_times: a walk alternating L2 hit / L2 miss runs at the "
+                                           "add rate, not at the overlap rate), so hits / R_L2 + misses / R_beyond_L2 is the time the launch's L1 "
+                                           "misses need; the L1 request pipeline (level l1) works in parallel with it"}
+    # the same requests priced at the data-sheet rates of /opt/skills/guides/MI355X_MICROARCH.md (L2 34.5 TB/s aggregate, HBM 8 TB/s), 64 bytes
+    # per request: what the kernel would need if the hierarchy served random 64-byte records at its streaming peaks
+    guide = None
+    if rec is not None and rec.get("tcp_tcc_read_req"):
+        l2_req_g = float(rec["tcp_tcc_read_req"])
+        miss_g = float(rec.get("tcc_miss") or rec["fetch_kb"] * 1024.0 / 64.0)
+        g_ms = (l2_req_g - miss_g) * 64.0 / 34.5e12 * 1e3 + miss_g * 64.0 / (HBM_PEAK_GBS * 1e9) * 1e3
+        guide = {"l2_tb_s": 34.5, "hbm_tb_s": HBM_PEAK_GBS / 1e3, "ms": round(g_ms, 4), "frac": round(g_ms / kernel_ms, 4),
+                 "what": "L2 hits x 64 B / 34.5 TB/s + L2 misses x 64 B / 8 TB/s over kernel_ms: the data-sheet ceiling beside the probe-measured one "
+                         "(frac above); the gap between the two is what dependent random 64-byte fetches cost over streaming"}
+    model_ms = None if levels is None else max(v["ms"] for v in levels.values())
+    sum_ms = None if levels is None else sum(v["ms"] for k, v in levels.items() if k in ("l1", "beyond_l1"))
+    peak_mrays = None if not model_ms else rays_here / model_ms / 1e3
+    achieved_mrays = rays_here / kernel_ms / 1e3
+    return {"bound": "memory hierarchy (L1 request pipeline | L2 hits + fabric misses behind it) under dependent random 64-byte record fetches",
+                "achieved": round(achieved_mrays, 1), "peak": None if peak_mrays is None else round(peak_mrays, 1), "unit": "Mrays/s",
+                "frac": None if peak_mrays is None else round(achieved_mrays / peak_mrays, 4),
+                "frac_is": "achieved / peak, peak from rates MEASURED IN THIS RUN by dependent-walk probes (not a hardware data-sheet peak); "
+                "`at_guide_rates` prices the same requests at the data-sheet rates, `hbm_algorithmic` is SURVEY.md 8(d)'s figure",
+                "at_guide_rates": guide,
+                "binding_level": None if levels is None else max(levels, key=lambda k: levels[k]["ms"]),
+                "model_ms": None if model_ms is None else round(model_ms, 4), "sum_of_levels_ms": None if sum_ms is None else round(sum_ms, 4),
+                "levels": levels, "probe": probe,
+                "what": "peak = rays per launch / max(time the L1 request pipeline needs for the launch's record fetches, time its L1 misses "
+                "need behind the L1 = L2 hits / R_L2 + L2 misses / R_beyond_L2), every rate measured in this run by a dependent-walk probe "
+                "in the kernel's own fetch mode; achieved = rays per launch / kernel_ms. HBM is NOT what binds this kernel: "
+                "see hbm_algorithmic below (SURVEY.md 8d's figure) and traffic",
+                "traffic": traffic, "traffic_unit": "GB/s at the L2's fabric side (FETCH_SIZE + WRITE_SIZE)",
+                "traffic_frac_of_hbm": None if traffic is None else round(traffic / HBM_PEAK_GBS, 4), "counters_source": pmc_note,
+                "hbm_algorithmic": {"bound": "hbm", "achieved": round(algorithmic, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(algorithmic / HBM_PEAK_GBS, 4), "bytes_per_ray": round(b_ray, 1),
+                "what": "algorithmic bytes (SURVEY.md 8d: 32 + 56 P + 48 T + 16 per ray) / kernel time over the 8 TB/s HBM "
+                "peak; > 1 is possible because L1 / L2 serve re-referenced nodes: not a ceiling of this kernel"},
+                "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
+                "pass_split_ms": {"ray_keys_and_radix_sort": round(reorder_ms, 4), "traversal_kernel": round(kernel_ms, 4),
+                "rest (launch gaps, counter reset)": round(max(0.0, pass_ms - reorder_ms - kernel_ms), 4)},
+                "ray_reordering": ("on: 24-bit origin-cell/octant key + three radix passes inside every timed pass" if reordered else "off"),
+                "record_fetch": "quad-cooperative" if coop else "per lane",
+                "launch_plan": {"reordered": bool(plan[0]), "quad_cooperative_fetch": bool(plan[1]), "refill_threshold": int(plan[2]),
+                "leaf_threshold": int(plan[3]),
+                "how": "measured by the library on this tree's first large batches (one whole batch per candidate), then fixed"},
+                "first_call": {"ms": round(first_call_ms, 4), "reordered": bool(first_plan[0]), "quad_cooperative_fetch": bool(first_plan[1]),
+                "over_settled_pass": round(first_call_ms / pass_ms, 4),
+                "what": "wall time of the FIRST large batch through the fresh tree (host clock around one call + "
+                "synchronisation, after a 4096-ray call that loads the code): traced with the predictor's plan; the "
+                "search explores the other plans from the second batch on"},
+                "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)}
+
 def mean_split_ancestors(nodes, n_prims):
     """L-bar of SURVEY.md 8(d): mean number of inner (split) ancestors per primitive of the built tree."""
     idx = nodes["index"].astype(np.int64)
@@ -354,6 +438,85 @@ def through_obj(tris):
         raise SystemExit("bench: the mesh read back from its OBJ file differs from the generated one")
     return back, size
 
+
+def scene_and_builds(args, gen, n_tris, label):
+    """Rank 0 / device 0: the mesh (synthetic through an OBJ file, or --obj), every DefaultBuilder quality built and timed on the GPU,
+    the BVH of --quality and its BVH-ordered PrecomputedTri array resident in HBM."""
+    import torch
+    import bvh_amd
+    from bvh_amd import synth
+    data = "synthetic"
+    if args.obj:
+        from bvh_amd.obj import load_obj
+        tris = load_obj(args.obj)
+        if len(tris) == 0:
+            raise SystemExit(f"{args.obj}: no faces")
+        n_tris = len(tris)
+        label = f"{n_tris}-tri OBJ mesh"
+        data = "Wavefront OBJ mesh + synthetic rays"
+    else:
+        tris = getattr(synth, gen)(n_tris)
+        if not args.no_obj_roundtrip and n_tris <= 2_000_000:
+            tris, obj_bytes = through_obj(tris)
+            data = (f"synthetic mesh via OBJ (written as a {obj_bytes / 1e6:.0f} MB Wavefront OBJ, read back with the reference loader's semantics, "
+                    "triangle bytes identical) + synthetic rays")
+        else:
+            data = "synthetic mesh (arrays; OBJ round trip skipped at this size) + synthetic rays"
+    d_tris = torch.from_numpy(tris).cuda()
+    pool = None if args.serial_builder else bvh_amd.ThreadPool()
+    builds, high_profile = {}, None
+    for qname in ("low", "medium", "high"):                               # build Mtris/s of every DefaultBuilder mode
+        cfg = bvh_amd.Config(quality=bvh_amd.Quality[qname.capitalize()])
+        bb, cc = bvh_amd.tri_bounds(d_tris)
+        bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)   # warm-up build (allocations, code load)
+        times, times_host = [], []
+        for _ in range(5 if qname != "high" else 3):                          # SURVEY.md 8(d): median of >= 5 after a warm-up
+            bvh_q = None                                                      # (destroying the previous BVH is not part of a build)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bb, cc = bvh_amd.tri_bounds(d_tris)
+            bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)   # triangles in HBM -> BVH resident in HBM
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        # + the device-to-host copy of the reference-layout Bvh, timed in its own builds: releasing a host mirror makes the NEXT build
+        # ~0.4 ms slower (measured: 2.39 -> 2.76-2.94 ms at 1M), which is an artifact of this loop, not part of a resident build
+        for _ in range(3 if qname != "high" else 1):
+            bvh_q = None
+            bb, cc = bvh_amd.tri_bounds(d_tris)
+            bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            bvh_q.sync_host()
+            times_host.append(time.perf_counter() - t1)                       # the copy alone; reported on top of the median build above
+        if qname == "high":                                                   # what the ReinsertionOptimizer step of the last High build did
+            p = bvh_amd.last_optimize_profile()
+            high_profile = dict(p, us_per_replacement=None if not p["replacements"] else round(p["heap_ms"] * 1e3 / p["replacements"], 4),
+                                heap_ms=round(p["heap_ms"], 3),
+                                what="ReinsertionOptimizer of the last High build: iterations run, iterations that replayed the libstdc++ candidate heap "
+                                     "exactly (the heap-free fast path was refused: a tie at the top-k threshold or equal gains sharing a node), "
+                                     "pop_heap + push_heap replacements of those replays, GPU ms of the heap kernels (one sequential wave pair)")
+        # SURVEY.md 8(d): B_build = 36 (tri) + 36 (bbox + center) + 76 L-bar + 28 N/n + 4 algorithmic bytes per triangle
+        lbar = mean_split_ancestors(bvh_q.nodes, n_tris)
+        b_build = 36.0 + 36.0 + 76.0 * lbar + 28.0 * bvh_q.node_count / n_tris + 4.0
+        builds[qname] = (sorted(times)[len(times) // 2] * 1e3, bvh_q, (sorted(times)[len(times) // 2] + sorted(times_host)[len(times_host) // 2]) * 1e3, lbar, b_build)
+    build_ms, bvh, build_host_ms = builds[args.quality][:3]
+    prims = bvh_amd.precompute_tris(d_tris, bvh.device_prim_ids())
+    return {"tris": tris, "n_tris": n_tris, "label": label, "data": data, "builds": builds, "high_profile": high_profile, "build_ms": build_ms,
+            "bvh": bvh, "build_host_ms": build_host_ms, "prims": prims}
+
+def build_section(n_tris, builds, high_profile, build_ms, build_host_ms):
+    """The `build` object of the line: Mtris/s of every DefaultBuilder quality against SURVEY.md 8(d)'s B_build."""
+    return {"mtris_s": round(n_tris / (build_ms * 1e-3) / 1e6, 2), "ms": round(build_ms, 3),
+        "roofline": {q: {"bound": "hbm", "achieved": round(v[4] * n_tris / (v[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(v[4] * n_tris / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_tri": round(v[4], 1),
+        "mean_split_ancestors": round(v[3], 2)} for q, v in builds.items()},
+        "all_qualities_ms": {k: round(v[0], 3) for k, v in builds.items()},
+        "all_qualities_mtris_s": {k: round(n_tris / (v[0] * 1e-3) / 1e6, 2) for k, v in builds.items()},
+        "high": high_profile,
+        "ms_with_host_mirror": round(build_host_ms, 3),
+        "mtris_s_with_host_mirror": round(n_tris / (build_host_ms * 1e-3) / 1e6, 2),
+        "what": "tri bounds + DefaultBuilder, triangles resident in HBM -> BVH resident in HBM; *_with_host_mirror adds "
+        "the device-to-host copy of the reference-layout Bvh; median of 5 (High: 3) after a warm-up build"}
 
 def pmc_child(args):
     """Child of a `rocprofv3 --pmc` pass (pmc_live): the same scene, rays and launch plan as the timed run, 1 + 3 batches, no output."""
@@ -399,11 +562,158 @@ def rendezvous_only(args, rank, local_rank, world):
                           "rendezvous_only": True}), flush=True)
 
 
+def one_process(args):
+    """`--one-process`: the N > 1 path WITHOUT torch.distributed — one process, `bvh3f_replicate` (the library's own ncclCommInitAll + one
+    grouped ncclBroadcast of the Bvh::serialize stream and the primitives), then one host thread + one stream per device, each tracing
+    its shard with `bvh3f_intersect_rays_tri`: what a C caller of the reference API writes (tests/c/replicate.c; `Bvh::intersect` is a
+    re-entrant const method, bvh.h:160-182, so contiguous ray ranges shard freely). Same timing contract as the torchrun path: W warm-up
+    steps, a barrier, EXACTLY K steps per device, every device synchronised, the slowest device's time counts. Afterwards device 0
+    traces every other device's shard itself and the hit records must be byte-equal (`hits_equal_single_gpu`)."""
+    import ctypes
+    import threading
+    import torch
+    import bvh_amd
+    from bvh_amd import synth
+    from bvh_amd.parallel import replicate_scene, shard_range
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: bvh_amd has no CPU path")
+    n_dev = args.gpus
+    if torch.cuda.device_count() < n_dev:
+        raise SystemExit(f"bench.py --one-process --gpus {n_dev}: only {torch.cuda.device_count()} device(s) visible")
+    lib = bvh_amd._lib.load()
+    torch.cuda.set_device(0)
+    gen, n_tris, desc, label = WORKLOADS[args.workload]
+    if args.obj:
+        args.workload = "obj:" + os.path.basename(args.obj)
+        gen, desc = None, f"{os.path.basename(args.obj)} (Wavefront OBJ, reference loader semantics: load_obj.cpp:57-96)"
+    robust = not args.fast
+    sc = scene_and_builds(args, gen, n_tris, label)
+    tris, n_tris, label, data, bvh, prims = sc["tris"], sc["n_tris"], sc["label"], sc["data"], sc["bvh"], sc["prims"]
+    rep = {}
+    copies = replicate_scene(bvh, prims, list(range(n_dev)), timing=rep)
+    lo, hi = synth.scene_bounds(tris)
+    sort_rays = False if args.no_reorder else None
+    shard = [shard_range(args.rays, k, n_dev) if args.strong else (0, args.rays) for k in range(n_dev)]
+    rays_h = [synth.rays_closest(e - b, lo, hi, seed=1234 + k) for k, (b, e) in enumerate(shard)]
+    state = [dict() for _ in range(n_dev)]
+    gate = threading.Barrier(n_dev + 1)
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(k)
+            stream = torch.cuda.Stream(device=k)
+            bvh_k, prims_k = copies[k]
+            with torch.cuda.stream(stream):
+                rays = torch.from_numpy(rays_h[k]).cuda(k)
+                hits = torch.empty((len(rays_h[k]), 4), dtype=torch.float32, device=f"cuda:{k}")
+
+                def step():
+                    bvh_amd.intersect(bvh_k, prims_k, rays, any_hit=False, robust=robust, out=hits, sort_rays=sort_rays)
+                for _ in range(10):                           # the library settles its launch plan for this copy of the tree (see main())
+                    step()
+                    stream.synchronize()
+                for _ in range(args.warmup):
+                    step()
+                stream.synchronize()
+                gate.wait()                                   # ---- timed region starts (main thread reads the clock behind this barrier)
+                for _ in range(args.steps):
+                    step()
+                stream.synchronize()
+                state[k]["t_done"] = time.perf_counter()
+                gate.wait()                                   # ---- timed region ends
+                state[k]["rays"], state[k]["hits"] = rays, hits
+        except Exception as exc:                              # noqa: BLE001
+            errors.append((k, repr(exc)))
+            gate.abort()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_dev)]
+    for t in threads:
+        t.start()
+    try:
+        gate.wait()
+        t0 = time.perf_counter()
+        gate.wait()
+        elapsed = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        for t in threads:
+            t.join()
+        raise SystemExit(f"bench.py --one-process: a device thread failed: {errors}")
+    for t in threads:
+        t.join()
+    if errors:
+        raise SystemExit(f"bench.py --one-process: {errors}")
+    per_device = [{"device": k, "rays_per_step": len(rays_h[k]), "ms_per_step": round((state[k]["t_done"] - t0) / args.steps * 1e3, 4),
+                   "mrays_s": round(len(rays_h[k]) * args.steps / (state[k]["t_done"] - t0) / 1e6, 1)} for k in range(n_dev)]
+    # every shard once more on device 0 alone: the sharded result must be the single-GPU result, byte for byte
+    torch.cuda.set_device(0)
+    equal = True
+    for k in range(1, n_dev):
+        r0 = state[k]["rays"].to("cuda:0")
+        h0 = bvh_amd.intersect(bvh, prims, r0, any_hit=False, robust=robust, sort_rays=sort_rays)
+        equal = equal and bool(torch.equal(h0.view(torch.int32), state[k]["hits"].to("cuda:0").view(torch.int32)))
+    # the roofline of device 0's launches, measured on device 0 alone after the timed region (the library's kernel-time ring is one per process)
+    rays0, hits0 = state[0]["rays"], state[0]["hits"]
+    rays_here = len(rays_h[0])
+    _, cnt = bvh_amd.intersect(bvh, prims, rays0, any_hit=False, robust=robust, counters=True, sort_rays=sort_rays)
+    cnt = cnt.cpu().numpy()
+    P, T = cnt[0] / rays_here, cnt[1] / rays_here
+    b_ray = 32.0 + 56.0 * P + 48.0 * T + 16.0
+    plan = (ctypes.c_int * 4)()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    lib.bvh_amd_kernel_timing(1)
+    ev[0].record()
+    for i in range(args.steps):
+        bvh_amd.intersect(bvh, prims, rays0, any_hit=False, robust=robust, out=hits0, sort_rays=sort_rays)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    lib.bvh_amd_last_launch_plan(plan)
+    pass_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))
+    kt, rt = (ctypes.c_float * 256)(), (ctypes.c_float * 256)()
+    got = ctypes.c_size_t(0)
+    bvh_amd._lib.check(lib.bvh_amd_kernel_times(kt, min(args.steps, 256), ctypes.byref(got)), "kernel_times")
+    kernel_ms = float(np.mean(kt[:got.value])) if got.value else pass_ms
+    bvh_amd._lib.check(lib.bvh_amd_reorder_times(rt, min(args.steps, 256), ctypes.byref(got)), "reorder_times")
+    reorder_ms = float(np.mean(rt[:got.value])) if got.value else 0.0
+    lib.bvh_amd_kernel_timing(0)
+    roofline = roofline_section(args, lib, robust=robust, rays_here=rays_here, kernel_ms=kernel_ms, pass_ms=pass_ms, reorder_ms=reorder_ms, P=P, T=T,
+                                b_ray=b_ray, node_count=bvh.node_count, n_tris=n_tris, plan=plan, first_plan=plan, first_call_ms=pass_ms,
+                                device_index=0, reordered=bool(plan[0]))
+    roofline["first_call"] = None                             # (not measured in this mode)
+    roofline["measured"] = "device 0 alone, after the timed region of all devices"
+    total_rays = (args.rays if args.strong else args.rays * n_dev) * args.steps
+    out = {"metric": f"Mrays/s closest-hit ({label})", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": n_dev,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": data,
+           "config": {"workload": f"{args.workload}: {desc}; {'robust' if robust else 'fast'} traversal, DefaultBuilder "
+                                  f"{'serial' if args.serial_builder else 'with thread pool (mini-trees)'} Quality::{args.quality.capitalize()} built on the GPU",
+                      "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(rays_here),
+                      "rays_per_step_all_gpus": int(args.rays if args.strong else args.rays * n_dev),
+                      "parallelism": f"ONE process, {n_dev} device(s): bvh3f_replicate + one host thread and stream per device "
+                                     f"({'strong' if args.strong else 'weak'} scaling); no torch.distributed",
+                      "per_device": per_device, "hits_equal_single_gpu": equal, "launched_by": "single process (--one-process)"},
+           "roofline": roofline,
+           "build": build_section(n_tris, sc["builds"], sc["high_profile"], sc["build_ms"], sc["build_host_ms"]),
+           "broadcast": {"ms": round(rep.get("replicate_ms", 0.0), 3), "transport": rep.get("transport"),
+                         "what": "bvh3f_replicate, all devices, wall time incl. ncclCommInitAll on first use (outside the timed steps)"}}
+    if not args.no_cpu_baseline:
+        ns = min(args.cpu_sample, rays_here)
+        out["cpu_baseline"] = cpu_baseline(tris, bvh, rays_h[0][:ns], int(robust), bvh_amd.hits_to_numpy(hits0[:ns]), args.quality, args.serial_builder)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if not equal:
+        raise SystemExit("bench.py --one-process: a device's shard differs from device 0 tracing the same rays")
+
+
 def main():
     args = parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs across processes on this driver
     if args.pmc_child:
         pmc_child(args)
+        return
+    if args.one_process:
+        one_process(args)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # not under torchrun: N ranks are started here (one process per GPU)
         raise SystemExit(self_launch(args))
@@ -456,61 +766,9 @@ def main():
     build_ms = None
     data = "synthetic"
     if rank == 0:
-        if args.obj:
-            from bvh_amd.obj import load_obj
-            tris = load_obj(args.obj)
-            if len(tris) == 0:
-                raise SystemExit(f"{args.obj}: no faces")
-            n_tris = len(tris)
-            label = f"{n_tris}-tri OBJ mesh"
-            data = "Wavefront OBJ mesh + synthetic rays"
-        else:
-            tris = getattr(synth, gen)(n_tris)
-            if not args.no_obj_roundtrip and n_tris <= 2_000_000:
-                tris, obj_bytes = through_obj(tris)
-                data = (f"synthetic mesh via OBJ (written as a {obj_bytes / 1e6:.0f} MB Wavefront OBJ, read back with the reference loader's semantics, "
-                        "triangle bytes identical) + synthetic rays")
-            else:
-                data = "synthetic mesh (arrays; OBJ round trip skipped at this size) + synthetic rays"
-        d_tris = torch.from_numpy(tris).cuda()
-        pool = None if args.serial_builder else bvh_amd.ThreadPool()
-        builds, high_profile = {}, None
-        for qname in ("low", "medium", "high"):                               # build Mtris/s of every DefaultBuilder mode
-            cfg = bvh_amd.Config(quality=bvh_amd.Quality[qname.capitalize()])
-            bb, cc = bvh_amd.tri_bounds(d_tris)
-            bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)   # warm-up build (allocations, code load)
-            times, times_host = [], []
-            for _ in range(5 if qname != "high" else 3):                          # median of >= 5 after a warm-up
-                bvh_q = None                                                      # (destroying the previous BVH is not part of a build)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                bb, cc = bvh_amd.tri_bounds(d_tris)
-                bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)   # triangles in HBM -> BVH resident in HBM
-                torch.cuda.synchronize()
-                times.append(time.perf_counter() - t0)
-            # + the device-to-host copy of the reference-layout Bvh, timed in its own builds: releasing a host mirror makes the NEXT build
-            # ~0.4 ms slower (measured: 2.39 -> 2.76-2.94 ms at 1M), which is an artifact of this loop, not part of a resident build
-            for _ in range(3 if qname != "high" else 1):
-                bvh_q = None
-                bb, cc = bvh_amd.tri_bounds(d_tris)
-                bvh_q = bvh_amd.DefaultBuilder.build(bb, cc, cfg, thread_pool=pool)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                bvh_q.sync_host()
-                times_host.append(time.perf_counter() - t1)                       # the copy alone; reported on top of the median build above
-            if qname == "high":                                                   # what the ReinsertionOptimizer step of the last High build did
-                p = bvh_amd.last_optimize_profile()
-                high_profile = dict(p, us_per_replacement=None if not p["replacements"] else round(p["heap_ms"] * 1e3 / p["replacements"], 4),
-                                    heap_ms=round(p["heap_ms"], 3),
-                                    what="ReinsertionOptimizer of the last High build: iterations run, iterations that replayed the libstdc++ candidate heap "
-                                         "exactly (the heap-free fast path was refused: a tie at the top-k threshold or equal gains sharing a node), "
-                                         "pop_heap + push_heap replacements of those replays, GPU ms of the heap kernels (one sequential wave pair)")
-            # B_build = 36 (tri) + 36 (bbox + center) + 76 L-bar + 28 N/n + 4 algorithmic bytes per triangle
-            lbar = mean_split_ancestors(bvh_q.nodes, n_tris)
-            b_build = 36.0 + 36.0 + 76.0 * lbar + 28.0 * bvh_q.node_count / n_tris + 4.0
-            builds[qname] = (sorted(times)[len(times) // 2] * 1e3, bvh_q, (sorted(times)[len(times) // 2] + sorted(times_host)[len(times_host) // 2]) * 1e3, lbar, b_build)
-        build_ms, bvh, build_host_ms = builds[args.quality][:3]
-        prims = bvh_amd.precompute_tris(d_tris, bvh.device_prim_ids())
+        sc = scene_and_builds(args, gen, n_tris, label)
+        tris, n_tris, label, data, builds, high_profile = sc["tris"], sc["n_tris"], sc["label"], sc["data"], sc["builds"], sc["high_profile"]
+        build_ms, bvh, build_host_ms, prims = sc["build_ms"], sc["bvh"], sc["build_host_ms"], sc["prims"]
     else:
         bvh, prims = None, None
     bcast = {}
@@ -602,67 +860,22 @@ def main():
     reorder_ms = float(np.mean(rt[:got.value])) if got.value else 0.0                        # ray keys + radix sort in front of it
     lib.bvh_amd_kernel_timing(0)
 
+    mine = {"rank": rank, "rays_per_step": int(rays_here), "pass_ms": round(pass_ms, 4), "kernel_ms": round(kernel_ms, 4),
+            "mrays_s": round(rays_here / pass_ms / 1e3, 1)}           # this rank's own device clock (HIP events), not the job's wall clock
+    per_rank = [mine]
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     elapsed = float(t.item())
 
     if rank == 0:
         total_rays = (args.rays if args.strong else args.rays * world) * args.steps
         value = total_rays / elapsed / 1e6
-        algorithmic = b_ray * rays_here / (kernel_ms * 1e-3) / 1e9
-        kernel_name = lib.bvh_amd_last_kernel_name().decode()
-        coop = kernel_name.startswith("trace_kernel_coop")
-        rec, pmc_note = (None, "--no-pmc") if args.no_pmc or world > 1 else pmc_live(args, robust, kernel_name, [plan[0], plan[1], plan[2], plan[3]], rays_here)
-        if rec is None:                                       # no live counters (rocprofv3 missing / failed, N > 1): a stored pass of this very kernel, if any
-            live_note = pmc_note
-            rec, pmc_note = pmc_record(args, robust, kernel_name, reordered, rays_here)
-            pmc_note = f"{pmc_note} (live collection: {live_note})"
-        traffic = None if rec is None else round((rec["fetch_kb"] + rec["write_kb"]) * 1024.0 / (kernel_ms * 1e-3) / 1e9, 1)
-        # ---- the ceiling that binds: the memory hierarchy under the kernel's own access pattern ---------------------------------
-        # A ray fetches P pair records, T primitives (48 B = 3/4 of a record's requests) and itself (2 requests); each fetch is served
-        # by the L1, an L2 or the fabric side, and each level has a measured rate for dependent random 64-byte record fetches
-        # (csrc/probe.hip, live). Lower bound of the launch time: the slowest level; `sum_ms` = the no-overlap estimate.
-        working_set = bvh.node_count // 2 * 64 + n_tris * 48
-        lanes = 28 if rec is None or not rec.get("lane_utilisation") else max(8, min(64, int(round(64 * rec["lane_utilisation"]))))
-        probe = None if args.no_probe else hierarchy_ceilings(working_set, coop, lanes)
-        records = rays_here * (float(P) + 0.75 * float(T) + 0.5)          # record-equivalents every launch asks of the L1
-        levels = None
-        if probe is not None:
-            levels = {"l1": {"records_per_launch": round(records), "grec_s": probe["l1_grec_s"], "ms": round(records / probe["l1_grec_s"] / 1e6, 4),
-                             "what": "every record fetch passes the L1's request pipeline: rays x (P + 3/4 T + 1/2) record-equivalents at the "
-                                     "L1-resident rate of the probe"}}
-            if rec is not None and rec.get("tcp_tcc_read_req"):
-                l2_req, misses = float(rec["tcp_tcc_read_req"]), float(rec.get("tcc_miss") or rec["fetch_kb"] * 1024.0 / 64.0)
-                levels["l2"] = {"requests_per_launch": round(l2_req), "grec_s": probe["l2_grec_s"], "ms": round(l2_req / probe["l2_grec_s"] / 1e6, 4),
-                                "what": "L1 misses (TCP_TCC_READ_REQ) at the L2-resident rate of the probe"}
-                levels["fabric"] = {"requests_per_launch": round(misses), "grec_s": probe["beyond_l2_grec_s"],
-                                    "ms": round(misses / probe["beyond_l2_grec_s"] / 1e6, 4),
-                                    "what": "L2 misses (TCC_MISS; FETCH_SIZE / 64 B agrees within 15 %, FETCH_SIZE itself calibrated at 0.998 of a known byte "
-                                            "count in this pattern: profiles/r03_fetch_calibration.json) at the beyond-L2 rate of the probe, whose every record is a miss"}
-                l2_hits = max(0.0, l2_req - misses)
-                mix = probe["l2_and_fabric_times"]                    # the ceiling takes the BEST rate this run measured for each level
-                r_l2, r_far = max(probe["l2_grec_s"], mix["pure_l2_grec_s"]), max(probe["beyond_l2_grec_s"], mix["pure_beyond_l2_grec_s"])
-                levels["beyond_l1"] = {"l2_hits_per_launch": round(l2_hits), "l2_misses_per_launch": round(misses), "l2_grec_s": r_l2, "beyond_l2_grec_s": r_far,
-                                       "ms": round(l2_hits / r_l2 / 1e6 + misses / r_far / 1e6, 4),
-                                       "what": "every L1 miss holds one of the CU's outstanding lines until the L2 (hit) or the fabric (miss) has served it: "
-                                               "the two service times ADD (probe.l2_and_fabric_times: a walk alternating L2 hit / L2 miss runs at the "
-                                               "add rate, not at the overlap rate), so hits / R_L2 + misses / R_beyond_L2 is the time the launch's L1 "
-                                               "misses need; the L1 request pipeline (level l1) works in parallel with it"}
-        # the same requests priced at the data-sheet rates of /opt/skills/guides/MI355X_MICROARCH.md (L2 34.5 TB/s aggregate, HBM 8 TB/s), 64 bytes
-        # per request: what the kernel would need if the hierarchy served random 64-byte records at its streaming peaks
-        guide = None
-        if rec is not None and rec.get("tcp_tcc_read_req"):
-            l2_req_g = float(rec["tcp_tcc_read_req"])
-            miss_g = float(rec.get("tcc_miss") or rec["fetch_kb"] * 1024.0 / 64.0)
-            g_ms = (l2_req_g - miss_g) * 64.0 / 34.5e12 * 1e3 + miss_g * 64.0 / (HBM_PEAK_GBS * 1e9) * 1e3
-            guide = {"l2_tb_s": 34.5, "hbm_tb_s": HBM_PEAK_GBS / 1e3, "ms": round(g_ms, 4), "frac": round(g_ms / kernel_ms, 4),
-                     "what": "L2 hits x 64 B / 34.5 TB/s + L2 misses x 64 B / 8 TB/s over kernel_ms: the data-sheet ceiling beside the probe-measured one "
-                             "(frac above); the gap between the two is what dependent random 64-byte fetches cost over streaming"}
-        model_ms = None if levels is None else max(v["ms"] for v in levels.values())
-        sum_ms = None if levels is None else sum(v["ms"] for k, v in levels.items() if k in ("l1", "beyond_l1"))
-        peak_mrays = None if not model_ms else rays_here / model_ms / 1e3
-        achieved_mrays = rays_here / kernel_ms / 1e3
+        roofline = roofline_section(args, lib, robust=robust, rays_here=rays_here, kernel_ms=kernel_ms, pass_ms=pass_ms, reorder_ms=reorder_ms, P=P, T=T,
+                                    b_ray=b_ray, node_count=bvh.node_count, n_tris=n_tris, plan=plan, first_plan=first_plan, first_call_ms=first_call_ms,
+                                    device_index=device_index, reordered=reordered)
         out = {
             "metric": f"Mrays/s closest-hit ({label})", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -676,53 +889,11 @@ def main():
                        "rays_per_step_all_gpus": int(args.rays if args.strong else args.rays * world),
                        "parallelism": (f"rays sharded x{world} ({'strong' if args.strong else 'weak'} scaling), scene broadcast once: "
                                        + bcast.get("transport", "?")) if world > 1 else "single GPU",
-                       "ranks": ranks, "rccl_ranks": ranks[0]["rccl_ranks"],
+                       "ranks": ranks, "rccl_ranks": ranks[0]["rccl_ranks"], "per_rank": per_rank,
                        "launched_by": "bench.py itself (python -m torch.distributed.run, one process per GPU)"
                                       if os.environ.get("BVH_AMD_BENCH_SELF_LAUNCHED") == "1" else "torchrun environment" if world > 1 else "single process"},
-            "roofline": {"bound": "memory hierarchy (L1 request pipeline | L2 hits + fabric misses behind it) under dependent random 64-byte record fetches",
-                         "achieved": round(achieved_mrays, 1), "peak": None if peak_mrays is None else round(peak_mrays, 1), "unit": "Mrays/s",
-                         "frac": None if peak_mrays is None else round(achieved_mrays / peak_mrays, 4),
-                         "frac_is": "achieved / peak, peak from rates MEASURED IN THIS RUN by dependent-walk probes (not a hardware data-sheet peak); "
-                                    "`at_guide_rates` prices the same requests at the data-sheet rates, `hbm_algorithmic` is SURVEY.md 8(d)'s figure",
-                         "at_guide_rates": guide,
-                         "binding_level": None if levels is None else max(levels, key=lambda k: levels[k]["ms"]),
-                         "model_ms": None if model_ms is None else round(model_ms, 4), "sum_of_levels_ms": None if sum_ms is None else round(sum_ms, 4),
-                         "levels": levels, "probe": probe,
-                         "what": "peak = rays per launch / max(time the L1 request pipeline needs for the launch's record fetches, time its L1 misses "
-                                 "need behind the L1 = L2 hits / R_L2 + L2 misses / R_beyond_L2), every rate measured in this run by a dependent-walk probe "
-                                 "in the kernel's own fetch mode; achieved = rays per launch / kernel_ms. HBM is NOT what binds this kernel: "
-                                 "see hbm_algorithmic below (SURVEY.md 8d's figure) and traffic",
-                         "traffic": traffic, "traffic_unit": "GB/s at the L2's fabric side (FETCH_SIZE + WRITE_SIZE)",
-                         "traffic_frac_of_hbm": None if traffic is None else round(traffic / HBM_PEAK_GBS, 4), "counters_source": pmc_note,
-                         "hbm_algorithmic": {"bound": "hbm", "achieved": round(algorithmic, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": round(algorithmic / HBM_PEAK_GBS, 4), "bytes_per_ray": round(b_ray, 1),
-                                             "what": "algorithmic bytes (SURVEY.md 8d: 32 + 56 P + 48 T + 16 per ray) / kernel time over the 8 TB/s HBM "
-                                                     "peak; > 1 is possible because L1 / L2 serve re-referenced nodes: not a ceiling of this kernel"},
-                         "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
-                         "pass_split_ms": {"ray_keys_and_radix_sort": round(reorder_ms, 4), "traversal_kernel": round(kernel_ms, 4),
-                                           "rest (launch gaps, counter reset)": round(max(0.0, pass_ms - reorder_ms - kernel_ms), 4)},
-                         "ray_reordering": ("on: 24-bit origin-cell/octant key + three radix passes inside every timed pass" if reordered else "off"),
-                         "record_fetch": "quad-cooperative" if coop else "per lane",
-                         "launch_plan": {"reordered": bool(plan[0]), "quad_cooperative_fetch": bool(plan[1]), "refill_threshold": int(plan[2]),
-                                         "leaf_threshold": int(plan[3]),
-                                         "how": "measured by the library on this tree's first large batches (one whole batch per candidate), then fixed"},
-                         "first_call": {"ms": round(first_call_ms, 4), "reordered": bool(first_plan[0]), "quad_cooperative_fetch": bool(first_plan[1]),
-                                        "over_settled_pass": round(first_call_ms / pass_ms, 4),
-                                        "what": "wall time of the FIRST large batch through the fresh tree (host clock around one call + "
-                                                "synchronisation, after a 4096-ray call that loads the code): traced with the predictor's plan; the "
-                                                "search explores the other plans from the second batch on"},
-                         "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)},
-            "build": {"mtris_s": round(n_tris / (build_ms * 1e-3) / 1e6, 2), "ms": round(build_ms, 3),
-                      "roofline": {q: {"bound": "hbm", "achieved": round(v[4] * n_tris / (v[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": round(v[4] * n_tris / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_tri": round(v[4], 1),
-                                       "mean_split_ancestors": round(v[3], 2)} for q, v in builds.items()},
-                      "all_qualities_ms": {k: round(v[0], 3) for k, v in builds.items()},
-                      "all_qualities_mtris_s": {k: round(n_tris / (v[0] * 1e-3) / 1e6, 2) for k, v in builds.items()},
-                      "high": high_profile,
-                      "ms_with_host_mirror": round(build_host_ms, 3),
-                      "mtris_s_with_host_mirror": round(n_tris / (build_host_ms * 1e-3) / 1e6, 2),
-                      "what": "tri bounds + DefaultBuilder, triangles resident in HBM -> BVH resident in HBM; *_with_host_mirror adds "
-                              "the device-to-host copy of the reference-layout Bvh; median of 5 (High: 3) after a warm-up build"},
+            "roofline": roofline,
+            "build": build_section(n_tris, builds, high_profile, build_ms, build_host_ms),
         }
         if world > 1:
             bms = bcast.get("broadcast_ms", 0.0)
@@ -739,6 +910,18 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if distributed:
+        # the ranks that have finished wait on the HOST (a key of the rendezvous store; no collective kernel spinning on their GPUs, no
+        # second process group whose start-up chatter would land on stdout) while rank 0 collects the traversal kernel's counters and
+        # times the CPU baseline; then one last collective so that nobody tears the group down under a peer
+        import datetime
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("bvh_amd_bench_done", "1")
+            else:
+                store.wait(["bvh_amd_bench_done"], datetime.timedelta(minutes=45))
+        except Exception as exc:                              # noqa: BLE001  (no store to be had: the plain barrier, as before)
+            print(f"[bench] rank {rank}: store wait unavailable ({exc!r}), falling back to the collective barrier", file=sys.stderr)
         dist.barrier()
         from bvh_amd.parallel import release_default_comm
         release_default_comm()                                # the library's own RCCL communicator, on every rank

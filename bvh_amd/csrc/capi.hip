@@ -526,6 +526,7 @@ int bvh_amd_kernel_times(float* ms_out, size_t capacity, size_t* count_out) {
 }
 void bvh_amd_last_optimize_profile(struct bvh_amd_optimize_profile* out) { if (out) last_optimize_profile(out); }
 int bvh_amd_experiment(const char* name, int value) { return set_experiment(name, value); }
+int bvh_amd_wave_times(unsigned long long* out, size_t capacity_waves, size_t* n_waves) { return wave_times(out, capacity_waves, n_waves); }
 void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch, int ticket_ranges) { set_tuning(refill_threshold, leaf_threshold, coop_fetch, ticket_ranges); }
 void bvh_amd_last_launch_plan(int out[4]) { if (out) last_launch_plan(out); }
 int bvh_amd_reorder_times(float* ms_out, size_t capacity, size_t* count_out) {

@@ -126,7 +126,11 @@ struct BvhImpl {
     // 0 = not measured yet; otherwise 1 | reorder << 1 | coop << 2 | refill << 8 | leaf << 16. Reset whenever the tree is re-laid out.
     mutable std::atomic<uint32_t> launch_plan[2] = {};
     struct PlanSearch {                        // the measurement in progress: one candidate per large batch, timed by events on its stream
-        int index = 0;                         // measurements made so far (8 = all four candidates measured twice; the predictor's plan goes first)
+        int index = 0;                         // measurements made so far (the predictor's plan goes first)
+        int trying = -1;                       // the candidate the pending measurement belongs to
+        uint8_t count[4] = {0, 0, 0, 0};       // measurements of each candidate (at most two; the better time counts)
+        uint8_t dropped = 0;                   // candidates out of the race (bit c): > 10 % behind the best after a measurement, or of a
+                                               // family (reordered / as given) that lost by > 25 % — they are not traced again
         bool pending = false;                  // a thread has claimed the events for candidate `index`
         bool recorded = false;                 // ... and both of them are on its stream: only then may another call read them
         hipEvent_t start = nullptr, stop = nullptr;
@@ -240,6 +244,7 @@ template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
                     typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream);
 void last_launch_plan(int out[4]);                            // traverse.hip: {reordered, coop, refill, leaf} of the calling thread's latest launch
+int wave_times(unsigned long long* out, size_t capacity_waves, size_t* n_waves);   // traverse.hip: developer library only
 int set_experiment(const char* name, int value);                             // traverse.hip: developer experiments of the calling thread
 void set_tuning(int refill, int leaf, int coop, int parts);               // traverse.hip: per-thread overrides for A/B runs (< 0: default)
 const char* last_kernel_name();

@@ -267,3 +267,85 @@ def intersect_sharded(bvh, prims, rays, **kw):
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     b, e = shard_range(len(rays), rank, world)
     return b, e, intersect(bvh, prims, rays[b:e], **kw)
+
+
+class _DeviceBlock:
+    """A device allocation handed out by the library (bvhXX_replicate's primitive copies), exposed to torch without a copy through
+    `__cuda_array_interface__`; freed with bvh_amd_device_free on its own device when the last tensor viewing it is gone."""
+
+    def __init__(self, ptr: int, shape, typestr: str, device: int):
+        self._ptr, self._device = ptr, device
+        self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+    def __del__(self):
+        try:
+            import torch
+            from . import _lib
+            if self._ptr:
+                with torch.cuda.device(self._device):
+                    _lib.load().bvh_amd_device_free(C.c_void_p(self._ptr))
+        except Exception:                                     # noqa: BLE001  (interpreter shutdown)
+            pass
+        self._ptr = 0
+
+
+def replicate_scene(bvh, prims, devices=None, timing: dict = None):
+    """ONE process, several GPUs — what a C caller of the reference API would write (tests/c/replicate.c): `bvhXX_replicate` copies the
+    scene from the BVH's own device to every device of `devices` (default: all visible) with the library's ncclCommInitAll + one
+    grouped ncclBroadcast of the `Bvh::serialize` stream and the BVH-ordered primitive array. No torch.distributed anywhere.
+    Returns [(Bvh, prims tensor on that device)] in the order of `devices`; the entry of the BVH's own device holds the originals."""
+    import time
+    import torch
+    from . import _lib
+    from .api import Bvh
+    lib = _lib.load()
+    if devices is None:
+        devices = list(range(torch.cuda.device_count()))
+    devices = [int(d) for d in devices]
+    n = len(devices)
+    prims = prims.contiguous()
+    home = prims.device.index
+    if home not in devices:
+        raise ValueError("replicate_scene: the scene's own device must be among `devices`")
+    s = bvh._s
+    arr = (C.c_int * n)(*devices)
+    bvhs_out, prims_out = (C.c_void_p * n)(), (C.c_void_p * n)()
+    torch.cuda.synchronize(home)
+    t0 = time.perf_counter()
+    with torch.cuda.device(home):
+        _lib.check(getattr(lib, f"bvh{s}_replicate")(bvh._h, C.c_void_p(prims.data_ptr()), prims.numel() * prims.element_size(), n, arr,
+                                                     C.cast(bvhs_out, C.POINTER(C.c_void_p)), C.cast(prims_out, C.POINTER(C.c_void_p))),
+                   f"bvh{s}_replicate")
+    for d in devices:
+        torch.cuda.synchronize(d)
+    if timing is not None:
+        timing["replicate_ms"] = (time.perf_counter() - t0) * 1e3
+        timing["transport"] = "RCCL inside libbvh_amd.so (bvhXX_replicate: ncclCommInitAll + grouped ncclBroadcast), one process"
+    typestr = "<f8" if prims.dtype == torch.float64 else "<f4"
+    out = []
+    for i, d in enumerate(devices):
+        if d == home:
+            out.append((bvh, prims))
+            continue
+        with torch.cuda.device(d):
+            block = _DeviceBlock(prims_out[i], prims.shape, typestr, d)
+            t = torch.as_tensor(block, device=f"cuda:{d}")
+            t._bvh_amd_block = block                              # the tensor keeps the allocation alive
+            out.append((_DeviceBvh(bvhs_out[i], s, d), t))
+    return out
+
+
+def _DeviceBvh(handle, suffix, device):
+    """A Bvh living on `device`: destroyed with that device current (include/bvh_amd.h: bvhXX_replicate)."""
+    from .api import Bvh
+
+    class _Bound(Bvh):
+        def __del__(self):
+            try:
+                import torch
+                with torch.cuda.device(device):
+                    Bvh.__del__(self)
+            except Exception:                                 # noqa: BLE001
+                pass
+
+    return _Bound(handle, suffix)

@@ -450,6 +450,12 @@ BVH_AMD_API void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int co
  * logs per launch of the per-ray callback walk: a short log makes the tests continue a walk from the device's stack); value < 0 = the default;
  * "reset" clears all of them. Returns BVH_AMD_ERR_ARG for an unknown name.                                                       */
 BVH_AMD_API int bvh_amd_experiment(const char* name, int value);
+/* Developer library only (libbvh_amd_dev.so; the release library returns BVH_AMD_ERR_ARG and its kernels carry no such code): after
+ * bvh_amd_experiment("wave_times", 1), every batch launch of the calling thread records, per wavefront of the persistent grid, six
+ * 64-bit words {begin, last ticket draw, end} in s_memrealtime ticks (100 MHz), {XCC id << 32 | rays traced}, {ticks spent inside
+ * refills (ticket atomic -> order -> ray loads arrived), number of refills}; this copies the latest
+ * launch's records out (it waits for the device). The drain-tail study of profiles/r05_tail_timeline.txt (tools/tail_timeline.py). */
+BVH_AMD_API int bvh_amd_wave_times(unsigned long long* out, size_t capacity_waves, size_t* n_waves);
 /* How the calling thread's latest batch launch was traced: out = {reordered 0/1, record fetch 0 per lane / 1 quad-cooperative, refill
  * threshold, leaf threshold}. For 3D trees whose traversal records exceed the 32 MB of L2 and batches of >= 2^20 rays the library
  * MEASURES this once per tree and kind of ray (closest / any-hit): the first such batch is traced with the plan a static predictor

