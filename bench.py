@@ -398,9 +398,10 @@ def roofline_section(args, lib, *, robust, rays_here, kernel_ms, pass_ms, reorde
                 "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "pass_ms": round(pass_ms, 4),
                 "pass_split_ms": {"ray_keys_and_radix_sort": round(reorder_ms, 4), "traversal_kernel": round(kernel_ms, 4),
                 "rest (launch gaps, counter reset)": round(max(0.0, pass_ms - reorder_ms - kernel_ms), 4)},
-                "ray_reordering": ("on: 24-bit origin-cell/octant key + three radix passes inside every timed pass" if reordered else "off"),
+                "ray_reordering": ("off" if not reordered else "on: 24-bit origin-cell/octant key + three radix passes inside every timed pass"
+                                   + ("; long rays first (one chord-class bit in the key: the plan search measured it faster on this tree)" if int(plan[0]) == 2 else "")),
                 "record_fetch": "quad-cooperative" if coop else "per lane",
-                "launch_plan": {"reordered": bool(plan[0]), "quad_cooperative_fetch": bool(plan[1]), "refill_threshold": int(plan[2]),
+                "launch_plan": {"reordered": bool(plan[0]), "long_rays_first": int(plan[0]) == 2, "quad_cooperative_fetch": bool(plan[1]), "refill_threshold": int(plan[2]),
                 "leaf_threshold": int(plan[3]),
                 "how": "measured by the library on this tree's first large batches (one whole batch per candidate), then fixed"},
                 "first_call": {"ms": round(first_call_ms, 4), "reordered": bool(first_plan[0]), "quad_cooperative_fetch": bool(first_plan[1]),
@@ -540,6 +541,8 @@ def pmc_child(args):
     rays = torch.from_numpy(synth.rays_closest(args.rays, lo, hi, seed=1234)).cuda()
     hits = torch.empty((args.rays, 4), dtype=torch.float32, device="cuda")
     bvh_amd._lib.load().bvh_amd_tuning(refill, leaf, coop, -1)
+    if reorder == 2:                                          # the plan the timed run settled on orders the long rays first (chord classes)
+        bvh_amd._lib.load().bvh_amd_experiment(b"key_class_bits", 1)
     for _ in range(args.warmup + args.steps):
         bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=not args.fast, out=hits, sort_rays=bool(reorder))
         torch.cuda.synchronize()

@@ -127,15 +127,16 @@ struct BvhImpl {
     mutable std::atomic<uint32_t> launch_plan[2] = {};
     struct PlanSearch {                        // the measurement in progress: one candidate per large batch, timed by events on its stream
         int index = 0;                         // measurements made so far (the predictor's plan goes first)
+        static constexpr int kCandidates = 5;
         int trying = -1;                       // the candidate the pending measurement belongs to
-        uint8_t count[4] = {0, 0, 0, 0};       // measurements of each candidate (at most two; the better time counts)
+        uint8_t count[kCandidates] = {};       // measurements of each candidate (at most two; the better time counts)
         uint8_t dropped = 0;                   // candidates out of the race (bit c): > 10 % behind the best after a measurement, or of a
                                                // family (reordered / as given) that lost by > 25 % — they are not traced again
         bool pending = false;                  // a thread has claimed the events for candidate `index`
         bool recorded = false;                 // ... and both of them are on its stream: only then may another call read them
         hipEvent_t start = nullptr, stop = nullptr;
         size_t rays = 0;
-        float ns_per_ray[4] = {0, 0, 0, 0};
+        float ns_per_ray[kCandidates] = {};
     };
     mutable PlanSearch plan_search[2];
     mutable std::mutex plan_mutex;

@@ -103,6 +103,7 @@ struct TraceArgs {
     uint32_t coop;                             // host side only: launch the quad-cooperative variant (float, 3D, trees below 2^26 pairs)
     uint32_t prim_stride;                      // scalars from one primitive to the next in `prims` (12: PrecomputedTri; developer knob: 16 = padded to a 64-byte line)
     uint32_t stream_hints;                     // bit 0: rays / order / hit records are touched once: load / store them non-temporally (developer knob)
+    uint32_t stagger;                          // 0: off; else tickets per eighth of the grid (see trace_body.inc: staggered drain)
     uint32_t one_shot;                         // 1: grid = ceil(n / 256) blocks, wave w traces rays [64 w, 64 w + 64) and leaves (small batches)
     unsigned long long* wave_times;            // developer library only (bvh_amd_experiment("wave_times", 1)): per wave {begin, last refill, end, xcc | rays, ticks inside refills, refills} in
                                                // s_memrealtime ticks (100 MHz) + {XCC id, rays traced}; nullptr otherwise — the release kernels never read it

@@ -117,9 +117,16 @@ __global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop_plan_search(Trace
 // 7.79 / 7.41 / 7.09; octant-major and direction-cube keys lose (soup 7.81, mesh 8.25). The third pass costs ~0.13 ms.
 // `hilbert_bits` > 0 (developer experiment, bvh_amd_experiment("key_curve", 1)): the cell's index along the 3D Hilbert curve of that
 // many bits per axis instead of its Morton code (Skilling's axes-to-transpose transform): consecutive keys are always adjacent cells.
+// Round 5 — `class_bits` > 0: LONG RAYS FIRST. The drain of the persistent grid (profiles/r05_tail_timeline_before.txt: every wave draws its
+// last ticket at ~6.5 of 7.5 ms, then needs a median of 0.45 ms to finish the rays it holds; 7.5 % of the grid's time is lost there)
+// is as long as the longest walks still in flight, and on the scenes that are reordered at all a walk's length goes with the length of
+// the ray's chord through the root box. So the key carries, right below the three top bits of the cell index (the bits that roughly
+// select the XCD's ticket range), the chord class of the ray, longest class first, and the cell index gives up its lowest `class_bits`
+// bits (neighbours along the curve merge): every XCD still sweeps its part of space in curve order, once per class, and the tickets
+// drawn last are the short rays. Per-ray results do not depend on the order.
 template <typename T>
 __global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys, uint32_t cells = 64,
-                                                       int hilbert_bits = 0) {
+                                                       int hilbert_bits = 0, int class_bits = 0, T class_scale = T(0)) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     T r[8];
@@ -157,6 +164,29 @@ __global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n
         code |= s << k;
     }
     const uint32_t oct = (Num<T>::sign(r[3]) ? 1u : 0u) | (Num<T>::sign(r[4]) ? 2u : 0u) | (Num<T>::sign(r[5]) ? 4u : 0u);
+    if (class_bits > 0) {
+        // chord of the ray through the root box, in units of the box diagonal: slab test against [l, l + cells / s] with the ray's own
+        // tmin / tmax (plain arithmetic: the key only orders rays)
+        const T l[3] = { lx, ly, lz }, sc[3] = { sx, sy, sz };
+        T t0 = r[6], t1 = r[7], d2 = T(0), diag2 = T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T ext = sc[k] > T(0) ? T(cells) / sc[k] : T(0);
+            const T inv = T(1) / r[3 + k];
+            const T a = (l[k] - r[k]) * inv, b = (l[k] + ext - r[k]) * inv;
+            const T lo_t = a < b ? a : b, hi_t = a < b ? b : a;         // (NaN from 0 * inf compares false: that slab does not clip)
+            t0 = lo_t > t0 ? lo_t : t0; t1 = hi_t < t1 ? hi_t : t1;
+            d2 += r[3 + k] * r[3 + k]; diag2 += ext * ext;
+        }
+        const T chord = t1 > t0 ? (t1 - t0) * Num<T>::sqrt_(d2) : T(0);
+        const T rel = diag2 > T(0) ? chord / Num<T>::sqrt_(diag2) * class_scale : T(0);
+        const uint32_t top = (1u << class_bits) - 1u;
+        uint32_t cls = rel >= T(top) ? top : rel > T(0) ? static_cast<uint32_t>(rel) : 0u;
+        cls = top - cls;                                                // longest class first
+        const int code_bits = 3 * (hilbert_bits > 0 ? hilbert_bits : 31 - __clz(cells));
+        const uint32_t high = code >> (code_bits - 3), low = (code & ((1u << (code_bits - 3)) - 1u)) >> class_bits;
+        code = (((high << class_bits) | cls) << (code_bits - 3 - class_bits)) | low;
+    }
     keys[i] = (code << 3) | oct;
 }
 
@@ -215,7 +245,20 @@ thread_local int t_refill = -1, t_leaf = -1, t_coop = -1, t_parts = -1;
 //   key_bits      bits per axis of that cell grid (1..8)
 //   wave_times    (developer library only) 1: the next launches record per-wave begin / last-refill / end timestamps (bvh_amd_wave_times)
 //   one_shot      1 / 0: force / forbid the one-shot grid of small batches (default: launch_planned decides by batch size)
-struct Experiments { int grid_blocks = -1, stream_hints = -1, tri_stride = -1, key_curve = -1, key_bits = -1, step_events = -1, wave_times = -1, one_shot = -1; };
+//   key_class_bits / key_class_scale   chord classes of the reordering key (0 = none) / classes per 100 box diagonals (ray_keys_kernel)
+struct Experiments { int grid_blocks = -1, stream_hints = -1, tri_stride = -1, key_curve = -1, key_bits = -1, step_events = -1, wave_times = -1, one_shot = -1,
+                     key_class_bits = -1, key_class_scale = -1, stagger = -1; };
+// Round-5 measurements (profiles/r05_key_class_ab.txt, r05_stagger_ab.txt; 2^24 rays, kernel ms): 1M soup 6.92 without classes, one class bit
+// 6.99 / 6.80 / 6.76 / 6.70 / 6.64 at 2 / 2.5 / 3 / 4 / 5 classes per diagonal (only the shortest chords go last), two bits 6.80-6.84, three
+// 6.91-6.95; the 10M soup LOSES 6 % with any of them (83 % of its rays end at a hit long before their chord does: the chord predicts nothing
+// there, and two sweeps cost coherence) — so the classes are not a default but one more candidate of the measured plan search.
+constexpr int kKeyClassBits = 0, kKeyClassScalePercent = 500;
+// Staggered drain (trace_body.inc), tickets per eighth of the grid: kernel ms against it — 1M soup 2^24 rays 7.03 / 6.93 / 6.90 / 7.17 at
+// 0 / 84k / 168k / 262k (with the chord classes 6.74 / 6.60 / 6.81 / 6.97), 2^22 rays 2.57 -> 2.46 at 131k, 10M soup 12.5M rays 5.50 -> 5.46
+// at 125k; light trees want less: Sponza proxy 1M rays 0.264 -> 0.236 at 44k (configs[1]: 3.7 -> 4.0 Grays/s), 4M rays 0.628 -> 0.597 at 42k,
+// terrain 4M 0.649 -> 0.636 at 65k; a tenth of a batch per class is always too much.
+constexpr uint32_t kStaggerHeavy = 100000, kStaggerLight = 50000;
+thread_local bool g_last_classes = false;
 thread_local Experiments t_exp;
 #if defined(BVH_AMD_DEVELOPER)
 // per-wave timeline of the calling thread's latest traversal launch (drain-tail study, profiles/r05_tail_timeline.txt)
@@ -546,6 +589,9 @@ int set_experiment(const char* name, int value) {
     else if (k == "key_bits") t_exp.key_bits = value;
     else if (k == "step_events") t_exp.step_events = value;
     else if (k == "one_shot") t_exp.one_shot = value;
+    else if (k == "stagger") t_exp.stagger = value;
+    else if (k == "key_class_bits") t_exp.key_class_bits = value;
+    else if (k == "key_class_scale") t_exp.key_class_scale = value;
     else if (k == "wave_times") {
 #if defined(BVH_AMD_DEVELOPER)
         t_exp.wave_times = value;
@@ -620,7 +666,7 @@ constexpr float kReorderMinVisits = 100.0f;
 
 // How one launch is traced: the batch reordered or as given, records fetched per lane or quad-cooperatively, the refill / leaf
 // thresholds of the persistent waves. Never affects results.
-struct Plan { bool reorder; bool coop; int refill, leaf; };
+struct Plan { bool reorder; bool coop; int refill, leaf; bool classes = false; };   // classes: long rays first (chord class in the reordering key)
 
 template <typename T>
 static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
@@ -664,7 +710,9 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     args.order = nullptr;
     args.prim_stride = leaf_kind == LEAF_TRIANGLE ? (t_exp.tri_stride > 0 ? static_cast<uint32_t>(t_exp.tri_stride) : 12u) : 4u;
     args.stream_hints = 0;                                    // (decided below, with the order)
-    args.one_shot = t_exp.one_shot > 0 && n < (size_t{1} << 31) && !d_counters ? 1u : 0u;   // (experiment for now)
+    // one-shot grid for batches of up to 2^18 rays (profiles/r05_one_shot_ab.txt: Sponza proxy closest 2^16 0.120 -> 0.100 ms, 2^18 0.181 ->
+    // 0.159, any-hit 2^18 0.183 -> 0.152; f64 spheres 2^18 0.283 -> 0.259; from 2^20 rays on the persistent grid wins, 0.278 against 0.299)
+    args.one_shot = (t_exp.one_shot >= 0 ? t_exp.one_shot > 0 : n <= (size_t{1} << 18)) && !d_counters ? 1u : 0u;
     // one ticket range per XCD (trace_body.inc: refill): free for incoherent batches, a win for every batch whose neighbouring
     // rays are close (coherence-sorted below, or generated that way by the caller)
     static const int parts_env = BVH_DEV_INT("BVH_AMD_PARTS", 0);            // tuning knob
@@ -799,8 +847,12 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
             static const int cell_bits_env = std::max(1, std::min(8, BVH_DEV_INT("BVH_AMD_RAY_KEY_BITS", 7)));   // developer knob
             const int cell_bits = t_exp.key_bits > 0 ? std::min(8, t_exp.key_bits) : cell_bits_env;
             const T rescale = static_cast<T>(1u << cell_bits) / T(64);
+            const int class_bits = cell_bits < 3 ? 0 : t_exp.key_class_bits >= 0 ? std::min(3, t_exp.key_class_bits) : (plan && plan->classes) ? 1 : kKeyClassBits;
+            g_last_classes = class_bits > 0;
+            const T class_scale = static_cast<T>(t_exp.key_class_scale > 0 ? t_exp.key_class_scale : kKeyClassScalePercent) / T(100);
             hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0] * rescale, sc[1] * rescale,
-                               sc[2] * rescale, keys, 1u << cell_bits, t_exp.key_curve == 0 ? 0 : cell_bits);      // Hilbert index by default (round 4); "key_curve" 0 = Morton
+                               sc[2] * rescale, keys, 1u << cell_bits, t_exp.key_curve == 0 ? 0 : cell_bits,      // Hilbert index by default (round 4); "key_curve" 0 = Morton
+                               class_bits, class_scale);
             key_bits = 3 * cell_bits + 3;
         }
         uint32_t* order = nullptr;
@@ -808,7 +860,13 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
         if (rc) return release(rc);
         args.order = order;
     }
-    g_last_plan[0] = g_last_reordered; g_last_plan[1] = static_cast<int>(args.coop); g_last_plan[2] = args.refill_threshold; g_last_plan[3] = args.leaf_threshold;
+    // staggered drain: `stagger` tickets per eighth of the grid over the whole launch -> per ticket range
+    {
+        const size_t dflt = std::min<size_t>(n / 16, heavy ? kStaggerHeavy : kStaggerLight);
+        const size_t whole = t_exp.stagger > 0 ? static_cast<size_t>(t_exp.stagger) : t_exp.stagger == 0 ? 0 : dflt;
+        args.stagger = whole ? std::max<uint32_t>(1u, static_cast<uint32_t>(whole / args.parts)) : 0u;
+    }
+    g_last_plan[0] = g_last_reordered ? (g_last_classes ? 2 : 1) : 0; g_last_plan[1] = static_cast<int>(args.coop); g_last_plan[2] = args.refill_threshold; g_last_plan[3] = args.leaf_threshold;
     int rc = leaf_kind == LEAF_TRIANGLE ? dispatch<T, LEAF_TRIANGLE>(b, args, flags, d_counters != nullptr, stream)
                                         : dispatch<T, LEAF_SPHERE>(b, args, flags, d_counters != nullptr, stream);
     if (rc == BVH_AMD_OK && (flags & BVH_AMD_RAY_ORIGINAL_IDS)) rc = to_original_ids<T>(b, d_hits, n, stream);
@@ -829,8 +887,8 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
 // depend on the plan. BVH_AMD_CALIBRATE=0 keeps the predictor.
 constexpr float kSortNsPerRay = 0.031f;                    // ray keys + three radix passes: 0.52 ms per 2^24 rays (profiles/r03_*)
 
-static uint32_t pack_plan(const Plan& p) { return 1u | (p.reorder ? 2u : 0u) | (p.coop ? 4u : 0u) | (uint32_t(p.refill) << 8) | (uint32_t(p.leaf) << 16); }
-static Plan unpack_plan(uint32_t w) { return Plan{(w & 2u) != 0, (w & 4u) != 0, int((w >> 8) & 0xFFu), int((w >> 16) & 0xFFu)}; }
+static uint32_t pack_plan(const Plan& p) { return 1u | (p.reorder ? 2u : 0u) | (p.coop ? 4u : 0u) | (p.classes ? 8u : 0u) | (uint32_t(p.refill) << 8) | (uint32_t(p.leaf) << 16); }
+static Plan unpack_plan(uint32_t w) { return Plan{(w & 2u) != 0, (w & 4u) != 0, int((w >> 8) & 0xFFu), int((w >> 16) & 0xFFu), (w & 8u) != 0}; }
 
 template <typename T>
 int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const T* d_rays, size_t n, unsigned flags,
@@ -852,11 +910,16 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         const Plan plan = unpack_plan(cached);
         return launch_planned<T>(b, leaf_kind, d_prims, d_rays, n, flags, d_hits, d_counters, stream, &plan);
     }
-    const Plan candidates[4] = {
+    constexpr int kCand = BvhImpl<T>::PlanSearch::kCandidates;
+    const int n_cand = any_hit ? 4 : 5;
+    const Plan candidates[kCand] = {
         {false, false, kRefillThreshold, kLeafThreshold},
         {false, true, any_hit ? kCoopRefillAny : kCoopRefillHeavy, any_hit ? kCoopLeafAny : kCoopLeafHeavy},
         any_hit ? Plan{false, true, kCoopRefillHeavy, kCoopLeafHeavy} : Plan{true, false, kRefillThreshold, kLeafThreshold},
         {true, true, any_hit ? kCoopRefillAny : kCoopRefillHeavy, any_hit ? kCoopLeafAny : kCoopLeafHeavy},
+        // round 5, closest-hit only: reordered with the LONG RAYS FIRST (ray_keys_kernel: chord classes) — 4 % faster on the 1M soup, 6 %
+        // slower on the 10M soup, so it is measured like everything else
+        {true, true, kCoopRefillHeavy, kCoopLeafHeavy, true},
     };
     // The order in which the candidates are tried starts with the PREDICTOR's plan (VERDICT r3 Weak 4: the first large batch through
     // a tree — all a single-shot caller ever sends, e.g. one GPU's 12.5M-ray shard of configs[3] — used to get candidate 0, traced
@@ -873,13 +936,13 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     // traced as given take 12 ms against 7: one of them is enough to know). Candidates still in the race are measured twice (a kernel's first
     // launch also pays its code load); the search ends when every survivor has both measurements or only one survivor is left:
     // 1M soup 5 batches instead of 8 (3, 1, 2, 3, 2), none of them the 12.7 ms plans twice.
-    int order[4], n_order = 0;
+    int order[kCand], n_order = 0;
     {
         auto push = [&](int c) { for (int k = 0; k < n_order; ++k) if (order[k] == c) return; order[n_order++] = c; };
         push(predicted);
-        for (int c = 0; c < 4; ++c) if (candidates[c].reorder != candidates[predicted].reorder && candidates[c].coop == candidates[predicted].coop) push(c);
-        for (int c = 0; c < 4; ++c) if (candidates[c].reorder == candidates[predicted].reorder) push(c);
-        for (int c = 0; c < 4; ++c) push(c);
+        for (int c = 0; c < n_cand; ++c) if (candidates[c].reorder != candidates[predicted].reorder && candidates[c].coop == candidates[predicted].coop && !candidates[c].classes) push(c);
+        for (int c = 0; c < n_cand; ++c) if (candidates[c].reorder == candidates[predicted].reorder) push(c);
+        for (int c = 0; c < n_cand; ++c) push(c);
     }
     std::pair<hipEvent_t, hipEvent_t> events{nullptr, nullptr};
     int trying = -1;
@@ -899,15 +962,15 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
                 ++ps.count[c];
                 ++ps.index;
                 int best = c;
-                for (int k = 0; k < 4; ++k) if (ps.count[k] && !(ps.dropped >> k & 1) && ps.ns_per_ray[k] < ps.ns_per_ray[best]) best = k;
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < n_cand; ++k) if (ps.count[k] && !(ps.dropped >> k & 1) && ps.ns_per_ray[k] < ps.ns_per_ray[best]) best = k;
+                for (int k = 0; k < n_cand; ++k) {
                     if (!ps.count[k] || k == best) continue;
                     // (a candidate's FIRST time may carry its kernel's code load — on a 2^20-ray batch that is tens of per cent — so a single
                     //  measurement only drops a clear loser; the 10 % rule needs both)
                     const float behind = ps.ns_per_ray[k] / ps.ns_per_ray[best];
                     if (behind > (ps.count[k] >= 2 ? 1.10f : 1.40f)) ps.dropped |= uint8_t(1u << k);
                     if (behind > 1.40f && candidates[k].reorder != candidates[best].reorder)
-                        for (int f = 0; f < 4; ++f) if (candidates[f].reorder == candidates[k].reorder) ps.dropped |= uint8_t(1u << f);
+                        for (int f = 0; f < n_cand; ++f) if (candidates[f].reorder == candidates[k].reorder) ps.dropped |= uint8_t(1u << f);
                 }
             }
             ps.pending = false; ps.recorded = false; ps.trying = -1;

@@ -448,6 +448,8 @@ BVH_AMD_API void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int co
  * "tri_stride" (floats between PrecomputedTri records of the caller's array: 12, or 16 = padded to a 64-byte line), "key_curve"
  * (0 Morton, 1 Hilbert order of the reordering key), "key_bits" (bits per axis of its grid, 1..8), "step_events" (events the device
  * logs per launch of the per-ray callback walk: a short log makes the tests continue a walk from the device's stack); value < 0 = the default;
+ * "one_shot" (1 / 0: force / forbid the one-shot grid of batches of up to 2^18 rays), "stagger" (tickets per eighth of the persistent grid
+ * of the staggered drain; 0 = off), "key_class_bits" / "key_class_scale" (chord classes of the reordering key: long rays first);
  * "reset" clears all of them. Returns BVH_AMD_ERR_ARG for an unknown name.                                                       */
 BVH_AMD_API int bvh_amd_experiment(const char* name, int value);
 /* Developer library only (libbvh_amd_dev.so; the release library returns BVH_AMD_ERR_ARG and its kernels carry no such code): after
