@@ -456,15 +456,16 @@ BVH_AMD_API int bvh_amd_experiment(const char* name, int value);
  * bvh_amd_experiment("wave_times", 1), every batch launch of the calling thread records, per wavefront of the persistent grid, six
  * 64-bit words {begin, last ticket draw, end} in s_memrealtime ticks (100 MHz), {XCC id << 32 | rays traced}, {ticks spent inside
  * refills (ticket atomic -> order -> ray loads arrived), number of refills}; this copies the latest
- * launch's records out (it waits for the device). The drain-tail study of profiles/r05_tail_timeline.txt (tools/tail_timeline.py). */
+ * launch's records out (it waits for the device). The drain-tail study of profiles/r05_tail_timeline_before.txt / _after.txt (tools/tail_timeline.py). */
 BVH_AMD_API int bvh_amd_wave_times(unsigned long long* out, size_t capacity_waves, size_t* n_waves);
-/* How the calling thread's latest batch launch was traced: out = {reordered 0/1, record fetch 0 per lane / 1 quad-cooperative, refill
- * threshold, leaf threshold}. For 3D trees whose traversal records exceed the 32 MB of L2 and batches of >= 2^20 rays the library
- * MEASURES this once per tree and kind of ray (closest / any-hit): the first such batch is traced with the plan a static predictor
- * gives the tree, the following seven WHOLE batches with the four candidate plans {as given, reordered} x {per-lane, cooperative
- * fetch} in turn (each twice, timed by events on the launch stream; csrc/traverse.hip: launch_traverse), and the fastest is kept
- * until the tree is re-laid out. Smaller trees and batches use the predictor. BVH_AMD_CALIBRATE=0 in the environment keeps the
- * predictor everywhere. */
+/* How the calling thread's latest batch launch was traced: out = {0 as given / 1 reordered / 2 reordered with the long rays first,
+ * record fetch 0 per lane / 1 quad-cooperative, refill threshold, leaf threshold}. For 3D trees whose traversal records exceed the
+ * 32 MB of L2 and batches of >= 2^20 rays the library MEASURES this once per tree and kind of ray (closest / any-hit): the first such
+ * batch is traced with the plan a static predictor gives the tree, the following ones with the other candidate plans — {as given,
+ * reordered} x {per-lane, cooperative fetch} and, closest-hit, reordered with the long rays first — one WHOLE batch each, timed by
+ * events on the launch stream (csrc/traverse.hip: launch_traverse); a candidate that loses clearly is not traced again, survivors are
+ * measured twice (3 to 8 batches in all), and the fastest is kept until the tree is re-laid out. Smaller trees and batches use the
+ * predictor. BVH_AMD_CALIBRATE=0 in the environment keeps the predictor everywhere. */
 BVH_AMD_API void bvh_amd_last_launch_plan(int out[4]);
 /* ReinsertionOptimizer iterations run so far in this process: out[0] = through the heap-free fast path, out[1] = through the
  * exact replay of the reference's candidate heap + std::sort (taken when ties make their layout matter).

@@ -258,6 +258,24 @@ def gpu_checker():
     return load_oracle()
 
 
+def load_ref_native():
+    """The reference compiled with the GPU box's own `-march=native` expansion (oracle/Makefile: ref_native); None where the file is not in
+    the tree. Loading it on a CPU without AVX-512 would fault at the first vector instruction: callers check cpu_has_avx512() first."""
+    path = os.path.join(_HERE, "_ref", "libbvh_ref_native.so")
+    return CpuLib(path, "ref") if os.path.exists(path) else None
+
+
+def cpu_has_avx512() -> bool:
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+    except (OSError, StopIteration):
+        return False
+    need = ("avx512f", "avx512vl", "avx512bw", "avx512dq", "avx512cd", "avx512vbmi", "avx512_vbmi2", "avx512_vnni", "avx512_bitalg", "avx512_vpopcntdq")
+    if os.environ.get("BVH_AMD_NATIVE_REF_STRICT", "1") != "0":          # (0: run it on a CPU that has the common subsets only — a developer's try)
+        need += ("avx512_vp2intersect", "avx512_bf16", "avx512ifma")
+    return all(f in flags for f in need)
+
+
 def load_ref():
     if not os.path.exists(REF_SO):
         if os.path.isdir("/root/reference/src/bvh/v2"):

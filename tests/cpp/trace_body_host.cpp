@@ -44,14 +44,14 @@ template <typename V> inline V __shfl(V v, int) { return v; }
 template <typename V> inline V __shfl_down(V, int) { return V(0); }
 template <typename V> inline V atomicAdd(V* p, V v) { V old = *p; *p = old + v; return old; }
 template <typename V> inline V atomicOr(V* p, V v) { V old = *p; *p = old | v; return old; }
-static const struct { unsigned x; } threadIdx = {0}, blockIdx = {0};
+static const struct { unsigned x; } threadIdx = {0}, blockIdx = {0}, gridDim = {1};
 #else
 // BVH_HOST_WAVE64: one wavefront of 64 lanes = 64 fibers (ucontext) run round-robin by on_all_lanes(), switching at the wave
 // intrinsics — every one of them sits in wave-uniform control flow in trace_body.inc, so after one round all lanes stand at the
 // same intrinsic. Real refill / leaf-parking thresholds. Single OS thread: the "atomics" need no atomicity.
 #include <ucontext.h>
 static struct { unsigned x; } threadIdx = {0};                   // set by the scheduler before a lane resumes
-static const struct { unsigned x; } blockIdx = {0};
+static const struct { unsigned x; } blockIdx = {0}, gridDim = {1};
 static ucontext_t g_main, g_lane[64];
 static uint64_t g_slot[2][64];                                   // double buffered: a lane may run ahead to the next intrinsic
 static unsigned g_phase[64];
@@ -187,7 +187,7 @@ int run_any(const void* pairs, uint32_t root_index, const void* prims, const voi
     a.n = n_rays; a.work = work; a.parts = g_parts; a.part_size = g_parts > 1 ? ((n_rays + g_parts - 1) / g_parts + 63) / 64 * 64 : n_rays; a.counters = &cnt; a.order = nullptr; a.deep = deep; a.deep_cap = deep_cap;
     a.root_index = root_index;
     a.refill_threshold = kHostRefill; a.leaf_threshold = kHostLeaf;
-    a.coop = 0; a.prim_stride = 12; a.stream_hints = 0;
+    a.coop = 0; a.prim_stride = 12; a.stream_hints = 0; a.stagger = 0; a.one_shot = 0; a.wave_times = nullptr;
     if (dim == 2) { if (deep) run_variant<T, LEAF_SPHERE, 2, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 2, false>(a, any, robust); }
     else if (leaf == LEAF_SPHERE) { if (deep) run_variant<T, LEAF_SPHERE, 3, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 3, false>(a, any, robust); }
     else { if (deep) run_variant<T, LEAF_TRIANGLE, 3, true>(a, any, robust); else run_variant<T, LEAF_TRIANGLE, 3, false>(a, any, robust); }
@@ -211,7 +211,7 @@ int run_coop(const void* pairs, uint32_t root_index, const void* prims, const vo
     a.n = n_rays; a.work = work; a.parts = g_parts; a.part_size = g_parts > 1 ? ((n_rays + g_parts - 1) / g_parts + 63) / 64 * 64 : n_rays;
     a.counters = &cnt; a.order = nullptr; a.deep = nullptr; a.deep_cap = 0; a.root_index = root_index;
     a.refill_threshold = refill; a.leaf_threshold = leaf_threshold;
-    a.coop = 1; a.prim_stride = Leaf == LEAF_SPHERE ? 4 : 12; a.stream_hints = 0;
+    a.coop = 1; a.prim_stride = Leaf == LEAF_SPHERE ? 4 : 12; a.stream_hints = 0; a.stagger = 0; a.one_shot = 0; a.wave_times = nullptr;
     on_all_lanes([&] {
         if (any) { if (robust) host_trace_coop<T, true, true, Leaf, true, D>(a); else host_trace_coop<T, true, false, Leaf, true, D>(a); }
         else { if (robust) host_trace_coop<T, false, true, Leaf, true, D>(a); else host_trace_coop<T, false, false, Leaf, true, D>(a); }
