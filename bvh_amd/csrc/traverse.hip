@@ -257,7 +257,7 @@ constexpr int kKeyClassBits = 0, kKeyClassScalePercent = 500;
 // 0 / 84k / 168k / 262k (with the chord classes 6.74 / 6.60 / 6.81 / 6.97), 2^22 rays 2.57 -> 2.46 at 131k, 10M soup 12.5M rays 5.50 -> 5.46
 // at 125k; light trees want less: Sponza proxy 1M rays 0.264 -> 0.236 at 44k (configs[1]: 3.7 -> 4.0 Grays/s), 4M rays 0.628 -> 0.597 at 42k,
 // terrain 4M 0.649 -> 0.636 at 65k; a tenth of a batch per class is always too much.
-constexpr uint32_t kStaggerHeavy = 100000, kStaggerLight = 50000;
+constexpr uint32_t kStaggerHeavy = 100000, kStaggerLight = 50000, kStaggerDouble = 20000;
 thread_local bool g_last_classes = false;
 thread_local Experiments t_exp;
 #if defined(BVH_AMD_DEVELOPER)
@@ -862,7 +862,10 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
     }
     // staggered drain: `stagger` tickets per eighth of the grid over the whole launch -> per ticket range
     {
-        const size_t dflt = std::min<size_t>(n / 16, heavy ? kStaggerHeavy : kStaggerLight);
+        // (double precision: four waves per SIMD, not eight, share the issue slots — the drain is not what costs there: 1M f64 spheres, 4M
+        //  rays 1.560 ms without, 1.553 at 21k, 1.62-1.92 from 87k up; profiles/r05_stagger_ab_spheres.txt)
+        const size_t dflt = std::is_same_v<T, double> ? std::min<size_t>(n / 64, kStaggerDouble)
+                                                      : std::min<size_t>(n / 16, heavy ? kStaggerHeavy : kStaggerLight);
         const size_t whole = t_exp.stagger > 0 ? static_cast<size_t>(t_exp.stagger) : t_exp.stagger == 0 ? 0 : dflt;
         args.stagger = whole ? std::max<uint32_t>(1u, static_cast<uint32_t>(whole / args.parts)) : 0u;
     }

@@ -666,8 +666,12 @@ private:
 };
 
 // ---- mini_tree_builder.h ------------------------------------------------------------------------------------------------------
+// MortonCode: any unsigned integer type. The reference reads it in ONE place, a debug assert on log2_grid_dim (mini_tree_builder.h:171;
+// the codes themselves are computed in size_t, :183-186), so it never changes a tree; the device path takes log2_grid_dim 1..10 whatever
+// the type (11 would be 2^33 grid bins in the reference too).
 template <typename Node, typename MortonCode = uint32_t>
 class MiniTreeBuilder {                                       // reference mini_tree_builder.h:24-58 (3D; the grid reads three components)
+    static_assert(std::is_unsigned_v<MortonCode>, "MiniTreeBuilder: MortonCode is an unsigned integer type");
     using Scalar = typename Node::Scalar;
     using Vec = bvh::v2::Vec<Scalar, Node::dimension>;
     using BBox = bvh::v2::BBox<Scalar, Node::dimension>;

@@ -60,6 +60,13 @@ int main() {
     typename bvh::v2::MiniTreeBuilder<Node>::Config mini;
     mini.parallel_threshold = 1;
     auto by_hand = bvh::v2::MiniTreeBuilder<Node>::build(thread_pool, bboxes, centers, mini);
+    // MiniTreeBuilder<Node, MortonCode>: the reference only reads MortonCode in a debug assert (mini_tree_builder.h:171; the codes
+    // themselves are size_t, :183-186), so a 64-bit MortonCode builds the same tree — here too
+    {
+        typename bvh::v2::MiniTreeBuilder<Node, uint64_t>::Config mini64;
+        mini64.parallel_threshold = 1;
+        if (!(by_hand == bvh::v2::MiniTreeBuilder<Node, uint64_t>::build(thread_pool, bboxes, centers, mini64))) { std::cout << "MortonCode = uint64_t mismatch" << std::endl; return 2; }
+    }
     typename bvh::v2::ReinsertionOptimizer<Node>::Config reinsertion;       // reinsertion_optimizer.h:18-24, the defaults spelled out
     reinsertion.batch_size_ratio = 0.05f;
     reinsertion.max_iter_count = 3;

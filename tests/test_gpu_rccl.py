@@ -12,7 +12,10 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+
+from bvh_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -227,3 +230,78 @@ def test_two_ranks_receiver_failure_reaches_the_root(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_dev_env(BVH_AMD_BROADCAST_FAIL_RANK="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "fault injection" in (tmp_path / "failed1.txt").read_text() and "another rank" in (tmp_path / "failed0.txt").read_text()
+
+
+def test_library_memory_wrapped_for_torch_traces_like_a_tensor():
+    """bvh_amd.parallel._DeviceBlock: a device allocation of the LIBRARY (what bvhXX_replicate hands out for the primitives of every other
+    device) seen by torch through __cuda_array_interface__ without a copy — traced with, it must give the hits of the tensor it was
+    filled from, and the allocation goes back to the library when the last view dies."""
+    import ctypes as C
+    import torch
+    import bvh_amd
+    from bvh_amd import _lib
+    from bvh_amd.parallel import _DeviceBlock
+    tris = synth.soup(30_000, seed=4, jitter=0.01)
+    bb, cc = bvh_amd.tri_bounds(tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+    prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    rays = torch.from_numpy(synth.rays_closest(200_000, lo, hi)).cuda()
+    want = bvh_amd.intersect(bvh, prims, rays, robust=True)
+    lib = _lib.load()
+    ptr = lib.bvh_amd_device_alloc(prims.numel() * 4)
+    assert ptr
+    block = _DeviceBlock(ptr, prims.shape, "<f4", torch.cuda.current_device())
+    view = torch.as_tensor(block, device="cuda")
+    assert view.data_ptr() == ptr and view.shape == prims.shape and view.dtype == torch.float32
+    view.copy_(prims)
+    got = bvh_amd.intersect(bvh, view, rays, robust=True)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    del view, block
+
+
+def test_replicate_scene_python_path_every_visible_device():
+    """bvh_amd.parallel.replicate_scene (bench.py --one-process): bvh3f_replicate over every visible device, one shard per device traced on
+    the device's own copy; the concatenation equals device 0 tracing the whole batch. On a one-GPU box this is the degenerate list [0]."""
+    import torch
+    import bvh_amd
+    from bvh_amd.parallel import replicate_scene, shard_range
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(0)
+    tris = synth.soup(60_000, seed=3, jitter=0.01)
+    bb, cc = bvh_amd.tri_bounds(tris)
+    bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())
+    prims = bvh_amd.precompute_tris(tris, bvh.device_prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    rays_h = synth.rays_closest(300_001, lo, hi)
+    whole = bvh_amd.intersect(bvh, prims, torch.from_numpy(rays_h).cuda(), robust=True).cpu().numpy()
+    timing = {}
+    copies = replicate_scene(bvh, prims, list(range(n_dev)), timing=timing)
+    assert len(copies) == n_dev and "replicate_ms" in timing
+    parts = []
+    for k, (b_k, p_k) in enumerate(copies):
+        b, e = shard_range(len(rays_h), k, n_dev)
+        with torch.cuda.device(k):
+            assert p_k.device.index == k
+            assert b_k.serialize() == bvh.serialize()
+            parts.append(bvh_amd.intersect(b_k, p_k, torch.from_numpy(rays_h[b:e]).cuda(k), robust=True).cpu().numpy())
+    torch.cuda.set_device(0)
+    assert np.concatenate(parts).tobytes() == whole.tobytes()
+    del copies
+
+
+def test_bench_one_process_mode_line():
+    """`python bench.py --one-process --gpus N` on every visible device: one JSON line, hits_equal_single_gpu, a per-device entry each."""
+    import json
+    import torch
+    n_dev = torch.cuda.device_count()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--one-process", "--gpus", str(n_dev), "--workload", "sponza_262k", "--quality", "medium",
+           "--rays", "2000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-probe"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n_dev and out["config"]["hits_equal_single_gpu"] is True
+    assert [d["device"] for d in out["config"]["per_device"]] == list(range(n_dev))
+    assert out["value"] > 0 and out["scaling"] == "weak"

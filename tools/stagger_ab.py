@@ -39,17 +39,24 @@ def main():
              ("soup_10m Medium pool", "soup", 10_000_000, "Medium", True, [12_500_000]),
              ("sponza_262k Low serial", "sponza_proxy", 262_144, "Low", False, [1 << 20, 1 << 22]),
              ("terrain_1m Low serial", "terrain", 1_000_000, "Low", False, [1 << 22])]
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "spheres":
+        cases = [("spheres_1m f64 High pool (configs[4])", "spheres", 1_000_000, "High", True, [1 << 20, 1 << 22])]
     for name, gen, n, q, pool, batches in cases:
         tris = getattr(synth, gen)(n)
         d = torch.from_numpy(tris).cuda()
-        bb, cc = bvh_amd.tri_bounds(d)
+        leaf = "sphere" if gen == "spheres" else "tri"
+        bb, cc = bvh_amd.sphere_bounds(d) if leaf == "sphere" else bvh_amd.tri_bounds(d)
         bvh = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality[q]), thread_pool=bvh_amd.ThreadPool() if pool else None)
-        prims = bvh_amd.precompute_tris(d, bvh.device_prim_ids())
-        lo, hi = synth.scene_bounds(tris)
+        prims = bvh_amd.gather(d, bvh.device_prim_ids()) if leaf == "sphere" else bvh_amd.precompute_tris(d, bvh.device_prim_ids())
+        if leaf == "sphere":
+            lo, hi = (tris[:, :3] - tris[:, 3:4]).min(axis=0), (tris[:, :3] + tris[:, 3:4]).max(axis=0)
+        else:
+            lo, hi = synth.scene_bounds(tris)
         for nr in batches:
-            rays = torch.from_numpy(synth.rays_closest(nr, lo, hi, seed=1234)).cuda()
-            hits = torch.empty((nr, 4), dtype=torch.float32, device="cuda")
-            fn = lambda: bvh_amd.intersect(bvh, prims, rays, robust=True, out=hits)   # noqa: E731
+            rays = torch.from_numpy(synth.rays_closest(nr, lo, hi, seed=1234, dtype=tris.dtype)).cuda()
+            hits = torch.empty((nr, 4), dtype=torch.float64 if tris.dtype == np.float64 else torch.float32, device="cuda")
+            fn = lambda: bvh_amd.intersect(bvh, prims, rays, robust=True, leaf=leaf, out=hits)   # noqa: E731
             for _ in range(12):
                 fn()
                 torch.cuda.synchronize()
@@ -65,7 +72,7 @@ def main():
                 for st in (0, nr // 400, nr // 200, nr // 100, nr // 64, nr // 48, nr // 32, nr // 24, nr // 16):
                     lib.bvh_amd_experiment(b"stagger", st)
                     p, k = measure(lib, fn, 10)
-                    assert torch.equal(ref.view(torch.int32), hits.view(torch.int32))
+                    assert torch.equal(ref.view(torch.uint8), hits.view(torch.uint8))
                     if base is None:
                         base = p
                     row.append(f"{st}: {p:.4f}/{k:.4f}")
