@@ -318,7 +318,7 @@ def hierarchy_ceilings(working_set_bytes, coop, active):
 
 
 def roofline_section(args, lib, *, robust, rays_here, kernel_ms, pass_ms, reorder_ms, P, T, b_ray, node_count, n_tris, plan, first_plan,
-                     first_call_ms, device_index, reordered):
+                     first_call_ms, device_index, reordered, search=None):
     """The `roofline` object of the line for ONE device's launches (rank 0 / device 0): algorithmic bytes, the kernel's counters collected
     now by child passes (pmc_live), the probe-measured ceilings of every level of the memory hierarchy, the data-sheet pricing."""
     algorithmic = b_ray * rays_here / (kernel_ms * 1e-3) / 1e9
@@ -403,11 +403,12 @@ def roofline_section(args, lib, *, robust, rays_here, kernel_ms, pass_ms, reorde
                 "record_fetch": "quad-cooperative" if coop else "per lane",
                 "launch_plan": {"reordered": bool(plan[0]), "long_rays_first": int(plan[0]) == 2, "quad_cooperative_fetch": bool(plan[1]), "refill_threshold": int(plan[2]),
                 "leaf_threshold": int(plan[3]),
-                "how": "measured by the library on this tree's first large batches (one whole batch per candidate), then fixed"},
+                "how": "measured by the library on this tree's first large batches (one whole batch per candidate), then fixed",
+                "search": search},
                 "first_call": {"ms": round(first_call_ms, 4), "reordered": bool(first_plan[0]), "quad_cooperative_fetch": bool(first_plan[1]),
                 "over_settled_pass": round(first_call_ms / pass_ms, 4),
-                "what": "wall time of the FIRST large batch through the fresh tree (host clock around one call + "
-                "synchronisation, after a 4096-ray call that loads the code): traced with the predictor's plan; the "
+                "what": "wall time of the FIRST batch through the fresh tree (host clock around one call + synchronisation; the "
+                "process's one-off code loads were paid on a throwaway tree before): traced with the predictor's plan; the "
                 "search explores the other plans from the second batch on"},
                 "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)}
 
@@ -613,7 +614,7 @@ def one_process(args):
 
                 def step():
                     bvh_amd.intersect(bvh_k, prims_k, rays, any_hit=False, robust=robust, out=hits, sort_rays=sort_rays)
-                for _ in range(10):                           # the library settles its launch plan for this copy of the tree (see main())
+                for _ in range(12):                           # the library settles its launch plan for this copy of the tree (see main())
                     step()
                     stream.synchronize()
                 for _ in range(args.warmup):
@@ -807,12 +808,22 @@ def main():
         bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, out=hits, sort_rays=sort_rays)
 
     # the FIRST large batch through the fresh tree, as a single-shot caller sees it (VERDICT r3 Weak 4): traced with the plan the
-    # library's predictor gives this tree — the measured search only starts exploring with the second batch. A 4096-ray call comes
-    # first so that the one-off code load of the process is not charged to it.
+    # library's predictor gives this tree — the measured search only starts exploring with the second batch. What a PROCESS pays once
+    # (the code load of every kernel a large batch can use: ray keys, the radix passes, both record fetches) is paid first on a THROWAWAY
+    # tree, so that `first_call` holds exactly what is per tree: its depth pass, the first scratch of this size, the predictor's plan.
     import ctypes
     lib = bvh_amd._lib.load()
-    bvh_amd.intersect(bvh, prims, rays[:4096], any_hit=False, robust=robust, out=hits[:4096], sort_rays=sort_rays)
+    warm_tris = torch.from_numpy(synth.soup(20000, seed=99)).cuda()
+    warm_bb, warm_cc = bvh_amd.tri_bounds(warm_tris)
+    warm_bvh = bvh_amd.DefaultBuilder.build(warm_bb, warm_cc, bvh_amd.Config(quality=bvh_amd.Quality.Low))
+    warm_prims = bvh_amd.precompute_tris(warm_tris, warm_bvh.device_prim_ids())
+    for coop_fetch in (0, 1):
+        lib.bvh_amd_tuning(-1, -1, coop_fetch, -1)
+        for order in (True, False):
+            bvh_amd.intersect(warm_bvh, warm_prims, rays[:70000], any_hit=False, robust=robust, out=hits[:70000], sort_rays=order)
+    lib.bvh_amd_tuning(-1, -1, -1, -1)
     torch.cuda.synchronize()
+    del warm_bvh, warm_prims, warm_tris, warm_bb, warm_cc
     t_first = time.perf_counter()
     step()
     torch.cuda.synchronize()
@@ -828,9 +839,9 @@ def main():
 
     # set-up, like the build: the library measures how to trace large batches through THIS tree (reordered or as given, record fetch,
     # thresholds) on its first few large batches — one whole batch per candidate plan — and keeps the fastest (csrc/traverse.hip:
-    # launch_traverse). Ten untimed passes, each waited for (the search reads a candidate's events once they have completed), let it
+    # launch_traverse: 3 to 9 batches). Twelve untimed passes, each waited for (the search reads a candidate's events once they have completed), let it
     # settle before the W warm-up and K timed steps.
-    for _ in range(10):
+    for _ in range(12):
         step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -839,6 +850,16 @@ def main():
     plan = (ctypes.c_int * 4)()
     lib.bvh_amd_last_launch_plan(plan)
     reordered = bool(plan[0])
+    search = None
+    if hasattr(lib, "bvh_amd_last_plan_search"):              # what the library's plan search measured on this tree before it settled
+        s_ns, s_cnt, s_drop = (ctypes.c_float * 5)(), (ctypes.c_int * 5)(), ctypes.c_uint(0)
+        lib.bvh_amd_last_plan_search(s_ns, s_cnt, ctypes.byref(s_drop))
+        names = ["as given, per lane", "as given, cooperative", "reordered, per lane", "reordered, cooperative", "reordered, cooperative, long rays first"]
+        if any(s_cnt):
+            search = {"ns_per_ray": {names[c]: round(float(s_ns[c]), 4) for c in range(5) if s_cnt[c]}, "measurements": {names[c]: int(s_cnt[c]) for c in range(5)},
+                      "dropped_as_clear_losers": [names[c] for c in range(5) if (s_drop.value >> c) & 1],
+                      "what": "ns per ray of every candidate plan the search traced a whole batch with (better of its measurements; keys + sort charged to "
+                              "the reordering ones), how often, and which were pruned"}
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -878,7 +899,7 @@ def main():
         value = total_rays / elapsed / 1e6
         roofline = roofline_section(args, lib, robust=robust, rays_here=rays_here, kernel_ms=kernel_ms, pass_ms=pass_ms, reorder_ms=reorder_ms, P=P, T=T,
                                     b_ray=b_ray, node_count=bvh.node_count, n_tris=n_tris, plan=plan, first_plan=first_plan, first_call_ms=first_call_ms,
-                                    device_index=device_index, reordered=reordered)
+                                    device_index=device_index, reordered=reordered, search=search)
         out = {
             "metric": f"Mrays/s closest-hit ({label})", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -57,6 +57,7 @@ _SIGS = {
     "bvh_amd_kernel_times": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "bvh_amd_reorder_times": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "bvh_amd_tuning": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bvh_amd_last_plan_search": (None, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_uint)]),
     "bvh_amd_experiment": (_I, [C.c_char_p, C.c_int]),
     "bvh_amd_wave_times": (_I, [_P, _Z, C.POINTER(C.c_size_t)]),
     "bvh_amd_last_launch_plan": (None, [C.POINTER(C.c_int)]),

@@ -529,6 +529,7 @@ int bvh_amd_experiment(const char* name, int value) { return set_experiment(name
 int bvh_amd_wave_times(unsigned long long* out, size_t capacity_waves, size_t* n_waves) { return wave_times(out, capacity_waves, n_waves); }
 void bvh_amd_tuning(int refill_threshold, int leaf_threshold, int coop_fetch, int ticket_ranges) { set_tuning(refill_threshold, leaf_threshold, coop_fetch, ticket_ranges); }
 void bvh_amd_last_launch_plan(int out[4]) { if (out) last_launch_plan(out); }
+void bvh_amd_last_plan_search(float ns_per_ray[5], int measurements[5], unsigned* dropped_mask) { last_plan_search(ns_per_ray, measurements, dropped_mask); }
 int bvh_amd_reorder_times(float* ms_out, size_t capacity, size_t* count_out) {
     if (!ms_out && capacity) return fail(BVH_AMD_ERR_ARG, "bvh_amd_reorder_times: null output");
     return reorder_times(ms_out, capacity, count_out);

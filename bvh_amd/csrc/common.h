@@ -246,6 +246,7 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
                     typename HitOf<T>::Type* d_hits, bvh_amd_counters* d_counters, hipStream_t stream);
 void last_launch_plan(int out[4]);                            // traverse.hip: {reordered, coop, refill, leaf} of the calling thread's latest launch
 int wave_times(unsigned long long* out, size_t capacity_waves, size_t* n_waves);   // traverse.hip: developer library only
+void last_plan_search(float ns_per_ray[5], int measurements[5], unsigned* dropped);   // traverse.hip
 int set_experiment(const char* name, int value);                             // traverse.hip: developer experiments of the calling thread
 void set_tuning(int refill, int leaf, int coop, int parts);               // traverse.hip: per-thread overrides for A/B runs (< 0: default)
 const char* last_kernel_name();

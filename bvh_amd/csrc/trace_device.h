@@ -23,6 +23,7 @@ constexpr int kLdsDepth = 20;
 // 5.07 -> 5.77 Grays/s, 1M-triangle terrain 5.35 -> 6.59). Only a walk that misses the L2s all the time (unsorted uniform rays on
 // the 1M soup) would rather have rare, full refills, and by little: 1404 Mrays/s at 54 / 8, 1382 at 36 / 12.
 constexpr int kRefillThreshold = 36;
+constexpr int kRefillThresholdSmall = 20;          // per-lane kernel, batches of up to 2^21 rays (traverse.hip: launch_planned)
 constexpr int kLeafThreshold = 12;
 // Quad-cooperative record fetch (coop_load_pair below) and the thresholds that go with it, by kind of launch. Measured on the
 // device (profiles/r03_traversal_experiments.md): the cooperative fetch cuts the L1's lane requests per visited record from 4 to

@@ -259,6 +259,10 @@ constexpr int kKeyClassBits = 0, kKeyClassScalePercent = 500;
 // terrain 4M 0.649 -> 0.636 at 65k; a tenth of a batch per class is always too much.
 constexpr uint32_t kStaggerHeavy = 100000, kStaggerLight = 50000, kStaggerDouble = 20000;
 thread_local bool g_last_classes = false;
+// what the plan search of the calling thread's latest finished search had measured (bvh_amd_last_plan_search: the bench line quotes it)
+thread_local float g_search_ns[5] = {0, 0, 0, 0, 0};
+thread_local int g_search_count[5] = {0, 0, 0, 0, 0};
+thread_local unsigned g_search_dropped = 0;
 thread_local Experiments t_exp;
 #if defined(BVH_AMD_DEVELOPER)
 // per-wave timeline of the calling thread's latest traversal launch (drain-tail study, profiles/r05_tail_timeline.txt)
@@ -320,7 +324,8 @@ int launch_variant_d(const BvhImpl<T>& b, const TraceArgs<T>& args, hipStream_t 
         // (configs[1], 1M rays: 0.283 -> 0.254-0.268 ms; 512k rays: 0.234 -> 0.202 ms).
         int cus = blocks / 7 > 0 ? blocks / 7 : 1;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device);
-        const int cap = (args.n <= (1ull << 21) ? 5 : 6) * cus;
+        // (round 5: with the staggered drain and the earlier refill of small batches 6 is as good as 5 there too — 1M rays 0.2472 / 0.2519)
+        const int cap = 6 * cus;
         if (grid > cap) grid = cap;
     }
     static const int grid_env = BVH_DEV_INT("BVH_AMD_GRID_BLOCKS", 0);   // developer knob: fewer resident waves (occupancy studies)
@@ -616,6 +621,10 @@ int wave_times(unsigned long long* out, size_t capacity_waves, size_t* n_waves) 
     return fail(BVH_AMD_ERR_ARG, "bvh_amd_wave_times: developer library only");
 #endif
 }
+void last_plan_search(float ns_per_ray[5], int measurements[5], unsigned* dropped) {
+    for (int c = 0; c < 5; ++c) { if (ns_per_ray) ns_per_ray[c] = g_search_ns[c]; if (measurements) measurements[c] = g_search_count[c]; }
+    if (dropped) *dropped = g_search_dropped;
+}
 const char* last_kernel_name() { return g_last_kernel; }
 bool last_launch_reordered() { return g_last_reordered; }
 
@@ -769,7 +778,10 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
         //  cooperative fetch makes longer: configs[4], 1M rays: 0.60 ms per lane, 0.65 cooperative; 4M: 1.86 / 1.66; 16M: 6.68 / 5.62.
         //  Any-hit gains at every size: 0.58 / 0.55, 1.83 / 1.41, 6.76 / 4.74 ms; profiles/r04_experiments_call3_double.txt)
         args.coop = (coop_capable && (forced >= 0 ? forced != 0 : (any_hit || (heavy && n >= (size_t{1} << 21))))) ? 1u : 0u;
-        const int refill_default = !args.coop ? kRefillThreshold : any_hit ? kCoopRefillAny : heavy ? kCoopRefillHeavy : kCoopRefillAny;
+        // (round 5, with the staggered drain: a batch of up to 2^21 rays refills earlier — configs[1], 1M rays, per lane: 0.2534 ms at 36 / 12,
+        //  0.2460-0.2472 at 20 / 12; 2M rays 0.3741 -> 0.3648; profiles/r05_small_batch_sweep.txt)
+        const int refill_lane = n <= (size_t{1} << 21) && std::is_same_v<T, float> ? kRefillThresholdSmall : kRefillThreshold;
+        const int refill_default = !args.coop ? refill_lane : any_hit ? kCoopRefillAny : heavy ? kCoopRefillHeavy : kCoopRefillAny;
         const int leaf_default = !args.coop ? kLeafThreshold : any_hit ? kCoopLeafAny : heavy ? kCoopLeafHeavy : kCoopLeafAny;
         args.refill_threshold = t_refill > 0 ? t_refill : refill_env > 0 ? refill_env : refill_default;
         args.leaf_threshold = t_leaf > 0 ? t_leaf : leaf_env > 0 ? leaf_env : leaf_default;
@@ -989,7 +1001,20 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
             else if (ps.count[c] == 1 && next < 0) next = c;
         }
         if (alive == 1 && winner >= 0) next = -1;                           // nobody left to compare with
+        if (next < 0 && alive >= 2 && winner >= 0) {
+            // a photo finish (the runner-up within 5 % after two measurements each: the soup's "long rays first" beats the plain reordered
+            // plan by 3-5 % in the search's own numbers, and one run in five settled on the wrong one) gets a third measurement of both
+            int second = -1;
+            for (int c = 0; c < n_cand; ++c)
+                if (c != winner && !(ps.dropped >> c & 1) && ps.count[c] && (second < 0 || ps.ns_per_ray[c] < ps.ns_per_ray[second])) second = c;
+            if (second >= 0 && ps.ns_per_ray[second] < 1.05f * ps.ns_per_ray[winner]) {
+                if (ps.count[winner] < 3) next = winner;
+                else if (ps.count[second] < 3) next = second;
+            }
+        }
         if (!ps.pending && next < 0 && winner >= 0) {                       // every survivor measured twice (or alone): keep the winner
+            for (int c = 0; c < 5; ++c) { g_search_ns[c] = c < n_cand ? ps.ns_per_ray[c] : 0.0f; g_search_count[c] = c < n_cand ? ps.count[c] : 0; }
+            g_search_dropped = ps.dropped;
             b.launch_plan[kind].store(pack_plan(candidates[winner]));
             plan = candidates[winner]; have_plan = true;
         } else if (!ps.pending && !d_counters && next >= 0) {               // try the next candidate on this batch

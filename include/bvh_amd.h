@@ -467,6 +467,12 @@ BVH_AMD_API int bvh_amd_wave_times(unsigned long long* out, size_t capacity_wave
  * measured twice (3 to 8 batches in all), and the fastest is kept until the tree is re-laid out. Smaller trees and batches use the
  * predictor. BVH_AMD_CALIBRATE=0 in the environment keeps the predictor everywhere. */
 BVH_AMD_API void bvh_amd_last_launch_plan(int out[4]);
+/* The table of the latest plan search the calling thread FINISHED (the call that settled a tree's plan): nanoseconds per ray of the five
+ * candidates {0 as given + per lane, 1 as given + cooperative, 2 reordered + per lane (any-hit: as given + cooperative, heavy thresholds),
+ * 3 reordered + cooperative, 4 reordered + cooperative + long rays first (closest-hit only)} — the better of a candidate's measurements,
+ * the keys + sort of a reordering candidate charged at their measured rate —, how often each was measured (0: pruned before its turn)
+ * and the mask of candidates dropped as clear losers. Measurement aid: bench.py quotes it in `roofline.launch_plan.search`. */
+BVH_AMD_API void bvh_amd_last_plan_search(float ns_per_ray[5], int measurements[5], unsigned* dropped_mask);
 /* ReinsertionOptimizer iterations run so far in this process: out[0] = through the heap-free fast path, out[1] = through the
  * exact replay of the reference's candidate heap + std::sort (taken when ties make their layout matter).
  * Both produce the reference's result bit for bit; BVH_AMD_REINSERT=exact in the environment forces the replay. */

@@ -106,7 +106,7 @@ def test_bench_json_contract(monkeypatch, orc):
         out[0], out[1], out[2], out[3] = 1, 1, 12, 12
     fake_lib = types.SimpleNamespace(bvh_amd_last_kernel_name=lambda: b"trace_kernel_coop<float, false, true, 0, false>", bvh_amd_kernel_timing=lambda on: None,
                                      bvh_amd_last_launch_reordered=lambda: 0, bvh_amd_kernel_times=fake_kernel_times, bvh_amd_reorder_times=fake_reorder_times,
-                                     bvh_amd_last_launch_plan=fake_plan)
+                                     bvh_amd_last_launch_plan=fake_plan, bvh_amd_tuning=lambda *a: None, bvh_amd_experiment=lambda *a: 0)
     monkeypatch.setattr(bvh_amd, "last_optimize_profile", lambda: {"iterations": 3, "replayed": 2, "replacements": 1000, "heap_ms": 0.5})
     monkeypatch.setattr(bvh_amd._lib, "load", lambda: fake_lib)
     monkeypatch.setitem(bench.WORKLOADS, "soup_1m", ("soup", 3000, "tiny stand-in scene of the contract test", "3000-tri stand-in"))
