@@ -781,7 +781,9 @@ size_t radix_sort_hist_words(uint32_t n, uint32_t batch) { return size_t{batch} 
 
 template <typename K>
 int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, uint32_t n, uint32_t batch, int bits, hipStream_t stream,
-                     uint32_t* hist_buf, bool iota_vals, bool keys_wanted, uint32_t** vals_result) {
+                     uint32_t* hist_buf, bool iota_vals, bool keys_wanted, uint32_t** vals_result, bool first_hist_done) {
+    static_assert(RadixShape<uint32_t>::kTile == kRadixTileU32, "ray_keys_kernel writes the first histogram in tiles of kRadixTileU32 keys");
+    if (first_hist_done && (sizeof(K) != 4 || batch != 1 || !hist_buf)) return fail(BVH_AMD_ERR_ARG, "radix_sort_pairs: first_hist_done needs 32-bit keys, one array and the caller's histogram buffer");
     if (vals_result) *vals_result = vals;
     if (n == 0 || batch == 0) return BVH_AMD_OK;
     StreamScope scratch_on(stream);
@@ -796,7 +798,7 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
     // (a caller that passes vals_result takes the values wherever the last pass leaves them and gives up the keys)
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kThreads), 0, stream, kin, n, bpa, shift, hist);
+        if (!(p == 0 && first_hist_done)) hipLaunchKernelGGL(k_radix_hist<K>, dim3(batch * bpa), dim3(kThreads), 0, stream, kin, n, bpa, shift, hist);
         if (256 * bpa > 16384) {                              // long histograms: the multi-block scan (one block per array crawls: 1 ms at 10M keys)
             for (uint32_t a = 0; a < batch; ++a) {
                 int rc = scan_u32_async(hist + size_t{a} * 256 * bpa, hist + size_t{a} * 256 * bpa, 256 * bpa, nullptr, stream);
@@ -921,9 +923,9 @@ int std_sort_ids(uint32_t* d_ids, const T* d_keys, uint32_t n, uint32_t batch, u
     return radix_sort_pairs<U>(skeys.p, d_ids, skeys_tmp.p, vals_tmp.p, n, batch, int(sizeof(U) * 8), stream);
 }
 
-template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**);
-template int radix_sort_pairs<uint16_t>(uint16_t*, uint32_t*, uint16_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**);
-template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**);
+template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**, bool);
+template int radix_sort_pairs<uint16_t>(uint16_t*, uint32_t*, uint16_t*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**, bool);
+template int radix_sort_pairs<unsigned long long>(unsigned long long*, uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, int, hipStream_t, uint32_t*, bool, bool, uint32_t**, bool);
 template int std_sort_ids<float>(uint32_t*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 template int std_sort_ids<double>(uint32_t*, const double*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 

@@ -124,13 +124,10 @@ __global__ void __launch_bounds__(kBlock, 8) trace_kernel_coop_plan_search(Trace
 // select the XCD's ticket range), the chord class of the ray, longest class first, and the cell index gives up its lowest `class_bits`
 // bits (neighbours along the curve merge): every XCD still sweeps its part of space in curve order, once per class, and the tickets
 // drawn last are the short rays. Per-ray results do not depend on the order.
+__device__ inline float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }       // v_rcp_f32; ordering keys only
+__device__ inline double rcp_fast(double x) { return 1.0 / x; }
 template <typename T>
-__global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys, uint32_t cells = 64,
-                                                       int hilbert_bits = 0, int class_bits = 0, T class_scale = T(0)) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    T r[8];
-    load_ray(rays + 8ull * i, r);
+__device__ inline uint32_t ray_key(const T (&r)[8], T lx, T ly, T lz, T sx, T sy, T sz, uint32_t cells, int hilbert_bits, int class_bits, T class_scale) {
     const T q[3] = { (r[0] - lx) * sx, (r[1] - ly) * sy, (r[2] - lz) * sz };
     uint32_t code = 0;
     uint32_t cell[3];
@@ -165,29 +162,61 @@ __global__ void __launch_bounds__(256) ray_keys_kernel(const T* rays, uint32_t n
     }
     const uint32_t oct = (Num<T>::sign(r[3]) ? 1u : 0u) | (Num<T>::sign(r[4]) ? 2u : 0u) | (Num<T>::sign(r[5]) ? 4u : 0u);
     if (class_bits > 0) {
-        // chord of the ray through the root box, in units of the box diagonal: slab test against [l, l + cells / s] with the ray's own
-        // tmin / tmax (plain arithmetic: the key only orders rays)
+        // chord of the ray through the root box against the box diagonal: slab test against [l, l + cells / s] with the ray's own tmin /
+        // tmax. The key only ORDERS rays, so this is the one place of the library that uses the hardware's approximate reciprocal
+        // (v_rcp_f32, 1 ulp) instead of an IEEE division — the kernel is bound by its instructions (16.8 M rays x ~400), not by the 512 MB
+        // it reads — and the one-bit case compares squares instead of taking two square roots.
         const T l[3] = { lx, ly, lz }, sc[3] = { sx, sy, sz };
         T t0 = r[6], t1 = r[7], d2 = T(0), diag2 = T(0);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const T ext = sc[k] > T(0) ? T(cells) / sc[k] : T(0);
-            const T inv = T(1) / r[3 + k];
+            const T ext = sc[k] > T(0) ? T(cells) * rcp_fast(sc[k]) : T(0);
+            const T inv = rcp_fast(r[3 + k]);
             const T a = (l[k] - r[k]) * inv, b = (l[k] + ext - r[k]) * inv;
             const T lo_t = a < b ? a : b, hi_t = a < b ? b : a;         // (NaN from 0 * inf compares false: that slab does not clip)
             t0 = lo_t > t0 ? lo_t : t0; t1 = hi_t < t1 ? hi_t : t1;
             d2 += r[3 + k] * r[3 + k]; diag2 += ext * ext;
         }
-        const T chord = t1 > t0 ? (t1 - t0) * Num<T>::sqrt_(d2) : T(0);
-        const T rel = diag2 > T(0) ? chord / Num<T>::sqrt_(diag2) * class_scale : T(0);
         const uint32_t top = (1u << class_bits) - 1u;
-        uint32_t cls = rel >= T(top) ? top : rel > T(0) ? static_cast<uint32_t>(rel) : 0u;
+        uint32_t cls = 0;
+        const T len = t1 > t0 ? t1 - t0 : T(0);
+        if (class_bits == 1) cls = len * len * d2 * class_scale * class_scale >= diag2 && diag2 > T(0) ? 1u : 0u;
+        else {
+            const T rel = diag2 > T(0) ? len * Num<T>::sqrt_(d2) / Num<T>::sqrt_(diag2) * class_scale : T(0);
+            cls = rel >= T(top) ? top : rel > T(0) ? static_cast<uint32_t>(rel) : 0u;
+        }
         cls = top - cls;                                                // longest class first
         const int code_bits = 3 * (hilbert_bits > 0 ? hilbert_bits : 31 - __clz(cells));
         const uint32_t high = code >> (code_bits - 3), low = (code & ((1u << (code_bits - 3)) - 1u)) >> class_bits;
         code = (((high << class_bits) | cls) << (code_bits - 3 - class_bits)) | low;
     }
-    keys[i] = (code << 3) | oct;
+    return (code << 3) | oct;
+}
+
+// One block = one tile of the radix sort's first pass (kRadixTileU32 keys: 1024 threads x 4, strided so that a wave's loads are contiguous):
+// the keys are written AND the tile's histogram of their lowest digit is left where k_radix_hist would have put it, so the sort's first
+// histogram pass — a second read of all keys — is not launched (round 5: 132 + 27 -> ~115 us per 2^24 rays; the rays are loaded
+// non-temporally: they are read once here and once, much later, by the traversal).
+template <typename T>
+__global__ void __launch_bounds__(1024) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys, uint32_t cells,
+                                                        int hilbert_bits, int class_bits, T class_scale, uint32_t* hist, uint32_t tiles) {
+    __shared__ uint32_t h[256];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * uint32_t(kRadixTileU32);
+#pragma unroll
+    for (int s0 = 0; s0 < kRadixTileU32 / 1024; ++s0) {
+        const uint32_t i = base + uint32_t(s0) * 1024u + threadIdx.x;
+        if (i < n) {
+            T r[8];
+            load_ray_nt(rays + 8ull * i, r);
+            const uint32_t key = ray_key<T>(r, lx, ly, lz, sx, sy, sz, cells, hilbert_bits, class_bits, class_scale);
+            keys[i] = key;
+            atomicAdd(&h[key & 0xFFu], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[size_t{threadIdx.x} * tiles + blockIdx.x] = h[threadIdx.x];   // digit-major, tile-minor: k_radix_hist's layout (sort_emul.hip)
 }
 
 // Developer experiment (BVH_AMD_RAY_KEY_DEPTH=k; profiles/r03_traversal_experiments.md §6): a TREE-ENTRY key — the ray descends the
@@ -847,7 +876,7 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
         }
         static const int entry_depth = std::min(29, BVH_DEV_INT("BVH_AMD_RAY_KEY_DEPTH", 0));   // developer experiment
         int key_bits = 21;
-        bool entry_keys = false;
+        bool entry_keys = false, first_hist_done = false;
         if constexpr (std::is_same_v<T, float>) entry_keys = entry_depth > 0 && b.dim == 3;
         if constexpr (std::is_same_v<T, float>) {
             if (entry_keys) {
@@ -862,13 +891,15 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
             const int class_bits = cell_bits < 3 ? 0 : t_exp.key_class_bits >= 0 ? std::min(3, t_exp.key_class_bits) : (plan && plan->classes) ? 1 : kKeyClassBits;
             g_last_classes = class_bits > 0;
             const T class_scale = static_cast<T>(t_exp.key_class_scale > 0 ? t_exp.key_class_scale : kKeyClassScalePercent) / T(100);
-            hipLaunchKernelGGL(ray_keys_kernel<T>, dim3((n32 + 255) / 256), dim3(256), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0] * rescale, sc[1] * rescale,
+            const uint32_t tiles = (n32 + kRadixTileU32 - 1) / kRadixTileU32;
+            hipLaunchKernelGGL(ray_keys_kernel<T>, dim3(tiles), dim3(1024), 0, stream, d_rays, n32, lo[0], lo[1], lo[2], sc[0] * rescale, sc[1] * rescale,
                                sc[2] * rescale, keys, 1u << cell_bits, t_exp.key_curve == 0 ? 0 : cell_bits,      // Hilbert index by default (round 4); "key_curve" 0 = Morton
-                               class_bits, class_scale);
+                               class_bits, class_scale, hist, tiles);
+            first_hist_done = true;
             key_bits = 3 * cell_bits + 3;
         }
         uint32_t* order = nullptr;
-        int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, key_bits, stream, hist, /*iota_vals=*/true, /*keys_wanted=*/false, &order);
+        int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, key_bits, stream, hist, /*iota_vals=*/true, /*keys_wanted=*/false, &order, first_hist_done);
         if (rc) return release(rc);
         args.order = order;
     }

@@ -89,8 +89,12 @@ int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
     if (b.max_depth.load() >= 0) return BVH_AMD_OK;
     if (b.pair_count == 0) { b.max_depth = 0; return BVH_AMD_OK; }
     const uint32_t n = static_cast<uint32_t>(b.pair_count);
+    // (round 5: from the scratch block cache like every other temporary — a plain hipMalloc + hipFree pair, the latter a device
+    //  synchronisation, was a good part of what the FIRST batch through a fresh tree paid over a settled one)
+    StreamScope scratch_on(stream);
+    ScratchTag buf_tag;
     uint32_t* buf = nullptr;
-    BVH_HIP_TRY(hipMalloc(&buf, (size_t{4} * n + 4) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(scratch_alloc(reinterpret_cast<void**>(&buf), (size_t{4} * n + 4) * sizeof(uint32_t), &buf_tag), BVH_AMD_ERR_HIP);
     uint32_t *anc = buf, *dist = buf + n, *anc2 = buf + 2 * size_t{n}, *dist2 = buf + 3 * size_t{n};
     uint32_t* d_max = buf + 4 * size_t{n};                    // {max depth, pad, 64-bit sum of expected visits}: 16-byte aligned
     unsigned long long* d_visits = reinterpret_cast<unsigned long long*>(d_max + 2);
@@ -125,7 +129,7 @@ int tree_depth(const BvhImpl<T>& b, hipStream_t stream) {
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess || words[1] == 0) break;                   // every chain ends at a fixed point: the depth is final
     }
-    (void)hipFree(buf);
+    scratch_free(buf, buf_tag);
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("tree_depth: ") + hipGetErrorString(e));
     const uint32_t deepest = words[0];
     b.expected_visits = static_cast<float>(static_cast<double>((static_cast<unsigned long long>(words[3]) << 32) | words[2]) / 65536.0);
