@@ -104,6 +104,7 @@ _SIGS_T = {
     "bvh{S}_build_device": (_P, [_P, _P, _Z, _P, _I, _P]),
     "bvh{S}_build_sah": (_P, [_P, _P, _P, _Z, _P, _P]),
     "bvh{S}_build_device_sah": (_P, [_P, _P, _Z, _P, _I, _P, _P]),
+    "bvh{S}_build_device_binned": (_P, [_P, _P, _Z, _P, _P, _Z, _P]),
     "bvh{S}_build_minitree_device": (_P, [_P, _P, _Z, _P, _P]),
     "bvh{S}_from_nodes": (_P, [_P, _Z, _P, _Z]),
     "bvh{S}_extract": (_P, [_P, _Z]),

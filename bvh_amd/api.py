@@ -281,7 +281,7 @@ class Bvh:
                                                       ids.ctypes.data_as(C.c_void_p), len(ids)), s)
 
 
-def _build(bboxes, centers, config: Config, builder: _Builder) -> Bvh:
+def _build(bboxes, centers, config: Config, builder: _Builder, bin_count: int | None = None) -> Bvh:
     lib = _lib.load()
     dim = int(np.shape(centers)[-1])                          # (n,6) + (n,3), or (n,4) {min.x,min.y,max.x,max.y} + (n,2)
     bb = _dev(bboxes, 2 * dim)
@@ -291,7 +291,10 @@ def _build(bboxes, centers, config: Config, builder: _Builder) -> Bvh:
     s = _suffix(bb.dtype, dim)
     cfg = config._c()
     sah = config.sah._c()
-    h = getattr(lib, f"bvh{s}_build_device_sah")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), int(builder), C.byref(sah), _stream())
+    if bin_count is not None:                                 # BinnedSahBuilder<Node, BinCount> with a BinCount of its own
+        h = getattr(lib, f"bvh{s}_build_device_binned")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), C.byref(sah), int(bin_count), _stream())
+    else:
+        h = getattr(lib, f"bvh{s}_build_device_sah")(bb.data_ptr(), cc.data_ptr(), bb.shape[0], C.byref(cfg), int(builder), C.byref(sah), _stream())
     return Bvh(h, s)
 
 
@@ -308,11 +311,12 @@ class DefaultBuilder:
 
 
 class BinnedSahBuilder:
-    """bvh::v2::BinnedSahBuilder<Node>::build (binned_sah_builder.h:32-38)."""
+    """bvh::v2::BinnedSahBuilder<Node, BinCount>::build (binned_sah_builder.h:18, :32-38); bin_count = the BinCount template
+    argument (4, 8 = the reference's default, 16 or 32)."""
 
     @staticmethod
-    def build(bboxes, centers, config: Config | None = None) -> Bvh:
-        return _build(bboxes, centers, config or Config(), _Builder.BINNED)
+    def build(bboxes, centers, config: Config | None = None, bin_count: int = 8) -> Bvh:
+        return _build(bboxes, centers, config or Config(), _Builder.BINNED, None if bin_count == 8 else bin_count)
 
 
 class SweepSahBuilder:

@@ -39,9 +39,10 @@ namespace {
 // =====================================================================================================
 
 // fill_bins (binned_sah_builder.h:82-99) for one chunk of one segment.
-template <typename T>
+template <typename T, int NB = kBins>
 __global__ void __launch_bounds__(256) k_bin(BuildCtx<T> c) {
-    __shared__ SlotBins<T> sb;
+    constexpr int kBins = NB;            // BinCount of this instantiation (binned_sah_builder.h:18)
+    __shared__ SlotBins<T, NB> sb;
     const Task tk = c.tasks[blockIdx.x];
     const ANode<T>& nd = c.nodes[c.state[tk.slot].node];
     const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
@@ -61,14 +62,14 @@ __global__ void __launch_bounds__(256) k_bin(BuildCtx<T> c) {
         for (int k = 0; k < 3; ++k) { ctr[k] = c.centers[3ull * id + k]; blo[k] = c.bboxes[6ull * id + k]; bhi[k] = c.bboxes[6ull * id + 3 + k]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const uint32_t s = bin_of(Ord<T>::fma_(ctr[k], scale[k], shift[k]));   // :92-95
+            const uint32_t s = bin_of_n<NB>(Ord<T>::fma_(ctr[k], scale[k], shift[k]));   // :92-95
 #pragma unroll
             for (int j = 0; j < 3; ++j) { atomicMin(&sb.lo[k][s][j], Ord<T>::enc(blo[j])); atomicMax(&sb.hi[k][s][j], Ord<T>::enc(bhi[j])); }
             atomicAdd(&sb.cnt[k][s], 1u);
         }
     }
     __syncthreads();
-    SlotBins<T>& gb = c.bins[tk.slot];
+    SlotBins<T, NB>& gb = reinterpret_cast<SlotBins<T, NB>*>(c.bins)[tk.slot];
     for (int w = threadIdx.x; w < 3 * kBins; w += 256) {
         const uint32_t n = (&sb.cnt[0][0])[w];
         if (!n) continue;
@@ -82,18 +83,19 @@ __global__ void __launch_bounds__(256) k_bin(BuildCtx<T> c) {
 }
 
 // try_split's decision (binned_sah_builder.h:128-148), one thread per segment.
-template <typename T>
+template <typename T, int NB = kBins>
 __global__ void __launch_bounds__(64) k_decide(BuildCtx<T> c, uint32_t n_active) {
+    constexpr int kBins = NB;
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= n_active) return;
     SlotState<T>& st = c.state[slot];
     const ANode<T>& nd = c.nodes[st.node];
-    const SlotBins<T>& b = c.bins[slot];
+    const SlotBins<T, NB>& b = reinterpret_cast<const SlotBins<T, NB>*>(c.bins)[slot];
     const int wide = widest_axis(nd.lo, nd.hi, c.dim);
     uint32_t best_bin = kBins / 2; T best_cost = Ord<T>::kMax; int best_axis = wide;     // :132-133
     for (int k = 0; k < c.dim; ++k) {
         T cost; uint32_t bin;
-        sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
+        sweep_axis_n<T, NB>([&](int i, T* lo, T* hi, uint32_t& n) {
             for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(b.lo[k][i][j]); hi[j] = Ord<T>::dec(b.hi[k][i][j]); }
             n = b.cnt[k][i];
         }, cost, bin, c.dim, c.sah_log);
@@ -215,10 +217,10 @@ __global__ void __launch_bounds__(256) k_swap(BuildCtx<T> c) {
 // Phase B: one wavefront builds a whole subtree of <= 64 primitives
 // =====================================================================================================
 
-template <typename T>
+template <typename T, int NB = kBins>
 struct WaveLds {
-    typename Ord<T>::U lo[3][kBins][3], hi[3][kBins][3];
-    uint32_t cnt[3][kBins];
+    typename Ord<T>::U lo[3][NB][3], hi[3][NB][3];
+    uint32_t cnt[3][NB];
     T nbox[2 * kSmall][6];               // local node boxes {lo xyz, hi xyz}
     uint32_t stack[kSmall + 4];
     uint32_t ltab[kSmall], rtab[kSmall];
@@ -228,13 +230,14 @@ struct WaveLds {
     uint32_t axis_bin[3];
 };
 
-template <typename T>
+template <typename T, int NB = kBins>
 __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) {
-    __shared__ WaveLds<T> lds_all[4];
+    constexpr int kBins = NB;
+    __shared__ WaveLds<T, NB> lds_all[4];
     const int lane = threadIdx.x & 63;
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_small) return;
-    WaveLds<T>& L = lds_all[threadIdx.x >> 6];
+    WaveLds<T, NB>& L = lds_all[threadIdx.x >> 6];
     const uint32_t node_id = c.small_list[w];
     ANode<T>& A = c.nodes[node_id];
     const uint32_t B = A.begin, s = A.end - A.begin;
@@ -269,14 +272,14 @@ __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) 
             // ---- fill_bins
             const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
             for (int q = lane; q < 3 * kBins * 3; q += 64) { (&L.lo[0][0][0])[q] = lo0; (&L.hi[0][0][0])[q] = hi0; }
-            if (lane < 3 * kBins) (&L.cnt[0][0])[lane] = 0;
+            for (int q = lane; q < 3 * kBins; q += 64) (&L.cnt[0][0])[q] = 0;
             wave_sync();
             if (in) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const T scale = T(kBins) / (nhi[k] - nlo[k]);
                     const T shift = (-nlo[k]) * scale;
-                    const uint32_t b = bin_of(Ord<T>::fma_(ctr[k], scale, shift));
+                    const uint32_t b = bin_of_n<NB>(Ord<T>::fma_(ctr[k], scale, shift));
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { atomicMin(&L.lo[k][b][j], Ord<T>::enc(blo[j])); atomicMax(&L.hi[k][b][j], Ord<T>::enc(bhi[j])); }
                     atomicAdd(&L.cnt[k][b], 1u);
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(256) k_small(BuildCtx<T> c, uint32_t n_small) 
             if (lane < c.dim) {
                 T cost; uint32_t bin;
                 const int k = lane;
-                sweep_axis<T>([&](int i, T* lo, T* hi, uint32_t& n) {
+                sweep_axis_n<T, NB>([&](int i, T* lo, T* hi, uint32_t& n) {
                     for (int j = 0; j < 3; ++j) { lo[j] = Ord<T>::dec(L.lo[k][i][j]); hi[j] = Ord<T>::dec(L.hi[k][i][j]); }
                     n = L.cnt[k][i];
                 }, cost, bin, c.dim, c.sah_log);
@@ -1180,7 +1183,7 @@ struct BinnedWs {
     DevBuf<Counters> counters;
 
     // capacities: typical on the first attempt, worst case (degenerate chains of big nodes) on retry
-    int alloc(BuildCtx<T>& c, uint32_t n, uint32_t roots, int attempt, bool own_ids) {
+    int alloc(BuildCtx<T>& c, uint32_t n, uint32_t roots, int attempt, bool own_ids, int nb = kBins) {
         const uint32_t node_cap = (attempt == 0 ? n / 8 + 1024 : 2 * n + 2) + roots;
         const uint32_t slot_cap = n / (kSmall + 1) + 2;
         const uint32_t task_cap = n / kChunk + slot_cap + 2;
@@ -1188,13 +1191,14 @@ struct BinnedWs {
         auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
         if (own_ids) A(ids.alloc(n));
         A(chunk_true.alloc(task_cap)); A(ltab.alloc(n)); A(rtab.alloc(n)); A(small_list.alloc(node_cap));
-        A(nodes.alloc(node_cap)); A(bins.alloc(slot_cap)); A(st_a.alloc(slot_cap)); A(st_b.alloc(slot_cap));
+        // (a slot's bins hold 3 * nb boxes + counts: a BinCount other than the default takes proportionally more of the default-sized records)
+        A(nodes.alloc(node_cap)); A(bins.alloc((size_t{slot_cap} * static_cast<size_t>(nb) + kBins - 1) / kBins)); A(st_a.alloc(slot_cap)); A(st_b.alloc(slot_cap));
         A(tk_a.alloc(task_cap)); A(tk_b.alloc(task_cap)); A(stage.alloc(2 * size_t{n})); A(counters.alloc(1));
         // segments of 65 .. medium_cap primitives go to k_medium — on the first attempt only: a retry (capacity exceeded, or a segment
         // whose lopsided splits outgrow k_medium's local tables) takes the plain Phase A path
         static const bool medium_off = BVH_DEV_INT("BVH_AMD_MEDIUM", 1) == 0;   // A/B runs
         const uint32_t medium_slots = n / (kSmall + 1) + roots + 2;
-        c.medium_cap = attempt == 0 && !medium_off ? medium_cap<T>() : 0u;
+        c.medium_cap = attempt == 0 && !medium_off && nb == kBins ? medium_cap<T>() : 0u;   // (k_medium is written for the default BinCount)
         c.medium_slots = medium_slots;
         // segments are listed by size class; run_binned_phases decides which kernel serves which list
         c.medium_min_class = 0;
@@ -1212,9 +1216,11 @@ struct BinnedWs {
 };
 
 // Phase A levels + Phase B. Expects the roots already registered (state_next / tasks_next / counters) and `h` read back.
+// nb: BinnedSahBuilder's BinCount (binned_sah_builder.h:18). 8 = the reference's default and the tuned path (k_medium, level-synchronous
+// Phase B); 4 / 16 / 32 run the same Phase A levels with their own fill_bins / decision kernels and the node-by-node Phase B.
 template <typename T>
 int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_start, bool& overflow, hipStream_t stream,
-                      const std::function<int(PhaseB*)>* roots_final = nullptr) {
+                      const std::function<int(PhaseB*)>* roots_final = nullptr, int nb = kBins) {
     uint32_t n_active = h.n_active_next, n_tasks = h.n_tasks_next;
     overflow = h.error != 0;
     while (n_active > 0 && !overflow) {
@@ -1222,9 +1228,17 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
         std::swap(c.tasks, c.tasks_next);
         BVH_HIP_TRY(hipMemsetAsync(&c.counters->n_active_next, 0, 3 * sizeof(uint32_t), stream), BVH_AMD_ERR_HIP);
         const unsigned slot_grid = (n_active + 63) / 64;
-        hipLaunchKernelGGL(k_init_slots<T>, dim3(n_active), dim3(64), 0, stream, c);
-        hipLaunchKernelGGL(k_bin<T>, dim3(n_tasks), dim3(256), 0, stream, c);
-        hipLaunchKernelGGL(k_decide<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
+        switch (nb) {
+#define BVH_BINNED_LEVEL(NB)                                                                                 \
+        case NB:                                                                                             \
+            hipLaunchKernelGGL((k_init_slots<T, NB>), dim3(n_active), dim3(64), 0, stream, c);               \
+            hipLaunchKernelGGL((k_bin<T, NB>), dim3(n_tasks), dim3(256), 0, stream, c);                      \
+            hipLaunchKernelGGL((k_decide<T, NB>), dim3(slot_grid), dim3(64), 0, stream, c, n_active);        \
+            break;
+        BVH_BINNED_LEVEL(4) BVH_BINNED_LEVEL(8) BVH_BINNED_LEVEL(16) BVH_BINNED_LEVEL(32)
+#undef BVH_BINNED_LEVEL
+        default: return fail(BVH_AMD_ERR_UNSUPPORTED, "build: BinCount must be 4, 8, 16 or 32");
+        }
         hipLaunchKernelGGL(k_count<T>, dim3(n_tasks), dim3(256), 0, stream, c);
         hipLaunchKernelGGL(k_scatter<T>, dim3(n_tasks), dim3(256), 0, stream, c);
         hipLaunchKernelGGL(k_fallback<T>, dim3(slot_grid), dim3(64), 0, stream, c, n_active);
@@ -1299,7 +1313,10 @@ int run_binned_phases(BuildCtx<T>& c, Counters& h, std::vector<uint32_t>& level_
         static const bool dfs = BVH_DEV_IS("BVH_AMD_SMALL", "dfs");   // the node-by-node walk (A/B runs)
         hipStream_t on = lane.stream ? lane.stream : stream;
         if (lane.stream) BVH_HIP_TRY(hipStreamWaitEvent(lane.stream, lane.start, 0), BVH_AMD_ERR_HIP);
-        if (dfs) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, on, c, h.n_small);
+        if (nb == 4) hipLaunchKernelGGL((k_small<T, 4>), dim3((h.n_small + 3) / 4), dim3(256), 0, on, c, h.n_small);
+        else if (nb == 16) hipLaunchKernelGGL((k_small<T, 16>), dim3((h.n_small + 3) / 4), dim3(256), 0, on, c, h.n_small);
+        else if (nb == 32) hipLaunchKernelGGL((k_small<T, 32>), dim3((h.n_small + 3) / 4), dim3(256), 0, on, c, h.n_small);
+        else if (dfs) hipLaunchKernelGGL(k_small<T>, dim3((h.n_small + 3) / 4), dim3(256), 0, on, c, h.n_small);
         else hipLaunchKernelGGL(k_small_levels<T>, dim3((h.n_small + 1) / 2), dim3(128), 0, on, c, h.n_small);
         if (lane.stream) {
             BVH_HIP_TRY(hipEventRecord(lane.done, lane.stream), BVH_AMD_ERR_HIP);
@@ -1390,6 +1407,8 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
                         hipStream_t stream)
 {
     if (n >= (size_t{1} << 28)) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: more than 2^28 primitives");
+    const int nb = static_cast<int>(ambient_sah().bin_count);  // BinnedSahBuilder<Node, BinCount>: 8 unless bvhXX_build_device_binned says otherwise
+    if (nb != 4 && nb != 8 && nb != 16 && nb != 32) return fail(BVH_AMD_ERR_UNSUPPORTED, "build: BinCount must be 4, 8, 16 or 32");
     BVH_HIP_TRY(hipGetDevice(&out.device), BVH_AMD_ERR_HIP);
     for (int attempt = 0; attempt < 2; ++attempt) {
         BinnedWs<T> ws;
@@ -1399,7 +1418,7 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
         c.min_leaf = static_cast<uint32_t>(cfg.min_leaf_size); c.max_leaf = static_cast<uint32_t>(cfg.max_leaf_size);
         c.dim = out.dim;
         c.sah_log = ambient_sah().log_cluster; c.sah_ratio = static_cast<T>(ambient_sah().cost_ratio);
-        int rc = ws.alloc(c, static_cast<uint32_t>(n), 1, attempt, true);
+        int rc = ws.alloc(c, static_cast<uint32_t>(n), 1, attempt, true, nb);
         if (rc) return rc;
         hipLaunchKernelGGL(k_prepare_root<T>, dim3(1), dim3(1), 0, stream, c);
         const unsigned root_grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 2048));
@@ -1409,7 +1428,7 @@ int build_binned_device(BvhImpl<T>& out, const T* d_bboxes, const T* d_centers, 
         { int rb_ = readback(&h, c.counters, sizeof(h), stream); if (rb_) return rb_; }
         std::vector<uint32_t> level_start{0, 1};              // A-node id ranges per level
         bool overflow = false;
-        rc = run_binned_phases(c, h, level_start, overflow, stream);
+        rc = run_binned_phases(c, h, level_start, overflow, stream, nullptr, nb);
         if (rc) return rc;
         if (overflow) {
             if (attempt == 0) continue;

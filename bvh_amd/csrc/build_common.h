@@ -90,10 +90,11 @@ template <typename T> __device__ inline int widest_axis(const T* lo, const T* hi
     return axis;
 }
 // min(BinCount - 1, size_t(max(pos, 0)))  (binned_sah_builder.h:94-95); NaN -> 0, +inf saturates to 7.
-template <typename T> __device__ inline uint32_t bin_of(T pos) {
+template <int NB, typename T> __device__ inline uint32_t bin_of_n(T pos) {
     T v = pick_max(pos, T(0));
-    return v >= T(kBins - 1) ? uint32_t(kBins - 1) : static_cast<uint32_t>(v);
+    return v >= T(NB - 1) ? uint32_t(NB - 1) : static_cast<uint32_t>(v);
 }
+template <typename T> __device__ inline uint32_t bin_of(T pos) { return bin_of_n<kBins>(pos); }
 
 // ---- data structures ---------------------------------------------------------------------------------
 template <typename T>
@@ -108,11 +109,13 @@ struct ANode {                           // Phase A tree node (BFS allocation or
     uint32_t tree;                       // which tree of a forest build (mini-trees); 0 for single-tree builds
 };
 
-template <typename T>
-struct SlotBins {                        // 3 axes x 8 bins of {box, count}
-    typename Ord<T>::U lo[3][kBins][3];
-    typename Ord<T>::U hi[3][kBins][3];
-    uint32_t cnt[3][kBins];
+// BinCount (binned_sah_builder.h:18) is a template parameter of the reference's builder: NB = 8 is its default and what DefaultBuilder
+// and the mini-tree builder instantiate; 4 / 16 / 32 are served by the plain Phase A + node-by-node Phase B kernels (build_binned.hip).
+template <typename T, int NB = kBins>
+struct SlotBins {                        // 3 axes x NB bins of {box, count}
+    typename Ord<T>::U lo[3][NB][3];
+    typename Ord<T>::U hi[3][NB][3];
+    uint32_t cnt[3][NB];
 };
 
 template <typename T>
@@ -246,8 +249,9 @@ __device__ void partial_sort_replay(uint32_t* a, long middle, long last, KeyFn k
 // ---- SAH candidate sweep over one axis (binned_sah_builder.h:101-116) -----------------------------------
 // Starts from (FLT_MAX, -) and reports the first strict minimum; combining axes 0,1,2 with strict `<`
 // afterwards equals the reference's carried `best_split`.
-template <typename T, typename LoadBin>
-__device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin, int dim, uint32_t sah_log) {
+template <typename T, int NB, typename LoadBin>
+__device__ inline void sweep_axis_n(LoadBin load, T& best_cost, uint32_t& best_bin, int dim, uint32_t sah_log) {
+    constexpr int kBins = NB;            // (shadows the default: BinCount of this instantiation)
     T right_cost[kBins];
     {
         T lo[3] = { Ord<T>::kMax, Ord<T>::kMax, Ord<T>::kMax }, hi[3] = { -Ord<T>::kMax, -Ord<T>::kMax, -Ord<T>::kMax };
@@ -276,6 +280,11 @@ __device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin
         T cost = half_area(lo, hi, dim) * sah_prims<T>(cnt, sah_log) + right_cost[i + 1];
         if (cost < best_cost) { best_cost = cost; best_bin = i + 1; }
     }
+}
+
+template <typename T, typename LoadBin>
+__device__ inline void sweep_axis(LoadBin load, T& best_cost, uint32_t& best_bin, int dim, uint32_t sah_log) {
+    sweep_axis_n<T, kBins>(load, best_cost, best_bin, dim, sah_log);
 }
 
 template <typename T>
@@ -507,14 +516,14 @@ __global__ void k_make_root(BuildCtx<T> c) {
 }
 
 // One block per active slot: reset its accumulators.
-template <typename T>
+template <typename T, int NB = kBins>
 __global__ void __launch_bounds__(64) k_init_slots(BuildCtx<T> c) {
     const uint32_t slot = blockIdx.x;
     const auto lo0 = Ord<T>::enc(Ord<T>::kMax), hi0 = Ord<T>::enc(-Ord<T>::kMax);
     if (c.bins) {
-        SlotBins<T>& b = c.bins[slot];
-        for (int w = threadIdx.x; w < 3 * kBins * 3; w += 64) { (&b.lo[0][0][0])[w] = lo0; (&b.hi[0][0][0])[w] = hi0; }
-        for (int w = threadIdx.x; w < 3 * kBins; w += 64) (&b.cnt[0][0])[w] = 0;
+        SlotBins<T, NB>& b = reinterpret_cast<SlotBins<T, NB>*>(c.bins)[slot];
+        for (int w = threadIdx.x; w < 3 * NB * 3; w += 64) { (&b.lo[0][0][0])[w] = lo0; (&b.hi[0][0][0])[w] = hi0; }
+        for (int w = threadIdx.x; w < 3 * NB; w += 64) (&b.cnt[0][0])[w] = 0;
     }
     SlotState<T>& st = c.state[slot];
     if (threadIdx.x < 6) {

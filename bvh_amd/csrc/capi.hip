@@ -63,6 +63,16 @@ auto with_sah(const bvh_amd_sah_config* sah, Build&& build) -> decltype(build())
     return build();
 }
 
+// BinnedSahBuilder<Node, BinCount>::build (binned_sah_builder.h:18, :32-38) with a BinCount other than the reference's default
+template <typename Build>
+auto with_bins(const bvh_amd_sah_config* sah, size_t bin_count, Build&& build) -> decltype(build()) {
+    if (bin_count != 4 && bin_count != 8 && bin_count != 16 && bin_count != 32) {
+        set_error("build: bin_count must be 4, 8, 16 or 32 (BinnedSahBuilder's BinCount, binned_sah_builder.h:18)");
+        return nullptr;
+    }
+    return with_sah(sah, [&] { ambient_sah().bin_count = static_cast<uint32_t>(bin_count); return build(); });
+}
+
 template <typename T>
 typename CTypes<T>::Bvh* build_device(const T* d_bboxes, const T* d_centers, size_t n, const bvh_build_config* config,
                                       bvh_amd_builder builder, void* stream)
@@ -595,6 +605,9 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
     bvh##S* bvh##S##_build_device_sah(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,          \
                                       enum bvh_amd_builder builder, const bvh_amd_sah_config* sah, void* stream) {  \
         return with_sah(sah, [&] { return build_device<T>(d_bb, d_cc, n, cfg, builder, stream); }); }               \
+    bvh##S* bvh##S##_build_device_binned(const T* d_bb, const T* d_cc, size_t n, const bvh_build_config* cfg,       \
+                                         const bvh_amd_sah_config* sah, size_t bin_count, void* stream) {           \
+        return with_bins(sah, bin_count, [&] { return build_device<T>(d_bb, d_cc, n, cfg, BVH_AMD_BUILDER_BINNED, stream); }); } \
     bvh##S* bvh##S##_build_minitree_device(const T* d_bb, const T* d_cc, size_t n, const bvh_amd_minitree_config* cfg, void* stream) { \
         return build_minitree<T>(d_bb, d_cc, n, cfg, stream); }                                                     \
     bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return handle<T>(extract<T>(impl<T>(b), root_id)); }      \
@@ -694,6 +707,9 @@ BVH_AMD_IMPL_RAY(double, 3d, bvh_intersect_callbackd, bvh_amd_ray_visitord, 3, i
     bvh##S* bvh##S##_build_device_sah(const T* d_bb4, const T* d_cc2, size_t n, const bvh_build_config* cfg,        \
                                       enum bvh_amd_builder builder, const bvh_amd_sah_config* sah, void* stream) {  \
         return with_sah(sah, [&] { return build2_device<T>(d_bb4, d_cc2, n, cfg, builder, stream); }); }            \
+    bvh##S* bvh##S##_build_device_binned(const T* d_bb4, const T* d_cc2, size_t n, const bvh_build_config* cfg,     \
+                                         const bvh_amd_sah_config* sah, size_t bin_count, void* stream) {           \
+        return with_bins(sah, bin_count, [&] { return build2_device<T>(d_bb4, d_cc2, n, cfg, BVH_AMD_BUILDER_BINNED, stream); }); } \
     bvh##S* bvh##S##_extract(bvh##S* b, size_t root_id) { return handle2<T>(extract<T>(impl2<T>(b), root_id)); }    \
     bvh##S* bvh##S##_from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) {                       \
         return from_nodes2<T>(nodes, nn, ids, np); }                                                                \

@@ -175,7 +175,9 @@ inline bool dev_env_is_(const char* name, const char* value) { const char* v = s
 // The SplitHeuristic (reference split_heuristic.h:17-23) of the build in progress on the calling thread. The reference's C
 // struct bvh_build_config has no room for it, so the C-ABI entry points that accept one (bvh_amd_sah_config) set it for the
 // duration of the call and the builders read it where they fill their kernel arguments; the default is the reference's {0, 1}.
-struct SahParams { uint32_t log_cluster = 0; double cost_ratio = 1.0; };
+// bin_count: BinnedSahBuilder's BinCount template argument (binned_sah_builder.h:18), read by the explicit binned builder only — the
+// mini-tree builder and DefaultBuilder instantiate the default (mini_tree_builder.h:129, default_builder.h:52) and keep 8.
+struct SahParams { uint32_t log_cluster = 0; double cost_ratio = 1.0; uint32_t bin_count = 8; };
 SahParams& ambient_sah();                     // build_device.hip
 struct SahScope {
     SahParams saved;

@@ -140,8 +140,12 @@ struct Ray {
 // ---- index.h / node.h -------------------------------------------------------------------------------------------------
 template <size_t Bits, size_t PrimCountBits>
 struct Index {
+    static_assert(Bits == 32 || Bits == 64, "bvh_amd: Index of 32 or 64 bits (the reference's UnsignedIntType also knows 8 and 16)");
+    static_assert(PrimCountBits >= 1 && PrimCountBits < Bits, "index.h:41");
     using Type = std::conditional_t<Bits == 32, uint32_t, uint64_t>;
+    static constexpr size_t bits = Bits, prim_count_bits = PrimCountBits, first_id_bits = Bits - PrimCountBits;   // index.h:36-37
     static constexpr Type max_prim_count = (Type{1} << PrimCountBits) - 1;
+    static constexpr Type max_first_id = static_cast<Type>(~Type{0}) >> PrimCountBits;                            // index.h:39
     Type value;
     Index() = default;
     explicit Index(Type v) : value(v) {}
@@ -150,6 +154,8 @@ struct Index {
     Type prim_count() const { return value & max_prim_count; }
     bool is_leaf() const { return prim_count() != 0; }
     bool is_inner() const { return !is_leaf(); }
+    void set_first_id(size_t first) { *this = prim_count() ? make_leaf(first, prim_count()) : make_inner(first); }      // index.h:55-57
+    void set_prim_count(size_t count) { value = (value & ~max_prim_count) | (static_cast<Type>(count) & max_prim_count); }  // index.h:59-61
     static Index make_leaf(size_t first, size_t count) { return Index((static_cast<Type>(first) << PrimCountBits) | static_cast<Type>(count)); }
     static Index make_inner(size_t first) { return Index(static_cast<Type>(first) << PrimCountBits); }
 };
@@ -289,6 +295,7 @@ template <> struct Api<float, 3> {
     static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh3f_build_device(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, b, nullptr); }
     static Handle* build_sah(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h) { return bvh3f_build_sah(p, static_cast<const bvh_bbox3f*>(bb), static_cast<const bvh_vec3f*>(cc), n, c, h); }
     static Handle* build_device_sah(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b, const bvh_amd_sah_config* h) { return bvh3f_build_device_sah(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, b, h, nullptr); }
+    static Handle* build_device_binned(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h, size_t bins) { return bvh3f_build_device_binned(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, h, bins, nullptr); }
     static Handle* build_minitree(const void* d_bb, const void* d_cc, size_t n, const bvh_amd_minitree_config* c) { return bvh3f_build_minitree_device(static_cast<const float*>(d_bb), static_cast<const float*>(d_cc), n, c, nullptr); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3f_from_nodes(nodes, nn, ids, np); }
     static void destroy(Handle* h) { bvh3f_destroy(h); }
@@ -317,6 +324,7 @@ template <> struct Api<double, 3> {
     static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh3d_build_device(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, b, nullptr); }
     static Handle* build_sah(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h) { return bvh3d_build_sah(p, static_cast<const bvh_bbox3d*>(bb), static_cast<const bvh_vec3d*>(cc), n, c, h); }
     static Handle* build_device_sah(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b, const bvh_amd_sah_config* h) { return bvh3d_build_device_sah(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, b, h, nullptr); }
+    static Handle* build_device_binned(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h, size_t bins) { return bvh3d_build_device_binned(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, h, bins, nullptr); }
     static Handle* build_minitree(const void* d_bb, const void* d_cc, size_t n, const bvh_amd_minitree_config* c) { return bvh3d_build_minitree_device(static_cast<const double*>(d_bb), static_cast<const double*>(d_cc), n, c, nullptr); }
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh3d_from_nodes(nodes, nn, ids, np); }
     static void destroy(Handle* h) { bvh3d_destroy(h); }
@@ -348,6 +356,7 @@ template <> struct Api<T, 2> {                                                  
     static Handle* build_device(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b) { return bvh##S##_build_device(static_cast<const T*>(d_bb), static_cast<const T*>(d_cc), n, c, b, nullptr); } \
     static Handle* build_sah(bvh_thread_pool* p, const void* bb, const void* cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h) { return bvh##S##_build_sah(p, static_cast<const bvh_bbox##S*>(bb), static_cast<const bvh_vec##S*>(cc), n, c, h); } \
     static Handle* build_device_sah(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, bvh_amd_builder b, const bvh_amd_sah_config* h) { return bvh##S##_build_device_sah(static_cast<const T*>(d_bb), static_cast<const T*>(d_cc), n, c, b, h, nullptr); } \
+    static Handle* build_device_binned(const void* d_bb, const void* d_cc, size_t n, const bvh_build_config* c, const bvh_amd_sah_config* h, size_t bins) { return bvh##S##_build_device_binned(static_cast<const T*>(d_bb), static_cast<const T*>(d_cc), n, c, h, bins, nullptr); } \
     static Handle* from_nodes(const void* nodes, size_t nn, const size_t* ids, size_t np) { return bvh##S##_from_nodes(nodes, nn, ids, np); } \
     static void destroy(Handle* h) { bvh##S##_destroy(h); }                                                                               \
     static size_t node_count(const Handle* h) { return bvh##S##_get_node_count(h); }                                                      \
@@ -461,7 +470,10 @@ struct Bvh {
         } visit{ this, &ray, &leaf_fn, &inner_fn };
         const unsigned flags = (IsAnyHit ? unsigned(BVH_AMD_RAY_ANY_HIT) : 0u) | (IsRobust ? unsigned(BVH_AMD_RAY_ROBUST) : 0u);
         constexpr bool wants_inner = !std::is_same_v<std::remove_cvref_t<InnerFn>, IgnoreArgs>;
-        amd::check(amd::Api<Scalar, Node::dimension>::visit(device(), &ray, static_cast<size_t>(start.value), flags, &visit, &Visit::on_leaf,
+        // (the device twin keeps the default Index packing whatever this Node's: the start index is handed over in that form)
+        using DeviceIndex = typename bvh::v2::Node<Scalar, Node::dimension>::Index;
+        const auto dev_start = start.is_leaf() ? DeviceIndex::make_leaf(start.first_id(), start.prim_count()) : DeviceIndex::make_inner(start.first_id());
+        amd::check(amd::Api<Scalar, Node::dimension>::visit(device(), &ray, static_cast<size_t>(dev_start.value), flags, &visit, &Visit::on_leaf,
                                                             wants_inner ? &Visit::on_inner : nullptr), "intersect_ray_visit");
     }
 
@@ -550,15 +562,47 @@ struct Bvh {
 
 private:
     std::shared_ptr<typename amd::Api<Scalar, Node::dimension>::Handle> device_;
+    // The device twin always holds the reference's DEFAULT node (node.h:20-22: IndexBits = bits of the scalar, PrimCountBits = 4). A Node
+    // with other Index parameters (node.h:21-22, index.h:32-41) is the same tree with its index word packed differently: the mirror
+    // re-packs (first_id, prim_count) at this boundary and refuses, loudly, what the other side cannot represent.
+    using DeviceNode = bvh::v2::Node<Scalar, Node::dimension>;
+    static constexpr bool device_layout = std::is_same_v<Node, DeviceNode>;
     void push() {                                             // host mirror -> device
-        auto* h = amd::Api<Scalar, Node::dimension>::from_nodes(nodes.data(), nodes.size(), prim_ids.data(), prim_ids.size());
+        const void* src = nodes.data();
+        std::vector<DeviceNode> packed;
+        if constexpr (!device_layout) {
+            packed.resize(nodes.size());
+            for (size_t i = 0; i < nodes.size(); ++i) {
+                const auto first = static_cast<uint64_t>(nodes[i].index.first_id()), count = static_cast<uint64_t>(nodes[i].index.prim_count());
+                if (count > static_cast<uint64_t>(DeviceNode::Index::max_prim_count) || first > static_cast<uint64_t>(DeviceNode::Index::max_first_id))
+                    throw amd::Error("bvh_amd: a node of this Bvh does not fit the device node (4-bit primitive count, first_id in the remaining bits)");
+                packed[i].bounds = nodes[i].bounds;
+                packed[i].index = count ? DeviceNode::Index::make_leaf(first, count) : DeviceNode::Index::make_inner(first);
+            }
+            src = packed.data();
+        }
+        auto* h = amd::Api<Scalar, Node::dimension>::from_nodes(src, nodes.size(), prim_ids.data(), prim_ids.size());
         if (!h) throw amd::Error(bvh_amd_last_error());
         device_ = std::shared_ptr<typename amd::Api<Scalar, Node::dimension>::Handle>(h, [](auto* p) { amd::Api<Scalar, Node::dimension>::destroy(p); });
     }
     void pull() {                                             // device -> host mirror
         nodes.resize(amd::Api<Scalar, Node::dimension>::node_count(device_.get()));
         prim_ids.resize(amd::Api<Scalar, Node::dimension>::prim_count(device_.get()));
-        amd::Api<Scalar, Node::dimension>::copy_nodes(device_.get(), nodes.data());
+        if constexpr (device_layout) {
+            amd::Api<Scalar, Node::dimension>::copy_nodes(device_.get(), nodes.data());
+        } else {
+            std::vector<DeviceNode> packed(nodes.size());
+            amd::Api<Scalar, Node::dimension>::copy_nodes(device_.get(), packed.data());
+            constexpr uint64_t first_limit = static_cast<uint64_t>(Index::max_first_id);
+            for (size_t i = 0; i < nodes.size(); ++i) {
+                const auto first = static_cast<uint64_t>(packed[i].index.first_id()), count = static_cast<uint64_t>(packed[i].index.prim_count());
+                if (count > static_cast<uint64_t>(Index::max_prim_count) || first > first_limit)
+                    throw amd::Error("bvh_amd: the built tree does not fit this Node's Index (index.h:38-41: PrimCountBits / first_id bits); "
+                                     "lower Config::max_leaf_size or widen the Index");
+                nodes[i].bounds = packed[i].bounds;
+                nodes[i].index = count ? Index::make_leaf(first, count) : Index::make_inner(first);
+            }
+        }
         amd::Api<Scalar, Node::dimension>::copy_prim_ids(device_.get(), prim_ids.data());
     }
     template <typename N> friend class ReinsertionOptimizer;
@@ -594,7 +638,7 @@ public:
         size_t max_leaf_size = 8;
     };
 protected:
-    static Bvh<Node> run(bvh_amd_builder which, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config) {
+    static Bvh<Node> run(bvh_amd_builder which, std::span<const BBox> bboxes, std::span<const Vec> centers, const Config& config, size_t bin_count = 8) {
         if (bboxes.size() != centers.size()) throw amd::Error("bvh_amd: bboxes and centers differ in length");
         bvh_build_config c;
         c.quality = BVH_BUILD_QUALITY_HIGH;                   // (unused by the explicit builders)
@@ -602,7 +646,9 @@ protected:
         const bvh_amd_sah_config sah = config.sah.c_config();
         amd::DeviceArray<BBox> d_bb(bboxes);
         amd::DeviceArray<Vec> d_cc(centers);
-        auto* h = amd::Api<Scalar, Node::dimension>::build_device_sah(d_bb.data(), d_cc.data(), bboxes.size(), &c, which, &sah);
+        auto* h = which == BVH_AMD_BUILDER_BINNED && bin_count != 8
+            ? amd::Api<Scalar, Node::dimension>::build_device_binned(d_bb.data(), d_cc.data(), bboxes.size(), &c, &sah, bin_count)
+            : amd::Api<Scalar, Node::dimension>::build_device_sah(d_bb.data(), d_cc.data(), bboxes.size(), &c, which, &sah);
         if (!h) throw amd::Error(bvh_amd_last_error());
         Bvh<Node> bvh;
         bvh.adopt(h);
@@ -612,12 +658,14 @@ protected:
 
 template <typename Node, size_t BinCount = 8>
 class BinnedSahBuilder : public TopDownSahBuilder<Node> {     // reference binned_sah_builder.h:18-38
-    static_assert(BinCount == 8, "bvh_amd: the device binned builder is written for the reference's default of 8 bins per axis");
+    // BinCount (reference binned_sah_builder.h:18): the default 8 runs the tuned device path; 4, 16 and 32 run the same builder with
+    // their own fill_bins / find_best_split instantiations (bvhXX_build_device_binned), bit-identical to the reference's template
+    static_assert(BinCount == 4 || BinCount == 8 || BinCount == 16 || BinCount == 32, "bvh_amd: BinnedSahBuilder is instantiated for BinCount 4, 8, 16 and 32");
     using Base = TopDownSahBuilder<Node>;
 public:
     using typename Base::Config;
     [[nodiscard]] static Bvh<Node> build(std::span<const typename Base::BBox> bboxes, std::span<const typename Base::Vec> centers, const Config& config = {}) {
-        return Base::run(BVH_AMD_BUILDER_BINNED, bboxes, centers, config);
+        return Base::run(BVH_AMD_BUILDER_BINNED, bboxes, centers, config, BinCount);
     }
 };
 

@@ -262,6 +262,15 @@ BVH_AMD_API struct bvh3f* bvh3f_build_device_sah(const float* d_bboxes, const fl
 BVH_AMD_API struct bvh3d* bvh3d_build_device_sah(const double* d_bboxes, const double* d_centers, size_t prim_count,
     const struct bvh_build_config* config, enum bvh_amd_builder builder, const struct bvh_amd_sah_config* sah, void* stream);
 
+/* Additive: BinnedSahBuilder<Node, BinCount>::build (src/bvh/v2/binned_sah_builder.h:18, :32-38) with its BinCount template argument
+ * as a run-time value: 4, 8 (the reference's default, = bvhXX_build_device_sah with BVH_AMD_BUILDER_BINNED), 16 or 32 bins per axis.
+ * Same inputs as bvhXX_build_device_sah; NULL for anything else (bvh_amd_last_error). DefaultBuilder and MiniTreeBuilder always
+ * instantiate the default (default_builder.h:52, mini_tree_builder.h:129), so only a direct user of BinnedSahBuilder has this knob. */
+BVH_AMD_API struct bvh3f* bvh3f_build_device_binned(const float* d_bboxes, const float* d_centers, size_t prim_count,
+    const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah, size_t bin_count, void* stream);
+BVH_AMD_API struct bvh3d* bvh3d_build_device_binned(const double* d_bboxes, const double* d_centers, size_t prim_count,
+    const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah, size_t bin_count, void* stream);
+
 /* Additive: MiniTreeBuilder::build(pool, bboxes, centers, config) itself (src/bvh/v2/mini_tree_builder.h:29-58) with its own
  * configuration; DefaultBuilder(pool)'s three qualities are three settings of it (default_builder.h:65-73). log2_grid_dim
  * may be 1..10 (three coordinates in the reference's 32-bit Morton code, mini_tree_builder.h:169); the cell histogram takes
@@ -523,6 +532,8 @@ BVH_AMD_API struct bvh2f* bvh2f_build_sah(struct bvh_thread_pool*, const struct 
     size_t prim_count, const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah);
 BVH_AMD_API struct bvh2f* bvh2f_build_device_sah(const float* d_bboxes4, const float* d_centers2, size_t prim_count,
     const struct bvh_build_config* config, enum bvh_amd_builder builder, const struct bvh_amd_sah_config* sah, void* stream);
+BVH_AMD_API struct bvh2f* bvh2f_build_device_binned(const float* d_bboxes4, const float* d_centers2, size_t prim_count,
+    const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah, size_t bin_count, void* stream);
 BVH_AMD_API struct bvh2f* bvh2f_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
 BVH_AMD_API struct bvh2f* bvh2f_extract(struct bvh2f* bvh, size_t root_id);
 BVH_AMD_API void bvh2f_destroy(struct bvh2f*);
@@ -567,6 +578,8 @@ BVH_AMD_API struct bvh2d* bvh2d_build_sah(struct bvh_thread_pool*, const struct 
     size_t prim_count, const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah);
 BVH_AMD_API struct bvh2d* bvh2d_build_device_sah(const double* d_bboxes4, const double* d_centers2, size_t prim_count,
     const struct bvh_build_config* config, enum bvh_amd_builder builder, const struct bvh_amd_sah_config* sah, void* stream);
+BVH_AMD_API struct bvh2d* bvh2d_build_device_binned(const double* d_bboxes4, const double* d_centers2, size_t prim_count,
+    const struct bvh_build_config* config, const struct bvh_amd_sah_config* sah, size_t bin_count, void* stream);
 BVH_AMD_API struct bvh2d* bvh2d_from_nodes(const void* nodes, size_t node_count, const size_t* prim_ids, size_t prim_count);
 BVH_AMD_API struct bvh2d* bvh2d_extract(struct bvh2d* bvh, size_t root_id);
 BVH_AMD_API void bvh2d_destroy(struct bvh2d*);

@@ -156,6 +156,13 @@ class CpuLib:
         f.restype, f.argtypes = None, [C.c_size_t, C.c_double]
         f(log_cluster_size, cost_ratio)
 
+    def set_bin_count(self, bin_count: int = 8):
+        """BinnedSahBuilder<Node, BinCount> (binned_sah_builder.h:18) for the BUILDER_BINNED builds that follow; () restores the default."""
+        f = getattr(self.dll, f"{self.prefix}_set_bin_count")
+        f.restype, f.argtypes = C.c_int, [C.c_size_t]
+        if f(bin_count) != 0:
+            raise ValueError(f"bin_count {bin_count} is not available in this checker")
+
     def hardware_threads(self) -> int:
         return int(getattr(self.dll, f"{self.prefix}_hardware_threads")())
 

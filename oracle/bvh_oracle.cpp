@@ -53,7 +53,9 @@ static int g_dim = 3;
 struct DimScope { int saved; explicit DimScope(int d) : saved(g_dim) { g_dim = d; } ~DimScope() { g_dim = saved; } };
 
 constexpr unsigned kCountBits = 4;       // node.h:22 PrimCountBits
-constexpr size_t   kBins = 8;            // binned_sah_builder.h:19 BinCount
+constexpr size_t   kBins = 8;            // binned_sah_builder.h:19 BinCount (the default; what DefaultBuilder / MiniTreeBuilder instantiate)
+constexpr size_t   kMaxBins = 32;        // largest BinCount the explicit binned builder is asked for (orc_set_bin_count)
+inline size_t      g_bin_count = kBins;  // BinnedSahBuilder<Node, BinCount>: the template argument of ORC_BUILDER_BINNED builds
 
 // utils.h:41-43: the *second* argument is returned when the first is NaN or when they compare equal.
 template <typename T> inline T pick_min(T a, T b) { return a < b ? a : b; }
@@ -194,8 +196,9 @@ struct BinnedSplitter {
     const T* centers;                                        // n x 3
     LeafLimits lim;
     std::vector<size_t> order;
+    size_t bins;                                             // BinCount (:18)
 
-    BinnedSplitter(const Box<T>* b, const T* c, size_t n, LeafLimits l) : boxes(b), centers(c), lim(l), order(n) {
+    BinnedSplitter(const Box<T>* b, const T* c, size_t n, LeafLimits l, size_t bin_count = kBins) : boxes(b), centers(c), lim(l), order(n), bins(bin_count) {
         std::iota(order.begin(), order.end(), size_t{0});    // :77
     }
     std::vector<size_t>& ids() { return order; }
@@ -210,7 +213,8 @@ struct BinnedSplitter {
     }
 
     bool try_split(const Box<T>& nb, size_t b, size_t e, size_t& cut) {    // :128-156
-        Slot slots[3][kBins];
+        const size_t kBins = bins;                           // (shadows the default)
+        Slot slots[3][kMaxBins];
         T scale[3], shift[3];
         for (int k = 0; k < g_dim; ++k) {                        // :88-89
             scale[k] = T(kBins) / (nb.hi[k] - nb.lo[k]);
@@ -229,7 +233,7 @@ struct BinnedSplitter {
         size_t best_bin = kBins / 2; T best_cost = std::numeric_limits<T>::max(); int best_axis = wide;   // :132-133
         for (int k = 0; k < g_dim; ++k) {                        // :101-116
             Slot acc;
-            T right_cost[kBins];
+            T right_cost[kMaxBins];
             for (size_t i = kBins - 1; i > 0; --i) {
                 acc.box.grow(slots[k][i].box); acc.count += slots[k][i].count;
                 right_cost[i] = acc.box.half_area() * lim.template prims<T>(acc.count);
@@ -257,8 +261,8 @@ struct BinnedSplitter {
 };
 
 template <typename T>
-Tree<T> build_binned(const Box<T>* boxes, const T* centers, size_t n, LeafLimits lim) {
-    BinnedSplitter<T> sp(boxes, centers, n, lim);
+Tree<T> build_binned(const Box<T>* boxes, const T* centers, size_t n, LeafLimits lim, size_t bin_count = kBins) {
+    BinnedSplitter<T> sp(boxes, centers, n, lim, bin_count);
     return build_top_down<T>(sp, boxes, n, lim);
 }
 
@@ -644,7 +648,7 @@ Tree<T> build_dispatch(const T* bboxes6, const T* centers, size_t n, int builder
         return t;
     };
     switch (builder) {
-    case ORC_BUILDER_BINNED: return build_binned<T>(boxes.data(), centers, n, lim);
+    case ORC_BUILDER_BINNED: return build_binned<T>(boxes.data(), centers, n, lim, g_bin_count);
     case ORC_BUILDER_SWEEP:  return build_sweep<T>(boxes.data(), centers, n, lim);
     case ORC_BUILDER_DEFAULT_PARALLEL: {                                               // :33-46
         if (n < par_threshold) return serial();
@@ -936,6 +940,12 @@ size_t serialize_tree(const Tree<T>& t, uint8_t* out, size_t cap) {
 
 extern "C" {
 
+// BinnedSahBuilder's BinCount (binned_sah_builder.h:18) for the ORC_BUILDER_BINNED builds that follow; 2 .. 32
+ORC_EXPORT int orc_set_bin_count(size_t bin_count) {
+    if (bin_count < 2 || bin_count > kMaxBins) return -1;
+    g_bin_count = bin_count;
+    return 0;
+}
 ORC_EXPORT void orc_set_sah(size_t log_cluster_size, double cost_ratio) {
     g_sah_log_cluster = log_cluster_size; g_sah_cost_ratio = cost_ratio;
 }

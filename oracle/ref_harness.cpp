@@ -50,6 +50,8 @@ template <typename T> using Bvh3 = Bvh<Node3<T>>;
 // the SplitHeuristic (split_heuristic.h:17-23) the following builds use; ref_set_sah() changes it (default {0, 1})
 static size_t g_sah_log_cluster = 0;
 static double g_sah_cost_ratio = 1.;
+// BinnedSahBuilder<Node, BinCount>'s template argument for the ORC_BUILDER_BINNED builds that follow (ref_set_bin_count; default 8)
+static size_t g_bin_count = 8;
 
 template <typename T, size_t D> using BvhN = Bvh<Node<T, D>>;   // D = 2: the `2f` / `2d` families of the C API (c_api/bvh.cpp:7-10)
 
@@ -87,7 +89,13 @@ BvhN<T, D>* build(const T* bboxes, const T* centers, size_t n, int builder, int 
         break;
     }
     case ORC_BUILDER_BINNED:
-        *out = BinnedSahBuilder<N>::build(bb, cc, cfg);
+        switch (g_bin_count) {                                // binned_sah_builder.h:18: BinCount is a template argument
+        case 4:  *out = BinnedSahBuilder<N, 4>::build(bb, cc, cfg); break;
+        case 8:  *out = BinnedSahBuilder<N>::build(bb, cc, cfg); break;
+        case 16: *out = BinnedSahBuilder<N, 16>::build(bb, cc, cfg); break;
+        case 32: *out = BinnedSahBuilder<N, 32>::build(bb, cc, cfg); break;
+        default: return nullptr;
+        }
         break;
     case ORC_BUILDER_SWEEP:
         *out = SweepSahBuilder<N>::build(bb, cc, cfg);
@@ -331,6 +339,23 @@ struct Dispatch;
         else     { if (robust) fn<T, false, true>(__VA_ARGS__); else fn<T, false, false>(__VA_ARGS__); } \
     } while (0)
 
+/* Node<float, 3, IndexBits, PrimCountBits> with Index parameters other than the defaults (node.h:21-22, index.h:32-41): the serialized
+ * stream of one build, for the golden fixture that pins how the C++ mirror re-packs its nodes (tests/golden/make_golden.py).
+ * variant 0: Node<float, 3, 32, 2>, SweepSahBuilder, max_leaf_size = max_leaf;  1: Node<float, 3, 64, 6>, DefaultBuilder serial High;
+ * 2: variant 1's extract_bvh(root.first_id). Returns the stream's size (written when it fits). */
+template <typename N, typename Build>
+size_t index_variant_stream(const float* bboxes, const float* centers, size_t n, Build&& build_fn, uint8_t* out, size_t cap) {
+    std::vector<BBox<float, 3>> bb(n);
+    std::vector<Vec<float, 3>> cc(n);
+    for (size_t i = 0; i < n; ++i) for (size_t k = 0; k < 3; ++k) {
+        bb[i].min[k] = bboxes[6 * i + k]; bb[i].max[k] = bboxes[6 * i + 3 + k]; cc[i][k] = centers[3 * i + k]; }
+    Bvh<N> bvh = build_fn(bb, cc);
+    VecStream s;
+    bvh.serialize(s);
+    if (out && cap >= s.bytes.size()) std::memcpy(out, s.bytes.data(), s.bytes.size());
+    return s.bytes.size();
+}
+
 } // namespace
 
 extern "C" {
@@ -342,6 +367,24 @@ extern "C" {
     } while (0)
 
 /* everything that exists for every dimension (D = 2: bboxes n x 4, centers n x 2, nodes 20/40 bytes, spheres n x 3, rays n x 6) */
+ORC_EXPORT size_t ref_index_variant_stream(const float* bboxes, const float* centers, size_t n, int variant, size_t max_leaf, uint8_t* out, size_t cap) {
+    if (variant == 0) {
+        using N = Node<float, 3, 32, 2>;
+        return index_variant_stream<N>(bboxes, centers, n, [&](auto& bb, auto& cc) {
+            typename SweepSahBuilder<N>::Config cfg; cfg.max_leaf_size = max_leaf; return SweepSahBuilder<N>::build(bb, cc, cfg); }, out, cap);
+    }
+    using N = Node<float, 3, 64, 6>;
+    return index_variant_stream<N>(bboxes, centers, n, [&](auto& bb, auto& cc) {
+        typename DefaultBuilder<N>::Config cfg; cfg.quality = DefaultBuilder<N>::Quality::High; cfg.max_leaf_size = max_leaf;
+        auto bvh = DefaultBuilder<N>::build(bb, cc, cfg);
+        return variant == 2 ? bvh.extract_bvh(bvh.get_root().index.first_id()) : std::move(bvh); }, out, cap);
+}
+
+ORC_EXPORT int ref_set_bin_count(size_t bin_count) {
+    if (bin_count != 4 && bin_count != 8 && bin_count != 16 && bin_count != 32) return -1;   // the instantiations above
+    g_bin_count = bin_count;
+    return 0;
+}
 ORC_EXPORT void ref_set_sah(size_t log_cluster_size, double cost_ratio) { g_sah_log_cluster = log_cluster_size; g_sah_cost_ratio = cost_ratio; }
 
 #define REF_IMPL(T, D, S)                                                                               \

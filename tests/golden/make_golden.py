@@ -79,9 +79,45 @@ def scene_fixture(ref, name, prims, n_rays, dtype, kind="tri"):
     print(name, {k: (v.shape, str(v.dtype)) for k, v in fx.items() if k.startswith("bvh_")})
 
 
+def template_knob_fixture(ref):
+    """Template arguments other than the reference's defaults, on the inputs of the scene fixtures above -> template_knobs.npz:
+    BinnedSahBuilder<Node, BinCount> (binned_sah_builder.h:18) for BinCount = 4, 16, 32 (the scene files hold the default of 8 under
+    `bvh_binned`), and Node<float, 3, IndexBits, PrimCountBits> (node.h:21-22) as Node<float, 3, 32, 2> (SweepSahBuilder, leaves <= 3)
+    and Node<float, 3, 64, 6> (DefaultBuilder serial High, and extract_bvh of the root's first child): the reference's own template
+    instantiations through oracle/ref_harness.cpp."""
+    import ctypes as C
+    scenes = {"soup2k": (synth.soup(2048, seed=3, jitter=0.03), "tri"),
+              "terrain2k": (synth.terrain(2048), "tri"),
+              "soup2k_f64": (synth.soup(2048, seed=3, jitter=0.03, dtype=np.float64), "tri"),
+              "circles2k_2f": (synth.circles(2048, dtype=np.float32, rmin=0.002, rmax=0.02), "sphere")}
+    fx = {}
+    try:
+        for name, (prims, kind) in scenes.items():
+            bb, cc = ref.prep_tris(prims) if kind == "tri" else ref.sphere_bboxes(prims)
+            for bins in (4, 16, 32):
+                ref.set_bin_count(bins)
+                fx[f"{name}_bins{bins}"] = np.frombuffer(ref.build(bb, cc, builder=oracle.BUILDER_BINNED).serialize(), dtype=np.uint8)
+                fx[f"{name}_bins{bins}_leaf2to5"] = np.frombuffer(ref.build(bb, cc, builder=oracle.BUILDER_BINNED, min_leaf=2, max_leaf=5).serialize(), dtype=np.uint8)
+    finally:
+        ref.set_bin_count(8)
+    f = ref.dll.ref_index_variant_stream
+    f.restype, f.argtypes = C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+    bb, cc = ref.prep_tris(scenes["soup2k"][0])
+    for key, variant, max_leaf in (("count2bits_sweep", 0, 3), ("index64_high", 1, 8), ("index64_high_sub", 2, 8)):
+        size = f(bb.ctypes.data, cc.ctypes.data, len(bb), variant, max_leaf, None, 0)
+        buf = np.zeros(size, dtype=np.uint8)
+        f(bb.ctypes.data, cc.ctypes.data, len(bb), variant, max_leaf, buf.ctypes.data, size)
+        fx[f"soup2k_{key}"] = buf
+    np.savez_compressed(os.path.join(OUT, "template_knobs.npz"), **fx)
+    print("template_knobs", {k: v.shape for k, v in fx.items()})
+
+
 def main():
     ref = oracle.load_ref()
     assert ref is not None, "needs /root/reference"
+    if "--knobs" in sys.argv:                                 # only the template-knob fixture (the others are unchanged)
+        template_knob_fixture(ref)
+        return
 
     cornell = load_obj("/root/reference/test/scenes/cornell_box.obj")
     assert cornell.shape == (36, 9)
@@ -143,6 +179,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **ka)
     print("known answers:", ka["simple_hit"], bytes(ka["serialize_stream"]).hex(), counts, nodes,
           ka["cornell_render_counters_high"])
+    template_knob_fixture(ref)
 
 
 def c_api_symbol_list():

@@ -25,6 +25,7 @@ def test_cpp_mirror_compiles_with_gxx(tmp_path):
     _compile(str(tmp_path / "circles_2d_amd"), os.path.join(ROOT, "tests", "cpp", "circles_2d_amd.cpp"))     # Node<T, 2>
     _compile(str(tmp_path / "serialize_amd"), os.path.join(ROOT, "tests", "cpp", "serialize_amd.cpp"))       # streams
     _compile(str(tmp_path / "replicate_amd"), os.path.join(ROOT, "tests", "cpp", "replicate_amd.cpp"))       # multi-GPU mirror
+    _compile(str(tmp_path / "template_knobs_amd"), os.path.join(ROOT, "tests", "cpp", "template_knobs_amd.cpp"))   # BinCount, Index bits
     exe = _compile(str(tmp_path / "simple_example_amd"))
     import torch
     if not torch.cuda.is_available():                         # no GPU: the program must fail loudly, not fall back
@@ -87,6 +88,56 @@ def test_cpp_2d_circles_match_reference(tmp_path, orc):
     for line, w in zip(lines[1:], want):
         p, t, u = line.split()
         assert int(p) == int(w["prim"]) and np.float32(t) == w["t"] and np.float32(u) == w["u"]
+
+
+def _repack(stream: bytes, index_bits: int, count_bits: int) -> bytes:
+    """The reference's stream for the same tree held in Node<float, 3, index_bits, count_bits> (node.h:90-94, bvh.h:221-229: counts,
+    ids and the index word as Index::Type; index.h:73-77: first_id << PrimCountBits | prim_count)."""
+    import numpy as np
+    from conftest import parse_stream
+    nodes, ids = parse_stream(stream)
+    it = np.dtype("<u8" if index_bits == 64 else "<u4")
+    first, count = (nodes["index"] >> 4).astype(np.uint64), (nodes["index"] & 15).astype(np.uint64)
+    out = np.zeros(len(nodes), dtype=np.dtype([("bounds", "<f4", (6,)), ("index", it)]))
+    out["bounds"] = nodes["bounds"]
+    out["index"] = ((first << np.uint64(count_bits)) | count).astype(it)
+    return np.array([len(nodes), len(ids)], dtype=it).tobytes() + out.tobytes() + ids.astype(it).tobytes()
+
+
+def test_index_repacking_rule_matches_reference_streams(orc):
+    """What the mirror does to a Node with non-default Index parameters (re-pack first_id / prim_count of the same tree) is what the
+    reference's own instantiations serialize (tests/golden/template_knobs.npz, made by Node<float, 3, 32, 2> / Node<float, 3, 64, 6>)."""
+    import oracle
+    from conftest import load_golden
+    g, gk = load_golden("soup2k"), load_golden("template_knobs")
+    bb, cc = g["bboxes"], g["centers"]
+    assert gk["soup2k_count2bits_sweep"].tobytes() == _repack(orc.build(bb, cc, builder=oracle.BUILDER_SWEEP, max_leaf=3).serialize(), 32, 2)
+    high = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_SERIAL, quality=oracle.QUALITY_HIGH)
+    assert gk["soup2k_index64_high"].tobytes() == _repack(high.serialize(), 64, 6)
+    first = int(high.nodes()["index"][0]) >> 4
+    assert gk["soup2k_index64_high_sub"].tobytes() == _repack(high.extract(first).serialize(), 64, 6)
+
+
+@pytest.mark.gpu
+def test_cpp_template_knobs_match_reference(tmp_path):
+    """BinnedSahBuilder<Node, 4 | 16 | 32> and Node<T, Dim, IndexBits, PrimCountBits> through the mirror (tests/cpp/template_knobs_amd.cpp)
+    on the soup2k fixture's input: every stream equals the one the reference's own template instantiation wrote (template_knobs.npz)."""
+    import numpy as np
+    from conftest import load_golden
+    exe = _compile(str(tmp_path / "template_knobs_amd"), os.path.join(ROOT, "tests", "cpp", "template_knobs_amd.cpp"))
+    g, gk = load_golden("soup2k"), load_golden("template_knobs")
+    bb, cc = g["bboxes"], g["centers"]
+    with open(tmp_path / "input.bin", "wb") as f:
+        f.write(np.ascontiguousarray(bb, dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(cc, dtype=np.float32).tobytes())
+    r = subprocess.run([exe, str(tmp_path / "input.bin"), str(len(bb)), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+    read = lambda name: open(tmp_path / name, "rb").read()
+    for bins in (4, 16, 32):
+        assert read(f"bins{bins}.bin") == gk[f"soup2k_bins{bins}"].tobytes(), bins
+        assert read(f"bins{bins}_leaf2to5.bin") == gk[f"soup2k_bins{bins}_leaf2to5"].tobytes(), bins
+    for name in ("count2bits_sweep", "index64_high", "index64_high_sub"):
+        assert read(f"{name}.bin") == gk[f"soup2k_{name}"].tobytes(), name
 
 
 def test_cpp_traverse_top_down_with_a_steering_inner_fn(tmp_path):

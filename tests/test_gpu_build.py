@@ -49,6 +49,77 @@ def test_binned_scenes(orc, scene, n, dtype):
     assert gpu.serialize() == ref.serialize()
 
 
+# ---- BinnedSahBuilder<Node, BinCount> with BinCount != 8 (binned_sah_builder.h:18; bvhXX_build_device_binned) ----------------------
+
+@pytest.mark.parametrize("scene", ["soup2k", "terrain2k", "soup2k_f64", "circles2k_2f"])
+@pytest.mark.parametrize("bins", [4, 16, 32])
+def test_binned_bin_counts_match_golden_stream(scene, bins):
+    import bvh_amd
+    g, gb = load_golden(scene), load_golden("template_knobs")
+    bvh = bvh_amd.BinnedSahBuilder.build(g["bboxes"], g["centers"], bin_count=bins)
+    assert bvh.serialize() == gb[f"{scene}_bins{bins}"].tobytes()
+    cfg = bvh_amd.Config(quality=bvh_amd.Quality.Low, min_leaf_size=2, max_leaf_size=5)
+    assert bvh_amd.BinnedSahBuilder.build(g["bboxes"], g["centers"], cfg, bin_count=bins).serialize() == gb[f"{scene}_bins{bins}_leaf2to5"].tobytes()
+    # the default is the tuned path and stays what it was
+    assert bvh_amd.BinnedSahBuilder.build(g["bboxes"], g["centers"], bin_count=8).serialize() == g["bvh_binned"].tobytes()
+
+
+@pytest.mark.parametrize("bins", [4, 16, 32])
+@pytest.mark.parametrize("n", [1, 2, 9, 63, 64, 65, 129, 1000, 2049, 30000])
+def test_binned_bin_counts_sizes(orc, bins, n):
+    import bvh_amd
+    tris = synth.soup(n, seed=n + bins, jitter=0.05)
+    bb, cc = orc.prep_tris(tris)
+    try:
+        orc.set_bin_count(bins)
+        ref = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    finally:
+        orc.set_bin_count(8)
+    assert bvh_amd.BinnedSahBuilder.build(bb, cc, bin_count=bins).serialize() == ref.serialize()
+
+
+@pytest.mark.parametrize("bins", [4, 16, 32])
+@pytest.mark.parametrize("scene,n,dtype", [("soup", 300_000, np.float32), ("terrain", 300_000, np.float32), ("sponza", 262_144, np.float32),
+                                           ("soup", 200_000, np.float64), ("sponza", 100_000, np.float64), ("soup", 1_000_000, np.float32)])
+def test_binned_bin_counts_scenes(orc, bins, scene, n, dtype):
+    import bvh_amd
+    tris = {"soup": lambda: synth.soup(n, dtype=dtype), "terrain": lambda: synth.terrain(n, dtype=dtype),
+            "sponza": lambda: synth.sponza_proxy(n, dtype=dtype)}[scene]()
+    bb, cc = orc.prep_tris(tris)
+    sah = bvh_amd.SplitHeuristic(1, 0.7) if scene == "sponza" else bvh_amd.SplitHeuristic()
+    try:
+        orc.set_bin_count(bins)
+        if scene == "sponza":
+            orc.set_sah(1, 0.7)
+        ref = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    finally:
+        orc.set_bin_count(8)
+        orc.set_sah()
+    gpu = bvh_amd.BinnedSahBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.Low, sah=sah), bin_count=bins)
+    assert gpu.node_count == ref.node_count
+    assert gpu.serialize() == ref.serialize()
+
+
+def test_binned_bin_counts_degenerate_and_refused(orc):
+    """Duplicates / flat input force fallback_split under every bin count; a BinCount outside {4, 8, 16, 32} is refused loudly."""
+    import bvh_amd
+    base = synth.soup(40, seed=1, jitter=0.05)
+    t = synth.soup(5000, seed=2, jitter=0.03)
+    t[:, 2::3] = 0.5
+    t = (np.round(t * 8) / 8).astype(np.float32)
+    for tris in (np.repeat(base, 50, axis=0), np.repeat(base[:1], 300, axis=0), t):
+        bb, cc = orc.prep_tris(np.ascontiguousarray(tris))
+        for bins in (4, 16, 32):
+            try:
+                orc.set_bin_count(bins)
+                ref = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+            finally:
+                orc.set_bin_count(8)
+            assert bvh_amd.BinnedSahBuilder.build(bb, cc, bin_count=bins).serialize() == ref.serialize()
+    with pytest.raises(Exception):
+        bvh_amd.BinnedSahBuilder.build(bb, cc, bin_count=12)
+
+
 @pytest.mark.parametrize("min_leaf,max_leaf", [(1, 1), (1, 4), (2, 8), (4, 4), (1, 15), (8, 15)])
 def test_binned_leaf_limits(orc, min_leaf, max_leaf):
     tris = synth.soup(20000, seed=11, jitter=0.02)

@@ -108,3 +108,20 @@ def test_2d_golden_builders_and_traversal(orc, scene):
     assert orc.build(bb, cc, builder=1, quality=1, parallel_threshold=10**6).serialize() == g["bvh_serial_med"].tobytes()
     with pytest.raises(RuntimeError):
         orc.build(bb, cc, builder=1, quality=1)
+
+
+@pytest.mark.parametrize("scene", ["soup2k", "terrain2k", "soup2k_f64", "circles2k_2f"])
+@pytest.mark.parametrize("bins", [4, 16, 32])
+def test_binned_bin_counts_bit_exact(orc, scene, bins):
+    """BinnedSahBuilder<Node, BinCount> for BinCount != 8 (binned_sah_builder.h:18): streams of the reference's own template
+    instantiations (tests/golden/make_golden.py: template_knob_fixture)."""
+    g, gb = load_golden(scene), load_golden("template_knobs")
+    try:
+        orc.set_bin_count(bins)
+        assert orc.build(g["bboxes"], g["centers"], builder=oracle.BUILDER_BINNED).serialize() == gb[f"{scene}_bins{bins}"].tobytes()
+        assert orc.build(g["bboxes"], g["centers"], builder=oracle.BUILDER_BINNED, min_leaf=2, max_leaf=5).serialize() == \
+            gb[f"{scene}_bins{bins}_leaf2to5"].tobytes()
+    finally:
+        orc.set_bin_count(8)
+    # and the default is untouched by the knob
+    assert orc.build(g["bboxes"], g["centers"], builder=oracle.BUILDER_BINNED).serialize() == g["bvh_binned"].tobytes()

@@ -141,3 +141,37 @@ def test_split_heuristic_and_optimizer_config_match_reference(orc, ref):
         a.optimize(threads=2, batch_size_ratio=ratio, max_iter_count=iters)
         b.optimize(batch_size_ratio=ratio, max_iter_count=iters)
         assert a.serialize() == b.serialize(), (ratio, iters)
+
+
+@pytest.mark.parametrize("bins", [4, 16, 32])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_binned_builder_bin_counts_match_reference(orc, ref, bins, dtype):
+    """BinnedSahBuilder<Node, BinCount> (binned_sah_builder.h:18): the restatement's run-time bin count against the reference's
+    template instantiations, 3D and 2D, default and non-default leaf limits / SplitHeuristic."""
+    try:
+        for name in ("soup", "terrain", "sponza"):
+            tris = _scene(name).astype(dtype)
+            bb, cc = ref.prep_tris(tris)
+            ref.set_bin_count(bins)
+            orc.set_bin_count(bins)
+            for min_leaf, max_leaf, sah in ((1, 8, (0, 1.0)), (2, 5, (1, 0.7))):
+                ref.set_sah(*sah)
+                orc.set_sah(*sah)
+                a = ref.build(bb, cc, builder=oracle.BUILDER_BINNED, min_leaf=min_leaf, max_leaf=max_leaf)
+                b = orc.build(bb, cc, builder=oracle.BUILDER_BINNED, min_leaf=min_leaf, max_leaf=max_leaf)
+                assert a.serialize() == b.serialize(), (name, min_leaf, max_leaf, sah)
+            ref.set_sah()
+            orc.set_sah()
+            # a different bin count really is a different tree
+            ref.set_bin_count(8)
+            assert ref.build(bb, cc, builder=oracle.BUILDER_BINNED).serialize() != a.serialize()
+        circ = synth.circles(3000, dtype=dtype, rmin=0.001, rmax=0.01)               # Node<T, 2>
+        bb2, cc2 = ref.sphere_bboxes(circ)
+        ref.set_bin_count(bins)
+        orc.set_bin_count(bins)
+        assert ref.build(bb2, cc2, builder=oracle.BUILDER_BINNED).serialize() == orc.build(bb2, cc2, builder=oracle.BUILDER_BINNED).serialize()
+    finally:
+        ref.set_bin_count(8)
+        orc.set_bin_count(8)
+        ref.set_sah()
+        orc.set_sah()
