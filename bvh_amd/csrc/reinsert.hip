@@ -548,6 +548,14 @@ constexpr uint32_t kSpinLimit = 1u << 24;
 constexpr int kSplitLevel = 5;
 
 template <typename T> struct PipeToken { uint32_t pos; uint32_t id; T cost; };
+
+// Developer builds only: where the two waves' time goes (clock ticks of s_memtime, printed once per launch by each wave's lane 0).
+#if defined(BVH_AMD_DEVELOPER)
+#define BVH_PIPE_PROF 1
+#else
+#define BVH_PIPE_PROF 0
+#endif
+__device__ inline unsigned long long pipe_clock() { return BVH_PIPE_PROF ? __builtin_readcyclecounter() : 0ull; }
 struct PipeCtrl { uint32_t head, tail, a_done, b_done, drain_req, drain_ack, error, open5; };   // open5: bit i = level-5 node i is an open hole
 
 // Control words in LDS with acquire / release at workgroup scope. (Relaxed accesses that rely on the LDS unit performing one
@@ -601,13 +609,17 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
         };
         uint32_t done = 0;
         T unused_root = T(0);
+        unsigned long long t_idle = 0, t_resolve = 0, n_resolve = 0;
+        const unsigned long long t_begin = pipe_clock();
         for (;;) {
             bool stop = false;
+            const unsigned long long t_w0 = pipe_clock();
             const bool ok = wait_until([&]() {
                 if (ctrl_load(&ctrl->head) != done) return true;
                 if (ctrl_load(&ctrl->a_done) && ctrl_load(&ctrl->head) == done) { stop = true; return true; }
                 return false;
             });
+            t_idle += pipe_clock() - t_w0;
             if (!ok || stop) break;
             const PipeToken<T> tok = queue[done % kQueueCap];
             Ent<T> v; v.cost = tok.cost; v.id = tok.id;
@@ -616,13 +628,16 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                 if (static_cast<uint32_t>(lane) == n_tasks) { task_pos = hand; task_value = v; }
                 if (lane == 0) h.lds[hand].id = kOpenHole;
                 heap_sync();
-                if (++n_tasks == 64) resolve_tasks();
+                if (++n_tasks == 64) { const unsigned long long t_r0 = pipe_clock(); resolve_tasks(); t_resolve += pipe_clock() - t_r0; ++n_resolve; }
             }
             if (lane == 0) __hip_atomic_fetch_and(&ctrl->open5, ~(1u << (tok.pos - 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             ++done;
             ctrl_store(&ctrl->tail, done);
         }
         resolve_tasks();
+        if (BVH_PIPE_PROF && lane == 0)
+            printf("[heap pipe] wave B: %u tokens, %llu ticks in all, %llu idle (waiting for a token), %llu in %llu full HBM batches\n", done,
+                   pipe_clock() - t_begin, t_idle, t_resolve, n_resolve);
         __threadfence();
         ctrl_store(&ctrl->b_done, 1u);
         return;
@@ -638,6 +653,8 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
     bool failed = false;
     // A's own deferred HBM tasks: pops whose path stays on the chain at level 5 are walked by A alone (B never enters that
     // subtree and A never shares an entry of it with B), their HBM parts collected and sifted like in the one-wave loop
+    unsigned long long ta_ring = 0, ta_open = 0, ta_repl = 0, na_own = 0;
+    const unsigned long long ta_begin = pipe_clock();
     uint32_t a_tasks = 0; uint32_t a_task_pos = 0; Ent<T> a_task_value{};
     auto resolve_a = [&]() {
         if (a_tasks) {
@@ -668,6 +685,7 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                 const T cj = lane_value(c, j);
                 if (!(root_cost < cj)) continue;
                 ++n_replaced;
+                const unsigned long long ta_r0 = pipe_clock();
                 Ent<T> v; v.cost = lane_value(chain.reg.cost, 0); v.id = lane_value(chain.reg.id, 0);      // position k-1 lives in registers
                 // levels 0 .. 5 (the subtree under the root: heap position == BFS index == lane)
                 uint32_t hand = 0;
@@ -686,7 +704,9 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                     for (int sidx = 1; sidx < kSplitLevel; ++sidx) { r = __builtin_amdgcn_readlane(next, r); path |= uint64_t{1} << r; }
                     const uint32_t pair_bits = 3u << (2 * r + 1 - 31);            // the level-5 children of the level-4 path node
                     if (open & pair_bits) {                   // one of them was an open hole when this round was loaded
+                        const unsigned long long t_o0 = pipe_clock();
                         if (!wait_until([&]() { return (ctrl_load(&ctrl->open5) & pair_bits) == 0; })) { failed = true; break; }
+                        ta_open += pipe_clock() - t_o0;
                         continue;
                     }
                     const bool on_path = (path >> lane) & 1u;
@@ -707,6 +727,7 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                 if (failed) break;
                 if (handed) {
                     if (chain.holds(hand, kSplitLevel)) {
+                        ++na_own;
                         uint32_t hand13 = 0;
                         T unused_root = T(0);
                         if (fast_top_round<T, kSplitLevel, HeapLevels<T>::v - 1>(h, v, lane, hand, d, in_level, hand13, unused_root, resolve_a)) {
@@ -720,8 +741,11 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                             }
                         }
                     } else {
-                        if (sent - tail_seen >= kQueueCap &&
-                            !wait_until([&]() { tail_seen = ctrl_load(&ctrl->tail); return sent - tail_seen < kQueueCap; })) { failed = true; break; }
+                        if (sent - tail_seen >= kQueueCap) {
+                            const unsigned long long t_q0 = pipe_clock();
+                            if (!wait_until([&]() { tail_seen = ctrl_load(&ctrl->tail); return sent - tail_seen < kQueueCap; })) { failed = true; break; }
+                            ta_ring += pipe_clock() - t_q0;
+                        }
                         if (lane == 0) {
                             PipeToken<T> tok; tok.pos = hand; tok.id = v.id; tok.cost = v.cost;
                             queue[sent % kQueueCap] = tok;
@@ -735,10 +759,14 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                 if (failed) break;
                 Ent<T> w; w.cost = cj; w.id = base + j;
                 if (wave_push_chain(h, chain, w, lane) == chain.top_level) root_cost = cj;
+                ta_repl += pipe_clock() - ta_r0;
             }
         }
     }
     resolve_a();
+    if (BVH_PIPE_PROF && lane == 0)
+        printf("[heap pipe] wave A: %u replacements (%llu walked alone along the chain), %u tokens, %llu ticks in all, %llu inside replacements, of which "
+               "%llu waiting for ring space and %llu for open level-5 holes\n", n_replaced, na_own, sent, pipe_clock() - ta_begin, ta_repl, ta_ring, ta_open);
     ctrl_store(&ctrl->a_done, 1u);
     if (!wait_until([&]() { return ctrl_load(&ctrl->b_done) != 0; })) failed = true;
     if (failed || ctrl_load(&ctrl->error)) { if (lane == 0) atomicOr(&sc->error, 2u); return; }
