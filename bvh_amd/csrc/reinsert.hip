@@ -245,7 +245,10 @@ __device__ bool wave_adjust_heap(WaveHeap<T>& h, Chain<T>& chain, uint32_t hole0
     return flushed;
 }
 
-constexpr uint32_t kStreamChunk = 512;                     // node costs fetched per HBM round trip of the replacement loop
+// Node costs fetched per HBM round trip of the replacement loop. (Round 5 measured a register prefetch of the NEXT chunk, 2048 costs = 32
+// loads per lane in flight: the stream's share of wave A fell from 16 % to 12 %, but the scalar registers the loads' bounds handling took
+// pushed spills into the replacement itself, +7 % there: 2 % slower in all, profiles/r05_heap_pipe_profile_prefetch.txt. Not kept.)
+constexpr uint32_t kStreamChunk = 512;
 constexpr uint32_t kOpenHole = 0xffffffffu;                // id of an LDS entry whose content is owed by a deferred task
 
 // Top part of a pop from the root: walks the LDS levels only. Returns true when the hole has to continue below the last LDS
@@ -349,10 +352,16 @@ __device__ inline bool fast_top_adjust(WaveHeap<T>& h, int full_levels, Ent<T> v
 
 // __push_heap(first, hole = k - 1, top = 0, w) on the chain: ancestors greater than w move down one place, w lands above them
 // Returns how many ancestors moved (== chain.top_level when w became the new root).
+// (the chain's LDS part as the push will see it; the two-wave loop issues this read ahead of its token hand-off, whose release
+//  store waits for the LDS anyway — nobody but the calling wave writes chain positions, so the values stay current)
 template <typename T>
-__device__ int wave_push_chain(WaveHeap<T>& h, Chain<T>& chain, Ent<T> w, int lane) {
+__device__ inline Ent<T> chain_fetch(const WaveHeap<T>& h, const Chain<T>& chain, int lane) {
     Ent<T> e = chain.reg;
     if (chain.on && !chain.bottom && lane >= 1) e = h.get_lds(chain.pos);
+    return e;
+}
+template <typename T>
+__device__ int wave_push_chain(WaveHeap<T>& h, Chain<T>& chain, Ent<T> w, int lane, Ent<T> e) {
     const bool valid = chain.on && lane >= 1;
     const uint64_t above = __ballot(valid && e.cost > w.cost) >> 1;       // bit j-1: ancestor j is moved down
     const int moves = above == ~uint64_t{0} ? 64 : __ffsll(static_cast<long long>(~above)) - 1;   // leading run of ones
@@ -364,6 +373,8 @@ __device__ int wave_push_chain(WaveHeap<T>& h, Chain<T>& chain, Ent<T> w, int la
     heap_sync();
     return moves;
 }
+template <typename T>
+__device__ int wave_push_chain(WaveHeap<T>& h, Chain<T>& chain, Ent<T> w, int lane) { return wave_push_chain(h, chain, w, lane, chain_fetch(h, chain, lane)); }
 
 // literal __adjust_heap by ONE lane on the HBM copy (level-parallel make_heap below)
 template <typename T>
@@ -690,6 +701,7 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                 // levels 0 .. 5 (the subtree under the root: heap position == BFS index == lane)
                 uint32_t hand = 0;
                 bool handed = false;
+                Ent<T> chain_e{}; bool chain_ready = false;
                 for (;;) {
                     const uint32_t open = ctrl_load(&ctrl->open5);
                     const bool inner = lane < 31;
@@ -741,6 +753,8 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                             }
                         }
                     } else {
+                        chain_e = chain_fetch(h, chain, lane);             // (in flight during the hand-off)
+                        chain_ready = true;
                         if (sent - tail_seen >= kQueueCap) {
                             const unsigned long long t_q0 = pipe_clock();
                             if (!wait_until([&]() { tail_seen = ctrl_load(&ctrl->tail); return sent - tail_seen < kQueueCap; })) { failed = true; break; }
@@ -758,7 +772,8 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
                 }
                 if (failed) break;
                 Ent<T> w; w.cost = cj; w.id = base + j;
-                if (wave_push_chain(h, chain, w, lane) == chain.top_level) root_cost = cj;
+                if (!chain_ready) chain_e = chain_fetch(h, chain, lane);
+                if (wave_push_chain(h, chain, w, lane, chain_e) == chain.top_level) root_cost = cj;
                 ta_repl += pipe_clock() - ta_r0;
             }
         }
