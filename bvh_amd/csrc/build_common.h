@@ -713,7 +713,7 @@ int finish_build(BvhImpl<T>& out, DevBuf<HostNode<T>>& final_nodes, uint32_t* d_
     int rc = relayout_on_device(out, final_nodes.p, stream);
     if (rc) return rc;
     if (!out.d_work) BVH_HIP_TRY(hipMalloc(&out.d_work, size_t{BvhImpl<T>::kWorkSlots} * BvhImpl<T>::kWorkStride * sizeof(unsigned long long)), BVH_AMD_ERR_HIP);
-    if (out.d_prim_ids) { (void)hipFree(out.d_prim_ids); out.d_prim_ids = nullptr; }
+    if (out.d_prim_ids) { scratch_forget(out.d_prim_ids); (void)hipFree(out.d_prim_ids); out.d_prim_ids = nullptr; }
     if (take_ids) out.d_prim_ids = d_ids;
     else {
         BVH_HIP_TRY(hipMalloc(&out.d_prim_ids, std::max<size_t>(n, 1) * sizeof(uint32_t)), BVH_AMD_ERR_HIP);
@@ -721,7 +721,7 @@ int finish_build(BvhImpl<T>& out, DevBuf<HostNode<T>>& final_nodes, uint32_t* d_
     }
     HostNode<T> root;
     { int rb_ = readback(&root, final_nodes.p, sizeof(root), stream); if (rb_) return rb_; }
-    if (out.d_nodes) (void)hipFree(out.d_nodes);
+    if (out.d_nodes) { scratch_forget(out.d_nodes); (void)hipFree(out.d_nodes); }
     out.d_nodes = final_nodes.p;
     out.d_nodes_count = out.node_count;
     final_nodes.p = nullptr;

@@ -91,6 +91,38 @@ struct ScratchCache {
 };
 ScratchCache& scratch_cache() { static ScratchCache* c = new ScratchCache; return *c; }      // outlives the runtime's own teardown
 
+// Developer builds, BVH_AMD_SCRATCH_CHECK=1: every block the runtime's pool hands out is remembered until it goes back; a block that
+// overlaps one still out is reported (stderr) — the pool (or this file) handing the same memory to two owners.
+#if defined(BVH_AMD_DEVELOPER)
+struct LiveBlocks {
+    std::mutex m;
+    std::map<uintptr_t, size_t> out;           // start -> bytes
+    bool on = std::getenv("BVH_AMD_SCRATCH_CHECK") != nullptr;
+    void add(void* p, size_t bytes, const char* who) {
+        if (!on || !p) return;
+        std::lock_guard<std::mutex> lock(m);
+        const uintptr_t b = reinterpret_cast<uintptr_t>(p), e = b + bytes;
+        auto it = out.lower_bound(b);
+        if (it != out.end() && it->first < e) fprintf(stderr, "[scratch check] %s: %p + %zu overlaps the live block %p + %zu\n", who, p, bytes, reinterpret_cast<void*>(it->first), it->second);
+        if (it != out.begin()) { auto pr = std::prev(it); if (pr->first + pr->second > b) fprintf(stderr, "[scratch check] %s: %p + %zu overlaps the live block %p + %zu\n", who, p, bytes, reinterpret_cast<void*>(pr->first), pr->second); }
+        out[b] = bytes;
+    }
+    void remove(void* p, const char* who, bool must_be_out = true) {
+        if (!on || !p) return;
+        std::lock_guard<std::mutex> lock(m);
+        if (!out.erase(reinterpret_cast<uintptr_t>(p)) && must_be_out) fprintf(stderr, "[scratch check] %s: %p goes back but was not out\n", who, p);
+    }
+};
+LiveBlocks& live_blocks() { static LiveBlocks* l = new LiveBlocks; return *l; }
+#define BVH_LIVE_ADD(p, bytes, who) live_blocks().add(p, bytes, who)
+#define BVH_LIVE_REMOVE(p, who) live_blocks().remove(p, who)
+#define BVH_LIVE_FORGET(p) live_blocks().remove(p, "owner", false)
+#else
+#define BVH_LIVE_FORGET(p) ((void)0)
+#define BVH_LIVE_ADD(p, bytes, who) ((void)0)
+#define BVH_LIVE_REMOVE(p, who) ((void)0)
+#endif
+
 Fence::~Fence() {
     if (!ev || dev < 0 || dev >= kMaxDevices) return;
     ScratchCache& c = scratch_cache();
@@ -145,6 +177,7 @@ bool wait_for_fence(hipStream_t stream, const std::shared_ptr<Fence>& f, Scratch
 // (mutex held) the block goes back to the runtime's pool, on the library's stream, behind the fence of the scope that freed it
 void pool_free_locked(ScratchCache& c, int dev, void* p, const std::shared_ptr<Fence>& f) {
     hipStream_t lib = c.lib_stream(dev);
+    BVH_LIVE_REMOVE(p, "pool_free");
     if (!lib) { (void)hipDeviceSynchronize(); (void)hipFree(p); return; }
     if (f && f->waitable.load(std::memory_order_acquire) && hipStreamWaitEvent(lib, f->ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
     if (hipFreeAsync(p, lib) != hipSuccess) (void)hipGetLastError();
@@ -161,6 +194,8 @@ void close_scope(ScratchScope& sc) {
     if (f && f->ev && hipEventRecord(f->ev, sc.stream) == hipSuccess) waitable = true;
     else { (void)hipGetLastError(); (void)hipStreamSynchronize(sc.stream); }         // no event: the work itself is waited for, once
     if (f) { f->waitable.store(waitable, std::memory_order_release); f->recorded.store(true, std::memory_order_release); }
+    static const bool sync_free = BVH_DEV_INT("BVH_AMD_SYNC_FREE", 0) != 0;          // developer knob: wait the scope's work out before its blocks go back
+    if (sync_free && !sc.deferred.empty()) (void)hipStreamSynchronize(sc.stream);
     if (!sc.deferred.empty()) {
         std::lock_guard<std::mutex> lock(c.m);
         for (void* p : sc.deferred) pool_free_locked(c, sc.dev, p, f);
@@ -203,10 +238,17 @@ bool scratch_pool_enabled() {
         int supported = 0;
         if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) == hipSuccess && supported &&
             hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-            // what the pool itself keeps of freed blocks follows the cache's bound (never lowered below what the application set)
-            ScratchCache& c = scratch_cache();
-            uint64_t keep = 0, have = 0;
-            { std::lock_guard<std::mutex> l2(c.m); keep = c.limit_of(dev); }
+            // The runtime's pool must NEVER give memory back on its own (release threshold: everything). With a finite threshold it unmaps
+            // freed blocks at whatever synchronisation comes next, and memory mapped again right afterwards can be READ STALE by compute
+            // kernels: with BVH_AMD_CACHE_MB=0 (threshold 0) one run in six of tests/c/stream_lifetime.c traced through a ray order of
+            // which the compute units saw 15-20 % old node data while the copy engine saw every word of it correct — translations or
+            // lines of the range's previous mapping — and trimming behind a device-wide synchronisation at the end of every call made
+            // it one run in two (profiles/r05_pool_trim_stale_reads.txt). So nothing is unmapped while the library works: blocks the
+            // cache does not keep wait in the runtime's pool, mapped, for the next hipMallocAsync; bvh_amd_release_cached_memory() is
+            // the one place that hands memory back (everything idle before and after). BVH_AMD_CACHE_MB bounds this file's own cache.
+            uint64_t keep = ~uint64_t{0}, have = 0;
+            static const int keep_mb = BVH_DEV_INT("BVH_AMD_POOL_KEEP_MB", -1);      // developer knob: the runtime pool's release threshold on its own (reproduces the above)
+            if (keep_mb >= 0) keep = static_cast<uint64_t>(keep_mb) << 20;
             if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &have) != hipSuccess) { (void)hipGetLastError(); have = 0; }
             usable[dev] = have >= keep || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
         }
@@ -262,6 +304,7 @@ hipError_t scratch_alloc(void** p, size_t bytes, ScratchTag* tag) {
     // from the runtime's pool, in the order of the library's stream; the requesting stream continues behind that point
     hipError_t e = hipMallocAsync(p, bytes, lib);
     if (e != hipSuccess) return e;
+    BVH_LIVE_ADD(*p, bytes, "hipMallocAsync");
     if (hipEventRecord(lib_ev, lib) != hipSuccess || hipStreamWaitEvent(stream, lib_ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(lib); }
     return hipSuccess;
 }
@@ -307,6 +350,9 @@ void scratch_free(void* p, const ScratchTag& tag) {
         from->erase(oldest);
     }
 }
+
+// (a block that left the scratch system with a Bvh is released by hipFree: the developer build's overlap check is told)
+void scratch_forget(void* p) { BVH_LIVE_FORGET(p); (void)p; }    // (plain hipMalloc memory passes through here too)
 
 void scratch_cache_flush() {
     ScratchCache& c = scratch_cache();

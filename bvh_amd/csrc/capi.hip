@@ -557,6 +557,7 @@ int bvh_amd_release_cached_memory(void) {
     hipMemPool_t pool = nullptr;
     if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return BVH_AMD_OK; }
     BVH_HIP_TRY(hipMemPoolTrimTo(pool, 0), BVH_AMD_ERR_HIP);
+    BVH_HIP_TRY(hipDeviceSynchronize(), BVH_AMD_ERR_HIP);     // (nothing of the library's is queued between the unmapping and its next allocation)
     return BVH_AMD_OK;
 }
 

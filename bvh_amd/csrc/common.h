@@ -196,6 +196,7 @@ hipStream_t& ambient_stream();                 // build_device.hip
 // The stream of the API call in progress on this thread. The OUTERMOST scope of a call on its stream is also what the scratch cache
 // hangs its bookkeeping on: if the call freed scratch, one event (the scope's fence) is recorded on the stream when the scope ends.
 struct ScratchScope;                           // build_device.hip
+void scratch_forget(void* p);                  // build_device.hip (developer builds: bookkeeping of the overlap check; otherwise nothing)
 struct StreamScope {
     hipStream_t saved;
     ScratchScope* scope;                       // nullptr: shares the enclosing scope's (same stream)

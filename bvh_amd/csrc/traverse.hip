@@ -197,6 +197,16 @@ __device__ inline uint32_t ray_key(const T (&r)[8], T lx, T ly, T lz, T sx, T sy
 // the keys are written AND the tile's histogram of their lowest digit is left where k_radix_hist would have put it, so the sort's first
 // histogram pass — a second read of all keys — is not launched (round 5: 132 + 27 -> ~115 us per 2^24 rays; the rays are loaded
 // non-temporally: they are read once here and once, much later, by the traversal).
+#if defined(BVH_AMD_DEVELOPER)
+__global__ void __launch_bounds__(256) k_check_order(const uint32_t* order, uint32_t n, uint32_t* bad) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && order[i] >= n) {
+        const uint32_t k = atomicAdd(&bad[0], 1u);
+        if (k < 3) { bad[1 + 2 * k] = i; bad[2 + 2 * k] = order[i]; }
+    }
+}
+#endif
+
 template <typename T>
 __global__ void __launch_bounds__(1024) ray_keys_kernel(const T* rays, uint32_t n, T lx, T ly, T lz, T sx, T sy, T sz, uint32_t* keys, uint32_t cells,
                                                         int hilbert_bits, int class_bits, T class_scale, uint32_t* hist, uint32_t tiles) {
@@ -902,6 +912,30 @@ static int launch_planned(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, 
         int rc = radix_sort_pairs<uint32_t>(keys, vals, kt, vt, n32, 1, key_bits, stream, hist, /*iota_vals=*/true, /*keys_wanted=*/false, &order, first_hist_done);
         if (rc) return release(rc);
         args.order = order;
+#if defined(BVH_AMD_DEVELOPER)
+        if (getenv("BVH_AMD_CHECK_ORDER")) {                  // developer check: is the order a set of valid ray indices when the sort has run?
+            uint32_t* d_bad = nullptr;
+            if (hipMalloc(&d_bad, 8 * sizeof(uint32_t)) == hipSuccess) {
+                for (int round = 0; round < 2; ++round) {
+                    (void)hipMemsetAsync(d_bad, 0, 8 * sizeof(uint32_t), stream);
+                    hipLaunchKernelGGL(k_check_order, dim3((n32 + 255) / 256), dim3(256), 0, stream, order, n32, d_bad);
+                    uint32_t bad[8] = {};
+                    (void)hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream);
+                    (void)hipStreamSynchronize(stream);
+                    if (bad[0]) {                             // the same words as the copy engine sees them (memory, not a compute unit's caches)
+                        std::vector<uint32_t> host(n32);
+                        (void)hipMemcpy(host.data(), order, size_t{n32} * 4, hipMemcpyDeviceToHost);
+                        uint32_t host_bad = 0;
+                        for (uint32_t v : host) host_bad += v >= n32 ? 1u : 0u;
+                        fprintf(stderr, "[check order] look %d: the copy engine sees %u bad entries\n", round, host_bad);
+                    }
+                    if (bad[0]) fprintf(stderr, "[check order] look %d: %u of %u entries are not ray indices; first at %u = 0x%x, %u = 0x%x, %u = 0x%x (sort_mem %p, order %p)\n", round, bad[0], n32,
+                                        bad[1], bad[2], bad[3], bad[4], bad[5], bad[6], sort_mem, static_cast<void*>(order));
+                }
+                (void)hipFree(d_bad);
+            }
+        }
+#endif
     }
     // staggered drain: `stagger` tickets per eighth of the grid over the whole launch -> per ticket range
     {

@@ -145,12 +145,12 @@ BvhImpl<T>::~BvhImpl() {
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
-        if (d_pairs) (void)hipFree(d_pairs);
-        if (d_prim_ids) (void)hipFree(d_prim_ids);
+        if (d_pairs) { scratch_forget(d_pairs); (void)hipFree(d_pairs); }
+        if (d_prim_ids) { scratch_forget(d_prim_ids); (void)hipFree(d_prim_ids); }
         if (d_work) (void)hipFree(d_work);
         for (hipEvent_t& e : work_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         for (PlanSearch& ps : plan_search) { if (ps.start) (void)hipEventDestroy(ps.start); if (ps.stop) (void)hipEventDestroy(ps.stop); ps.start = ps.stop = nullptr; }
-        if (d_nodes) (void)hipFree(d_nodes);
+        if (d_nodes) { scratch_forget(d_nodes); (void)hipFree(d_nodes); }
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
 }
@@ -180,7 +180,7 @@ int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t st
     b.pair_count = (b.node_count - 1) / 2;
     b.max_depth = -1;
     { std::lock_guard<std::mutex> lock(b.plan_mutex); for (int k = 0; k < 2; ++k) { b.launch_plan[k] = 0; b.plan_search[k].index = 0; b.plan_search[k].pending = false; b.plan_search[k].trying = -1; b.plan_search[k].dropped = 0; for (auto& c : b.plan_search[k].count) c = 0; } }
-    if (b.d_pairs) { (void)hipFree(b.d_pairs); b.d_pairs = nullptr; }
+    if (b.d_pairs) { scratch_forget(b.d_pairs); (void)hipFree(b.d_pairs); b.d_pairs = nullptr; }
     if (b.pair_count) {
         // (from the stream-ordered pool when it is on: a plain hipMalloc of the 10M-triangle scene's 0.5 GB of records costs ~2 ms;
         //  BvhImpl releases it with hipFree, which accepts pool memory)

@@ -147,9 +147,12 @@ BVH_AMD_API int bvh_amd_synchronize(void* stream);
  * lifetime rule beyond _destroy, and neither has this library): a `stream` argument is only used during the call it is passed to;
  * it may be destroyed afterwards, whatever was built or cached while it lived (tests/c/stream_lifetime.c).
  * The cache holds at most BVH_AMD_CACHE_MB megabytes per device (default: min(1024, 5 % of the HBM free at first use); 0 = no
- * cache) and the pool keeps as much again of freed memory; a 10M-triangle build cycles ~3 GB of scratch, so a program that
- * rebuilds scenes of that size in a loop wants BVH_AMD_CACHE_MB=8192. bvh_amd_release_cached_memory() returns everything to the
- * driver (waits for the device). BVH_AMD_POOL=0 disables pool and cache (plain hipMalloc / hipFree).
+ * cache). Scratch the cache does not keep goes back to the device's default memory pool and STAYS MAPPED there for the next
+ * request: the pool's release threshold is set to "never on its own", because memory that the pool unmaps at some synchronisation
+ * and maps again right afterwards was read stale by compute kernels on this platform (profiles/r05_pool_trim_stale_reads.txt). So
+ * a process keeps reserved what its largest call needed (a 10M-triangle build cycles ~3 GB of scratch) until it calls
+ * bvh_amd_release_cached_memory(), which returns cache and pool to the driver with the device idle before and after.
+ * BVH_AMD_POOL=0 disables pool and cache (plain hipMalloc / hipFree).
  *
  * Environment variables a release library reads — all of them: BVH_AMD_CACHE_MB, BVH_AMD_POOL (above); BVH_AMD_CALIBRATE=0 (no
  * measured launch-plan search, the predictor's plan always); BVH_AMD_REINSERT=exact (ReinsertionOptimizer: replay the reference's
