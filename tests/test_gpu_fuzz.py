@@ -78,6 +78,15 @@ def test_fuzz_3d(orc, seed, kind):
         ref = orc.build(bb, cc, builder=builder, quality=quality, min_leaf=lim[0], max_leaf=lim[1], parallel_threshold=cfg.parallel_threshold)
         assert gpu.serialize() == ref.serialize(), (seed, kind, n, builder, quality, lim)
         last = (gpu, ref)
+    # BinnedSahBuilder<Node, BinCount> with another BinCount (binned_sah_builder.h:18): one of 4 / 16 / 32 per case
+    bins = (4, 16, 32)[seed % 3]
+    try:
+        orc.set_bin_count(bins)
+        ref_bins = orc.build(bb, cc, builder=2, quality=0, min_leaf=lim[0], max_leaf=lim[1])
+    finally:
+        orc.set_bin_count(8)
+    cfg = bvh_amd.Config(quality=bvh_amd.Quality.Low, min_leaf_size=lim[0], max_leaf_size=lim[1])
+    assert bvh_amd.BinnedSahBuilder.build(d_bb, d_cc, cfg, bin_count=bins).serialize() == ref_bins.serialize(), (seed, kind, n, "bins", bins, lim)
     gpu, ref = last
     prims = bvh_amd.precompute_tris(tris, gpu.device_prim_ids())
     lo, hi = tris.reshape(-1, 3).min(axis=0).astype(np.float64), tris.reshape(-1, 3).max(axis=0).astype(np.float64)

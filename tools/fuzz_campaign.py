@@ -5,7 +5,7 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import oracle
 import test_gpu_fuzz as F
 
-orc = oracle.load_oracle()
+orc = oracle.gpu_checker()        # the compiled reference where it travelled with the tree, else the pinned restatement
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 60.0
 t0 = time.time(); ran = 0; bad = []
