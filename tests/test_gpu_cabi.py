@@ -122,6 +122,22 @@ def test_a_callers_stream_may_die_after_the_call(tmp_path):
             env["BVH_AMD_CACHE_MB"] = mb
         r = subprocess.run([exe, "300000", "1048576"], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and "stream lifetime ok" in r.stdout, (mb, r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    # Round 5, second half: with the cache off this program faulted in one run of six — scratch that the runtime's memory pool had
+    # unmapped and mapped again was read stale by the kernels (profiles/r05_pool_trim_stale_reads.txt). The developer library's order
+    # check sees such reads in every second affected run, so four runs of it with no report (and no fault) hold the fix in place.
+    dev = os.path.join(lib, "libbvh_amd_dev.so")
+    if os.path.exists(dev):
+        import shutil
+        shutil.copy(dev, str(tmp_path / "libbvh_amd.so"))
+        exe_dev = str(tmp_path / "stream_lifetime_dev")
+        cmd_dev = [c for c in cmd if c != f"-Wl,-rpath,{lib}"]
+        cmd_dev[cmd_dev.index(exe)] = exe_dev
+        r = subprocess.run(cmd_dev, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        env = dict(os.environ, BVH_AMD_CACHE_MB="0", BVH_AMD_CHECK_ORDER="1", LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        for run in range(4):
+            r = subprocess.run([exe_dev, "300000", "1048576"], capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0 and "stream lifetime ok" in r.stdout and "check order" not in r.stderr, (run, r.returncode, r.stdout[-800:], r.stderr[-1500:])
 
 
 
