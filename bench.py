@@ -563,8 +563,8 @@ def rendezvous_only(args, rank, local_rank, world):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"n_gpus": world, "ranks": ranks, "self_launched": os.environ.get("BVH_AMD_BENCH_SELF_LAUNCHED") == "1",
-                          "rendezvous_only": True}), flush=True)
+        emit_line({"n_gpus": world, "ranks": ranks, "self_launched": os.environ.get("BVH_AMD_BENCH_SELF_LAUNCHED") == "1",
+                   "rendezvous_only": True})
 
 
 def one_process(args):
@@ -706,9 +706,37 @@ def one_process(args):
         out["cpu_baseline"] = cpu_baseline(tris, bvh, rays_h[0][:ns], int(robust), bvh_amd.hits_to_numpy(hits0[:ns]), args.quality, args.serial_builder)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    emit_line(out)
     if not equal:
         raise SystemExit("bench.py --one-process: a device's shard differs from device 0 tracing the same rays")
+
+
+_LINE_FD = None
+
+
+def own_stdout():
+    """The contract is ONE JSON line on stdout. Native libraries write there too (gloo announces its peers, a debug build of RCCL its
+    version): from here on file descriptor 1 is stderr for everybody — Python's print included — and emit_line() alone writes to what
+    stdout was."""
+    global _LINE_FD
+    try:
+        plain = sys.stdout is sys.__stdout__ and sys.stdout.fileno() == 1     # (not when a caller captures sys.stdout: tests/test_bench_contract.py)
+    except (AttributeError, OSError, ValueError):
+        plain = False
+    if _LINE_FD is None and plain:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _LINE_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, data)
 
 
 def main():
@@ -717,11 +745,12 @@ def main():
     if args.pmc_child:
         pmc_child(args)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.one_process:   # not under torchrun: N ranks are started here (one process per GPU)
+        raise SystemExit(self_launch(args))
+    own_stdout()
     if args.one_process:
         one_process(args)
         return
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # not under torchrun: N ranks are started here (one process per GPU)
-        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -934,7 +963,7 @@ def main():
                                                args.quality, args.serial_builder)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit_line(out)
     if distributed:
         # the ranks that have finished wait on the HOST (a key of the rendezvous store; no collective kernel spinning on their GPUs, no
         # second process group whose start-up chatter would land on stdout) while rank 0 collects the traversal kernel's counters and
