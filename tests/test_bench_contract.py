@@ -173,3 +173,16 @@ def test_bench_starts_its_own_ranks():
     env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_stdout_carries_the_line_and_nothing_else():
+    """bench.py hands file descriptor 1 to stderr for the run (native libraries print there: gloo announces its peers) and writes the
+    JSON line to what stdout was: whatever else is printed, through Python or straight to the descriptor, ends up on stderr."""
+    import subprocess
+    from conftest import ROOT
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.own_stdout(); os.write(1, b'native noise\\n'); "
+            "print('python noise'); bench.emit_line({'metric': 'x', 'value': 1})") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"metric": "x", "value": 1}\n'
+    assert "native noise" in r.stderr and "python noise" in r.stderr
