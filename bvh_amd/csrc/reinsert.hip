@@ -791,6 +791,8 @@ __global__ void __launch_bounds__(128) k_heap_select_pipe(const T* cost, uint32_
     if (lane == 0) atomicAdd(&sc->replacements, n_replaced);
 }
 
+#include "heap_head.inc"
+
 // ---- fast path: top-k by cost without the heap (valid when no tie straddles the threshold) --------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) k_cost_keys(const T* cost, uint32_t n, typename Ord<T>::U* keys, uint32_t* ids) {
@@ -1070,11 +1072,17 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
 
     const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>) + kStreamChunk * sizeof(T);
     const bool below_lds = k >= 1 && k - 1 >= HeapCap<T>::v;
-    const char* pipe_knob = BVH_DEV_STR("BVH_AMD_HEAP_PIPE");                      // 0: the one-wave replacement loop
-    const bool use_pipe = !(pipe_knob && std::atoi(pipe_knob) == 0);
+    // heaps that reach below LDS: the register-resident head (heap_head.inc). Developer knob BVH_AMD_HEAP_PIPE: 0 = the one-wave
+    // replacement loop, 1 = round 5's two-wave loop, anything else = the head kernel.
+    const char* pipe_knob = BVH_DEV_STR("BVH_AMD_HEAP_PIPE");
+    const int pipe_mode = pipe_knob ? std::atoi(pipe_knob) : 2;
+    const bool use_pipe = pipe_mode == 1, use_head = pipe_mode != 0 && pipe_mode != 1;
     const size_t pipe_lds = heap_lds + kQueueCap * sizeof(PipeToken<T>) + sizeof(PipeCtrl);
     if (below_lds && use_pipe)
         BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select_pipe<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pipe_lds)),
+                    BVH_AMD_ERR_HIP);
+    if (below_lds && use_head)
+        BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select_head<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(HeadLayout<T>::bytes)),
                     BVH_AMD_ERR_HIP);
     auto heap_kernel = below_lds ? k_heap_select<T, true> : k_heap_select<T, false>;
     BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(heap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(heap_lds)),
@@ -1119,7 +1127,10 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
                         hipLaunchKernelGGL(k_make_heap_level<T>, dim3((count + 63) / 64), dim3(64), 0, stream, heap_g.p, k, first, count);
                     }
                 }
-                if (below_lds && use_pipe)
+                if (below_lds && use_head) {
+                    hipLaunchKernelGGL(k_heap_select_head<T>, dim3(1), dim3(256), HeadLayout<T>::bytes, stream, cost.p, n, batch, heap_g.p, scalars.p);
+                    hipLaunchKernelGGL(k_heap_ids<T>, dim3((k + 255) / 256), dim3(256), 0, stream, heap_g.p, k, cand.p);
+                } else if (below_lds && use_pipe)
                     hipLaunchKernelGGL(k_heap_select_pipe<T>, dim3(1), dim3(128), pipe_lds, stream, cost.p, n, batch, heap_g.p, cand.p, scalars.p);
                 else
                     hipLaunchKernelGGL(heap_kernel, dim3(1), dim3(64), heap_lds, stream, cost.p, n, batch, heap_g.p, cand.p, scalars.p);
