@@ -1076,13 +1076,17 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
     // replacement loop, 1 = round 5's two-wave loop, anything else = the head kernel.
     const char* pipe_knob = BVH_DEV_STR("BVH_AMD_HEAP_PIPE");
     const int pipe_mode = pipe_knob ? std::atoi(pipe_knob) : 2;
-    const bool use_pipe = pipe_mode == 1, use_head = pipe_mode != 0 && pipe_mode != 1;
+    const bool use_head = pipe_mode != 0 && pipe_mode != 1 && n < kHeadMaxNodes;     // (its words tag node ids with two bits)
+    const bool use_pipe = pipe_mode == 1 || (pipe_mode != 0 && !use_head);
+    int heap_depth = 0;                                       // level of the last heap position k - 1
+    while ((uint64_t{2} << heap_depth) <= k) ++heap_depth;
+    auto head_kernel = heap_depth + 12 <= 32 ? k_heap_select_head<T, false> : k_heap_select_head<T, true>;     // ancestor masks of 32 / 64 lanes
     const size_t pipe_lds = heap_lds + kQueueCap * sizeof(PipeToken<T>) + sizeof(PipeCtrl);
     if (below_lds && use_pipe)
         BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select_pipe<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pipe_lds)),
                     BVH_AMD_ERR_HIP);
     if (below_lds && use_head)
-        BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select_head<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(HeadLayout<T>::bytes)),
+        BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(HeadLayout<T>::bytes)),
                     BVH_AMD_ERR_HIP);
     auto heap_kernel = below_lds ? k_heap_select<T, true> : k_heap_select<T, false>;
     BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(heap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(heap_lds)),
@@ -1128,7 +1132,7 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
                     }
                 }
                 if (below_lds && use_head) {
-                    hipLaunchKernelGGL(k_heap_select_head<T>, dim3(1), dim3(256), HeadLayout<T>::bytes, stream, cost.p, n, batch, heap_g.p, scalars.p);
+                    hipLaunchKernelGGL(head_kernel, dim3(1), dim3(64 * kHeadWaves), HeadLayout<T>::bytes, stream, cost.p, n, batch, heap_g.p, scalars.p);
                     hipLaunchKernelGGL(k_heap_ids<T>, dim3((k + 255) / 256), dim3(256), 0, stream, heap_g.p, k, cand.p);
                 } else if (below_lds && use_pipe)
                     hipLaunchKernelGGL(k_heap_select_pipe<T>, dim3(1), dim3(128), pipe_lds, stream, cost.p, n, batch, heap_g.p, cand.p, scalars.p);

@@ -1,22 +1,24 @@
 // Developer tool (CPU): lane-by-lane model of the round-6 candidate-heap replay (bvh_amd/csrc/heap_head.inc: k_heap_select_head),
 // checked against libstdc++ itself. NOT product code. The kernel is a transcription of this model: every array of 64 below is a
-// VGPR (one value per lane), every loop over lanes is one wave-wide instruction sequence, `mem` is the heap array (positions
-// [0, cap) in LDS, the rest in HBM), the three actors are three wavefronts of one workgroup and the scheduler below interleaves
-// them at random, so that every ordering of "token sent / first step published / hole closed" the hardware can produce is met.
+// VGPR (one value per lane), every 64-bit mask a scalar register pair, every loop over lanes one wave-wide instruction sequence, `mem`
+// the heap array (positions [0, cap) in LDS, the rest in HBM), the four actors are four wavefronts of one workgroup and the scheduler
+// below interleaves them at random, so that every ordering of "token written / first step done / value written back / hole closed"
+// the hardware can produce is met.
 //
 // One replacement of reinsertion_optimizer.h:96-103 = pop_heap + back() = x + push_heap:
-//   HEAD (one wave, everything the NEXT replacement depends on, in registers): one lane per PARENT position of the "head tree" =
-//        heap levels 0 .. HL-1 complete + the ancestors ("spine") of the last position k-1 below them. A lane keeps BOTH children of its
-//        parent {cost, id}, so the child choice of __adjust_heap (stl_heap.h:223-248) is lane-local; the min-child path is then ONE ballot
-//        of the choices tested against per-lane ancestor masks, the landing level of the popped value one more ballot, and every path lane
-//        takes its new child value from its chosen child's lane (a value that was fetched before the replacement began). The push
-//        (stl_heap.h:134-148) is a sorted insert into the spine: one ballot and one lane shift. Children that are not head parents
-//        are roots of subtrees the head never looks into:
-//   TAIL (one wave, lanes = pops in flight below the head): a pop that leaves the head tree becomes a token (sub-root e, value v). The tail
-//        sifts it down one heap level per iteration inside LDS; the FIRST step decides the new value of position e, which it publishes to
-//        the head (until then the head's copy of e is "pending" and a pop whose path needs it waits). A token that reaches the last LDS
-//        level is parked as a
-//   DEEP task (one wave, lane per task, the libstdc++ loop literally on HBM): the LDS entry is marked as an open hole until done.
+//   HEAD (wave A, everything the NEXT replacement depends on, in registers): one lane per PARENT position of the "head tree" = a virtual
+//        parent of the root (lane 0) + the ancestors ("spine") of the last position k-1 (lanes 1 .. D) + the other parents of heap levels
+//        0 .. HL-1. A lane keeps BOTH children of its parent, so the child choice of __adjust_heap (stl_heap.h:223-248) is lane-local
+//        (mask B); the min-child path is B tested against per-lane ancestor masks, the landing level of the popped value one more
+//        compare plus bit arithmetic, and every path lane takes its new child from its chosen child's lane (a value fetched before the
+//        replacement began). The push (stl_heap.h:134-148) is a sorted insert into the spine: one compare, one count of leading zeros, one
+//        lane shift. Children that are not head parents are roots of sub-heaps the head never looks into; their values live in WORDS
+//        the head re-reads every replacement. A pop that leaves the head tree writes a TOKEN {v | tag} into the word: the child is pending.
+//   T1   polls the words; for a token it does the first step below the head (that fixes the sub-root's new value), writes the value back
+//        into the word and hands the rest of the pop (hole, v) to
+//   T2   lanes = pops in flight inside the LDS levels, one level per iteration. The position a hole stands at is marked (kOpenHole)
+//        until its final entry is written; a pop that finds a marked child waits. A hole that reaches the last LDS level goes, marked, to
+//   DEEP one lane per task, the same top-down sift on the HBM levels.
 //
 //   g++ -std=c++20 -O2 tools/heap_head_sim.cpp -o /tmp/heap_head_sim && /tmp/heap_head_sim [seeds] [max_k]
 #include <algorithm>
@@ -31,7 +33,7 @@
 
 struct Ent { float cost = 0; uint32_t id = 0; };
 struct Cand { size_t id = 0; float cost = 0; bool operator>(const Cand& o) const { return cost > o.cost; } };
-constexpr uint32_t kOpenHole = 0xffffffffu;
+constexpr uint32_t kOpenHole = 0xffffffffu, kTokenTag = 0x80000000u, kHandedTag = 0x40000000u, kNoSlot = 0xffffffffu;
 
 static std::vector<Cand> reference(const std::vector<float>& cost, size_t k, size_t* replacements) {
     std::vector<Cand> h;
@@ -53,217 +55,260 @@ static std::vector<Cand> reference(const std::vector<float>& cost, size_t k, siz
 static int level_of(uint32_t p) { int l = 0; for (uint32_t q = p + 1; q > 1; q >>= 1) ++l; return l; }
 static int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
 
-enum Kind : int { kNone = 0, kHead = 1, kTail = 2, kBottom = 3 };
-
-struct Token { uint32_t pos, slot; Ent v; };
-struct DeepTask { uint32_t pos; int slot; Ent v; };           // slot < 0: nothing to publish
+struct Tok { uint32_t pos, slot; Ent v; };
 
 struct Model {
     std::vector<Ent> mem;
-    uint32_t k = 0, len = 0, cap = 0;
+    uint32_t k = 0, len = 0, cap = 0, first_parked = 0;
     int HL = 5, LL = 14, D = 0;
-    // ---- head: lane state -----------------------------------------------------------------------------------------------------
+    // ---- head: static lane state --------------------------------------------------------------------------------------------
     int n_lanes = 0;
-    uint32_t pos[64] = {};
-    Ent Lv[64], Rv[64];
-    int kindL[64] = {}, kindR[64] = {}, clL[64] = {}, clR[64] = {};
-    uint64_t ancmask[64] = {}, ancval[64] = {};
-    bool ischain[64] = {}; int side[64] = {};                 // chain lanes 0 .. D-1: which child continues the spine (0 = left)
-    int pend[64] = {};                                        // bit 0: left child owed by the tail, bit 1: right child
-    // derived (recomputed after every replacement)
-    bool b[64] = {}, ex[64] = {}; Ent C[64], NC[64]; int nl[64] = {}; uint64_t B = 0;
-    Ent root;
+    bool valid[64] = {}; uint32_t lpos[64] = {}, rpos[64] = {};
+    int kind_l[64] = {}, kind_r[64] = {}, nl_l[64] = {}, nl_r[64] = {};
+    uint64_t anc_mask[64] = {}, anc_val[64] = {};
+    uint64_t VALID = 0, EXL = 0, EXR = 0, HLm = 0, HRm = 0, TL = 0, TR = 0, CHAIN = 0, CHAINCMP = 0, SIDE = 0;
+    // ---- head: dynamic -----------------------------------------------------------------------------------------------------------
+    float lc[64] = {}, rc[64] = {}; uint32_t li[64] = {}, ri[64] = {};
+    uint64_t B = 0, EX = 0, CHH = 0, PEND = 0;
+    float chc[64] = {}, nchc[64] = {}; uint32_t chi[64] = {}, nchi[64] = {}; int nl[64] = {};
+    float vc = 0; uint32_t vi = 0; float root_c = 0;
     // ---- shared "LDS" ------------------------------------------------------------------------------------------------------------
-    std::deque<Token> ring; size_t ring_cap = 8;
-    std::deque<DeepTask> deep_ring; size_t deep_cap = 16;
-    Ent slot_val[128]; bool slot_flag[128] = {};
-    // ---- tail lanes ---------------------------------------------------------------------------------------------------------------
-    bool t_live[64] = {}; uint32_t t_pos[64] = {}, t_root[64] = {}; int t_steps[64] = {}, t_slot[64] = {}; Ent t_v[64];
-    long head_stalls = 0, tail_stalls = 0, tokens = 0, deep_tasks = 0, replacements = 0, forwarded = 0;
+    Ent words[128];
+    std::deque<Tok> ring, deep_ring; size_t ring_cap = 64, deep_cap = 64;             // (each at least one entry per lane: a whole look / iteration must fit, like kTokCap, kDeepCap)
+    // ---- T2 lanes ---------------------------------------------------------------------------------------------------------------
+    bool t_live[64] = {}; uint32_t t_pos[64] = {}; Ent t_v[64];
+    long head_blocked = 0, tokens = 0, first_steps = 0, deep_tasks = 0, replacements = 0, forwarded = 0;
+
+    uint32_t spine(int level) const { return (k >> (D - level)) - 1; }
+    bool on_spine(uint32_t p) const { const int lv = level_of(p); return lv <= D && spine(lv) == p; }
+    std::vector<uint32_t> lane_pos;                           // parent position per lane (lane 0: the virtual parent)
+    int lane_of(uint32_t p) const { for (int i = 1; i < int(lane_pos.size()); ++i) if (lane_pos[i] == p && valid[i]) return i; return -1; }
+    int kind_of(uint32_t c) const { return c == k - 1 ? 3 : c >= k - 1 ? 0 : lane_of(c) >= 0 ? 1 : 2; }
 
     Model(const std::vector<Ent>& heap, int head_levels, int lds_levels) : mem(heap), k(uint32_t(heap.size())), HL(head_levels), LL(lds_levels) {
         len = k - 1;
         cap = (1u << LL) - 1;
+        first_parked = cap >> 1;
         assert(len >= cap && HL >= 1 && HL < LL);
         D = level_of(k - 1);
         assert(D >= LL);
-        auto spine = [&](int j) { return (k >> (D - j)) - 1; };
-        // lane assignment: spine parents q_0 .. q_{D-1} -> lanes 0 .. D-1; the other parents of levels 0 .. HL-1 behind them in BFS order
-        std::vector<uint32_t> lane_pos;
+        // lanes: 0 virtual, 1 .. D spine parents q_0 .. q_{D-1}, then the other parents of levels 0 .. HL-2, then those of level HL-1
+        lane_pos.assign(1, 0xffffffffu);
         for (int j = 0; j < D; ++j) lane_pos.push_back(spine(j));
-        for (uint32_t p = 0; p < (1u << HL) - 1; ++p) if (spine(level_of(p)) != p) lane_pos.push_back(p);
+        for (uint32_t p = 0; p < (1u << (HL - 1)) - 1; ++p) if (!on_spine(p)) lane_pos.push_back(p);
+        for (uint32_t p = (1u << (HL - 1)) - 1; p < (1u << HL) - 1; ++p) if (!on_spine(p)) lane_pos.push_back(p);
         n_lanes = int(lane_pos.size());
         assert(n_lanes <= 64);
-        auto lane_of = [&](uint32_t p) { for (int i = 0; i < n_lanes; ++i) if (lane_pos[i] == p) return i; return -1; };
+        for (int i = 0; i < n_lanes; ++i) valid[i] = true;
         for (int i = 0; i < n_lanes; ++i) {
-            pos[i] = lane_pos[i];
-            ischain[i] = i < D;
-            const uint32_t l = 2 * pos[i] + 1, r = l + 1;
-            auto kind = [&](uint32_t c) { return c == k - 1 ? kBottom : c >= len ? kNone : lane_of(c) >= 0 ? kHead : kTail; };
-            kindL[i] = kind(l); kindR[i] = kind(r);
-            clL[i] = kindL[i] == kHead ? lane_of(l) : 64; clR[i] = kindR[i] == kHead ? lane_of(r) : 64;
-            if (kindL[i] != kNone) Lv[i] = mem[l];
-            if (kindR[i] != kNone) Rv[i] = mem[r];
-            if (ischain[i]) side[i] = spine(i + 1) == r ? 1 : 0;
-            // ancestors: walk up from pos[i]
-            for (uint32_t c = pos[i]; c != 0;) {
-                const uint32_t par = (c - 1) / 2; const int pl = lane_of(par);
-                assert(pl >= 0 && pl < i);                   // lane order = depth order along every path
-                ancmask[i] |= uint64_t{1} << pl;
-                if (c == 2 * par + 2) ancval[i] |= uint64_t{1} << pl;
-                c = par;
-            }
+            const bool super = i == 0;
+            lpos[i] = super ? 0 : 2 * lane_pos[i] + 1; rpos[i] = lpos[i] + 1;
+            kind_l[i] = super ? 1 : kind_of(lpos[i]); kind_r[i] = super ? 0 : kind_of(rpos[i]);
+            nl_l[i] = kind_l[i] == 1 ? (super ? 1 : lane_of(lpos[i])) : 64; nl_r[i] = kind_r[i] == 1 ? lane_of(rpos[i]) : 64;
+            if (kind_l[i]) { lc[i] = mem[lpos[i]].cost; li[i] = mem[lpos[i]].id; }
+            if (kind_r[i]) { rc[i] = mem[rpos[i]].cost; ri[i] = mem[rpos[i]].id; }
+            if (kind_l[i] == 2) words[2 * i] = mem[lpos[i]];
+            if (kind_r[i] == 2) words[2 * i + 1] = mem[rpos[i]];
+            if (!super)
+                for (uint32_t c = lane_pos[i]; c != 0;) {
+                    const uint32_t par = (c - 1) / 2; const int pl = lane_of(par);
+                    assert(pl >= 1 && pl < i);               // lane order = depth order along every path
+                    anc_mask[i] |= uint64_t{1} << pl;
+                    if (c == 2 * par + 2) anc_val[i] |= uint64_t{1} << pl;
+                    c = par;
+                }
+            const uint64_t bit = uint64_t{1} << i;
+            VALID |= bit;
+            if (kind_l[i] == 1 || kind_l[i] == 2) EXL |= bit;
+            if (kind_r[i] == 1 || kind_r[i] == 2) EXR |= bit;
+            if (kind_l[i] == 1) HLm |= bit;
+            if (kind_r[i] == 1) HRm |= bit;
+            if (kind_l[i] == 2) TL |= bit;
+            if (kind_r[i] == 2) TR |= bit;
+            if (i >= 1 && i <= D && spine(i) == rpos[i]) SIDE |= bit;
         }
-        root = mem[0];
+        CHAIN = (uint64_t{2} << D) - 1; CHAINCMP = (uint64_t{1} << D) - 1;
         recompute();
+        vc = (SIDE >> D & 1) ? rc[D] : lc[D]; vi = (SIDE >> D & 1) ? ri[D] : li[D];
+        root_c = lc[0];
     }
 
     void recompute() {
         B = 0;
-        for (int i = 0; i < n_lanes; ++i) {
-            const bool exL = kindL[i] == kHead || kindL[i] == kTail, exR = kindR[i] == kHead || kindR[i] == kTail;
-            b[i] = exR && !(Rv[i].cost > Lv[i].cost);         // comp(second, second - 1): take the left child iff right > left
-            C[i] = b[i] ? Rv[i] : Lv[i];
-            ex[i] = b[i] ? exR : exL;
-            const int ck = b[i] ? kindR[i] : kindL[i];
-            nl[i] = ck == kHead ? (b[i] ? clR[i] : clL[i]) : 64;
-            if (b[i]) B |= uint64_t{1} << i;
+        for (int i = 0; i < 64; ++i) if (!(rc[i] > lc[i])) B |= uint64_t{1} << i;       // comp(second, second - 1): take the left child iff right > left
+        B &= EXR;
+        for (int i = 0; i < 64; ++i) {
+            const bool b = B >> i & 1;
+            chc[i] = b ? rc[i] : lc[i]; chi[i] = b ? ri[i] : li[i]; nl[i] = b ? nl_r[i] : nl_l[i];
         }
-        for (int i = 0; i < n_lanes; ++i) NC[i] = nl[i] < 64 ? C[nl[i]] : Ent{};      // ds_bpermute
+        EX = EXL ^ (B & (EXL ^ EXR));
+        CHH = HLm ^ (B & (HLm ^ HRm));
+        for (int i = 0; i < 64; ++i) { nchc[i] = chc[nl[i] & 63]; nchi[i] = chi[nl[i] & 63]; }       // ds_bpermute (lane = address / 4 mod 64)
     }
-    void fold() {                                             // take what the tail has published
-        for (int i = 0; i < n_lanes; ++i)
-            for (int s = 0; s < 2; ++s)
-                if ((pend[i] >> s & 1) && slot_flag[2 * i + s]) {
-                    (s ? Rv[i] : Lv[i]) = slot_val[2 * i + s];
-                    slot_flag[2 * i + s] = false;
-                    pend[i] &= ~(1 << s);
-                }
+    void fold(const Ent* w) {                                 // w = the words as read (two per lane)
+        PEND = 0;
+        for (int i = 0; i < 64; ++i) {
+            if (TL >> i & 1) { lc[i] = w[2 * i].cost; li[i] = w[2 * i].id; }
+            if (TR >> i & 1) { rc[i] = w[2 * i + 1].cost; ri[i] = w[2 * i + 1].id; }
+            if (int32_t(li[i] | ri[i]) < 0) PEND |= uint64_t{1} << i;
+        }
     }
 
-    // one replacement; returns false when it has to wait (for a publish or for ring space) - nothing was changed then
-    bool head_replace(Ent x) {
-        fold(); recompute();                                  // (the kernel folds after the push of the previous replacement)
-        const Ent v = ischain[D - 1] ? (side[D - 1] ? Rv[D - 1] : Lv[D - 1]) : Ent{};
-        uint64_t P = 0, PG = 0, Pbad = 0;
-        for (int i = 0; i < n_lanes; ++i) {
-            const bool on = ((B ^ ancval[i]) & ancmask[i]) == 0;
-            const bool moves = ex[i] && !(C[i].cost > v.cost);
-            if (on) P |= uint64_t{1} << i;
-            if (on && moves) PG |= uint64_t{1} << i;
-            if (on && pend[i]) Pbad |= uint64_t{1} << i;
+    // one replacement; returns false when it has to wait for a pending child (registers re-folded, nothing else changed)
+    bool head_replace(float xc, uint32_t xi) {
+        uint64_t P = 0, G = 1;
+        for (int i = 0; i < 64; ++i) {
+            if (((B ^ anc_val[i]) & anc_mask[i]) == 0) P |= uint64_t{1} << i;
+            if (!(chc[i] > vc)) G |= uint64_t{1} << i;
         }
-        const int pstar = ffs64(P & ~PG), fb = ffs64(Pbad);
-        if (fb != 64 && fb <= pstar) { ++head_stalls; return false; }
-        const bool exits = pstar == 64;
-        if (exits && ring.size() >= ring_cap) { ++head_stalls; return false; }
-        const uint64_t M = exits ? PG : PG & ((uint64_t{1} << pstar) - 1);
-        const Ent C0 = C[0];
-        int z = -1;
-        for (int i = 0; i < n_lanes; ++i) {
-            if (!(M >> i & 1)) continue;
-            const int ck = b[i] ? kindR[i] : kindL[i];
-            if (ck == kHead) (b[i] ? Rv[i] : Lv[i]) = nl[i] < pstar ? NC[i] : v;
-            else { assert(ck == kTail && exits); assert(z < 0); z = i; }
+        P &= VALID;
+        const uint64_t PG = P & G & EX, stop = P & ~PG, below = stop - 1, M = PG & below;
+        if (P & PEND & (stop ^ below)) { ++head_blocked; fold(words); recompute(); return false; }
+        const uint32_t pstar = stop ? uint32_t(ffs64(stop)) : 0xffffffffu;
+        const uint64_t MH = M & CHH, TOK = M & ~CHH;
+        for (int i = 0; i < 64; ++i) {
+            const bool from_below = uint32_t(nl[i]) < pstar;
+            const float wc = from_below ? nchc[i] : vc; const uint32_t wi = from_below ? nchi[i] : vi;
+            if ((MH & B) >> i & 1) { rc[i] = wc; ri[i] = wi; }
+            if ((MH & ~B) >> i & 1) { lc[i] = wc; li[i] = wi; }
         }
-        root = (M & 1) ? C0 : v;
-        if (exits) {
-            assert(z >= 0 && z == 63 - __builtin_clzll(P));
-            Token t; t.pos = 2 * pos[z] + 1 + (b[z] ? 1 : 0); t.slot = uint32_t(2 * z + (b[z] ? 1 : 0)); t.v = v;
-            ring.push_back(t); ++tokens;
-            pend[z] |= 1 << (b[z] ? 1 : 0);
+        if (TOK) {
+            assert(stop == 0 && __builtin_popcountll(TOK) == 1);
+            const int z = ffs64(TOK);
+            assert(z == 63 - __builtin_clzll(P));
+            const int s = 2 * z + int(B >> z & 1);
+            assert(!(words[s].id & kTokenTag));
+            words[s] = Ent{vc, vi | kTokenTag};
+            ++tokens;
+        } else assert(stop != 0);
+        const Ent w_after[128] = {};                          // (the kernel reads the words here; the model folds from `words` below)
+        (void)w_after;
+        // push x: a sorted insert into the spine (lane i keeps level i, level D = position k - 1)
+        float cvc[64], upc[64]; uint32_t cvi[64], upi[64];
+        for (int i = 0; i < 64; ++i) { const bool sd = SIDE >> i & 1; cvc[i] = sd ? rc[i] : lc[i]; cvi[i] = sd ? ri[i] : li[i]; }
+        for (int i = 0; i < 64; ++i) { upc[i] = i ? cvc[i - 1] : cvc[0]; upi[i] = i ? cvi[i - 1] : cvi[0]; }       // DPP wave_shr:1
+        uint64_t gt = 0;
+        for (int i = 0; i < 64; ++i) if (cvc[i] > xc) gt |= uint64_t{1} << i;
+        const uint64_t stays = ~gt & CHAINCMP;
+        const int land = stays ? 64 - __builtin_clzll(stays) : 0;
+        const uint64_t SH = CHAIN & (~uint64_t{0} << land);
+        float wcD = 0; uint32_t wiD = 0;
+        for (int i = 0; i < 64; ++i) {
+            const bool not_here = i != land;
+            const float wc = not_here ? upc[i] : xc; const uint32_t wi = not_here ? upi[i] : xi;
+            if ((SH & SIDE) >> i & 1) { rc[i] = wc; ri[i] = wi; }
+            if ((SH & ~SIDE) >> i & 1) { lc[i] = wc; li[i] = wi; }
+            if (i == D) { wcD = wc; wiD = wi; }
         }
-        // push x: sorted insert into the spine (levels 0 .. D; lane i keeps level i + 1, the root is level 0)
-        Ent cv[64], up[64];
-        for (int i = 0; i < D; ++i) cv[i] = side[i] ? Rv[i] : Lv[i];
-        for (int i = 0; i < D; ++i) up[i] = i == 0 ? root : cv[i - 1];                 // DPP wave_shr:1, lane 0 keeps `old` = root
-        uint64_t W = root.cost > x.cost ? 1 : 0;
-        for (int i = 0; i + 1 < D; ++i) if (cv[i].cost > x.cost) W |= uint64_t{2} << i;      // bit j = level j moves down
-        const uint64_t Z = ~W & ((uint64_t{1} << D) - 1);
-        const int J = Z ? 64 - __builtin_clzll(Z) : 0;        // landing level: below the deepest ancestor that is not greater
-        for (int i = 0; i < D; ++i)
-            if (i + 1 >= J) (side[i] ? Rv[i] : Lv[i]) = i + 1 == J ? x : up[i];
-        if (J == 0) root = x;
+        vc = wcD; vi = wiD;
+        fold(words);
+        recompute();
+        root_c = lc[0];
         ++replacements;
         return true;
     }
 
-    // ---- tail: one iteration of the wave ---------------------------------------------------------------------------------------
-    void tail_iteration(std::mt19937& rng) {
-        // pick up new tokens into free lanes (in ring order; a token that follows another one into the same sub-heap keeps two levels behind)
-        int picked = 0;
-        while (!ring.empty() && picked < 2) {
-            const Token t = ring.front();
-            bool clash = false; int free_lane = -1;
-            for (int i = 0; i < 64; ++i) {
-                if (t_live[i] && t_root[i] == t.pos && t_steps[i] < 2) clash = true;
-                if (!t_live[i] && free_lane < 0) free_lane = i;
+    // ---- T1: one look at the words ---------------------------------------------------------------------------------------------
+    void t1_look() {
+        struct Plan { bool has = false, below_lds = false, act = false, lands = false; uint32_t e = 0, widx = 0, cpos = 0; Ent v, c; } pl[64];
+        size_t n_hands = 0;
+        for (int i = 0; i < n_lanes; ++i) {
+            const bool t0 = kind_l[i] == 2 && (words[2 * i].id & (kTokenTag | kHandedTag)) == kTokenTag;
+            const bool t1 = kind_r[i] == 2 && (words[2 * i + 1].id & (kTokenTag | kHandedTag)) == kTokenTag;
+            assert(!(t0 && t1));
+            Plan& p = pl[i];
+            p.has = t0 || t1;
+            if (!p.has) continue;
+            p.e = t1 ? rpos[i] : lpos[i]; p.widx = uint32_t(2 * i + (t1 ? 1 : 0));
+            p.v = words[p.widx]; p.v.id &= ~kTokenTag;
+            p.below_lds = p.e >= first_parked;
+            if (!p.below_lds) {
+                const Ent cl = mem[2 * p.e + 1], cr = mem[2 * p.e + 2];
+                p.act = cl.id != kOpenHole && cr.id != kOpenHole;
+                const bool right = !(cr.cost > cl.cost);
+                p.c = right ? cr : cl; p.cpos = 2 * p.e + 1 + (right ? 1 : 0);
+                p.lands = p.c.cost > p.v.cost;
             }
-            if (clash || free_lane < 0) break;
-            if (level_of(t.pos) >= LL - 1) {                  // the sub-root has no children inside LDS: straight to the deep wave
-                if (deep_ring.size() >= deep_cap) break;
-                deep_ring.push_back(DeepTask{t.pos, int(t.slot), t.v}); ++forwarded;
-                ring.pop_front(); ++picked;
-                continue;
-            }
-            ring.pop_front(); ++picked;
-            t_live[free_lane] = true; t_pos[free_lane] = t.pos; t_root[free_lane] = t.pos; t_steps[free_lane] = 0; t_slot[free_lane] = int(t.slot); t_v[free_lane] = t.v;
+            if (p.below_lds || (p.act && !p.lands)) ++n_hands;
         }
-        (void)rng;
-        // an open hole among the children any lane is about to read stalls the whole wave (a later token could otherwise overtake)
-        for (int i = 0; i < 64; ++i)
-            if (t_live[i] && (mem[2 * t_pos[i] + 1].id == kOpenHole || mem[2 * t_pos[i] + 2].id == kOpenHole)) { ++tail_stalls; return; }
-        // lanes about to park need room in the deep ring: count them first (reads happen before writes in lockstep)
-        Ent rl[64], rr[64];
-        for (int i = 0; i < 64; ++i) if (t_live[i]) { rl[i] = mem[2 * t_pos[i] + 1]; rr[i] = mem[2 * t_pos[i] + 2]; }
-        size_t parks = 0;
-        for (int i = 0; i < 64; ++i)
-            if (t_live[i]) {
-                const bool right = !(rr[i].cost > rl[i].cost);
-                const Ent c = right ? rr[i] : rl[i];
-                if (!(c.cost > t_v[i].cost) && level_of(2 * t_pos[i] + 1) == LL - 1) ++parks;
+        if (ring.size() + n_hands > ring_cap) return;
+        for (int i = 0; i < n_lanes; ++i) {
+            Plan& p = pl[i];
+            if (!p.has) continue;
+            if (p.act) {
+                const Ent w = p.lands ? p.v : p.c;
+                mem[p.e] = w;
+                if (!p.lands) mem[p.cpos].id = kOpenHole;
+                words[p.widx] = w;
+                ++first_steps;
             }
-        if (deep_ring.size() + parks > deep_cap) { ++tail_stalls; return; }
-        for (int i = 0; i < 64; ++i) {
-            if (!t_live[i]) continue;
-            const bool right = !(rr[i].cost > rl[i].cost);
-            const Ent c = right ? rr[i] : rl[i];
-            const uint32_t cpos = 2 * t_pos[i] + 1 + (right ? 1 : 0);
-            Ent written;
-            if (c.cost > t_v[i].cost) { written = t_v[i]; mem[t_pos[i]] = written; t_live[i] = false; }
-            else {
-                written = c; mem[t_pos[i]] = written;
-                t_pos[i] = cpos;
-                if (level_of(cpos) == LL - 1) {               // last LDS level: its children are in HBM
-                    mem[cpos].id = kOpenHole;
-                    deep_ring.push_back(DeepTask{cpos, -1, t_v[i]}); ++deep_tasks;
-                    t_live[i] = false;
-                }
-            }
-            if (t_steps[i] == 0) { slot_val[t_slot[i]] = written; slot_flag[t_slot[i]] = true; }
-            ++t_steps[i];
+            if (p.below_lds) { ring.push_back(Tok{p.e, p.widx, p.v}); words[p.widx].id = p.v.id | kTokenTag | kHandedTag; ++forwarded; }
+            else if (p.act && !p.lands) ring.push_back(Tok{p.cpos, kNoSlot, p.v});
         }
     }
 
-    // ---- deep: a batch of tasks, one lane each, the libstdc++ loop literally ----------------------------------------------------
+    // ---- T2: one iteration --------------------------------------------------------------------------------------------------------
+    void t2_iteration() {
+        int picked = 0;
+        while (!ring.empty() && picked < 2) {
+            const Tok t = ring.front();
+            if (t.pos >= first_parked) {
+                if (deep_ring.size() >= deep_cap) break;
+                deep_ring.push_back(t);
+            } else {
+                int free_lane = -1;
+                for (int i = 0; i < 64; ++i) if (!t_live[i]) { free_lane = i; break; }
+                if (free_lane < 0) break;
+                t_live[free_lane] = true; t_pos[free_lane] = t.pos; t_v[free_lane] = t.v;
+            }
+            ring.pop_front(); ++picked;
+        }
+        struct Plan { bool act = false, lands = false, parks = false; uint32_t cpos = 0; Ent c; } pl[64];
+        size_t n_parks = 0;
+        for (int i = 0; i < 64; ++i) {
+            if (!t_live[i]) continue;
+            const Ent cl = mem[2 * t_pos[i] + 1], cr = mem[2 * t_pos[i] + 2];
+            Plan& p = pl[i];
+            p.act = cl.id != kOpenHole && cr.id != kOpenHole;
+            const bool right = !(cr.cost > cl.cost);
+            p.c = right ? cr : cl; p.cpos = 2 * t_pos[i] + 1 + (right ? 1 : 0);
+            p.lands = p.c.cost > t_v[i].cost;
+            p.parks = p.act && !p.lands && p.cpos >= first_parked;
+            if (p.parks) ++n_parks;
+        }
+        if (deep_ring.size() + n_parks > deep_cap) return;
+        for (int i = 0; i < 64; ++i) {
+            const Plan& p = pl[i];
+            if (!t_live[i] || !p.act) continue;
+            mem[t_pos[i]] = p.lands ? t_v[i] : p.c;
+            if (!p.lands) mem[p.cpos].id = kOpenHole;
+            if (p.parks) { deep_ring.push_back(Tok{p.cpos, kNoSlot, t_v[i]}); ++deep_tasks; }
+            t_live[i] = !p.lands && !p.parks;
+            t_pos[i] = p.cpos;
+        }
+    }
+
+    // ---- deep: a batch of tasks, one lane each, top-down ------------------------------------------------------------------------------
     void deep_batch() {
         const size_t n = std::min<size_t>(deep_ring.size(), 64);
         for (size_t t = 0; t < n; ++t) {
-            const DeepTask task = deep_ring[t];
-            uint32_t hole = task.pos; const uint32_t top = hole; uint32_t child = hole;
-            while (child < (len - 1) / 2) {
-                child = 2 * (child + 1);
-                if (mem[child].cost > mem[child - 1].cost) --child;
-                mem[hole] = mem[child]; hole = child;
+            const Tok task = deep_ring[t];
+            uint32_t p = task.pos; Ent top_val = task.v;
+            for (;;) {
+                const uint32_t l = 2 * p + 1;
+                Ent w = task.v; uint32_t next = 0; bool lands = true;
+                if (l < len) {
+                    Ent c = mem[l]; next = l;
+                    if (l + 1 < len) { const Ent r = mem[l + 1]; if (!(r.cost > c.cost)) { c = r; next = l + 1; } }
+                    assert(c.id != kOpenHole);
+                    if (!(c.cost > task.v.cost)) { w = c; lands = false; }
+                }
+                if (p == task.pos) top_val = w;
+                mem[p] = w;
+                if (lands) break;
+                p = next;
             }
-            if ((len & 1u) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); mem[hole] = mem[child - 1]; hole = child - 1; }
-            while (hole > top) {
-                const uint32_t parent = (hole - 1) / 2;
-                if (!(mem[parent].cost > task.v.cost)) break;
-                mem[hole] = mem[parent]; hole = parent;
-            }
-            mem[hole] = task.v;
-            if (task.slot >= 0) { slot_val[task.slot] = mem[task.pos]; slot_flag[task.slot] = true; }
+            if (task.slot != kNoSlot) words[task.slot] = top_val;
         }
         deep_ring.erase(deep_ring.begin(), deep_ring.begin() + long(n));
     }
@@ -271,15 +316,13 @@ struct Model {
     bool idle() const {
         if (!ring.empty() || !deep_ring.empty()) return false;
         for (int i = 0; i < 64; ++i) if (t_live[i]) return false;
+        for (int i = 0; i < 128; ++i) if (words[i].id & kTokenTag) return false;
         return true;
     }
     void flush() {
-        fold();
-        for (int i = 0; i < n_lanes; ++i) assert(!pend[i]);
-        mem[0] = root;
         for (int i = 0; i < n_lanes; ++i) {
-            if (kindL[i] == kHead || kindL[i] == kBottom) mem[2 * pos[i] + 1] = Lv[i];
-            if (kindR[i] == kHead || kindR[i] == kBottom) mem[2 * pos[i] + 2] = Rv[i];
+            if (kind_l[i] == 1 || kind_l[i] == 3) mem[lpos[i]] = Ent{lc[i], li[i]};
+            if (kind_r[i] == 1 || kind_r[i] == 3) mem[rpos[i]] = Ent{rc[i], ri[i]};
         }
     }
 };
@@ -304,22 +347,24 @@ static bool run_case(uint32_t seed, size_t n, size_t k, int HL, int LL, int dist
     size_t i = k;
     long guard = 0;
     while (i < n || !m.idle()) {
-        if (++guard > 400000000L) { std::printf("  livelock\n"); return false; }
+        if (++guard > 3000000L + 200L * long(n)) { std::printf("  livelock at i=%zu of %zu: ring %zu deep %zu PEND %llx, blocked %ld tokens %ld first %ld\n", i, n, m.ring.size(), m.deep_ring.size(), (unsigned long long)m.PEND, m.head_blocked, m.tokens, m.first_steps); for (int q = 0; q < 128; ++q) if (m.words[q].id & kTokenTag) std::printf("    word %d id %x\n", q, m.words[q].id); for (int q = 0; q < 64; ++q) if (m.t_live[q]) std::printf("    t2 lane %d pos %u\n", q, m.t_pos[q]); return false; }
         const unsigned pick = rng() % 16;
         if (pick < unsigned(head_bias)) {
             if (i < n) {
-                if (!(m.root.cost < cost[i])) { ++i; continue; }
-                if (m.head_replace(Ent{cost[i], uint32_t(i)})) ++i;
+                if (!(m.root_c < cost[i])) { ++i; continue; }
+                if (m.head_replace(cost[i], uint32_t(i))) ++i;
             }
-        } else if (pick < unsigned(head_bias) + (16 - unsigned(head_bias)) * 2 / 3) m.tail_iteration(rng);
-        else m.deep_batch();
+        } else {
+            const unsigned r = rng() % 4;
+            if (r < 2) m.t1_look(); else if (r == 2) m.t2_iteration(); else m.deep_batch();
+        }
     }
     m.flush();
     bool ok = size_t(m.replacements) == ref_repl;
     for (size_t j = 0; j < k && ok; ++j) ok = m.mem[j].id == uint32_t(ref[j].id) && m.mem[j].cost == ref[j].cost;
     if (!ok || verbose)
-        std::printf("%s seed %u n %zu k %zu HL %d LL %d distinct %d: %ld replacements (ref %zu), %ld tokens (%ld forwarded), %ld deep, head stalls %ld, tail stalls %ld\n",
-                    ok ? "ok  " : "FAIL", seed, n, k, HL, LL, distinct, m.replacements, ref_repl, m.tokens, m.forwarded, m.deep_tasks, m.head_stalls, m.tail_stalls);
+        std::printf("%s seed %u n %zu k %zu HL %d LL %d distinct %d: %ld replacements (ref %zu), %ld tokens (%ld passed on whole), %ld first steps, %ld deep, head blocked %ld\n",
+                    ok ? "ok  " : "FAIL", seed, n, k, HL, LL, distinct, m.replacements, ref_repl, m.tokens, m.forwarded, m.first_steps, m.deep_tasks, m.head_blocked);
     return ok;
 }
 
@@ -339,6 +384,10 @@ int main(int argc, char** argv) {
         const int head_bias = 2 + int(rng() % 12);
         if (!run_case(uint32_t(s), n, k, HL, LL, distinct, head_bias, s < 8)) ++fails;
     }
-    std::printf("%d cases, %d failures\n", seeds, fails);
+    // the kernel's own configuration
+    for (size_t k : {16385u, 16386u, 32768u, 50000u})
+        for (int distinct : {0, 5, 1000})
+            if (!run_case(uint32_t(k + distinct), k * 3, k, 5, 14, distinct, 8, true)) ++fails;
+    std::printf("%d failures\n", fails);
     return fails != 0;
 }
