@@ -74,7 +74,7 @@ struct Model {
     float vc = 0; uint32_t vi = 0; float root_c = 0;
     // ---- shared "LDS" ------------------------------------------------------------------------------------------------------------
     Ent words[128];
-    std::deque<Tok> ring, deep_ring; size_t ring_cap = 64, deep_cap = 64;             // (each at least one entry per lane: a whole look / iteration must fit, like kTokCap, kDeepCap)
+    std::deque<Tok> deep_ring; size_t deep_cap = 64;             // (each at least one entry per lane: a whole look / iteration must fit, like kTokCap, kDeepCap)
     // ---- T2 lanes ---------------------------------------------------------------------------------------------------------------
     bool t_live[64] = {}; uint32_t t_pos[64] = {}; Ent t_v[64];
     long head_blocked = 0, tokens = 0, first_steps = 0, deep_tasks = 0, replacements = 0, forwarded = 0;
@@ -208,61 +208,44 @@ struct Model {
         return true;
     }
 
-    // ---- T1: one look at the words ---------------------------------------------------------------------------------------------
+    // ---- T1: one look at the words (one lane per sub-root; its mailbox holds at most one pop that goes on) ----------------------------
+    struct Box { uint32_t tag = 0, pos = 0; Ent v; };         // tag: 0 empty, 1 a pop that goes on at pos, 2 + w a whole sub-root for the deep wave
+    Box boxes[128];
     void t1_look() {
-        struct Plan { bool has = false, below_lds = false, act = false, lands = false; uint32_t e = 0, widx = 0, cpos = 0; Ent v, c; } pl[64];
-        size_t n_hands = 0;
-        for (int i = 0; i < n_lanes; ++i) {
-            const bool t0 = kind_l[i] == 2 && (words[2 * i].id & (kTokenTag | kHandedTag)) == kTokenTag;
-            const bool t1 = kind_r[i] == 2 && (words[2 * i + 1].id & (kTokenTag | kHandedTag)) == kTokenTag;
-            assert(!(t0 && t1));
-            Plan& p = pl[i];
-            p.has = t0 || t1;
-            if (!p.has) continue;
-            p.e = t1 ? rpos[i] : lpos[i]; p.widx = uint32_t(2 * i + (t1 ? 1 : 0));
-            p.v = words[p.widx]; p.v.id &= ~kTokenTag;
-            p.below_lds = p.e >= first_parked;
-            if (!p.below_lds) {
-                const Ent cl = mem[2 * p.e + 1], cr = mem[2 * p.e + 2];
-                p.act = cl.id != kOpenHole && cr.id != kOpenHole;
+        for (int i = 0; i < n_lanes; ++i)
+            for (int side = 0; side < 2; ++side) {
+                if ((side ? kind_r[i] : kind_l[i]) != 2) continue;
+                const uint32_t widx = uint32_t(2 * i + side), e = side ? rpos[i] : lpos[i];
+                if ((words[widx].id & (kTokenTag | kHandedTag)) != kTokenTag) continue;
+                Ent v = words[widx]; v.id &= ~kTokenTag;
+                Box& box = boxes[widx];
+                if (e >= first_parked) {                      // no children inside LDS: the deep wave does all of it
+                    if (box.tag) continue;
+                    words[widx].id = v.id | kTokenTag | kHandedTag;
+                    box = Box{2 + widx, e, v}; ++forwarded;
+                    continue;
+                }
+                const uint32_t c_l = 2 * e + 1;
+                const Ent cl = mem[c_l], cr = mem[c_l + 1];
+                if (cl.id == kOpenHole || cr.id == kOpenHole) continue;      // the pop ahead in this sub-heap has not moved on yet
                 const bool right = !(cr.cost > cl.cost);
-                p.c = right ? cr : cl; p.cpos = 2 * p.e + 1 + (right ? 1 : 0);
-                p.lands = p.c.cost > p.v.cost;
-            }
-            if (p.below_lds || (p.act && !p.lands)) ++n_hands;
-        }
-        if (ring.size() + n_hands > ring_cap) return;
-        for (int i = 0; i < n_lanes; ++i) {
-            Plan& p = pl[i];
-            if (!p.has) continue;
-            if (p.act) {
-                const Ent w = p.lands ? p.v : p.c;
-                mem[p.e] = w;
-                if (!p.lands) mem[p.cpos].id = kOpenHole;
-                words[p.widx] = w;
+                const Ent c = right ? cr : cl; const uint32_t cpos = c_l + (right ? 1 : 0);
+                const bool lands = c.cost > v.cost;
+                if (!lands && box.tag) continue;              // a pop that goes on needs the mailbox empty
+                words[widx] = lands ? v : c;
                 ++first_steps;
+                if (!lands) { mem[cpos].id = kOpenHole; box = Box{1, cpos, v}; }
             }
-            if (p.below_lds) { ring.push_back(Tok{p.e, p.widx, p.v}); words[p.widx].id = p.v.id | kTokenTag | kHandedTag; ++forwarded; }
-            else if (p.act && !p.lands) ring.push_back(Tok{p.cpos, kNoSlot, p.v});
+    }
+    void t1_flush() {                                         // the sub-roots' own heap entries: nobody's input, written once at the end
+        for (int i = 0; i < n_lanes; ++i) {
+            if (kind_l[i] == 2 && lpos[i] < first_parked) mem[lpos[i]] = words[2 * i];
+            if (kind_r[i] == 2 && rpos[i] < first_parked) mem[rpos[i]] = words[2 * i + 1];
         }
     }
 
     // ---- T2: one iteration --------------------------------------------------------------------------------------------------------
-    void t2_iteration() {
-        int picked = 0;
-        while (!ring.empty() && picked < 2) {
-            const Tok t = ring.front();
-            if (t.pos >= first_parked) {
-                if (deep_ring.size() >= deep_cap) break;
-                deep_ring.push_back(t);
-            } else {
-                int free_lane = -1;
-                for (int i = 0; i < 64; ++i) if (!t_live[i]) { free_lane = i; break; }
-                if (free_lane < 0) break;
-                t_live[free_lane] = true; t_pos[free_lane] = t.pos; t_v[free_lane] = t.v;
-            }
-            ring.pop_front(); ++picked;
-        }
+    void t2_iteration(std::mt19937& rng) {
         struct Plan { bool act = false, lands = false, parks = false; uint32_t cpos = 0; Ent c; } pl[64];
         size_t n_parks = 0;
         for (int i = 0; i < 64; ++i) {
@@ -276,15 +259,32 @@ struct Model {
             p.parks = p.act && !p.lands && p.cpos >= first_parked;
             if (p.parks) ++n_parks;
         }
-        if (deep_ring.size() + n_parks > deep_cap) return;
-        for (int i = 0; i < 64; ++i) {
-            const Plan& p = pl[i];
-            if (!t_live[i] || !p.act) continue;
-            mem[t_pos[i]] = p.lands ? t_v[i] : p.c;
-            if (!p.lands) mem[p.cpos].id = kOpenHole;
-            if (p.parks) { deep_ring.push_back(Tok{p.cpos, kNoSlot, t_v[i]}); ++deep_tasks; }
-            t_live[i] = !p.lands && !p.parks;
-            t_pos[i] = p.cpos;
+        if (deep_ring.size() + n_parks <= deep_cap)
+            for (int i = 0; i < 64; ++i) {
+                const Plan& p = pl[i];
+                if (!t_live[i] || !p.act) continue;
+                mem[t_pos[i]] = p.lands ? t_v[i] : p.c;
+                if (!p.lands) mem[p.cpos].id = kOpenHole;
+                if (p.parks) { deep_ring.push_back(Tok{p.cpos, kNoSlot, t_v[i]}); ++deep_tasks; }
+                t_live[i] = !p.lands && !p.parks;
+                t_pos[i] = p.cpos;
+            }
+        // new pops from the mailboxes, at most two per round (any two: the kernel takes the lowest lanes, which mailboxes those are is arbitrary)
+        int picked = 0;
+        const int start = int(rng() % 128);
+        for (int q = 0; q < 128 && picked < 2; ++q) {
+            Box& box = boxes[(start + q) % 128];
+            if (!box.tag) continue;
+            if (box.pos >= first_parked) {
+                if (deep_ring.size() >= deep_cap) break;
+                deep_ring.push_back(Tok{box.pos, box.tag >= 2 ? box.tag - 2 : kNoSlot, box.v});
+            } else {
+                int free_lane = -1;
+                for (int i = 0; i < 64; ++i) if (!t_live[i]) { free_lane = i; break; }
+                if (free_lane < 0) break;
+                t_live[free_lane] = true; t_pos[free_lane] = box.pos; t_v[free_lane] = box.v;
+            }
+            box.tag = 0; ++picked;
         }
     }
 
@@ -314,12 +314,14 @@ struct Model {
     }
 
     bool idle() const {
-        if (!ring.empty() || !deep_ring.empty()) return false;
+        if (!deep_ring.empty()) return false;
+        for (int i = 0; i < 128; ++i) if (boxes[i].tag) return false;
         for (int i = 0; i < 64; ++i) if (t_live[i]) return false;
         for (int i = 0; i < 128; ++i) if (words[i].id & kTokenTag) return false;
         return true;
     }
     void flush() {
+        t1_flush();
         for (int i = 0; i < n_lanes; ++i) {
             if (kind_l[i] == 1 || kind_l[i] == 3) mem[lpos[i]] = Ent{lc[i], li[i]};
             if (kind_r[i] == 1 || kind_r[i] == 3) mem[rpos[i]] = Ent{rc[i], ri[i]};
@@ -347,7 +349,7 @@ static bool run_case(uint32_t seed, size_t n, size_t k, int HL, int LL, int dist
     size_t i = k;
     long guard = 0;
     while (i < n || !m.idle()) {
-        if (++guard > 3000000L + 200L * long(n)) { std::printf("  livelock at i=%zu of %zu: ring %zu deep %zu PEND %llx, blocked %ld tokens %ld first %ld\n", i, n, m.ring.size(), m.deep_ring.size(), (unsigned long long)m.PEND, m.head_blocked, m.tokens, m.first_steps); for (int q = 0; q < 128; ++q) if (m.words[q].id & kTokenTag) std::printf("    word %d id %x\n", q, m.words[q].id); for (int q = 0; q < 64; ++q) if (m.t_live[q]) std::printf("    t2 lane %d pos %u\n", q, m.t_pos[q]); return false; }
+        if (++guard > 3000000L + 200L * long(n)) { std::printf("  livelock at i=%zu of %zu: deep %zu PEND %llx, blocked %ld tokens %ld first %ld\n", i, n, m.deep_ring.size(), (unsigned long long)m.PEND, m.head_blocked, m.tokens, m.first_steps); for (int q = 0; q < 128; ++q) if (m.words[q].id & kTokenTag) std::printf("    word %d id %x\n", q, m.words[q].id); for (int q = 0; q < 64; ++q) if (m.t_live[q]) std::printf("    t2 lane %d pos %u\n", q, m.t_pos[q]); return false; }
         const unsigned pick = rng() % 16;
         if (pick < unsigned(head_bias)) {
             if (i < n) {
@@ -356,7 +358,7 @@ static bool run_case(uint32_t seed, size_t n, size_t k, int HL, int LL, int dist
             }
         } else {
             const unsigned r = rng() % 4;
-            if (r < 2) m.t1_look(); else if (r == 2) m.t2_iteration(); else m.deep_batch();
+            if (r < 2) m.t1_look(); else if (r == 2) m.t2_iteration(rng); else m.deep_batch();
         }
     }
     m.flush();
