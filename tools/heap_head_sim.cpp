@@ -75,8 +75,6 @@ struct Model {
     // ---- shared "LDS" ------------------------------------------------------------------------------------------------------------
     Ent words[128];
     std::deque<Tok> deep_ring; size_t deep_cap = 64;             // (each at least one entry per lane: a whole look / iteration must fit, like kTokCap, kDeepCap)
-    // ---- T2 lanes ---------------------------------------------------------------------------------------------------------------
-    bool t_live[64] = {}; uint32_t t_pos[64] = {}; Ent t_v[64];
     long head_blocked = 0, tokens = 0, first_steps = 0, deep_tasks = 0, replacements = 0, forwarded = 0;
 
     uint32_t spine(int level) const { return (k >> (D - level)) - 1; }
@@ -208,9 +206,11 @@ struct Model {
         return true;
     }
 
-    // ---- T1: one look at the words (one lane per sub-root; its mailbox holds at most one pop that goes on) ----------------------------
-    struct Box { uint32_t tag = 0, pos = 0; Ent v; };         // tag: 0 empty, 1 a pop that goes on at pos, 2 + w a whole sub-root for the deep wave
-    Box boxes[128];
+    // ---- T1: one look at the words (one lane per sub-root; the rest of a pop goes into the mailbox of one of the walker waves, in turns) ----
+    static constexpr int kWalkWaves = 2;
+    struct Box { uint32_t tag = 0, pos = 0; Ent v; };         // tag: 0 empty, 1 a pop that goes on at pos
+    Box boxes[kWalkWaves][128];
+    int turn[128] = {};
     void t1_look() {
         for (int i = 0; i < n_lanes; ++i)
             for (int side = 0; side < 2; ++side) {
@@ -218,11 +218,10 @@ struct Model {
                 const uint32_t widx = uint32_t(2 * i + side), e = side ? rpos[i] : lpos[i];
                 if ((words[widx].id & (kTokenTag | kHandedTag)) != kTokenTag) continue;
                 Ent v = words[widx]; v.id &= ~kTokenTag;
-                Box& box = boxes[widx];
                 if (e >= first_parked) {                      // no children inside LDS: the deep wave does all of it
-                    if (box.tag) continue;
+                    if (deep_ring.size() >= deep_cap) continue;
                     words[widx].id = v.id | kTokenTag | kHandedTag;
-                    box = Box{2 + widx, e, v}; ++forwarded;
+                    deep_ring.push_back(Tok{e, widx, v}); ++forwarded;
                     continue;
                 }
                 const uint32_t c_l = 2 * e + 1;
@@ -231,10 +230,17 @@ struct Model {
                 const bool right = !(cr.cost > cl.cost);
                 const Ent c = right ? cr : cl; const uint32_t cpos = c_l + (right ? 1 : 0);
                 const bool lands = c.cost > v.cost;
+                if (!lands && cpos >= first_parked) {         // the hole would stand on the last LDS level: a task for the deep wave
+                    if (deep_ring.size() >= deep_cap) continue;
+                    words[widx] = c; mem[cpos].id = kOpenHole;
+                    deep_ring.push_back(Tok{cpos, kNoSlot, v}); ++deep_tasks; ++first_steps;
+                    continue;
+                }
+                Box& box = boxes[turn[widx]][widx];
                 if (!lands && box.tag) continue;              // a pop that goes on needs the mailbox empty
                 words[widx] = lands ? v : c;
                 ++first_steps;
-                if (!lands) { mem[cpos].id = kOpenHole; box = Box{1, cpos, v}; }
+                if (!lands) { mem[cpos].id = kOpenHole; box = Box{1, cpos, v}; turn[widx] = (turn[widx] + 1) % kWalkWaves; }
             }
     }
     void t1_flush() {                                         // the sub-roots' own heap entries: nobody's input, written once at the end
@@ -244,47 +250,35 @@ struct Model {
         }
     }
 
-    // ---- T2: one iteration --------------------------------------------------------------------------------------------------------
-    void t2_iteration(std::mt19937& rng) {
-        struct Plan { bool act = false, lands = false, parks = false; uint32_t cpos = 0; Ent c; } pl[64];
+    // ---- a walker wave: one look (lane j walks pops of sub-root j) ----------------------------------------------------------------------
+    bool w_live[kWalkWaves][128] = {}; uint32_t w_pos[kWalkWaves][128] = {}; Ent w_v[kWalkWaves][128];
+    void walker_look(int ww) {
+        struct Plan { bool act = false, lands = false, parks = false; uint32_t cpos = 0; Ent c; } pl[128];
         size_t n_parks = 0;
-        for (int i = 0; i < 64; ++i) {
-            if (!t_live[i]) continue;
-            const Ent cl = mem[2 * t_pos[i] + 1], cr = mem[2 * t_pos[i] + 2];
-            Plan& p = pl[i];
-            p.act = cl.id != kOpenHole && cr.id != kOpenHole;
+        for (int j = 0; j < 128; ++j) {
+            if (!w_live[ww][j]) continue;
+            const uint32_t p = w_pos[ww][j];
+            const Ent cl = mem[2 * p + 1], cr = mem[2 * p + 2];
+            Plan& q = pl[j];
+            q.act = cl.id != kOpenHole && cr.id != kOpenHole;
             const bool right = !(cr.cost > cl.cost);
-            p.c = right ? cr : cl; p.cpos = 2 * t_pos[i] + 1 + (right ? 1 : 0);
-            p.lands = p.c.cost > t_v[i].cost;
-            p.parks = p.act && !p.lands && p.cpos >= first_parked;
-            if (p.parks) ++n_parks;
+            q.c = right ? cr : cl; q.cpos = 2 * p + 1 + (right ? 1 : 0);
+            q.lands = q.c.cost > w_v[ww][j].cost;
+            q.parks = q.act && !q.lands && q.cpos >= first_parked;
+            if (q.parks) ++n_parks;
         }
-        if (deep_ring.size() + n_parks <= deep_cap)
-            for (int i = 0; i < 64; ++i) {
-                const Plan& p = pl[i];
-                if (!t_live[i] || !p.act) continue;
-                mem[t_pos[i]] = p.lands ? t_v[i] : p.c;
-                if (!p.lands) mem[p.cpos].id = kOpenHole;
-                if (p.parks) { deep_ring.push_back(Tok{p.cpos, kNoSlot, t_v[i]}); ++deep_tasks; }
-                t_live[i] = !p.lands && !p.parks;
-                t_pos[i] = p.cpos;
+        const bool room = deep_ring.size() + n_parks <= deep_cap;       // (no room: the parking pops wait a look)
+        for (int j = 0; j < 128; ++j) {
+            const Plan& q = pl[j];
+            if (w_live[ww][j] && q.act && (room || !q.parks)) {
+                mem[w_pos[ww][j]] = q.lands ? w_v[ww][j] : q.c;
+                if (!q.lands) mem[q.cpos].id = kOpenHole;
+                if (q.parks) { deep_ring.push_back(Tok{q.cpos, kNoSlot, w_v[ww][j]}); ++deep_tasks; }
+                w_live[ww][j] = !q.lands && !q.parks;
+                w_pos[ww][j] = q.cpos;
             }
-        // new pops from the mailboxes, at most two per round (any two: the kernel takes the lowest lanes, which mailboxes those are is arbitrary)
-        int picked = 0;
-        const int start = int(rng() % 128);
-        for (int q = 0; q < 128 && picked < 2; ++q) {
-            Box& box = boxes[(start + q) % 128];
-            if (!box.tag) continue;
-            if (box.pos >= first_parked) {
-                if (deep_ring.size() >= deep_cap) break;
-                deep_ring.push_back(Tok{box.pos, box.tag >= 2 ? box.tag - 2 : kNoSlot, box.v});
-            } else {
-                int free_lane = -1;
-                for (int i = 0; i < 64; ++i) if (!t_live[i]) { free_lane = i; break; }
-                if (free_lane < 0) break;
-                t_live[free_lane] = true; t_pos[free_lane] = box.pos; t_v[free_lane] = box.v;
-            }
-            box.tag = 0; ++picked;
+            Box& box = boxes[ww][j];
+            if (!w_live[ww][j] && box.tag) { w_live[ww][j] = true; w_pos[ww][j] = box.pos; w_v[ww][j] = box.v; box.tag = 0; }
         }
     }
 
@@ -315,8 +309,7 @@ struct Model {
 
     bool idle() const {
         if (!deep_ring.empty()) return false;
-        for (int i = 0; i < 128; ++i) if (boxes[i].tag) return false;
-        for (int i = 0; i < 64; ++i) if (t_live[i]) return false;
+        for (int w = 0; w < kWalkWaves; ++w) for (int i = 0; i < 128; ++i) if (boxes[w][i].tag || w_live[w][i]) return false;
         for (int i = 0; i < 128; ++i) if (words[i].id & kTokenTag) return false;
         return true;
     }
@@ -349,7 +342,7 @@ static bool run_case(uint32_t seed, size_t n, size_t k, int HL, int LL, int dist
     size_t i = k;
     long guard = 0;
     while (i < n || !m.idle()) {
-        if (++guard > 3000000L + 200L * long(n)) { std::printf("  livelock at i=%zu of %zu: deep %zu PEND %llx, blocked %ld tokens %ld first %ld\n", i, n, m.deep_ring.size(), (unsigned long long)m.PEND, m.head_blocked, m.tokens, m.first_steps); for (int q = 0; q < 128; ++q) if (m.words[q].id & kTokenTag) std::printf("    word %d id %x\n", q, m.words[q].id); for (int q = 0; q < 64; ++q) if (m.t_live[q]) std::printf("    t2 lane %d pos %u\n", q, m.t_pos[q]); return false; }
+        if (++guard > 3000000L + 200L * long(n)) { std::printf("  livelock at i=%zu of %zu: deep %zu PEND %llx, blocked %ld tokens %ld first %ld\n", i, n, m.deep_ring.size(), (unsigned long long)m.PEND, m.head_blocked, m.tokens, m.first_steps); for (int q = 0; q < 128; ++q) if (m.words[q].id & kTokenTag) std::printf("    word %d id %x\n", q, m.words[q].id); return false; }
         const unsigned pick = rng() % 16;
         if (pick < unsigned(head_bias)) {
             if (i < n) {
@@ -358,7 +351,7 @@ static bool run_case(uint32_t seed, size_t n, size_t k, int HL, int LL, int dist
             }
         } else {
             const unsigned r = rng() % 4;
-            if (r < 2) m.t1_look(); else if (r == 2) m.t2_iteration(rng); else m.deep_batch();
+            if (r < 2) m.t1_look(); else if (r == 2) m.walker_look(int(rng() % Model::kWalkWaves)); else m.deep_batch();
         }
     }
     m.flush();
