@@ -1080,7 +1080,9 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
     const bool use_pipe = pipe_mode == 1 || (pipe_mode != 0 && !use_head);
     int heap_depth = 0;                                       // level of the last heap position k - 1
     while ((uint64_t{2} << heap_depth) <= k) ++heap_depth;
-    auto head_kernel = heap_depth + 12 <= 32 ? k_heap_select_head<T, false> : k_heap_select_head<T, true>;     // ancestor masks of 32 / 64 lanes
+    const char* wide_knob = BVH_DEV_STR("BVH_AMD_HEAP_WIDE");                       // developer: the 64-lane ancestor masks on a heap that does not need them
+    const bool wide_masks = heap_depth + 12 > 32 || (wide_knob && std::atoi(wide_knob) != 0);
+    auto head_kernel = wide_masks ? k_heap_select_head<T, true> : k_heap_select_head<T, false>;               // ancestor masks of 64 / 32 lanes
     const size_t pipe_lds = heap_lds + kQueueCap * sizeof(PipeToken<T>) + sizeof(PipeCtrl);
     if (below_lds && use_pipe)
         BVH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_heap_select_pipe<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pipe_lds)),

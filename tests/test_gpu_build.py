@@ -446,6 +446,36 @@ def test_reinsertion_fast_path_and_exact_replay_agree_with_reference(orc, scene,
     assert (f2 - f1, e2 - e1) == (0, 3)
 
 
+@pytest.mark.parametrize("knobs", ["", "BVH_AMD_HEAP_WIDE=1", "BVH_AMD_HEAP_PIPE=1", "BVH_AMD_HEAP_PIPE=0"])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_every_candidate_heap_kernel_replays_the_reference(orc, knobs, dtype, tmp_path):
+    """find_candidates' heap array (reinsertion_optimizer.h:88-105) decides the order of equal gains downstream, so every kernel that
+    replays it must leave the reference's bytes: the register-resident head with 32- and 64-lane ancestor masks (heap_head.inc), round 5's
+    two-wave loop and the one-wave loop (developer library: the knobs are read once, own process), with the replay forced in all three
+    iterations and a candidate heap that reaches below the LDS levels (600k / 300k triangles -> k = 5 % of ~1M / ~0.5M nodes)."""
+    import subprocess, sys, os
+    n = 600_000 if dtype == "float32" else 300_000
+    tris = synth.soup(n, jitter=0.01, dtype=np.dtype(dtype).type)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_HIGH).serialize()
+    path = tmp_path / "tris.npy"
+    np.save(path, tris)
+    code = (
+        "import numpy as np, torch, bvh_amd, hashlib, sys\n"
+        f"tris = torch.from_numpy(np.load(r'{path}')).cuda()\n"
+        "bb, cc = bvh_amd.tri_bounds(tris)\n"
+        "b = bvh_amd.DefaultBuilder.build(bb, cc, bvh_amd.Config(quality=bvh_amd.Quality.High), thread_pool=bvh_amd.ThreadPool())\n"
+        "assert bvh_amd.last_optimize_profile()['replayed'] == 3\n"
+        "print('sha1', hashlib.sha1(b.serialize()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BVH_AMD_REINSERT="exact", BVH_AMD_LIB=os.path.join(root, "bvh_amd", "lib", "libbvh_amd_dev.so"))
+    if knobs:
+        env.update(dict([knobs.split("=")]))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    import hashlib
+    assert r.returncode == 0 and ("sha1 " + hashlib.sha1(ref).hexdigest()) in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_standalone_optimize_matches_reference(orc):
     """bvhXX_optimize on an existing BVH (here: a binned tree, which reinsertion improves a lot), twice."""
     import bvh_amd
