@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--one-process", action="store_true",
                     help="N > 1 without torch.distributed: ONE process, bvh3f_replicate (the library's ncclCommInitAll + grouped ncclBroadcast) "
                          "and one host thread + stream per device — what a C caller of the reference API would write (tests/c/replicate.c)")
+    ap.add_argument("--ray-batches", type=int, default=4,
+                    help="distinct ray batches (seeds 1234 + rank + 1000 i) the warm-up and timed steps rotate through, so that no step re-traces the "
+                         "rays of the step before it; the plan search settles on further batches of its own")
     ap.add_argument("--fast", action="store_true", help="intersect_fast instead of the robust slab test")
     ap.add_argument("--quality", default="high", choices=["low", "medium", "high"], help="DefaultBuilder quality of the traced BVH")
     ap.add_argument("--serial-builder", action="store_true", help="DefaultBuilder without a thread pool (binned/sweep) instead of mini-trees")
@@ -390,6 +393,9 @@ def roofline_section(args, lib, *, robust, rays_here, kernel_ms, pass_ms, reorde
                 "need behind the L1 = L2 hits / R_L2 + L2 misses / R_beyond_L2), every rate measured in this run by a dependent-walk probe "
                 "in the kernel's own fetch mode; achieved = rays per launch / kernel_ms. HBM is NOT what binds this kernel: "
                 "see hbm_algorithmic below (SURVEY.md 8d's figure) and traffic",
+                "sq": None if rec is None else {"wave_time": rec["wave_time"], "lane_utilisation": rec["lane_utilisation"],
+                       "what": "the kernel's SQ counters (same child passes): share of its wave-cycles parked at s_waitcnt / issue-stalled / issuing "
+                               "(SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES), and active lanes per VALU instruction over 64"},
                 "traffic": traffic, "traffic_unit": "GB/s at the L2's fabric side (FETCH_SIZE + WRITE_SIZE)",
                 "traffic_frac_of_hbm": None if traffic is None else round(traffic / HBM_PEAK_GBS, 4), "counters_source": pmc_note,
                 "hbm_algorithmic": {"bound": "hbm", "achieved": round(algorithmic, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -828,14 +834,28 @@ def main():
         lo, hi = box[0].cpu().numpy(), box[1].cpu().numpy()
 
     # ---- this rank's ray shard, resident in HBM ---------------------------------------------------------------
-    rays_h = synth.rays_closest(rays_here, lo, hi, seed=1234 + rank)
-    rays = torch.from_numpy(rays_h).cuda()
+    # B distinct batches rotate through the warm-up and the timed steps (no step re-traces the batch before it, VERDICT r5 Weak 4); the
+    # library's plan search settles on two further batches that the timed loop never sees
+    n_batches = max(1, args.ray_batches)
+    while n_batches > 1 and (n_batches + 2) * rays_here * 32 > 8 << 30:      # (ray memory on host and device stays below 8 GiB: --config3 on one GPU)
+        n_batches -= 1
+    rays_h_all = [synth.rays_closest(rays_here, lo, hi, seed=1234 + rank + 1000 * i) for i in range(n_batches)]
+    rays_all = [torch.from_numpy(r).cuda() for r in rays_h_all]
+    if (n_batches + 2) * rays_here * 32 > 8 << 30:
+        settle_rays = [rays_all[0], rays_all[0]]
+    else:
+        settle_rays = [torch.from_numpy(synth.rays_closest(rays_here, lo, hi, seed=777_000 + rank + 1000 * i)).cuda() for i in range(2)]
+    rays_h, rays = rays_h_all[0], rays_all[0]
     hits = torch.empty((rays_here, 4), dtype=torch.float32, device="cuda")
 
     sort_rays = False if args.no_reorder else None            # None: the library decides (include/bvh_amd.h: BVH_AMD_RAY_SORTED)
+    step_no = [0]
 
-    def step():
-        bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, out=hits, sort_rays=sort_rays)
+    def step(batch=None):
+        r = batch if batch is not None else rays_all[step_no[0] % n_batches]
+        if batch is None:
+            step_no[0] += 1
+        bvh_amd.intersect(bvh, prims, r, any_hit=False, robust=robust, out=hits, sort_rays=sort_rays)
 
     # the FIRST large batch through the fresh tree, as a single-shot caller sees it (VERDICT r3 Weak 4): traced with the plan the
     # library's predictor gives this tree — the measured search only starts exploring with the second batch. What a PROCESS pays once
@@ -856,15 +876,17 @@ def main():
     torch.cuda.synchronize()
     del warm_bvh, warm_prims, warm_tris, warm_bb, warm_cc
     t_first = time.perf_counter()
-    step()
+    step(settle_rays[0])
     torch.cuda.synchronize()
     first_call_ms = (time.perf_counter() - t_first) * 1e3
     first_plan = (ctypes.c_int * 4)()
     lib.bvh_amd_last_launch_plan(first_plan)
 
     # traversal statistics of this batch (stats variant of the kernel; equal to the oracle's counters, tests/)
-    _, cnt = bvh_amd.intersect(bvh, prims, rays, any_hit=False, robust=robust, counters=True, sort_rays=sort_rays)
-    cnt = cnt.cpu().numpy()
+    cnt = np.zeros(2, dtype=np.float64)
+    for r in rays_all:                                        # (mean over the batches the timed steps rotate through)
+        _, c1 = bvh_amd.intersect(bvh, prims, r, any_hit=False, robust=robust, counters=True, sort_rays=sort_rays)
+        cnt += c1.cpu().numpy()[:2].astype(np.float64) / n_batches
     P, T = cnt[0] / rays_here, cnt[1] / rays_here
     b_ray = 32.0 + 56.0 * P + 48.0 * T + 16.0            # ray + node pairs + triangles + hit record
 
@@ -872,8 +894,8 @@ def main():
     # thresholds) on its first few large batches — one whole batch per candidate plan — and keeps the fastest (csrc/traverse.hip:
     # launch_traverse: 3 to 9 batches). Twelve untimed passes, each waited for (the search reads a candidate's events once they have completed), let it
     # settle before the W warm-up and K timed steps.
-    for _ in range(12):
-        step()
+    for i in range(12):
+        step(settle_rays[i % 2])
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -915,6 +937,19 @@ def main():
     reorder_ms = float(np.mean(rt[:got.value])) if got.value else 0.0                        # ray keys + radix sort in front of it
     lib.bvh_amd_kernel_timing(0)
 
+    last_batch = (step_no[0] - 1) % n_batches               # whose hit records `hits` holds now (the CPU baseline checks them)
+    rays_h = rays_h_all[last_batch]
+    torch.cuda.synchronize()
+    e_rep0, e_rep1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step(rays_all[0])                                         # (untimed: the batch's first pass after other rays)
+    e_rep0.record()
+    for _ in range(args.steps):
+        step(rays_all[0])
+    e_rep1.record()
+    torch.cuda.synchronize()
+    repeated_ms = e_rep0.elapsed_time(e_rep1) / args.steps
+    step(rays_all[last_batch])                                # the checked hit records: the last timed step's batch again
+    torch.cuda.synchronize()
     mine = {"rank": rank, "rays_per_step": int(rays_here), "pass_ms": round(pass_ms, 4), "kernel_ms": round(kernel_ms, 4),
             "mrays_s": round(rays_here / pass_ms / 1e3, 1)}           # this rank's own device clock (HIP events), not the job's wall clock
     per_rank = [mine]
@@ -941,6 +976,11 @@ def main():
                                    f"built on the GPU (the reference's default configuration is thread pool + High)"
                                    + ("; rays reordered for coherence inside the timed pass (library default for this tree size)" if reordered else ""),
                        "tris": int(n_tris), "nodes": int(bvh.node_count), "rays_per_gpu_per_step": int(rays_here),
+                       "ray_batches": n_batches,
+                       "ray_batches_what": f"{n_batches} distinct batches (seeds 1234 + rank + 1000 i) rotate through the warm-up and timed steps; the plan "
+                                           f"search settled on 2 other batches (seeds 777000 + ...). The same {args.steps} steps on ONE repeated batch right "
+                                           f"afterwards: {round(repeated_ms, 4)} ms per pass = {round(rays_here / repeated_ms / 1e3, 1)} Mrays/s on this rank "
+                                           f"(rotating: {round(pass_ms, 4)} ms)",
                        "rays_per_step_all_gpus": int(args.rays if args.strong else args.rays * world),
                        "parallelism": (f"rays sharded x{world} ({'strong' if args.strong else 'weak'} scaling), scene broadcast once: "
                                        + bcast.get("transport", "?")) if world > 1 else "single GPU",
