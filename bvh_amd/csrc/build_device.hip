@@ -138,7 +138,8 @@ struct ScratchScope {
     ScratchScope* parent = nullptr;
     int dev = -1;
     std::shared_ptr<Fence> fence;              // made by the first scratch_free under this scope
-    std::vector<void*> deferred;               // blocks that go straight back to the pool when the scope closes
+    std::vector<void*> deferred;               // blocks that go straight back to the pool: when the scope closes, or earlier once they add up
+    size_t deferred_bytes = 0;                 // (see flush_deferred_locked)
     std::vector<const Fence*> waited;          // fences this scope's stream already waits for
     std::vector<std::shared_ptr<Fence>> keep;  // (keeps `waited`'s addresses unique while the scope lives)
 };
@@ -181,6 +182,33 @@ void pool_free_locked(ScratchCache& c, int dev, void* p, const std::shared_ptr<F
     if (!lib) { (void)hipDeviceSynchronize(); (void)hipFree(p); return; }
     if (f && f->waitable.load(std::memory_order_acquire) && hipStreamWaitEvent(lib, f->ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
     if (hipFreeAsync(p, lib) != hipSuccess) (void)hipGetLastError();
+}
+
+// (mutex held) Blocks the cache does not keep used to wait for the END of the outermost API call: a large build with the cache off
+// (BVH_AMD_CACHE_MB=0) or with blocks above the bound then held the SUM of its scratch instead of its live set. Once
+// kDeferredBudget bytes wait, they go back in the order of the freeing stream right away: an event recorded on the scope's stream marks
+// their last use, the library's stream waits for it and frees them (a wait captures the event's record of that moment, so the event
+// goes straight back to the idle list).
+constexpr size_t kDeferredBudget = size_t{128} << 20;
+void flush_deferred_locked(ScratchCache& c, ScratchScope& sc, int dev) {
+    if (sc.deferred.empty()) return;
+    hipStream_t lib = c.lib_stream(dev);
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c.ev_m);
+        if (!c.idle_events[dev].empty()) { ev = c.idle_events[dev].back(); c.idle_events[dev].pop_back(); }
+    }
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+    const bool ordered = lib && ev && hipEventRecord(ev, sc.stream) == hipSuccess && hipStreamWaitEvent(lib, ev, 0) == hipSuccess;
+    if (!ordered) { (void)hipGetLastError(); (void)hipStreamSynchronize(sc.stream); }        // no event to be had: the work itself is waited for
+    for (void* p : sc.deferred) {
+        BVH_LIVE_REMOVE(p, "pool_free");
+        if (!lib) { (void)hipFree(p); continue; }
+        if (hipFreeAsync(p, lib) != hipSuccess) (void)hipGetLastError();
+    }
+    sc.deferred.clear();
+    sc.deferred_bytes = 0;
+    if (ev) { std::lock_guard<std::mutex> lock(c.ev_m); c.idle_events[dev].push_back(ev); }
 }
 
 void close_scope(ScratchScope& sc) {
@@ -328,7 +356,12 @@ void scratch_free(void* p, const ScratchTag& tag) {
     std::shared_ptr<Fence> f = scope_fence(*sc, dev);
     std::lock_guard<std::mutex> lock(c.m);
     const size_t limit = c.limit_of(dev);
-    if (!f || !limit || tag.capacity > limit) { sc->deferred.push_back(p); return; }      // back to the pool when the scope closes
+    if (!f || !limit || tag.capacity > limit) {              // not kept: back to the pool when the scope closes, or now when enough has gathered
+        sc->deferred.push_back(p);
+        sc->deferred_bytes += tag.capacity;
+        if (sc->deferred_bytes > kDeferredBudget) flush_deferred_locked(c, *sc, dev);
+        return;
+    }
     c.lists[{ dev, sc->stream }].emplace(tag.capacity, CachedBlock{ p, ++c.clock, f });
     c.cached_bytes[dev] += tag.capacity;
     while (c.cached_bytes[dev] > limit) {                    // over the bound: the oldest block of this device whose scope has closed
@@ -344,11 +377,12 @@ void scratch_free(void* p, const ScratchTag& tag) {
             }
         }
         if (!from) break;
-        if (oldest->second.fence.get() == f.get() && !f->recorded.load(std::memory_order_acquire)) sc->deferred.push_back(oldest->second.p);
+        if (oldest->second.fence.get() == f.get() && !f->recorded.load(std::memory_order_acquire)) { sc->deferred.push_back(oldest->second.p); sc->deferred_bytes += oldest->first; }
         else pool_free_locked(c, dev, oldest->second.p, oldest->second.fence);
         c.cached_bytes[dev] -= oldest->first;
         from->erase(oldest);
     }
+    if (sc->deferred_bytes > kDeferredBudget) flush_deferred_locked(c, *sc, dev);
 }
 
 // (a block that left the scratch system with a Bvh is released by hipFree: the developer build's overlap check is told)

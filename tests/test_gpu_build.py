@@ -777,6 +777,26 @@ def test_scratch_block_cache_off_and_tiny(knob):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_cache_off_does_not_hold_the_sum_of_a_builds_scratch():
+    """With the block cache off (BVH_AMD_CACHE_MB=0) every freed block goes back to the runtime's pool. It must go back while the call
+    runs (in the order of the freeing stream, csrc/build_device.hip: flush_deferred_locked), not only when the outermost API call
+    ends: a 4M-triangle High build's peak pool usage with the cache off stays within reach of the default configuration's peak
+    (the deferred blocks used to add up to the SUM of the build's scratch). tests/helpers/pool_peak.py, own processes."""
+    import subprocess, sys, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    peak = {}
+    for knob in ("", "0"):
+        env = dict(os.environ)
+        if knob:
+            env["BVH_AMD_CACHE_MB"] = knob
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "pool_peak.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        m = re.search(r"pool_used_high_mb (\d+)", r.stdout)
+        assert r.returncode == 0 and m, (r.stdout[-500:], r.stderr[-2000:])
+        peak[knob] = int(m.group(1))
+    print("pool peak MB: default", peak[""], "cache off", peak["0"])
+    assert peak["0"] <= 1.3 * peak[""] + 384, peak
+
+
 def test_worker_streams_leave_nothing_cached_when_their_thread_ends():
     """A host thread that builds Quality::Low trees owns a worker stream (build_minitree.hip); when the thread ends the stream is destroyed,
     and scratch cached under its handle must be gone by then: the first eviction that met such a block crashed inside the runtime (a hang
