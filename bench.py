@@ -503,7 +503,7 @@ def scene_and_builds(args, gen, n_tris, label):
                                 heap_ms=round(p["heap_ms"], 3),
                                 what="ReinsertionOptimizer of the last High build: iterations run, iterations that replayed the libstdc++ candidate heap "
                                      "exactly (the heap-free fast path was refused: a tie at the top-k threshold or equal gains sharing a node), "
-                                     "pop_heap + push_heap replacements of those replays, GPU ms of the heap kernels (one sequential wave pair)")
+                                     "pop_heap + push_heap replacements of those replays, GPU ms of the heap kernels (csrc/heap_head.inc: one workgroup — a register-resident head wave, a first-step wave, two walker waves, a deep wave, a stream wave)")
         # B_build = 36 (tri) + 36 (bbox + center) + 76 L-bar + 28 N/n + 4 algorithmic bytes per triangle
         lbar = mean_split_ancestors(bvh_q.nodes, n_tris)
         b_build = 36.0 + 36.0 + 76.0 * lbar + 28.0 * bvh_q.node_count / n_tris + 4.0
