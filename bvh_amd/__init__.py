@@ -11,7 +11,7 @@ Host-side mirror of the reference's interface for the hot path (names follow bvh
 Everything computes in hand-written HIP kernels through the C-ABI of libbvh_amd.so
 (include/bvh_amd.h); torch is only used for device memory and streams. There is no CPU fallback.
 """
-from .api import (BinnedSahBuilder, MiniTreeBuilder, SplitHeuristic, Bvh, Config, DefaultBuilder, Quality, RayFlags, SweepSahBuilder, ThreadPool,  # noqa: F401
+from .api import (BinnedSahBuilder, MiniTreeBuilder, SplitHeuristic, Bvh, Config, DefaultBuilder, Quality, RayFlags, SweepSahBuilder, ThreadPool, prepare_trace,  # noqa: F401
                   HITD, HITF, INVALID, NODED, NODEF, NODE2D, NODE2F, hits_to_numpy, intersect, precompute_tris, sphere_bounds,
                   tri_bounds, gather, std_sort_ids, radix_sort_pairs, reinsertion_stats, last_optimize_profile, pinhole_rays, shade_eyelight)
 from ._lib import BvhAmdError  # noqa: F401

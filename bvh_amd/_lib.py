@@ -142,6 +142,7 @@ _SIGS_T = {
     "bvh_amd_sphere_bounds{S}": (_I, [_P, _Z, _P, _P, _P]),
     "bvh{S}_intersect_rays_tri": (_I, [_P, _P, _P, _Z, _U, _P, _P, _P]),
     "bvh{S}_intersect_rays_sphere": (_I, [_P, _P, _P, _Z, _U, _P, _P, _P]),
+    "bvh{S}_prepare_trace": (_I, [_P, _Z, _P]),
     # one ray, host leaf callback (c_api/bvh.h:277-295): (bvh, ray, callback struct)
     "bvh{S}_intersect_ray": (None, [_P, _P, _P]),
     "bvh{S}_intersect_ray_any": (None, [_P, _P, _P]),
@@ -174,7 +175,7 @@ def ray_visitor_types(suffix: str):
     return Visitor, leaf_t, inner_t
 
 
-_ONLY_3D = ("bvh_amd_tri_bounds{S}", "bvh_amd_precompute_tris{S}", "bvh{S}_intersect_rays_tri",     # tri.h is 3D only,
+_ONLY_3D = ("bvh_amd_tri_bounds{S}", "bvh_amd_precompute_tris{S}", "bvh{S}_intersect_rays_tri", "bvh{S}_prepare_trace",     # tri.h is 3D only,
             "bvh{S}_build_minitree_device")                                                           # and so is the mini-tree grid
 
 

@@ -430,6 +430,14 @@ def gather(records, perm):
     return out
 
 
+def prepare_trace(bvh: Bvh, n_rays_hint: int = 0):
+    """bvhXX_prepare_trace: the per-tree one-offs of the first large batch (depth pass, first reordering scratch for batches of
+    `n_rays_hint` rays) paid now, on the current stream. Optional; 3D families."""
+    if bvh.dim != 3:
+        return
+    _lib.check(getattr(_lib.load(), f"bvh{bvh._s}_prepare_trace")(bvh._h, int(n_rays_hint), _stream()), "prepare_trace")
+
+
 def intersect(bvh: Bvh, prims, rays, any_hit: bool = False, robust: bool = False, leaf: str = "tri",
               counters: bool = False, out=None, sort_rays=None, original_ids: bool = False):
     """Batched Bvh::intersect<IsAnyHit, IsRobust> (bvh.h:160-182) with the closest/any-hit leaf loop of

@@ -676,7 +676,13 @@ void bvh_thread_pool_destroy(bvh_thread_pool* p) { delete reinterpret_cast<Threa
         return intersect<T>(b, LEAF_TRIANGLE, prims, rays, n, flags, hits, cnt, s); }                               \
     int bvh##S##_intersect_rays_sphere(const bvh##S* b, const T* prims, const bvh_ray##S* rays, size_t n, unsigned flags, \
                                        bvh_hit##S* hits, bvh_amd_counters* cnt, void* s) {                          \
-        return intersect<T>(b, LEAF_SPHERE, prims, rays, n, flags, hits, cnt, s); }
+        return intersect<T>(b, LEAF_SPHERE, prims, rays, n, flags, hits, cnt, s); }                                 \
+    int bvh##S##_prepare_trace(const bvh##S* b, size_t n_rays_hint, void* s) {                                      \
+        if (!b) return fail(BVH_AMD_ERR_ARG, "prepare_trace: null bvh");                                            \
+        int cur = -1;                                                                                               \
+        BVH_HIP_TRY(hipGetDevice(&cur), BVH_AMD_ERR_HIP);                                                           \
+        if (cur != impl<T>(b)->device) return fail(BVH_AMD_ERR_ARG, "prepare_trace: BVH lives on another device than the current one"); \
+        return prepare_trace<T>(*impl<T>(b), n_rays_hint, static_cast<hipStream_t>(s)); }
 
 BVH_AMD_IMPL(float, 3f)
 BVH_AMD_IMPL(double, 3d)

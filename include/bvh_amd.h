@@ -430,6 +430,13 @@ BVH_AMD_API int bvh3f_intersect_rays_sphere(const struct bvh3f*, const float* d_
 BVH_AMD_API int bvh3d_intersect_rays_sphere(const struct bvh3d*, const double* d_sph4, const struct bvh_ray3d* d_rays,
     size_t n, unsigned flags, struct bvh_hit3d* d_hits, struct bvh_amd_counters* d_counters, void* stream);
 
+/* Optional, additive: pays NOW what the first large batch through a fresh tree would pay inside its own call — the tree's depth /
+ * expected-visits pass (one read-back) and the first allocation of the ray-reordering scratch for batches of `n_rays_hint` rays (kept
+ * in the library's block cache for that stream). A single Bvh::intersect on a fresh Bvh is the reference's normal use (bvh.h:160-182);
+ * a batch that comes unprepared does the same work itself. */
+BVH_AMD_API int bvh3f_prepare_trace(const struct bvh3f*, size_t n_rays_hint, void* stream);
+BVH_AMD_API int bvh3d_prepare_trace(const struct bvh3d*, size_t n_rays_hint, void* stream);
+
 /* ---- building blocks exposed for unit tests (order-defining sorts) ----------------------- */
 /* d_ids_out[0..n) = the permutation libstdc++ 11's std::sort(iota, [&](i,j){ return keys[i] < keys[j]; }) produces,
  * including the arrangement of equal keys (sweep_sah_builder.h:57-63 depends on it). */
