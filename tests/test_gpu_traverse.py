@@ -382,3 +382,29 @@ def test_ticket_ranges_thresholds_and_fetch_modes_never_change_results():
                         assert got.cpu().numpy().tobytes() == want, (any_hit, coop, refill, leaf, parts, sort)
     finally:
         lib.bvh_amd_tuning(-1, -1, -1, -1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_prepare_trace_changes_nothing_but_the_first_call(orc, dtype):
+    """bvhXX_prepare_trace (additive): the first batch's per-tree one-offs paid up front — depth pass, first reordering scratch. Hit
+    records are the reference's with and without it; the call is idempotent and accepts any hint."""
+    import torch
+    import bvh_amd
+    tris = synth.soup(300_000, dtype=dtype)
+    bb, cc = orc.prep_tris(tris)
+    ref = orc.build(bb, cc, builder=oracle.BUILDER_DEFAULT_PARALLEL, quality=oracle.QUALITY_MEDIUM)
+    oprims = orc.precompute_tris(tris, ref.prim_ids())
+    lo, hi = synth.scene_bounds(tris)
+    rays = synth.rays_closest(1_200_000, lo, hi, seed=11).astype(dtype)
+    want = ref.intersect_tri(oprims, rays, False, True, threads=8)
+    d_tris = torch.from_numpy(tris).cuda()
+    d_bb, d_cc = bvh_amd.tri_bounds(d_tris)
+    for prepared in (True, False):
+        gpu = bvh_amd.DefaultBuilder.build(d_bb, d_cc, bvh_amd.Config(quality=bvh_amd.Quality.Medium), thread_pool=bvh_amd.ThreadPool())
+        assert gpu.serialize() == ref.serialize()
+        if prepared:
+            for hint in (0, len(rays), len(rays), 1 << 22):
+                bvh_amd.prepare_trace(gpu, hint)
+        prims = bvh_amd.precompute_tris(d_tris, gpu.device_prim_ids())
+        got = bvh_amd.intersect(gpu, prims, torch.from_numpy(rays).cuda(), any_hit=False, robust=True)
+        assert bvh_amd.hits_to_numpy(got).tobytes() == want.tobytes()
