@@ -137,6 +137,7 @@ struct BvhImpl {
         hipEvent_t start = nullptr, stop = nullptr;
         size_t rays = 0;
         float ns_per_ray[kCandidates] = {};
+        size_t rays_of[kCandidates] = {};      // the batch size the kept time of each candidate was measured on (times of very different batches are not compared)
     };
     mutable PlanSearch plan_search[2];
     mutable std::mutex plan_mutex;

@@ -1038,7 +1038,7 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
             if (hipEventElapsedTime(&ms, ps.start, ps.stop) == hipSuccess && ps.rays && ms > 0.0f) {
                 const int c = ps.trying;                                     // survivors are measured twice; the better time counts
                 const float ns = ms * 1e6f / static_cast<float>(ps.rays) + (candidates[c].reorder ? kSortNsPerRay : 0.0f);
-                ps.ns_per_ray[c] = ps.count[c] == 0 ? ns : std::min(ps.ns_per_ray[c], ns);   // (a kernel's first launch also pays its code load)
+                if (ps.count[c] == 0 || ns < ps.ns_per_ray[c]) { ps.ns_per_ray[c] = ns; ps.rays_of[c] = ps.rays; }   // (a kernel's first launch also pays its code load)
                 ++ps.count[c];
                 ++ps.index;
                 int best = c;
@@ -1047,6 +1047,10 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
                     if (!ps.count[k] || k == best) continue;
                     // (a candidate's FIRST time may carry its kernel's code load — on a 2^20-ray batch that is tens of per cent — so a single
                     //  measurement only drops a clear loser; the 10 % rule needs both)
+                    // (times taken on batches of very different size say more about the batches than about the plans — a batch of
+                    //  short rays against one of long rays, 2^20 rays against 2^24: only batches within 2x of each other are compared)
+                    const size_t nk = ps.rays_of[k], nb = ps.rays_of[best];
+                    if (nk == 0 || nb == 0 || std::max(nk, nb) > 2 * std::min(nk, nb)) continue;
                     const float behind = ps.ns_per_ray[k] / ps.ns_per_ray[best];
                     if (behind > (ps.count[k] >= 2 ? 1.10f : 1.40f)) ps.dropped |= uint8_t(1u << k);
                     if (behind > 1.40f && candidates[k].reorder != candidates[best].reorder)

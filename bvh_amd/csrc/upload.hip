@@ -179,7 +179,7 @@ template <typename T>
 int relayout_on_device(BvhImpl<T>& b, const HostNode<T>* d_nodes, hipStream_t stream) {
     b.pair_count = (b.node_count - 1) / 2;
     b.max_depth = -1;
-    { std::lock_guard<std::mutex> lock(b.plan_mutex); for (int k = 0; k < 2; ++k) { b.launch_plan[k] = 0; b.plan_search[k].index = 0; b.plan_search[k].pending = false; b.plan_search[k].trying = -1; b.plan_search[k].dropped = 0; for (auto& c : b.plan_search[k].count) c = 0; } }
+    { std::lock_guard<std::mutex> lock(b.plan_mutex); for (int k = 0; k < 2; ++k) { b.launch_plan[k] = 0; b.plan_search[k].index = 0; b.plan_search[k].pending = false; b.plan_search[k].trying = -1; b.plan_search[k].dropped = 0; for (auto& c : b.plan_search[k].count) c = 0; for (auto& t : b.plan_search[k].ns_per_ray) t = 0.0f; for (auto& r : b.plan_search[k].rays_of) r = 0; } }
     if (b.d_pairs) { scratch_forget(b.d_pairs); (void)hipFree(b.d_pairs); b.d_pairs = nullptr; }
     if (b.pair_count) {
         // (from the stream-ordered pool when it is on: a plain hipMalloc of the 10M-triangle scene's 0.5 GB of records costs ~2 ms;
