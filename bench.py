@@ -412,7 +412,7 @@ def roofline_section(args, lib, *, robust, rays_here, kernel_ms, pass_ms, reorde
                 "leaf_threshold": int(plan[3]),
                 "how": "measured by the library on this tree's first large batches (one whole batch per candidate), then fixed",
                 "search": search},
-                "first_call": {"ms": round(first_call_ms, 4), "reordered": bool(first_plan[0]), "quad_cooperative_fetch": bool(first_plan[1]),
+                "first_call": {"ms": round(first_call_ms, 4), "reordered": bool(first_plan[0]), "long_rays_first": first_plan[0] == 2, "quad_cooperative_fetch": bool(first_plan[1]),
                 "over_settled_pass": round(first_call_ms / pass_ms, 4),
                 "what": "wall time of the FIRST batch through the fresh tree (host clock around one call + synchronisation; the "
                 "process's one-off code loads were paid on a throwaway tree before): traced with the predictor's plan; the "

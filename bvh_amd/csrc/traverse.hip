@@ -1008,7 +1008,12 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
     // cooperative fetch for any-hit and for such heavy trees), which is the winner or within a few per cent of it on 6 of the 7
     // scenes of profiles/r03_rule_check.txt; the exploration of the other three starts with the second batch.
     const bool heavy = b.expected_visits.load() >= kReorderMinVisits;       // (tree_depth has filled it: the candidate test needs a resident tree)
-    const int predicted = any_hit ? (heavy ? 3 : 1) : (heavy ? 3 : 0);
+    // Round 6 (the first call through a fresh tree): a heavy closest-hit tree whose records fit the 256 MB Infinity
+    // Cache gets the "long rays first" order straight away — it is what the search settles on there (1M soup: 0.427 against 0.446 ns per
+    // ray, profiles/r06_bench_default.json), while on a tree beyond it the split of the sort key costs more coherence than the shorter
+    // tail gives back (10M soup: 0.382 against 0.376, profiles/r05_bench_config3_1gpu_final.json). The search measures both either way.
+    const bool fits_infinity_cache = b.pair_count * sizeof(PairNode<T>) <= (size_t{256} << 20);
+    const int predicted = any_hit ? (heavy ? 3 : 1) : (heavy ? (fits_infinity_cache ? 4 : 3) : 0);
     // Round 5 (VERDICT r4 Weak 4): the search no longer spends eight batches whatever it sees. Order of exploration: the predictor's
     // plan, then the plan of the OTHER ray order with the same record fetch (it decides the family: reordered or as given), then the
     // rest. After every measurement a candidate more than 10 % behind the best so far (40 % while it has only one measurement) is out,

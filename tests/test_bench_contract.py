@@ -91,6 +91,7 @@ def test_bench_json_contract(monkeypatch, orc):
     monkeypatch.setattr(bvh_amd.DefaultBuilder, "build", staticmethod(build))
     monkeypatch.setattr(bvh_amd, "precompute_tris", precompute_tris)
     monkeypatch.setattr(bvh_amd, "intersect", intersect)
+    monkeypatch.setattr(bvh_amd, "prepare_trace", lambda bvh, n_rays_hint=0: None)
     def fake_kernel_times(ms_out, capacity, count_out):
         for i in range(capacity):
             ms_out[i] = 1.0
