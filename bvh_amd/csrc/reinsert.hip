@@ -912,7 +912,7 @@ __device__ void refit_upwards(HostNode<T>* nodes, const uint32_t* parent, uint32
 }
 
 template <typename T>
-__device__ inline void apply_move(HostNode<T>* nodes, uint32_t* parent, unsigned char* touched, const Move mv) {
+__device__ inline void apply_move(HostNode<T>* nodes, uint32_t* parent, unsigned char* touched, const Move mv, uint32_t* dirty, uint32_t& n_dirty) {
     using I = typename IndexOf<T>::Type;
     const uint32_t from = mv.from, to = mv.to;
     const uint32_t hot[5] = { to, from, sibling_of(from), parent[to], parent[from] };     // get_conflicts (:227-234)
@@ -929,8 +929,40 @@ __device__ inline void apply_move(HostNode<T>* nodes, uint32_t* parent, unsigned
     if (!is_leaf(sib_node)) { parent[first_of(sib_node)] = par; parent[first_of(sib_node) + 1] = par; }
     parent[sib] = to;
     parent[from] = to;
+    if (dirty) { dirty[n_dirty++] = to; dirty[n_dirty++] = par; return; }      // (refit after the iteration's last move: see k_deferrable)
     refit_upwards(nodes, parent, to);
     refit_upwards(nodes, parent, par);
+}
+
+// The two refit_from climbs of every applied move (:211-212, up to the root's children each: 2 x ~22 levels of dependent loads, 16 us
+// per move on a lone lane — 87 % of k_apply, 17 ms of a 10M-triangle High build) can be left to ONE parallel bottom-up pass after the
+// iteration's last move — over the ancestors, in the tree as the moves leave it, of every move's `to` and old parent (k_dirty_mark,
+// k_dirty_refit; the root is left alone like refit_from leaves it): every node whose subtree a move changed is among them, and
+// recomputing a node the reference did NOT recompute cannot change a bit of it exactly when
+//   * every inner node's box equals left.bbox.extend(right.bbox) BITWISE on entry (a builder's tree does; a caller's hand-made tree
+//     with loose boxes does not) — by induction every node then does after every move: refit_from recomputes the parent of every slot
+//     whose content changed, and all of its ancestors but the root, after the children have their final boxes;
+//   * no box holds -0.0 (the root's box is the union of all leaves whichever way it is associated — but `a < b ? a : b` picks between
+//     +0.0 and -0.0 by position, and the root is recomputed only by a move whose `from` hangs under it), and no NaN.
+// Otherwise (flag raised) the moves refit as they go, like the reference.
+template <typename T>
+__global__ void __launch_bounds__(256) k_deferrable(const HostNode<T>* nodes, uint32_t n, uint32_t* not_deferrable) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const HostNode<T>& nd = nodes[i];
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) bad = bad || !(nd.bounds[q] == nd.bounds[q]) || (nd.bounds[q] == T(0) && signbit(nd.bounds[q]));
+    if (!is_leaf(nd)) {
+        const HostNode<T>& l = nodes[first_of(nd)];
+        const HostNode<T>& r = nodes[first_of(nd) + 1];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {                         // (no -0.0 and no NaN anywhere: equal values are equal bits)
+            bad = bad || !(nd.bounds[2 * q] == pick_min(l.bounds[2 * q], r.bounds[2 * q]));
+            bad = bad || !(nd.bounds[2 * q + 1] == pick_max(l.bounds[2 * q + 1], r.bounds[2 * q + 1]));
+        }
+    }
+    if (bad) *not_deferrable = 1u;
 }
 
 // check_ties (fast path): `order` is sorted by gain but equal gains are in an arbitrary order. A group of equal gains is
@@ -939,8 +971,10 @@ __device__ inline void apply_move(HostNode<T>* nodes, uint32_t* parent, unsigned
 // below nodes of its own conflict set). Otherwise: flag and stop, the host rolls the iteration back.
 template <typename T>
 __global__ void k_apply(HostNode<T>* nodes, uint32_t* parent, unsigned char* touched, const Move* moves, const uint32_t* order,
-                        const T* neg_gain, uint32_t m, int check_ties, uint32_t* group_mark, uint32_t gid_base, ReScalars* sc) {
-    uint32_t gid = gid_base;
+                        const T* neg_gain, uint32_t m, int check_ties, uint32_t* group_mark, uint32_t gid_base, ReScalars* sc,
+                        uint32_t* dirty, uint32_t* dirty_count) {     // dirty != null: the refits are deferred, the ends of the applied moves are listed
+    uint32_t gid = gid_base, n_dirty = 0;
+    if (dirty) *dirty_count = 0;
     for (uint32_t j = 0; j < m;) {
         uint32_t e = j + 1;
         if (check_ties) {
@@ -954,13 +988,64 @@ __global__ void k_apply(HostNode<T>* nodes, uint32_t* parent, unsigned char* tou
                     bool clash = false, shared = false;
                     for (int h = 0; h < 5; ++h) { clash = clash || touched[hot[h]]; shared = shared || group_mark[hot[h]] == gid; }
                     if (clash) continue;
-                    if (shared) { sc->ambiguous = 1u; return; }
+                    if (shared) { sc->ambiguous = 1u; if (dirty) *dirty_count = n_dirty; return; }
                     for (int h = 0; h < 5; ++h) group_mark[hot[h]] = gid;
                 }
             }
         }
-        for (uint32_t q = j; q < e; ++q) apply_move(nodes, parent, touched, moves[order[q]]);
+        for (uint32_t q = j; q < e; ++q) apply_move(nodes, parent, touched, moves[order[q]], dirty, n_dirty);
         j = e;
+    }
+    if (dirty) *dirty_count = n_dirty;
+}
+
+// The deferred refit. state[] (zero on entry) per node: low byte = children among the nodes to recompute, 0x100 = listed itself,
+// 0x10000 x children that have been recomputed. Pass 1: every listed node climbs and announces itself to its parent until it meets a
+// node somebody has been at (every edge of the union of the paths is walked once). Pass 2: the listed nodes nobody announced to
+// recompute themselves and climb; a parent is recomputed by the last of its announced children to arrive (tickets like k_refit's).
+constexpr uint32_t kDirtyListed = 0x100u, kDirtyDone = 0x10000u;
+__global__ void __launch_bounds__(256) k_dirty_mark(const uint32_t* parent, const uint32_t* dirty, const uint32_t* dirty_count, uint32_t* state) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= *dirty_count) return;
+    uint32_t i = dirty[t];
+    if (i == 0 || atomicOr(&state[i], kDirtyListed) != 0) return;     // (the root is never refit; somebody from below has passed already)
+    for (;;) {
+        const uint32_t p = parent[i];
+        if (p == 0 || atomicAdd(&state[p], 1u) != 0) return;
+        i = p;
+    }
+}
+
+template <typename T>
+__device__ inline void refit_shared_node(HostNode<T>* nodes, uint32_t cur) {      // left.get_bbox().extend(right.get_bbox()), boxes exchanged between climbers
+    HostNode<T>& nd = nodes[cur];
+    const uint32_t f = first_of(nd);
+    const T* l = nodes[f].bounds;
+    const T* r = nodes[f + 1].bounds;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const T lo_l = __hip_atomic_load(&l[2 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), lo_r = __hip_atomic_load(&r[2 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const T hi_l = __hip_atomic_load(&l[2 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi_r = __hip_atomic_load(&r[2 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&nd.bounds[2 * q], pick_min(lo_l, lo_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&nd.bounds[2 * q + 1], pick_max(hi_l, hi_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_dirty_refit(HostNode<T>* nodes, const uint32_t* parent, const uint32_t* dirty, const uint32_t* dirty_count, uint32_t* state) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= *dirty_count) return;
+    uint32_t i = dirty[t];
+    if (i == 0 || (state[i] & 0xFFu) != 0) return;            // nodes to recompute below this one: the last of them to arrive does it
+    for (;;) {
+        if (!is_leaf(nodes[i])) refit_shared_node(nodes, i);
+        const uint32_t p = parent[i];
+        if (p == 0) return;
+        ticket_release();                                     // this lane's box before the ticket
+        const uint32_t old = atomicAdd(&state[p], kDirtyDone);
+        if ((old >> 16) + 1 < (old & 0xFFu)) return;          // an announced child is still on its way
+        ticket_acquire();
+        i = p;
     }
 }
 
@@ -1049,7 +1134,7 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
     const char* mode = std::getenv("BVH_AMD_REINSERT");
     const bool always_exact = mode && std::strcmp(mode, "exact") == 0;
 
-    DevBuf<uint32_t> parent, cand, keep, off, order, group_mark, ids, ids_tmp, hist;
+    DevBuf<uint32_t> parent, cand, keep, off, order, group_mark, ids, ids_tmp, hist, dirty_state, dirty, dirty_count, not_deferrable;
     DevBuf<Ent<T>> heap_g;
     DevBuf<T> cost, gains, neg_gain;
     DevBuf<U> keys, keys_tmp;
@@ -1061,7 +1146,7 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(parent.alloc(n)); A(heap_g.alloc(k)); A(cand.alloc(k)); A(keep.alloc(k)); A(off.alloc(k)); A(order.alloc(k));
     A(cost.alloc(n)); A(gains.alloc(k)); A(neg_gain.alloc(k)); A(moves.alloc(k)); A(kept.alloc(k));
-    A(touched.alloc(n)); A(scalars.alloc(1));
+    A(touched.alloc(n)); A(scalars.alloc(1)); A(dirty_state.alloc(n)); A(dirty.alloc(size_t{2} * k)); A(dirty_count.alloc(1)); A(not_deferrable.alloc(1));
     if (!always_exact) {
         A(group_mark.alloc(n)); A(ids.alloc(n)); A(ids_tmp.alloc(n)); A(keys.alloc(n)); A(keys_tmp.alloc(n));
         A(hist.alloc(radix_sort_hist_words(n, 1))); A(backup.alloc(n));
@@ -1069,6 +1154,17 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
     if (e != hipSuccess) return fail(BVH_AMD_ERR_HIP, std::string("optimize: hipMalloc: ") + hipGetErrorString(e));
     BVH_HIP_TRY(hipMemsetAsync(scalars.p, 0, sizeof(ReScalars), stream), BVH_AMD_ERR_HIP);
     if (!always_exact) BVH_HIP_TRY(hipMemsetAsync(group_mark.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
+    // may the moves leave their refits to one pass per iteration? (k_deferrable; developer knob BVH_AMD_APPLY_DEFER=0: refit move by move)
+    bool defer_refit = false;
+    if (BVH_DEV_INT("BVH_AMD_APPLY_DEFER", 1) != 0) {
+        uint32_t h_not = 1;
+        BVH_HIP_TRY(hipMemsetAsync(not_deferrable.p, 0, 4, stream), BVH_AMD_ERR_HIP);
+        hipLaunchKernelGGL(k_deferrable<T>, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, n, not_deferrable.p);
+        BVH_HIP_TRY(hipMemcpyAsync(&h_not, not_deferrable.p, 4, hipMemcpyDeviceToHost, stream), BVH_AMD_ERR_HIP);
+        BVH_HIP_TRY(hipStreamSynchronize(stream), BVH_AMD_ERR_HIP);
+        defer_refit = h_not == 0;
+        if (BVH_DEV_STR("BVH_AMD_REINSERT_DEBUG")) std::fprintf(stderr, "[bvh_amd] reinsertion: refits %s\n", defer_refit ? "deferred to one pass per iteration" : "move by move (loose boxes, -0.0 or NaN in the tree)");
+    }
 
     const size_t heap_lds = size_t{HeapCap<T>::v} * sizeof(Ent<T>) + kStreamChunk * sizeof(T);
     const bool below_lds = k >= 1 && k - 1 >= HeapCap<T>::v;
@@ -1174,7 +1270,13 @@ int reinsertion_optimize_config_device(HostNode<T>* d_nodes, size_t node_count, 
                 }
                 if (rc) return rc;
                 hipLaunchKernelGGL(k_apply<T>, dim3(1), dim3(1), 0, stream, d_nodes, parent.p, touched.p, kept.p, order.p, neg_gain.p, m,
-                                   exact ? 0 : 1, group_mark.p, static_cast<uint32_t>(gid_base), scalars.p);
+                                   exact ? 0 : 1, group_mark.p, static_cast<uint32_t>(gid_base), scalars.p,
+                                   defer_refit ? dirty.p : static_cast<uint32_t*>(nullptr), dirty_count.p);
+                if (defer_refit) {                            // the ancestors of the applied moves' ends, children before parents
+                    BVH_HIP_TRY(hipMemsetAsync(dirty_state.p, 0, size_t{n} * 4, stream), BVH_AMD_ERR_HIP);
+                    hipLaunchKernelGGL(k_dirty_mark, dim3(static_cast<uint32_t>((size_t{2} * m + 255) / 256)), dim3(256), 0, stream, parent.p, dirty.p, dirty_count.p, dirty_state.p);
+                    hipLaunchKernelGGL(k_dirty_refit<T>, dim3(static_cast<uint32_t>((size_t{2} * m + 255) / 256)), dim3(256), 0, stream, d_nodes, parent.p, dirty.p, dirty_count.p, dirty_state.p);
+                }
                 BVH_HIP_TRY(hipGetLastError(), BVH_AMD_ERR_HIP);
                 if (!exact) {
                     if ((rc = read_scalars(hs))) return rc;

@@ -446,7 +446,7 @@ def test_reinsertion_fast_path_and_exact_replay_agree_with_reference(orc, scene,
     assert (f2 - f1, e2 - e1) == (0, 3)
 
 
-@pytest.mark.parametrize("knobs", ["", "BVH_AMD_HEAP_WIDE=1", "BVH_AMD_HEAP_PIPE=1", "BVH_AMD_HEAP_PIPE=0"])
+@pytest.mark.parametrize("knobs", ["", "BVH_AMD_HEAP_WIDE=1", "BVH_AMD_HEAP_PIPE=1", "BVH_AMD_HEAP_PIPE=0", "BVH_AMD_APPLY_DEFER=0"])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_every_candidate_heap_kernel_replays_the_reference(orc, knobs, dtype, tmp_path):
     """find_candidates' heap array (reinsertion_optimizer.h:88-105) decides the order of equal gains downstream, so every kernel that
@@ -493,6 +493,51 @@ def test_standalone_optimize_matches_reference(orc):
     rays = synth.rays_closest(50_000, lo, hi)
     hits = bvh_amd.hits_to_numpy(bvh_amd.intersect(gpu, prims, rays, robust=True))
     assert hits.tobytes() == ref.intersect_tri(orc.precompute_tris(tris, ref.prim_ids()), rays, 0, 1, threads=8).tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_optimize_refits_like_the_reference_whatever_the_boxes(orc, dtype):
+    """refit_from (reinsertion_optimizer.h:215-225) recomputes the ancestors of a move's two ends and nothing else. The device leaves
+    the refits of an iteration to one pass after its last move only when that cannot change a bit (csrc/reinsert.hip: k_deferrable);
+    trees where it could — loose inner boxes a caller made by hand, -0.0 in a box (`a < b ? a : b` picks between the zeros by
+    position), a loose ROOT (which only a move from under the root recomputes) — keep every byte of the reference's result too."""
+    import bvh_amd
+    tris = synth.sponza_proxy(40_000).astype(dtype)
+    bb, cc = orc.prep_tris(tris)
+    base = orc.build(bb, cc, builder=oracle.BUILDER_BINNED)
+    prim_ids = base.prim_ids()
+    rng = np.random.default_rng(5)
+
+    def variant(kind):
+        nodes = base.nodes().copy()
+        bounds = nodes["bounds"]
+        inner = np.flatnonzero((nodes["index"] & 15) == 0)
+        if kind == "loose":
+            pick = rng.choice(inner[inner != 0], size=200, replace=False)
+            bounds[pick, 0::2] -= dtype(0.25)
+            bounds[pick, 1::2] += dtype(0.25)
+        elif kind == "loose_root":
+            bounds[0, 0::2] -= dtype(1.0)
+            bounds[0, 1::2] += dtype(1.0)
+        elif kind == "negative_zero":
+            # a scene moved so that boxes end at zero, with both zeros among the leaves
+            shift = bounds[0, 0::2].copy()
+            bounds[:, 0::2] -= shift
+            bounds[:, 1::2] -= shift
+            zeros = np.argwhere(bounds == 0)
+            assert len(zeros) > 2
+            for r, c in zeros[::2]:
+                bounds[r, c] = -dtype(0.0)
+        return nodes
+
+    for kind in ("tight", "loose", "loose_root", "negative_zero"):
+        nodes = variant(kind)
+        ref = orc.from_arrays(nodes, prim_ids)
+        gpu = bvh_amd.Bvh.from_nodes(nodes, prim_ids)
+        for ratio, iters in ((0.05, 3), (0.3, 2)):
+            ref.optimize(-1, batch_size_ratio=ratio, max_iter_count=iters)
+            gpu.optimize(batch_size_ratio=ratio, max_iter_count=iters)
+            assert gpu.serialize() == ref.serialize(), (kind, ratio, iters)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -192,7 +192,7 @@ def test_arrival_tickets_wait_for_the_waves_own_stores():
     from bvh_amd import _lib
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("no llvm-objdump")
-    for kernel in ("k_refit<float>", "k_refit<double>", "k_subtree_counts<float>", "k_subtree_counts<double>"):
+    for kernel in ("k_refit<float>", "k_refit<double>", "k_subtree_counts<float>", "k_subtree_counts<double>", "k_dirty_refit<float>", "k_dirty_refit<double>"):
         body = kernel_isa_lines(_lib.LIB_PATH, kernel)
         assert body, kernel
         tickets = [i for i, t in enumerate(body) if t.startswith("global_atomic_add") and " sc0" in t]
