@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--no-obj-roundtrip", action="store_true", help="feed the synthetic mesh to the builder directly instead of through an OBJ file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="rays of the CPU baseline sample (>= 1 s of work on the host cores)")
+    ap.add_argument("--no-fresh-tree", action="store_true", help="first_call: trace the first batch through the tree built at the start of the run "
+                    "(seconds earlier) instead of building the same tree once more immediately before it")
     ap.add_argument("--no-reorder", action="store_true", help="trace the rays in the order given (BVH_AMD_RAY_UNSORTED)")
     ap.add_argument("--no-probe", action="store_true", help="skip the record-walk probes behind roofline.peak")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect the traversal kernel's L1 / L2 / fabric counters with rocprofv3 --pmc passes of a child run")
@@ -416,7 +418,8 @@ def roofline_section(args, lib, *, robust, rays_here, kernel_ms, pass_ms, reorde
                 "over_settled_pass": round(first_call_ms / pass_ms, 4),
                 "what": "wall time of the FIRST batch through the fresh tree (host clock around one call + synchronisation; the "
                 "process's one-off code loads were paid on a throwaway tree before): traced with the predictor's plan; the "
-                "search explores the other plans from the second batch on"},
+                "search explores the other plans from the second batch on. `follows_build`: the tree was built (and bvhXX_prepare_trace "
+                "called) immediately before this batch, as in a single-shot caller; otherwise seconds of host work lie between"},
                 "P_node_pairs_per_ray": round(float(P), 3), "T_prim_tests_per_ray": round(float(T), 3)}
 
 def mean_split_ancestors(nodes, n_prims):
@@ -518,7 +521,13 @@ def scene_and_builds(args, gen, n_tris, label):
     bvh_amd.prepare_trace(bvh, rays_hint)
     torch.cuda.synchronize()
     prepare_ms = (time.perf_counter() - t0) * 1e3
-    return {"tris": tris, "n_tris": n_tris, "label": label, "data": data, "builds": builds, "high_profile": high_profile, "build_ms": build_ms,
+
+    def rebuild():                                            # the same tree once more (builds are deterministic): see `first_call`
+        bb2, cc2 = bvh_amd.tri_bounds(d_tris)
+        fresh = bvh_amd.DefaultBuilder.build(bb2, cc2, bvh_amd.Config(quality=bvh_amd.Quality[args.quality.capitalize()]), thread_pool=pool)
+        bvh_amd.prepare_trace(fresh, rays_hint)
+        return fresh
+    return {"rebuild": rebuild, "tris": tris, "n_tris": n_tris, "label": label, "data": data, "builds": builds, "high_profile": high_profile, "build_ms": build_ms,
             "bvh": bvh, "build_host_ms": build_host_ms, "prims": prims, "prepare_ms": prepare_ms}
 
 def build_section(n_tris, builds, high_profile, build_ms, build_host_ms, prepare_ms=None):
@@ -887,6 +896,15 @@ def main():
     lib.bvh_amd_tuning(-1, -1, -1, -1)
     torch.cuda.synchronize()
     del warm_bvh, warm_prims, warm_tris, warm_bb, warm_cc
+    # ... and the tree is built once more immediately before (rank 0: the bytes are the same, builds are deterministic), so that the
+    # first batch follows its tree's build and bvhXX_prepare_trace the way it does in a single-shot caller — not after the seconds of
+    # host-side ray synthesis above, during which the device clocks down (profiles/r06_first_call_probe.txt: the same plan on the same
+    # batches gets 7 % faster over its first six calls after a pause)
+    first_after_build = False
+    if rank == 0 and not args.no_fresh_tree:
+        bvh = sc["rebuild"]()
+        first_after_build = True
+        torch.cuda.synchronize()
     t_first = time.perf_counter()
     step(settle_rays[0])
     torch.cuda.synchronize()
@@ -978,6 +996,8 @@ def main():
         roofline = roofline_section(args, lib, robust=robust, rays_here=rays_here, kernel_ms=kernel_ms, pass_ms=pass_ms, reorder_ms=reorder_ms, P=P, T=T,
                                     b_ray=b_ray, node_count=bvh.node_count, n_tris=n_tris, plan=plan, first_plan=first_plan, first_call_ms=first_call_ms,
                                     device_index=device_index, reordered=reordered, search=search)
+        if roofline.get("first_call"):
+            roofline["first_call"]["follows_build"] = first_after_build
         out = {
             "metric": f"Mrays/s closest-hit ({label})", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
