@@ -44,14 +44,15 @@ template <typename V> inline V __shfl(V v, int) { return v; }
 template <typename V> inline V __shfl_down(V, int) { return V(0); }
 template <typename V> inline V atomicAdd(V* p, V v) { V old = *p; *p = old + v; return old; }
 template <typename V> inline V atomicOr(V* p, V v) { V old = *p; *p = old | v; return old; }
-static const struct { unsigned x; } threadIdx = {0}, blockIdx = {0}, gridDim = {1};
+static const struct { unsigned x; } threadIdx = {0};
+static struct { unsigned x; } blockIdx = {0}, gridDim = {1};     // trace_body_host_set_grid: the emulated blocks run one after another
 #else
 // BVH_HOST_WAVE64: one wavefront of 64 lanes = 64 fibers (ucontext) run round-robin by on_all_lanes(), switching at the wave
 // intrinsics — every one of them sits in wave-uniform control flow in trace_body.inc, so after one round all lanes stand at the
 // same intrinsic. Real refill / leaf-parking thresholds. Single OS thread: the "atomics" need no atomicity.
 #include <ucontext.h>
 static struct { unsigned x; } threadIdx = {0};                   // set by the scheduler before a lane resumes
-static const struct { unsigned x; } blockIdx = {0}, gridDim = {1};
+static struct { unsigned x; } blockIdx = {0}, gridDim = {1};     // trace_body_host_set_grid: the emulated blocks run one after another
 static ucontext_t g_main, g_lane[64];
 static uint64_t g_slot[2][64];                                   // double buffered: a lane may run ahead to the next intrinsic
 static unsigned g_phase[64];
@@ -164,13 +165,24 @@ void host_trace_coop(TraceArgs<T> a) {
 namespace {
 
 uint32_t g_parts = 1;                          // ticket ranges of the emulated launch (trace_body_host_set_parts)
+uint32_t g_blocks = 1, g_stagger = 0;          // blocks of the emulated grid and its staggered drain (trace_body_host_set_grid)
+
+// The blocks of the emulated grid, the LAST one first: a block of a higher drain class stops drawing tickets early and leaves what is
+// left of its range to the blocks after it; block 0 (always class 0) never stops early and runs last, so every ticket must be drawn.
+template <typename F> void on_all_blocks(F&& run_block) {
+    gridDim.x = g_blocks;
+    for (uint32_t b = g_blocks; b-- > 0;) { blockIdx.x = b; run_block(); }
+    blockIdx.x = 0; gridDim.x = 1;
+}
 
 template <typename T, int Leaf, int D, bool Deep>
 void run_variant(const bvh_amd::TraceArgs<T>& a, int any, int robust) {
     using namespace bvh_amd;
-    on_all_lanes([&] {
-        if (any) { if (robust) host_trace<T, true, true, Leaf, true, D, Deep>(a); else host_trace<T, true, false, Leaf, true, D, Deep>(a); }
-        else { if (robust) host_trace<T, false, true, Leaf, true, D, Deep>(a); else host_trace<T, false, false, Leaf, true, D, Deep>(a); }
+    on_all_blocks([&] {
+        on_all_lanes([&] {
+            if (any) { if (robust) host_trace<T, true, true, Leaf, true, D, Deep>(a); else host_trace<T, true, false, Leaf, true, D, Deep>(a); }
+            else { if (robust) host_trace<T, false, true, Leaf, true, D, Deep>(a); else host_trace<T, false, false, Leaf, true, D, Deep>(a); }
+        });
     });
 }
 
@@ -187,7 +199,7 @@ int run_any(const void* pairs, uint32_t root_index, const void* prims, const voi
     a.n = n_rays; a.work = work; a.parts = g_parts; a.part_size = g_parts > 1 ? ((n_rays + g_parts - 1) / g_parts + 63) / 64 * 64 : n_rays; a.counters = &cnt; a.order = nullptr; a.deep = deep; a.deep_cap = deep_cap;
     a.root_index = root_index;
     a.refill_threshold = kHostRefill; a.leaf_threshold = kHostLeaf;
-    a.coop = 0; a.prim_stride = 12; a.stream_hints = 0; a.stagger = 0; a.one_shot = 0; a.wave_times = nullptr;
+    a.coop = 0; a.prim_stride = 12; a.stream_hints = 0; a.stagger = g_stagger; a.one_shot = 0; a.wave_times = nullptr;
     if (dim == 2) { if (deep) run_variant<T, LEAF_SPHERE, 2, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 2, false>(a, any, robust); }
     else if (leaf == LEAF_SPHERE) { if (deep) run_variant<T, LEAF_SPHERE, 3, true>(a, any, robust); else run_variant<T, LEAF_SPHERE, 3, false>(a, any, robust); }
     else { if (deep) run_variant<T, LEAF_TRIANGLE, 3, true>(a, any, robust); else run_variant<T, LEAF_TRIANGLE, 3, false>(a, any, robust); }
@@ -241,6 +253,10 @@ extern "C" {
 
 // Number of ticket ranges (1..8) the following emulated launches cut their rays into.
 void trace_body_host_set_parts(int parts) { g_parts = parts < 1 ? 1u : parts > 8 ? 8u : static_cast<uint32_t>(parts); }
+
+// Blocks of the emulated grid (one wavefront each, run one after another, the last block first) and the staggered drain's tickets per
+// class and range (TraceArgs::stagger; 0 = off) of the following trace_body_host_any launches.
+void trace_body_host_set_grid(int blocks, int stagger) { g_blocks = blocks < 1 ? 1u : static_cast<uint32_t>(blocks); g_stagger = stagger < 0 ? 0u : static_cast<uint32_t>(stagger); }
 
 // The float / triangle / 3D body with counters on (`unused` keeps the historical signature). Returns 0.
 int trace_body_host(const void* pairs64, const void* unused, uint32_t root_index, const float* tris12, const float* rays8, size_t n_rays,

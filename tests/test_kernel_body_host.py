@@ -218,6 +218,31 @@ def test_body_full_wavefront_ticket_ranges(body64, orc, parts):
         body64.trace_body_host_set_parts(1)
 
 
+@pytest.mark.parametrize("parts", [1, 8])
+def test_body_staggered_drain_draws_every_ticket(body, body64, orc, parts):
+    """the staggered drain (trace_body.inc: the eighth of the grid a block belongs to stops drawing tickets once fewer than
+    class x stagger are left in the range it draws from) for grids of 1..9 blocks — fewer than eight, so that some classes are empty
+    and the class of a block is (8 b) / blocks — with one ticket range and with eight: block 0 is always class 0, never stops early and
+    walks every range, so every ray is traced exactly once (golden hits AND the golden visit counters, which a ray traced twice would
+    raise), whatever the stagger: a few tickets, a sixteenth of the batch per range (the launch default's upper end), more than a range."""
+    g = load_golden("soup2k")
+    nodes, ids = parse_stream(g["bvh_parallel_high"].tobytes(), False)
+    prims = orc.precompute_tris(g["prims"], ids)
+    n = len(g["rays_closest"])
+    for dll, grids in ((body64, (1, 2, 3, 5, 8, 9)), (body, (4, 7))):
+        dll.trace_body_host_set_parts(parts)
+        try:
+            for blocks in grids:
+                for stagger in (3, max(1, n // (16 * parts)), n):
+                    dll.trace_body_host_set_grid(blocks, stagger)
+                    hits, cnt = run(dll, nodes["bounds"], nodes["index"], prims, g["rays_closest"], 3, 0, False, True)
+                    assert hits.tobytes() == g["hits_parallel_high_closest_robust"].tobytes(), (blocks, stagger)
+                    assert (cnt == g["counters_parallel_high_closest_robust"]).all(), (blocks, stagger)
+        finally:
+            dll.trace_body_host_set_grid(1, 0)
+            dll.trace_body_host_set_parts(1)
+
+
 def test_body_nan_and_infinite_rays(body64, orc):
     """The slab test keeps its bounds with the hardware's min / max (the non-NaN operand wins) instead of the reference's
     robust_min / robust_max (the second operand wins on NaN); they differ only for a NaN tmin / tmax, which the body flags per ray.
