@@ -333,6 +333,10 @@ hipError_t scratch_alloc(void** p, size_t bytes, ScratchTag* tag) {
     hipError_t e = hipMallocAsync(p, bytes, lib);
     if (e != hipSuccess) return e;
     BVH_LIVE_ADD(*p, bytes, "hipMallocAsync");
+    // (ONE event per device, recorded and waited on by every requesting thread without a lock between the two calls: a thread may
+    //  therefore wait on ANOTHER thread's later record — which sits behind its own request on the same library stream and so covers
+    //  it; hipStreamWaitEvent takes the event's latest record at the time of the call. The price is the coupling ADVICE r5 names:
+    //  a request can end up ordered behind a free that the library stream is holding for an unrelated call's fence.)
     if (hipEventRecord(lib_ev, lib) != hipSuccess || hipStreamWaitEvent(stream, lib_ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(lib); }
     return hipSuccess;
 }
