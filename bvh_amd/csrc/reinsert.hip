@@ -937,7 +937,8 @@ __device__ inline void apply_move(HostNode<T>* nodes, uint32_t* parent, unsigned
 // The two refit_from climbs of every applied move (:211-212, up to the root's children each: 2 x ~22 levels of dependent loads, 16 us
 // per move on a lone lane — 87 % of k_apply, 17 ms of a 10M-triangle High build) can be left to ONE parallel bottom-up pass after the
 // iteration's last move — over the ancestors, in the tree as the moves leave it, of every move's `to` and old parent (k_dirty_mark,
-// k_dirty_refit; the root is left alone like refit_from leaves it): every node whose subtree a move changed is among them, and
+// k_dirty_refit; the root only when a move from under it was applied, like refit_from): every node whose subtree a move changed is
+// among them, and
 // recomputing a node the reference did NOT recompute cannot change a bit of it exactly when
 //   * every inner node's box equals left.bbox.extend(right.bbox) BITWISE on entry (a builder's tree does; a caller's hand-made tree
 //     with loose boxes does not) — by induction every node then does after every move: refit_from recomputes the parent of every slot
@@ -988,7 +989,16 @@ __global__ void k_apply(HostNode<T>* nodes, uint32_t* parent, unsigned char* tou
                     bool clash = false, shared = false;
                     for (int h = 0; h < 5; ++h) { clash = clash || touched[hot[h]]; shared = shared || group_mark[hot[h]] == gid; }
                     if (clash) continue;
-                    if (shared) { sc->ambiguous = 1u; if (dirty) *dirty_count = n_dirty; return; }
+                    if (shared) {
+#if defined(BVH_AMD_DEVELOPER)
+                        printf("[k_apply] tie group of %u moves at rank %u of %u, gain %.9g:\n", e - j, j, m, (double)-g);
+                        for (uint32_t qq = j; qq < e && qq < j + 8; ++qq) {
+                            const Move mm = moves[order[qq]];
+                            printf("    from %u (sibling %u, parent %u) -> to %u (parent %u)\n", mm.from, sibling_of(mm.from), parent[mm.from], mm.to, parent[mm.to]);
+                        }
+#endif
+                        sc->ambiguous = 1u; if (dirty) *dirty_count = n_dirty; return;
+                    }
                     for (int h = 0; h < 5; ++h) group_mark[hot[h]] = gid;
                 }
             }
@@ -1001,17 +1011,17 @@ __global__ void k_apply(HostNode<T>* nodes, uint32_t* parent, unsigned char* tou
 
 // The deferred refit. state[] (zero on entry) per node: low byte = children among the nodes to recompute, 0x100 = listed itself,
 // 0x10000 x children that have been recomputed. Pass 1: every listed node climbs and announces itself to its parent until it meets a
-// node somebody has been at (every edge of the union of the paths is walked once). Pass 2: the listed nodes nobody announced to
+// node somebody has been at (every edge of the union of the paths is walked once; the root is announced to like any node). Pass 2: the listed nodes nobody announced to
 // recompute themselves and climb; a parent is recomputed by the last of its announced children to arrive (tickets like k_refit's).
 constexpr uint32_t kDirtyListed = 0x100u, kDirtyDone = 0x10000u;
 __global__ void __launch_bounds__(256) k_dirty_mark(const uint32_t* parent, const uint32_t* dirty, const uint32_t* dirty_count, uint32_t* state) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= *dirty_count) return;
     uint32_t i = dirty[t];
-    if (i == 0 || atomicOr(&state[i], kDirtyListed) != 0) return;     // (the root is never refit; somebody from below has passed already)
+    if (atomicOr(&state[i], kDirtyListed) != 0 || i == 0) return;     // (somebody from below has passed already; the root has nobody above it)
     for (;;) {
         const uint32_t p = parent[i];
-        if (p == 0 || atomicAdd(&state[p], 1u) != 0) return;
+        if (atomicAdd(&state[p], 1u) != 0 || p == 0) return;
         i = p;
     }
 }
@@ -1036,14 +1046,18 @@ __global__ void __launch_bounds__(256) k_dirty_refit(HostNode<T>* nodes, const u
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= *dirty_count) return;
     uint32_t i = dirty[t];
-    if (i == 0 || (state[i] & 0xFFu) != 0) return;            // nodes to recompute below this one: the last of them to arrive does it
+    if ((state[i] & 0xFFu) != 0) return;                      // nodes to recompute below this one: the last of them to arrive does it
     for (;;) {
         if (!is_leaf(nodes[i])) refit_shared_node(nodes, i);
+        if (i == 0) return;
         const uint32_t p = parent[i];
-        if (p == 0) return;
         ticket_release();                                     // this lane's box before the ticket
         const uint32_t old = atomicAdd(&state[p], kDirtyDone);
         if ((old >> 16) + 1 < (old & 0xFFu)) return;          // an announced child is still on its way
+        // The root: refit_from stops below it (:224) — except refit_from(0), which a move whose `from` hung under the root makes: that
+        // move has put the sibling's node, box included, into slot 0 (:207), so the root MUST be recomputed then (it is listed), and
+        // must not be otherwise.
+        if (p == 0 && !(old & kDirtyListed)) return;
         ticket_acquire();
         i = p;
     }

@@ -538,6 +538,18 @@ def test_optimize_refits_like_the_reference_whatever_the_boxes(orc, dtype):
             ref.optimize(-1, batch_size_ratio=ratio, max_iter_count=iters)
             gpu.optimize(batch_size_ratio=ratio, max_iter_count=iters)
             assert gpu.serialize() == ref.serialize(), (kind, ratio, iters)
+    # small trees with every node a candidate: moves whose `from` hangs under the root put the sibling's node into slot 0
+    # (reinsertion_optimizer.h:207) and refit_from(0) recomputes the root — the only moves that do
+    for n in (4, 9, 50, 300, 3000):
+        for seed in range(6):
+            small = synth.soup(n, jitter=0.3, seed=seed).astype(dtype)
+            sb, sc_ = orc.prep_tris(small)
+            for builder in (oracle.BUILDER_BINNED, oracle.BUILDER_SWEEP):
+                ref = orc.build(sb, sc_, builder=builder)
+                gpu = bvh_amd.Bvh.from_nodes(ref.nodes(), ref.prim_ids())
+                ref.optimize(-1, batch_size_ratio=1.0, max_iter_count=4)
+                gpu.optimize(batch_size_ratio=1.0, max_iter_count=4)
+                assert gpu.serialize() == ref.serialize(), (n, seed, builder)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
