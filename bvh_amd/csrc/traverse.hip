@@ -1105,7 +1105,7 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
             }
             if (others >= 2 && comparable) {
                 if (closest > 1.10f) { next = -1; winner = predicted; }
-                else if (ps.count[predicted] == 1 && closest > 1.10f * 0.90f) next = predicted;
+                else if (ps.count[predicted] == 1 && closest > 1.10f * 0.85f) next = predicted;
             }
         }
         if (!ps.pending && next < 0 && winner >= 0) {                       // every survivor measured twice (or alone): keep the winner
