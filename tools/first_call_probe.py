@@ -1,6 +1,7 @@
 """Wall time of each of the first large batches through a fresh tree (host clock around call + synchronisation), with the plan each
 one was traced with: what the first call pays over the settled pass, and where.
-    python tools/first_call_probe.py [n_tris] [n_rays_log2]            BVH_AMD_CALIBRATE=0 keeps the predictor's plan throughout
+    python tools/first_call_probe.py [n_tris] [n_rays_log2]            BVH_AMD_CALIBRATE=0 keeps the predictor's plan throughout;
+    PROBE_HEAT=n: n streaming 1 GiB copies right before the first batch of each tree
 """
 import ctypes, os, sys, time
 import numpy as np, torch
@@ -39,6 +40,12 @@ for tree in range(2):
     bvh_amd.prepare_trace(bvh, n_rays)
     torch.cuda.synchronize()
     prep = (time.perf_counter() - t0) * 1e3
+    if os.environ.get("PROBE_HEAT"):                        # ~60 ms of streaming copies right before the first batch: is the handicap the device's state?
+        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); b2 = torch.empty_like(a)
+        for _ in range(int(os.environ["PROBE_HEAT"])):
+            b2.copy_(a)
+        torch.cuda.synchronize()
+        del a, b2
     rows = []
     for i in range(14):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
