@@ -1026,6 +1026,8 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
         auto push = [&](int c) { for (int k = 0; k < n_order; ++k) if (order[k] == c) return; order[n_order++] = c; };
         push(predicted);
         for (int c = 0; c < n_cand; ++c) if (candidates[c].reorder != candidates[predicted].reorder && candidates[c].coop == candidates[predicted].coop && !candidates[c].classes) push(c);
+        for (int c = 0; c < n_cand; ++c)                                     // the predictor's plan with the other order of the long rays: its closest rival
+            if (c != predicted && candidates[c].reorder && candidates[predicted].reorder && candidates[c].coop == candidates[predicted].coop) push(c);
         for (int c = 0; c < n_cand; ++c) if (candidates[c].reorder == candidates[predicted].reorder) push(c);
         for (int c = 0; c < n_cand; ++c) push(c);
     }
@@ -1086,26 +1088,35 @@ int launch_traverse(const BvhImpl<T>& b, int leaf_kind, const T* d_prims, const 
                 else if (ps.count[second] < 3) next = second;
             }
         }
-        // Round 6: the search ends after three batches when the predictor's plan leads everything measured so far —
-        // by then the other ray order and the other record fetch — by more than 10 %. Its one time is the first call's, which the device
-        // coming up to speed makes 5-15 % slower than the plan's settled time (profiles/r06_first_call_probe.txt): when the lead is
-        // inside that handicap the plan is measured again at once and the question asked once more. 1M soup: 3 or 4 batches instead of 8,
-        // the 12.9 ms "as given" batch the only expensive one.
+        // Round 6: the search ends early when the predictor's plan leads what has been measured — the other ray order
+        // and, where there is one, the predictor's plan with the other order of the long rays (its SIBLING: the two are within 5 % of
+        // each other and either can win, so the better of the pair is kept) — by more than 10 %. The predictor's first time is the first
+        // call's, which is 5-15 % slower than the plan's settled time (profiles/r06_first_call_probe.txt): it is measured once more
+        // before it is compared with its sibling, or when its lead over the others is inside that handicap. Closest-hit through a heavy
+        // tree: 4 batches (plan, as given, sibling, plan) instead of 8; any-hit: 3 (plan, as given, other fetch).
         if (!ps.pending && ps.index >= 3 && ps.count[predicted] && !(ps.dropped >> predicted & 1)) {
+            int sibling = -1;
+            for (int c = 0; c < n_cand; ++c)
+                if (c != predicted && candidates[c].reorder && candidates[predicted].reorder && candidates[c].coop == candidates[predicted].coop) sibling = c;
+            const bool pair_ready = sibling < 0 || (ps.dropped >> sibling & 1) || ps.count[sibling] >= 1;
+            int champ = predicted;
+            if (sibling >= 0 && ps.count[sibling] && !(ps.dropped >> sibling & 1) && ps.ns_per_ray[sibling] < ps.ns_per_ray[predicted]) champ = sibling;
             int others = 0;
-            float closest = 0.0f;                                           // the best other candidate's time over the predictor's
+            float closest = 0.0f;                                           // the best candidate outside the pair over the pair's better time
             bool comparable = true;
             for (int c = 0; c < n_cand; ++c) {
-                if (c == predicted || !ps.count[c]) continue;
+                if (c == predicted || c == sibling || !ps.count[c]) continue;
                 ++others;
-                const size_t nc = ps.rays_of[c], np = ps.rays_of[predicted];
+                const size_t nc = ps.rays_of[c], np = ps.rays_of[champ];
                 if (nc == 0 || np == 0 || std::max(nc, np) > 2 * std::min(nc, np)) comparable = false;
-                const float r = ps.ns_per_ray[c] / ps.ns_per_ray[predicted];
+                const float r = ps.ns_per_ray[c] / ps.ns_per_ray[champ];
                 if (closest == 0.0f || r < closest) closest = r;
             }
-            if (others >= 2 && comparable) {
-                if (closest > 1.10f) { next = -1; winner = predicted; }
-                else if (ps.count[predicted] == 1 && closest > 1.10f * 0.85f) next = predicted;
+            const int need_others = sibling >= 0 ? 1 : 2;
+            if (pair_ready && others >= need_others && comparable) {
+                const bool second_look = ps.count[predicted] == 1 && (sibling >= 0 ? !(ps.dropped >> sibling & 1) : closest <= 1.10f && closest > 1.10f * 0.85f);
+                if (second_look) next = predicted;
+                else if (closest > 1.10f) { next = -1; winner = champ; }
             }
         }
         if (!ps.pending && next < 0 && winner >= 0) {                       // every survivor measured twice (or alone): keep the winner

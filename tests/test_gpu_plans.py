@@ -169,9 +169,10 @@ def test_first_large_batch_uses_the_predicted_plan(soup):
         assert bvh_amd.hits_to_numpy(got).tobytes() == soup.want[False][0].tobytes(), i
     assert seen[0] == (2, 1), seen                            # (round 6: long rays first on a heavy tree that fits the Infinity Cache)
     # round 5: the search prunes — the other ray order with the same fetch is tried second and takes its family with it when it loses by
-    # > 40 % (it does on this tree), survivors are measured twice, at most eight batches are spent
+    # > 40 % (it does on this tree), survivors are measured twice, at most eight batches are spent; round 6: it ends after four batches
+    # (plan, as given, sibling, plan again) when the better of plan and sibling leads the rest by more than 10 %
     assert seen[1] == (0, 1), seen
-    assert (1, 0) in seen[:8], seen                           # the other fetch of the predicted ray order was explored ...
+    assert (1, 1) in seen[:4], seen                           # the predicted plan's sibling (the other order of the long rays) was measured ...
     assert seen[10] == seen[11] and seen[10] in seen[:9], seen   # ... and the search has settled (<= 9 batches, photo finish included) on a plan it measured
     assert seen[10][0] >= 1, seen                              # (reordered — 2 = with the long rays first: the as-given family loses by a wide margin on this tree)
 
