@@ -180,7 +180,11 @@ void pool_free_locked(ScratchCache& c, int dev, void* p, const std::shared_ptr<F
     hipStream_t lib = c.lib_stream(dev);
     BVH_LIVE_REMOVE(p, "pool_free");
     if (!lib) { (void)hipDeviceSynchronize(); (void)hipFree(p); return; }
-    if (f && f->waitable.load(std::memory_order_acquire) && hipStreamWaitEvent(lib, f->ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
+    // the library's stream is ordered behind the freeing call's fence only while that call is still running (a wait
+    // there puts every later request of every thread behind that call; a fence that has completed needs no wait)
+    bool must_wait = f && f->waitable.load(std::memory_order_acquire);
+    if (must_wait) { if (hipEventQuery(f->ev) == hipSuccess) must_wait = false; else (void)hipGetLastError(); }
+    if (must_wait && hipStreamWaitEvent(lib, f->ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
     if (hipFreeAsync(p, lib) != hipSuccess) (void)hipGetLastError();
 }
 
